@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests (fixture loading, seeded regeneration of inputs)."""
+import os
+
+import numpy as np
+import torch
+
+import cova_amd  # noqa: F401
+from cova_web_object_detection_amd import synthetic, weights
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FULL_CASES = ["cova_h64_n11", "cova_h64_n90", "cova_h128_ragged", "cova_h64_addfeat"]
+SAMPLE_STRIDE = 97
+
+
+def load_case(name):
+    """Golden fixture -> (fixture dict, cfg, state_dict, batch) with inputs regenerated from seeds."""
+    fx = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    boxes = [int(b) for b in fx["meta/boxes"]]
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True,
+               hidden_dim=int(fx["meta/hidden_dim"]), bbox_hidden_dim=int(fx["meta/bbox_hidden_dim"]),
+               n_additional_feat=int(fx["meta/n_additional_feat"]), drop_prob=0.0)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(int(fx["meta/seed"]), logit_gain=float(fx["meta/logit_gain"]), **wcfg)
+    batch = synthetic.make_batch(int(fx["meta/n_pages"]), img_h=int(fx["meta/img_h"]),
+                                 boxes_per_page=boxes, context_size=int(fx["meta/context_size"]),
+                                 n_additional_feat=cfg["n_additional_feat"], seed=int(fx["meta/seed"]))
+    return fx, cfg, sd, batch
+
+
+def check_grads(fx, grads, rtol, floor_frac=0.01):
+    """Compare a {key: tensor} gradient dict with a fixture's grad/gradsample/gradnorm entries.
+
+    Several parameters have analytically ZERO gradient (a bias in front of a train-mode
+    BatchNorm, anything softmax/BN shift-invariant), so the tolerance for tensor k is
+    ``rtol * max(max|ref_k|, floor_frac * max_k max|ref_k|)`` rather than purely relative.
+    """
+    keys = [k[len("gradnorm/"):] for k in fx if k.startswith("gradnorm/")]
+    refs = {}
+    for k in keys:
+        refs[k] = fx["grad/" + k] if "grad/" + k in fx else fx["gradsample/" + k]
+    gscale = max(float(np.abs(r).max()) for r in refs.values())
+    worst = {}
+    for k in keys:
+        g = grads[k].detach().cpu().numpy().astype(np.float32)
+        ref = refs[k]
+        got = g if "grad/" + k in fx else g.reshape(-1)[::SAMPLE_STRIDE]
+        scale = max(float(np.abs(ref).max()), floor_frac * gscale)
+        err = float(np.abs(got.reshape(ref.shape) - ref).max()) / scale
+        worst[k] = err
+        assert err <= rtol, "grad %s: max err/scale %.3e > %.1e" % (k, err, rtol)
+        nrm = float(np.linalg.norm(g.astype(np.float64)))
+        ref_norm = float(fx["gradnorm/" + k])
+        assert abs(nrm - ref_norm) <= rtol * max(ref_norm, floor_frac * gscale * np.sqrt(g.size)), \
+            (k, nrm, ref_norm)
+    return worst
+
+
+def margins_ok(logits, tol):
+    """Rows whose top-2 logit gap exceeds `tol` (integer predictions are asserted on these)."""
+    top2 = torch.topk(logits, 2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]) > tol

@@ -1,0 +1,91 @@
+"""ctypes binding of libcova_hip.so, generated from include/cova_hip.h (single source of truth).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception
+is raised (never a silent PyTorch/CPU substitute).
+"""
+import ctypes
+import os
+import re
+
+import torch  # noqa: F401  -- must be imported first so that libamdhip64 is torch's copy
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(PKG_DIR, "..", "include", "cova_hip.h")
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libcova_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
+    "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: [ctype, ...]} for every `int cova_*(...)` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(cova_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(1), m.group(2)
+        types = []
+        for a in [a.strip() for a in args.split(",") if a.strip()]:
+            if "*" in a:
+                types.append(ctypes.c_void_p)
+                continue
+            a = re.sub(r"\bconst\b", "", a).strip()
+            base = " ".join(a.split()[:-1])          # drop the parameter name
+            types.append(_CTYPES[base])
+        protos[name] = types
+    return protos
+
+
+class CovaHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise CovaHipError(
+                "libcova_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, types in self.protos.items():
+            f = getattr(self.cdll, name)       # AttributeError => header/library mismatch
+            f.argtypes = types
+            f.restype = ctypes.c_int
+            self.fn[name] = f
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+def _arg(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args, stream=None):
+    """Call a stream-taking entry point with tensors/None/scalars; raises on a non-zero status."""
+    L = lib()
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    rc = L.fn[name](*[_arg(a) for a in args], stream)
+    if rc != 0:
+        raise CovaHipError("%s failed with status %d" % (name, rc))
+
+
+def query(name, *args):
+    """Call a pure host query (no stream, returns its int result)."""
+    return lib().fn[name](*args)

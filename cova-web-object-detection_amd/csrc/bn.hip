@@ -1,0 +1,563 @@
+// BatchNorm (train-mode batch statistics / eval-mode running statistics), ReLU, residual add
+// and the 3x3/s2 max-pool of the conv stack; also serves the two BatchNorm1d layers.
+//
+// Reference semantics: nn.BatchNorm2d / nn.BatchNorm1d as the reference instantiates them
+// (models.py:49-51 via torchvision ResNet, models.py:68, :73, :86): biased variance for
+// normalisation, unbiased variance into running_var, momentum 0.1, eps 1e-5; train-mode
+// statistics couple the whole device batch (SURVEY.md section 8a row BN).
+//
+// Tensors are row-major [R, C] with a leading dimension (NHWC activations are R = B*H*W,
+// C = 64).  Statistics are reduced in two stages: fp32 per-chunk partials (produced here or
+// by the conv epilogues), then a finalize kernel that combines the partials in fp64.
+// These kernels are HBM-bound: algorithmic bytes = 4 B per element read or written.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int pow2_cols(int C)
+{
+    int cb = 1;
+    while (cb < C && cb < 256) cb <<= 1;
+    return cb;
+}
+inline int pow2_cols_host(int C)
+{
+    int cb = 1;
+    while (cb < C && cb < 256) cb <<= 1;
+    return cb;
+}
+
+// MODE 0: partial[chunk][0][c] = sum x, [1][c] = sum x^2
+// MODE 1: (BN backward) dy = dout * (act > 0 if act != null); [0] = sum dy, [1] = sum dy*xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(
+    const float *__restrict__ x, int ldx, const float *__restrict__ act, int lda,
+    const float *__restrict__ z, int ldz, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ partial, long long R, int C,
+    int rows_per_chunk)
+{
+    __shared__ float s_s[256], s_q[256];
+    const int CB = pow2_cols(C);
+    const int RPB = 256 / CB;
+    const int tx = threadIdx.x % CB, ty = threadIdx.x / CB;
+    const int col = blockIdx.y * CB + tx;
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float s = 0.f, q = 0.f;
+    if (col < C) {
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[col]; is = invstd[col]; }
+        for (long long r = r0 + ty; r < r1; r += RPB) {
+            float v = x[r * ldx + col];
+            if (MODE == 0) {
+                s += v;
+                q += v * v;
+            } else {
+                if (act != nullptr && !(act[r * lda + col] > 0.f)) v = 0.f;
+                const float xh = (z[r * ldz + col] - mu) * is;
+                s += v;
+                q += v * xh;
+            }
+        }
+    }
+    s_s[threadIdx.x] = s;
+    s_q[threadIdx.x] = q;
+    __syncthreads();
+    if (ty == 0 && col < C) {
+        for (int j = 1; j < RPB; ++j) { s += s_s[j * CB + tx]; q += s_q[j * CB + tx]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + col] = s;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + col] = q;
+    }
+}
+
+// Combine partials [nparts][2][C] in fp64.  Block = 64 channels x 16 slices.
+__device__ __forceinline__ void combine_partials(const float *__restrict__ partial, int nparts,
+                                                 int C, int c, int slice, double *s_a, double *s_b,
+                                                 double &tot_a, double &tot_b)
+{
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int p = slice; p < nparts; p += 16) {
+            a += (double)partial[((size_t)p * 2 + 0) * C + c];
+            b += (double)partial[((size_t)p * 2 + 1) * C + c];
+        }
+    s_a[slice * 64 + (threadIdx.x & 63)] = a;
+    s_b[slice * 64 + (threadIdx.x & 63)] = b;
+    __syncthreads();
+    tot_a = 0.0;
+    tot_b = 0.0;
+    if (slice == 0)
+        for (int j = 0; j < 16; ++j) {
+            tot_a += s_a[j * 64 + (threadIdx.x & 63)];
+            tot_b += s_b[j * 64 + (threadIdx.x & 63)];
+        }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(
+    const float *__restrict__ partial, int nparts, int C, double count,
+    const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float momentum, float eps,
+    float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean,
+    float *__restrict__ invstd)
+{
+    __shared__ double s_a[1024], s_b[1024];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double sum, sumsq;
+    combine_partials(partial, nparts, C, c, slice, s_a, s_b, sum, sumsq);
+    if (slice == 0 && c < C) {
+        const double mu = sum / count;
+        double var = sumsq / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * is;
+        mean[c] = (float)mu;
+        invstd[c] = is;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_params_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                      const float *__restrict__ running_mean,
+                                      const float *__restrict__ running_var, float eps, int C,
+                                      float *__restrict__ scale, float *__restrict__ shift,
+                                      float *__restrict__ mean, float *__restrict__ invstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+    if (mean) mean[c] = running_mean[c];
+    if (invstd) invstd[c] = is;
+}
+
+// dgamma = sum dy*xhat, dbeta = sum dy; coef[0][c] = dbeta/n, coef[1][c] = dgamma/n
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(
+    const float *__restrict__ partial, int nparts, int C, double count,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef)
+{
+    __shared__ double s_a[1024], s_b[1024];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double s1, s2;
+    combine_partials(partial, nparts, C, c, slice, s_a, s_b, s1, s2);
+    if (slice == 0 && c < C) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        coef[c] = (float)(s1 / count);
+        coef[C + c] = (float)(s2 / count);
+    }
+}
+
+// out = act(z*scale + shift (+ res));  V = vector width (1 or 4)
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(
+    const float *__restrict__ z, int ldz, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ res, int ldres,
+    float *__restrict__ out, int ldo, long long R, int C, int relu)
+{
+    const int CV = C / V;
+    const long long total = R * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / CV;
+        const int c = (int)(i - r * CV) * V;
+        float v[V], sc[V], sh[V], rr[V];
+        if (V == 4) {
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(z + r * ldz + c);
+            *reinterpret_cast<float4 *>(sc) = *reinterpret_cast<const float4 *>(scale + c);
+            *reinterpret_cast<float4 *>(sh) = *reinterpret_cast<const float4 *>(shift + c);
+            if (res) *reinterpret_cast<float4 *>(rr) = *reinterpret_cast<const float4 *>(res + r * ldres + c);
+        } else {
+            v[0] = z[r * ldz + c]; sc[0] = scale[c]; sh[0] = shift[c];
+            if (res) rr[0] = res[r * ldres + c];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float y = v[j] * sc[j] + sh[j];
+            if (res) y += rr[j];
+            if (relu) y = y > 0.f ? y : 0.f;
+            v[j] = y;
+        }
+        if (V == 4) *reinterpret_cast<float4 *>(out + r * ldo + c) = *reinterpret_cast<float4 *>(v);
+        else out[r * ldo + c] = v[0];
+    }
+}
+
+// dz = scale * (dy - c1 - xhat*c2), dy = dout * (act > 0) if act; optional dres = dy
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float *__restrict__ dout, int ldd, const float *__restrict__ act, int lda,
+    const float *__restrict__ z, int ldz, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ scale,
+    const float *__restrict__ coef, float *__restrict__ dz, int lddz, float *__restrict__ dres,
+    int lddres, long long R, int C)
+{
+    const int CV = C / V;
+    const long long total = R * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / CV;
+        const int c = (int)(i - r * CV) * V;
+        float g[V], a[V], zz[V], o[V];
+        if (V == 4) {
+            *reinterpret_cast<float4 *>(g) = *reinterpret_cast<const float4 *>(dout + r * ldd + c);
+            *reinterpret_cast<float4 *>(zz) = *reinterpret_cast<const float4 *>(z + r * ldz + c);
+            if (act) *reinterpret_cast<float4 *>(a) = *reinterpret_cast<const float4 *>(act + r * lda + c);
+        } else {
+            g[0] = dout[r * ldd + c]; zz[0] = z[r * ldz + c];
+            if (act) a[0] = act[r * lda + c];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float dy = g[j];
+            if (act && !(a[j] > 0.f)) dy = 0.f;
+            g[j] = dy;
+            const float xh = (zz[j] - mean[c + j]) * invstd[c + j];
+            o[j] = scale[c + j] * (dy - coef[c + j] - xh * coef[C + c + j]);
+        }
+        if (V == 4) {
+            *reinterpret_cast<float4 *>(dz + r * lddz + c) = *reinterpret_cast<float4 *>(o);
+            if (dres) *reinterpret_cast<float4 *>(dres + r * lddres + c) = *reinterpret_cast<float4 *>(g);
+        } else {
+            dz[r * lddz + c] = o[0];
+            if (dres) dres[r * lddres + c] = g[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 tail: relu(bn(y)) followed by 3x3 / stride 2 / pad 1 max-pool, NHWC C = 64.
+// idx[b,oy,ox,c] = window position (ky*3+kx) of the first maximum (row-major scan, strict >),
+// which is where torch's max_pool2d backward routes the gradient.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+    float *__restrict__ out, uint8_t *__restrict__ idx, int B, int H1, int W1, int H2, int W2)
+{
+    const long long total = (long long)B * H2 * W2 * 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i & 15);
+        long long p = i >> 4;
+        const int ox = (int)(p % W2);
+        p /= W2;
+        const int oy = (int)(p % H2);
+        const int b = (int)(p / H2);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int mi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if (iy < 0 || iy >= H1) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (ix < 0 || ix >= W1) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    y + (((size_t)b * H1 + iy) * W1 + ix) * 64 + c4 * 4);
+                float t[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z,
+                              v.w * sc.w + sh.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = t[j] > 0.f ? t[j] : 0.f;
+                    if (a > m[j]) { m[j] = a; mi[j] = ky * 3 + kx; }
+                }
+            }
+        }
+        const size_t o = (((size_t)b * H2 + oy) * W2 + ox) * 64 + c4 * 4;
+        *reinterpret_cast<float4 *>(out + o) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<uchar4 *>(idx + o) = make_uchar4(mi[0], mi[1], mi[2], mi[3]);
+    }
+}
+
+// Gradient w.r.t. the bn output before relu at input pixel (b, Y, X): gather from the <= 4
+// pooling windows that contain the pixel, then apply the relu mask.
+__device__ __forceinline__ void pool_relu_gather(const float *__restrict__ dp,
+                                                 const uint8_t *__restrict__ idx,
+                                                 const float t[4], int b, int Y, int X, int H2,
+                                                 int W2, int c4, float dy[4])
+{
+    dy[0] = dy[1] = dy[2] = dy[3] = 0.f;
+    const int oy_lo = Y >> 1, oy_hi = (Y + 1) >> 1;     // equal when Y is even
+    const int ox_lo = X >> 1, ox_hi = (X + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        if (oy >= H2) continue;
+        const int ky = Y - (2 * oy - 1);
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            if (ox >= W2) continue;
+            const int kx = X - (2 * ox - 1);
+            const int pos = ky * 3 + kx;
+            const size_t o = (((size_t)b * H2 + oy) * W2 + ox) * 64 + c4 * 4;
+            const uchar4 id = *reinterpret_cast<const uchar4 *>(idx + o);
+            const float4 g = *reinterpret_cast<const float4 *>(dp + o);
+            if (id.x == pos) dy[0] += g.x;
+            if (id.y == pos) dy[1] += g.y;
+            if (id.z == pos) dy[2] += g.z;
+            if (id.w == pos) dy[3] += g.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(t[j] > 0.f)) dy[j] = 0.f;
+}
+
+// PASS 0: per-block partial sums of dy and dy*xhat ([block][2][64]);
+// PASS 1: dz = scale*(dy - c1 - xhat*c2) written NHWC.
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(
+    const float *__restrict__ dp, const uint8_t *__restrict__ idx, const float *__restrict__ y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ coef, float *__restrict__ dz, float *__restrict__ partial, int B,
+    int H1, int W1, int H2, int W2)
+{
+    __shared__ float s_s[16][64], s_q[16][64];
+    const int c4 = threadIdx.x & 15, prow = threadIdx.x >> 4;   // 16 pixels per block pass
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4 * 4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4 * 4);
+    float c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    if (PASS == 1) {
+        *reinterpret_cast<float4 *>(c1) = *reinterpret_cast<const float4 *>(coef + c4 * 4);
+        *reinterpret_cast<float4 *>(c2) = *reinterpret_cast<const float4 *>(coef + 64 + c4 * 4);
+    }
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const long long npix = (long long)B * H1 * W1;
+    for (long long p = (long long)blockIdx.x * 16 + prow; p < npix; p += (long long)gridDim.x * 16) {
+        const int X = (int)(p % W1);
+        const long long pr = p / W1;
+        const int Y = (int)(pr % H1);
+        const int b = (int)(pr / H1);
+        const float4 v = *reinterpret_cast<const float4 *>(y + (size_t)p * 64 + c4 * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float t[4], dy[4], xh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = vv[j] * scv[j] + shv[j];
+            xh[j] = (vv[j] - muv[j]) * isv[j];
+        }
+        pool_relu_gather(dp, idx, t, b, Y, X, H2, W2, c4, dy);
+        if (PASS == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += dy[j]; q[j] += dy[j] * xh[j]; }
+        } else {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = scv[j] * (dy[j] - c1[j] - xh[j] * c2[j]);
+            *reinterpret_cast<float4 *>(dz + (size_t)p * 64 + c4 * 4) =
+                make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_s[prow][c4 * 4 + j] = s[j]; s_q[prow][c4 * 4 + j] = q[j]; }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float a = 0.f, bq = 0.f;
+            for (int r = 0; r < 16; ++r) { a += s_s[r][threadIdx.x]; bq += s_q[r][threadIdx.x]; }
+            partial[((size_t)blockIdx.x * 2 + 0) * 64 + threadIdx.x] = a;
+            partial[((size_t)blockIdx.x * 2 + 1) * 64 + threadIdx.x] = bq;
+        }
+    }
+}
+
+inline int ew_grid(long long total_threads)
+{
+    long long g = cdivll(total_threads, 256);
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline bool vec4_ok(const void *p, int ld)
+{
+    return p == nullptr || (((uintptr_t)p & 15) == 0 && (ld & 3) == 0);
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+COVA_API int cova_colreduce_rows_per_chunk(long long R, int C)
+{
+    const int rpb = 256 / pow2_cols_host(C);
+    long long rows = cdivll(R, 2048);
+    if (rows < 64) rows = 64;
+    rows = cdivll(rows, rpb) * rpb;
+    return (int)rows;
+}
+
+COVA_API int cova_colreduce_num_chunks(long long R, int C)
+{
+    return (int)cdivll(R, cova_colreduce_rows_per_chunk(R, C));
+}
+
+// partial [num_chunks][2][C]: column sums and sums of squares of x [R, C] (ld = ldx)
+COVA_API int cova_colstats(const float *x, int ldx, long long R, int C, float *partial, void *stream)
+{
+    COVA_REQUIRE(x && partial && R > 0 && C > 0);
+    const int rpc = cova_colreduce_rows_per_chunk(R, C);
+    const dim3 grid((unsigned)cdivll(R, rpc), (unsigned)cdiv(C, pow2_cols_host(C)));
+    hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (const float *)nullptr, 0, (const float *)nullptr, 0, (const float *)nullptr,
+                       (const float *)nullptr, partial, R, C, rpc);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// train-mode finalize: partial [nparts][2][C] -> scale/shift/mean/invstd (+ running stats update
+// when running_mean != NULL)
+COVA_API int cova_bn_finalize_fwd(const float *partial, int nparts, int C, double count,
+                                  const float *gamma, const float *beta, float *running_mean,
+                                  float *running_var, float momentum, float eps, float *scale,
+                                  float *shift, float *mean, float *invstd, void *stream)
+{
+    COVA_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && nparts > 0 && C > 0);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
+                       partial, nparts, C, count, gamma, beta, running_mean, running_var, momentum,
+                       eps, scale, shift, mean, invstd);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_bn_eval_params(const float *gamma, const float *beta, const float *running_mean,
+                                 const float *running_var, float eps, int C, float *scale,
+                                 float *shift, float *mean, float *invstd, void *stream)
+{
+    COVA_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// out = act(z*scale + shift (+ res))
+COVA_API int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const float *shift,
+                             const float *res, int ldres, float *out, int ldo, long long R, int C,
+                             int relu, void *stream)
+{
+    COVA_REQUIRE(z && scale && shift && out && R > 0 && C > 0);
+    const bool v4 = (C % 4 == 0) && vec4_ok(z, ldz) && vec4_ok(res, ldres) && vec4_ok(out, ldo) &&
+                    vec4_ok(scale, 0) && vec4_ok(shift, 0);
+    if (v4)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(ew_grid(R * (C / 4))), dim3(256), 0,
+                           (hipStream_t)stream, z, ldz, scale, shift, res, ldres, out, ldo, R, C, relu);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_grid(R * C)), dim3(256), 0,
+                           (hipStream_t)stream, z, ldz, scale, shift, res, ldres, out, ldo, R, C, relu);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// BN backward, stage 1: partial [num_chunks][2][C] of (sum dy, sum dy*xhat), dy = dout*(act>0)
+COVA_API int cova_bn_bwd_reduce(const float *dout, int ldd, const float *act, int lda,
+                                const float *z, int ldz, const float *mean, const float *invstd,
+                                long long R, int C, float *partial, void *stream)
+{
+    COVA_REQUIRE(dout && z && mean && invstd && partial && R > 0 && C > 0);
+    const int rpc = cova_colreduce_rows_per_chunk(R, C);
+    const dim3 grid((unsigned)cdivll(R, rpc), (unsigned)cdiv(C, pow2_cols_host(C)));
+    hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dout, ldd, act,
+                       lda, z, ldz, mean, invstd, partial, R, C, rpc);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// BN backward, stage 2: dgamma, dbeta (nullable) and coef [2][C] = (dbeta/n, dgamma/n)
+COVA_API int cova_bn_finalize_bwd(const float *partial, int nparts, int C, double count,
+                                  float *dgamma, float *dbeta, float *coef, void *stream)
+{
+    COVA_REQUIRE(partial && coef && nparts > 0 && C > 0);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
+                       partial, nparts, C, count, dgamma, dbeta, coef);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// BN backward, stage 3: dz = scale*(dy - coef0 - xhat*coef1); optional dres = dy
+COVA_API int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int lda, const float *z,
+                               int ldz, const float *mean, const float *invstd, const float *scale,
+                               const float *coef, float *dz, int lddz, float *dres, int lddres,
+                               long long R, int C, void *stream)
+{
+    COVA_REQUIRE(dout && z && mean && invstd && scale && coef && dz && R > 0 && C > 0);
+    const bool v4 = (C % 4 == 0) && vec4_ok(dout, ldd) && vec4_ok(act, lda) && vec4_ok(z, ldz) &&
+                    vec4_ok(dz, lddz) && vec4_ok(dres, lddres);
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(R * (C / 4))), dim3(256), 0,
+                           (hipStream_t)stream, dout, ldd, act, lda, z, ldz, mean, invstd, scale,
+                           coef, dz, lddz, dres, lddres, R, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(R * C)), dim3(256), 0,
+                           (hipStream_t)stream, dout, ldd, act, lda, z, ldz, mean, invstd, scale,
+                           coef, dz, lddz, dres, lddres, R, C);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// y NHWC [B,H1,W1,64] raw conv1 output -> out NHWC [B,H2,W2,64], idx uint8 same shape
+COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const float *shift,
+                                      float *out, uint8_t *idx, int B, int H1, int W1, void *stream)
+{
+    COVA_REQUIRE(y && scale && shift && out && idx && B > 0 && H1 > 0 && W1 > 0);
+    const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_grid((long long)B * H2 * W2 * 16)),
+                       dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, B, H1, W1, H2, W2);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_bn_relu_maxpool_bwd_num_partials(int B, int H1, int W1)
+{
+    long long g = cdivll((long long)B * H1 * W1, 16 * 64);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// stage 1: partial [num_partials][2][64]
+COVA_API int cova_bn_relu_maxpool_bwd_reduce(const float *dp, const uint8_t *idx, const float *y,
+                                             const float *scale, const float *shift,
+                                             const float *mean, const float *invstd, float *partial,
+                                             int B, int H1, int W1, void *stream)
+{
+    COVA_REQUIRE(dp && idx && y && scale && shift && mean && invstd && partial);
+    const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
+    const int grid = cova_bn_relu_maxpool_bwd_num_partials(B, H1, W1);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       dp, idx, y, scale, shift, mean, invstd, (const float *)nullptr,
+                       (float *)nullptr, partial, B, H1, W1, H2, W2);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// stage 3 (after cova_bn_finalize_bwd): dz NHWC [B,H1,W1,64] = gradient w.r.t. conv1's output
+COVA_API int cova_bn_relu_maxpool_bwd_apply(const float *dp, const uint8_t *idx, const float *y,
+                                            const float *scale, const float *shift,
+                                            const float *mean, const float *invstd,
+                                            const float *coef, float *dz, int B, int H1, int W1,
+                                            void *stream)
+{
+    COVA_REQUIRE(dp && idx && y && scale && shift && mean && invstd && coef && dz);
+    const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
+    const int grid = ew_grid((long long)B * H1 * W1 * 16);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       dp, idx, y, scale, shift, mean, invstd, coef, dz, (float *)nullptr, B, H1, W1,
+                       H2, W2);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

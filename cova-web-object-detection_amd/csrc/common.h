@@ -1,0 +1,51 @@
+// Internal helpers shared by the gfx950 kernels of the CoVA hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define COVA_OK 0
+#define COVA_ERR_BAD_ARG 10001
+
+#define COVA_LAUNCH_CHECK()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+#define COVA_REQUIRE(cond)                          \
+    do {                                            \
+        if (!(cond)) return COVA_ERR_BAD_ARG;       \
+    } while (0)
+
+#define COVA_API extern "C" __attribute__((visibility("default")))
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 FMA chain.
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

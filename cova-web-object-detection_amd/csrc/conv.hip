@@ -1,0 +1,609 @@
+// Convolution kernels of the truncated ResNet-18 stack (reference models.py:49-51):
+//   conv1   7x7 stride 2 pad 3, 3 -> 64   (NCHW image in, NHWC activation out)
+//   conv3x3 3x3 stride 1 pad 1, 64 -> 64  (NHWC in / out) -- forward and, with the
+//           transposed + tap-flipped weights, the data gradient
+//   weight-gradient kernels for both, as split-K (over pixels) persistent kernels
+//
+// All are implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact f32, 157 TF/s peak on gfx950):
+// the reference computes in fp32, so does this path.  Activations are NHWC so that the
+// 64 channels of a pixel are one 256-byte line: a wavefront's global loads are whole
+// lines, LDS tiles keep channels contiguous, and a pixel's K-slice is one ds_read_b128.
+//
+// Roofline bookkeeping: 2*64*64*9 = 73,728 FLOP per output pixel
+// for conv3x3 (fwd, dgrad and wgrad each), 2*64*147 = 18,816 FLOP per output pixel for conv1.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// shared epilogue: one wave owns a 32(pixel) x 64(channel) output strip held in two
+// 32x32 accumulators (channel blocks 0 and 1).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue_store_stats(const f32x16 &acc0, const f32x16 &acc1,
+                                                     float *__restrict__ out,
+                                                     const float *__restrict__ addend,
+                                                     size_t pix_row_base, int x0, int W,
+                                                     bool row_valid, int lane, float &s0,
+                                                     float &s1, float &q0, float &q1)
+{
+    const int li = lane & 31;
+    s0 = s1 = q0 = q1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = mfma32_row(r, lane);
+        const bool valid = row_valid && (x0 + px) < W;
+        if (valid) {
+            const size_t o = (pix_row_base + (size_t)px) * 64;
+            float v0 = acc0[r], v1 = acc1[r];
+            if (addend != nullptr) {
+                v0 += addend[o + li];
+                v1 += addend[o + 32 + li];
+            }
+            out[o + li] = v0;
+            out[o + 32 + li] = v1;
+            s0 += v0; q0 += v0 * v0;
+            s1 += v1; q1 += v1 * v1;
+        }
+    }
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    q0 += __shfl_xor(q0, 32, 64);
+    q1 += __shfl_xor(q1, 32, 64);
+}
+
+// Block-level reduction of the per-wave channel sums into stat_part[bid][2][64].
+__device__ __forceinline__ void block_stats_reduce(float *s_red, float *__restrict__ stat_part,
+                                                   int bid, int tid, int lane, int wave,
+                                                   int nwaves, float s0, float s1, float q0,
+                                                   float q1)
+{
+    if (lane < 32) {
+        s_red[wave * 128 + lane] = s0;
+        s_red[wave * 128 + 32 + lane] = s1;
+        s_red[wave * 128 + 64 + lane] = q0;
+        s_red[wave * 128 + 96 + lane] = q1;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += s_red[w * 128 + tid];
+        stat_part[(size_t)bid * 128 + tid] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv3x3, 64 -> 64, NHWC, stride 1, pad 1
+// ------------------------------------------------------------------------------------
+namespace c3 {
+constexpr int TH = 8, TW = 32;            // output tile: 8 rows x 32 cols = 256 pixels
+constexpr int PH = TH + 2, PW = TW + 2;   // input tile with halo
+constexpr int PSTR = 68;                  // floats per staged pixel (64 + 4 pad: b128 reads
+                                          // of 32 different pixels hit 16 distinct 16-B slots)
+constexpr int IN_FLOATS = PH * PW * PSTR; // 23,120 floats = 92,480 B
+constexpr int W_FLOATS = 64 * PSTR;       // one tap: 64 co rows x 68 = 17,408 B
+constexpr int LDS_FLOATS = IN_FLOATS + 2 * W_FLOATS;   // 127,296 B
+constexpr int THREADS = 512;              // 8 waves; wave w owns output row w of the tile
+}  // namespace c3
+
+// wt: [9 taps][64 out][64 in] (in contiguous).  out[p][o] = sum_{tap,c} in[p+off(tap)][c]*wt[tap][o][c]
+template <bool STATS>
+__global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_kernel(
+    const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
+    float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y)
+{
+    using namespace c3;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *s_in = lds;
+    float *s_w = lds + IN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int b = bid / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float *in_b = in + (size_t)b * H * W * 64;
+
+    // ---- stage the halo'd input tile (zero outside the image == conv zero padding)
+    for (int idx = tid; idx < PH * PW * 16; idx += THREADS) {
+        const int px = idx >> 4, c4 = idx & 15;
+        const int r = px / PW, c = px - r * PW;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+        *reinterpret_cast<float4 *>(s_in + px * PSTR + c4 * 4) = v;
+    }
+    // ---- tap 0 weights -> buffer 0 (1024 float4 per tap, 2 per thread)
+    {
+        const int co = tid >> 4, c4 = tid & 15;
+        const float4 w0 = *reinterpret_cast<const float4 *>(wt + co * 64 + c4 * 4);
+        const float4 w1 = *reinterpret_cast<const float4 *>(wt + (co + 32) * 64 + c4 * 4);
+        *reinterpret_cast<float4 *>(s_w + co * PSTR + c4 * 4) = w0;
+        *reinterpret_cast<float4 *>(s_w + (co + 32) * PSTR + c4 * 4) = w1;
+    }
+    __syncthreads();
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int li = lane & 31, kh2 = lane >> 5;
+
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        // prefetch the next tap's weights into registers while this tap computes
+        float4 wn0 = make_float4(0, 0, 0, 0), wn1 = wn0;
+        const int pco = tid >> 4, pc4 = tid & 15;
+        if (tap < 8) {
+            const float *wsrc = wt + (size_t)(tap + 1) * 4096;
+            wn0 = *reinterpret_cast<const float4 *>(wsrc + pco * 64 + pc4 * 4);
+            wn1 = *reinterpret_cast<const float4 *>(wsrc + (pco + 32) * 64 + pc4 * 4);
+        }
+        // K permutation: in step s the low half-wave holds channels 8s..8s+3 and the high
+        // half-wave 8s+4..8s+7 (one ds_read_b128 each); MFMA t of the step contracts channel
+        // 8s+t (k=0) and 8s+4+t (k=1).  A and B use the same permutation, so the sum is exact.
+        const float *a_base = s_in + ((wave + kh) * PW + (li + kw)) * PSTR + kh2 * 4;
+        const float *b_base = s_w + (tap & 1) * W_FLOATS + li * PSTR + kh2 * 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4 *>(a_base + s * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(b_base + s * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(b_base + 32 * PSTR + s * 8);
+            acc0 = mfma32(a.x, b0.x, acc0);
+            acc1 = mfma32(a.x, b1.x, acc1);
+            acc0 = mfma32(a.y, b0.y, acc0);
+            acc1 = mfma32(a.y, b1.y, acc1);
+            acc0 = mfma32(a.z, b0.z, acc0);
+            acc1 = mfma32(a.z, b1.z, acc1);
+            acc0 = mfma32(a.w, b0.w, acc0);
+            acc1 = mfma32(a.w, b1.w, acc1);
+        }
+        if (tap < 8) {
+            float *wdst = s_w + ((tap + 1) & 1) * W_FLOATS;
+            *reinterpret_cast<float4 *>(wdst + pco * PSTR + pc4 * 4) = wn0;
+            *reinterpret_cast<float4 *>(wdst + (pco + 32) * PSTR + pc4 * 4) = wn1;
+        }
+        __syncthreads();
+    }
+
+    const int oy = y0 + wave;
+    float s0, s1, q0, q1;
+    epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W, oy < H,
+                         lane, s0, s1, q0, q1);
+    if (STATS) block_stats_reduce(s_in, stat_part, bid, tid, lane, wave, 8, s0, s1, q0, q1);
+}
+
+// ------------------------------------------------------------------------------------
+// conv1: 7x7, stride 2, pad 3, 3 -> 64.  NCHW image -> NHWC activation.
+// K = 147 (+1 zero row) = 74 MFMA k-pairs.
+// ------------------------------------------------------------------------------------
+namespace c1 {
+constexpr int TH = 8, TW = 32;                 // output tile
+constexpr int PR = 2 * TH + 5;                 // 21 input rows
+constexpr int PCH = 36;                        // columns per parity plane (35 used + 1 pad)
+constexpr int RSTR = 2 * PCH;                  // 72 floats per staged row (even | odd columns)
+constexpr int CSTR = PR * RSTR;                // 1512 floats per channel plane
+constexpr int IN_FLOATS = 3 * CSTR;            // 4536 floats
+constexpr int KROWS = 148;
+constexpr int W_FLOATS = KROWS * 64;           // 9472 floats
+constexpr int THREADS = 512;
+// LDS offset of tap k = (c, kh, kw) relative to the lane's pixel origin
+__host__ __device__ constexpr int tap_off(int k)
+{
+    return k >= 147 ? 0
+                    : (k / 49) * CSTR + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH + ((k % 7) >> 1);
+}
+}  // namespace c1
+
+// wk: [148][64] (k = c*49 + kh*7 + kw, row 147 = 0)
+template <bool STATS>
+__global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
+    const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
+    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y)
+{
+    using namespace c1;
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS];
+    float *s_in = lds;
+    float *s_w = lds + IN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int b = bid / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float *img_b = img + (size_t)b * 3 * H * W;
+
+    // input patch: rows 2*y0-3 .. +20, cols 2*x0-3 .. +68; column j of the patch is stored at
+    // [parity j&1][j>>1] so that a stride-2 walk over output columns is contiguous in LDS.
+    for (int idx = tid; idx < 3 * PR * 69; idx += THREADS) {
+        const int c = idx / (PR * 69);
+        const int rem = idx - c * (PR * 69);
+        const int r = rem / 69, j = rem - r * 69;
+        const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img_b[((size_t)c * H + gy) * W + gx];
+        s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = v;
+    }
+    for (int idx = tid; idx < W_FLOATS / 4; idx += THREADS)
+        reinterpret_cast<float4 *>(s_w)[idx] = reinterpret_cast<const float4 *>(wk)[idx];
+    __syncthreads();
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int li = lane & 31, kh2 = lane >> 5;
+    const float *a_base = s_in + (2 * wave) * RSTR + li;   // output (row wave, col li) origin
+    const float *b_base = s_w + kh2 * 64 + li;
+#pragma unroll
+    for (int kk = 0; kk < 74; ++kk) {
+        const int off = kh2 ? tap_off(2 * kk + 1) : tap_off(2 * kk);
+        const float a = a_base[off];
+        const float b0 = b_base[kk * 128];
+        const float b1 = b_base[kk * 128 + 32];
+        acc0 = mfma32(a, b0, acc0);
+        acc1 = mfma32(a, b1, acc1);
+    }
+    __syncthreads();   // s_in is reused as reduction scratch below
+
+    const int oy = y0 + wave;
+    float s0, s1, q0, q1;
+    epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
+                         oy < H1, lane, s0, s1, q0, q1);
+    if (STATS) block_stats_reduce(s_in, stat_part, bid, tid, lane, wave, 8, s0, s1, q0, q1);
+}
+
+// ------------------------------------------------------------------------------------
+// weight layout transforms (tiny; run once per step because the weights change every step)
+// ------------------------------------------------------------------------------------
+__global__ void prep_w3x3_kernel(const float *__restrict__ w, float *__restrict__ w_fwd,
+                                 float *__restrict__ w_dgrad)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][a][b]
+    if (idx >= 9 * 64 * 64) return;
+    const int tap = idx >> 12, a = (idx >> 6) & 63, bb = idx & 63;
+    const int kh = tap / 3, kw = tap % 3;
+    // forward: w_fwd[tap][co=a][ci=b] = w[co][ci][kh][kw]
+    w_fwd[idx] = w[((a * 64 + bb) * 3 + kh) * 3 + kw];
+    // dgrad: dx[p][ci] = sum_{tap',co} dz[p+off(tap')][co] * w[co][ci][2-kh'][2-kw']
+    w_dgrad[idx] = w[((bb * 64 + a) * 3 + (2 - kh)) * 3 + (2 - kw)];
+}
+
+__global__ void prep_w7x7_kernel(const float *__restrict__ w, float *__restrict__ wk)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [148][64]
+    if (idx >= c1::W_FLOATS) return;
+    const int k = idx >> 6, co = idx & 63;
+    wk[idx] = (k < 147) ? w[co * 147 + k] : 0.f;             // w[co][c][kh][kw], k = c*49+kh*7+kw
+}
+
+// ------------------------------------------------------------------------------------
+// conv3x3 weight gradient: dW[tap][co][ci] = sum_p dz[p][co] * a[p+off(tap)][ci]
+// GEMM M = co, N = ci (per tap), K = pixels; persistent blocks, partial results per block.
+// wave w: co block (w&1), ci block ((w>>1)&1), pixel half (w>>2); 9 taps x 16 accumulators.
+// ------------------------------------------------------------------------------------
+namespace wg3 {
+constexpr int TH = 4, TW = 32;
+constexpr int PH = TH + 2, PW = TW + 2;
+constexpr int A_FLOATS = PH * PW * 64;      // 13,056 floats = 52,224 B
+constexpr int DZ_FLOATS = TH * TW * 64;     //  8,192 floats = 32,768 B
+constexpr int THREADS = 512;
+}  // namespace wg3
+
+__global__ __launch_bounds__(wg3::THREADS) void conv3x3_wgrad_kernel(
+    const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part,
+    int B, int H, int W, int tiles_x, int tiles_y)
+{
+    using namespace wg3;
+    __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + DZ_FLOATS];
+    float *s_a = lds;
+    float *s_dz = lds + A_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int cob = wave & 1, cib = (wave >> 1) & 1, phalf = wave >> 2;
+    const int ntiles = B * tiles_x * tiles_y;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const float *act_b = act + (size_t)b * H * W * 64;
+        const float *dz_b = dz + (size_t)b * H * W * 64;
+        __syncthreads();   // previous tile fully consumed
+        for (int idx = tid; idx < PH * PW * 16; idx += THREADS) {
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / PW, c = px - r * PW;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+            *reinterpret_cast<float4 *>(s_a + px * 64 + c4 * 4) = v;
+        }
+        for (int idx = tid; idx < TH * TW * 16; idx += THREADS) {
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / TW, c = px - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W)
+                v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+            *reinterpret_cast<float4 *>(s_dz + px * 64 + c4 * 4) = v;
+        }
+        __syncthreads();
+        // this wave's 64 pixels: tile rows 2*phalf, 2*phalf+1; k-pair t -> pixels 2t, 2t+1
+#pragma unroll 4
+        for (int t = 0; t < 32; ++t) {
+            const int p = 2 * t + kh2;                     // 0..63 within the half
+            const int row = phalf * 2 + (p >> 5), col = p & 31;
+            const float a = s_dz[(row * TW + col) * 64 + cob * 32 + li];
+            const float *bsrc = s_a + (row * PW + col) * 64 + cib * 32 + li;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float bv = bsrc[((tap / 3) * PW + (tap % 3)) * 64];
+                acc[tap] = mfma32(a, bv, acc[tap]);
+            }
+        }
+    }
+    // partial layout: part[(block*2 + phalf)][tap][co][ci]
+    float *dst = part + ((size_t)(blockIdx.x * 2 + phalf)) * (9 * 4096);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob * 32 + mfma32_row(r, lane);
+            dst[tap * 4096 + co * 64 + cib * 32 + li] = acc[tap][r];
+        }
+}
+
+// sum partials and write dW in the reference's OIHW layout: dW[co][ci][kh][kw]
+__global__ void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts,
+                                            float *__restrict__ dw)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][co][ci]
+    if (idx >= 9 * 4096) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * (9 * 4096) + idx];
+    const int tap = idx >> 12, co = (idx >> 6) & 63, ci = idx & 63;
+    dw[(co * 64 + ci) * 9 + tap] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 weight gradient: dW[co][k] = sum_p dy[p][co] * x[patch(p, k)],  k = (c,kh,kw) < 147
+// M = co (2 blocks), N = taps padded to 160 (5 blocks), K = pixels.  Each wave holds all
+// 10 accumulators and owns one output row of the 8x32 tile.
+// ------------------------------------------------------------------------------------
+namespace wg1 {
+constexpr int TH = 8, TW = 32;
+constexpr int THREADS = 512;
+constexpr int DY_FLOATS = TH * TW * 64;     // 16,384 floats = 65,536 B
+}  // namespace wg1
+
+__global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_kernel(
+    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
+    int B, int H, int W, int H1, int W1, int tiles_x, int tiles_y)
+{
+    using namespace c1;
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS];
+    float *s_in = lds;
+    float *s_dy = lds + IN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int ntiles = B * tiles_x * tiles_y;
+
+    // per-lane LDS offset of this lane's tap in each of the 5 tap blocks
+    int toff[5];
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb) {
+        const int k = tb * 32 + li;
+        toff[tb] = (k < 147) ? ((k / 49) * CSTR + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH +
+                                ((k % 7) >> 1))
+                             : 0;
+    }
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const float *img_b = img + (size_t)b * 3 * H * W;
+        const float *dy_b = dy + (size_t)b * H1 * W1 * 64;
+        __syncthreads();
+        for (int idx = tid; idx < 3 * PR * 69; idx += wg1::THREADS) {
+            const int c = idx / (PR * 69);
+            const int rem = idx - c * (PR * 69);
+            const int r = rem / 69, j = rem - r * 69;
+            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img_b[((size_t)c * H + gy) * W + gx];
+            s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = v;
+        }
+        for (int idx = tid; idx < TH * TW * 16; idx += wg1::THREADS) {
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / TW, c = px - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H1 && gx < W1)
+                v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
+            *reinterpret_cast<float4 *>(s_dy + px * 64 + c4 * 4) = v;
+        }
+        __syncthreads();
+        // wave = output row of the tile; k-pair t -> output columns 2t, 2t+1
+#pragma unroll 2
+        for (int t = 0; t < 16; ++t) {
+            const int col = 2 * t + kh2;
+            const float a0 = s_dy[(wave * TW + col) * 64 + li];
+            const float a1 = s_dy[(wave * TW + col) * 64 + 32 + li];
+            const float *bsrc = s_in + (2 * wave) * RSTR + col;
+#pragma unroll
+            for (int tb = 0; tb < 5; ++tb) {
+                const float bv = bsrc[toff[tb]];
+                acc[tb] = mfma32(a0, bv, acc[tb]);
+                acc[5 + tb] = mfma32(a1, bv, acc[5 + tb]);
+            }
+        }
+    }
+    // partial layout: part[(block*8 + wave)][co 64][k 160]
+    float *dst = part + ((size_t)(blockIdx.x * 8 + wave)) * (64 * 160);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int tb = 0; tb < 5; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + mfma32_row(r, lane);
+                dst[co * 160 + tb * 32 + li] = acc[cb * 5 + tb][r];
+            }
+}
+
+__global__ void conv1_wgrad_reduce_kernel(const float *__restrict__ part, int nparts,
+                                          float *__restrict__ dw)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [co][147]
+    if (idx >= 64 * 147) return;
+    const int co = idx / 147, k = idx - co * 147;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * (64 * 160) + co * 160 + k];
+    dw[idx] = (float)s;    // OIHW flattened: co*147 + c*49 + kh*7 + kw
+}
+
+inline int persistent_grid(int ntiles)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return ntiles < cus ? ntiles : cus;
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+COVA_API int cova_conv_out_size(int in_size, int kernel, int stride, int pad)
+{
+    return (in_size + 2 * pad - kernel) / stride + 1;
+}
+
+COVA_API int cova_conv3x3_num_tiles(int B, int H, int W)
+{
+    return B * cdiv(H, c3::TH) * cdiv(W, c3::TW);
+}
+
+COVA_API int cova_conv1_num_tiles(int B, int H, int W)
+{
+    const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    return B * cdiv(H1, c1::TH) * cdiv(W1, c1::TW);
+}
+
+COVA_API int cova_conv3x3_prep_weights(const float *w_oihw, float *w_fwd, float *w_dgrad,
+                                       void *stream)
+{
+    COVA_REQUIRE(w_oihw && w_fwd && w_dgrad);
+    hipLaunchKernelGGL(prep_w3x3_kernel, dim3(cdiv(9 * 4096, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w_oihw, w_fwd, w_dgrad);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_conv1_prep_weights(const float *w_oihw, float *w_k, void *stream)
+{
+    COVA_REQUIRE(w_oihw && w_k);
+    hipLaunchKernelGGL(prep_w7x7_kernel, dim3(cdiv(c1::W_FLOATS, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w_oihw, w_k);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// in/out NHWC [B,H,W,64]; w_t [9][64][64]; addend (nullable) is added to the result;
+// stat_part (nullable): [cova_conv3x3_num_tiles][2][64] per-tile channel sum / sum of squares.
+COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *addend, float *out,
+                              float *stat_part, int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(in && w_t && out && B > 0 && H > 0 && W > 0);
+    const int tiles_x = cdiv(W, c3::TW), tiles_y = cdiv(H, c3::TH);
+    const dim3 grid(B * tiles_x * tiles_y), block(c3::THREADS);
+    if (stat_part)
+        hipLaunchKernelGGL(conv3x3_c64_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,
+                           addend, out, stat_part, H, W, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(conv3x3_c64_kernel<false>, grid, block, 0, (hipStream_t)stream, in, w_t,
+                           addend, out, stat_part, H, W, tiles_x, tiles_y);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// img NCHW [B,3,H,W]; w_k [148][64]; out NHWC [B,H1,W1,64]
+COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part,
+                            int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(img && w_k && out && B > 0 && H > 0 && W > 0);
+    const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    const int tiles_x = cdiv(W1, c1::TW), tiles_y = cdiv(H1, c1::TH);
+    const dim3 grid(B * tiles_x * tiles_y), block(c1::THREADS);
+    if (stat_part)
+        hipLaunchKernelGGL(conv1_7x7_kernel<true>, grid, block, 0, (hipStream_t)stream, img, w_k,
+                           out, stat_part, H, W, H1, W1, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(conv1_7x7_kernel<false>, grid, block, 0, (hipStream_t)stream, img, w_k,
+                           out, stat_part, H, W, H1, W1, tiles_x, tiles_y);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
+{
+    const int ntiles = B * cdiv(W, wg3::TW) * cdiv(H, wg3::TH);
+    return persistent_grid(ntiles) * 2 * 9 * 4096;
+}
+
+// act, dz NHWC [B,H,W,64]; dw OIHW [64,64,3,3]; ws >= cova_conv3x3_wgrad_workspace_floats
+COVA_API int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw, float *ws, int B,
+                                int H, int W, void *stream)
+{
+    COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
+    const int tiles_x = cdiv(W, wg3::TW), tiles_y = cdiv(H, wg3::TH);
+    const int grid = persistent_grid(B * tiles_x * tiles_y);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(wg3::THREADS), 0, (hipStream_t)stream,
+                       act, dz, ws, B, H, W, tiles_x, tiles_y);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(9 * 4096, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ws, grid * 2, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_conv1_wgrad_workspace_floats(int B, int H, int W)
+{
+    return persistent_grid(cova_conv1_num_tiles(B, H, W)) * 8 * 64 * 160;
+}
+
+// img NCHW [B,3,H,W]; dy NHWC [B,H1,W1,64]; dw OIHW [64,3,7,7]
+COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, float *ws, int B, int H,
+                              int W, void *stream)
+{
+    COVA_REQUIRE(img && dy && dw && ws && B > 0 && H > 0 && W > 0);
+    const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
+    const int grid = persistent_grid(B * tiles_x * tiles_y);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(grid), dim3(wg1::THREADS), 0, (hipStream_t)stream,
+                       img, dy, ws, B, H, W, H1, W1, tiles_x, tiles_y);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(cdiv(64 * 147, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ws, grid * 8, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

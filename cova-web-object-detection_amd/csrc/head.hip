@@ -1,0 +1,290 @@
+// Decoder tail and training-step utilities: inverted dropout (models.py:84,88), the
+// n_classes-wide last Linear (models.py:89) fwd/bwd, CrossEntropyLoss(reduction="sum") with its
+// gradient and the per-box argmax (main.py:139, train.py:53,56), and the Adam update as
+// configured at main.py:133-135 (L2 weight decay added to the gradient, bias-corrected).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+}
+
+// out = x * keep / (1-p); keep is generated (and stored) unless given
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                          float *__restrict__ out, int ldo,
+                                                          uint8_t *__restrict__ mask, long long R,
+                                                          int C, float p, unsigned long long seed,
+                                                          int given)
+{
+    const float inv = 1.f / (1.f - p);
+    const long long total = R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        uint8_t keep;
+        if (given) keep = mask[i];
+        else { keep = hash_uniform(seed, (unsigned long long)i) >= p ? 1 : 0; mask[i] = keep; }
+        out[r * ldo + c] = keep ? x[r * ldx + c] * inv : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float *__restrict__ g, int ldg,
+                                                          const uint8_t *__restrict__ mask,
+                                                          float *__restrict__ dx, int ldx,
+                                                          long long R, int C, float p)
+{
+    const float inv = 1.f / (1.f - p);
+    const long long total = R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        dx[r * ldx + c] = mask[i] ? g[r * ldg + c] * inv : 0.f;
+    }
+}
+
+constexpr int MAXNC = 16;
+
+// y[n][k] = x[n] . W[k] + b[k]; one wave per row
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                               const float *__restrict__ W,
+                                                               const float *__restrict__ b,
+                                                               float *__restrict__ y, int N, int Cin,
+                                                               int NC)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc[MAXNC];
+#pragma unroll
+    for (int k = 0; k < MAXNC; ++k) acc[k] = 0.f;
+    for (int c = lane; c < Cin; c += 64) {
+        const float xv = x[(size_t)n * ldx + c];
+#pragma unroll
+        for (int k = 0; k < MAXNC; ++k)
+            if (k < NC) acc[k] += xv * W[(size_t)k * Cin + c];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXNC; ++k)
+        if (k < NC) {
+            const float t = wave_sum(acc[k]);
+            if (lane == 0) y[(size_t)n * NC + k] = t + b[k];
+        }
+}
+
+// dx[n][c] = sum_k dy[n][k] * W[k][c]
+__global__ __launch_bounds__(256) void linear_small_bwd_x_kernel(const float *__restrict__ dy,
+                                                                 const float *__restrict__ W,
+                                                                 float *__restrict__ dx, int ldx,
+                                                                 int N, int Cin, int NC)
+{
+    const long long total = (long long)N * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Cin), c = (int)(i - (long long)n * Cin);
+        float a = 0.f;
+        for (int k = 0; k < NC; ++k) a += dy[(size_t)n * NC + k] * W[(size_t)k * Cin + c];
+        dx[(size_t)n * ldx + c] = a;
+    }
+}
+
+// dW[k][c] = sum_n dy[n][k]*x[n][c]; block = 64 columns x 4 row slices; db by block 0
+__global__ __launch_bounds__(256) void linear_small_bwd_w_kernel(const float *__restrict__ dy,
+                                                                 const float *__restrict__ x, int ldx,
+                                                                 float *__restrict__ dW,
+                                                                 float *__restrict__ db, int N,
+                                                                 int Cin, int NC)
+{
+    __shared__ float s[4][MAXNC][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float acc[MAXNC];
+#pragma unroll
+    for (int k = 0; k < MAXNC; ++k) acc[k] = 0.f;
+    if (c < Cin)
+        for (int n = ty; n < N; n += 4) {
+            const float xv = x[(size_t)n * ldx + c];
+#pragma unroll
+            for (int k = 0; k < MAXNC; ++k)
+                if (k < NC) acc[k] += dy[(size_t)n * NC + k] * xv;
+        }
+#pragma unroll
+    for (int k = 0; k < MAXNC; ++k) s[ty][k][tx] = acc[k];
+    __syncthreads();
+    if (ty == 0 && c < Cin)
+        for (int k = 0; k < NC; ++k)
+            dW[(size_t)k * Cin + c] = s[0][k][tx] + s[1][k][tx] + s[2][k][tx] + s[3][k][tx];
+    if (blockIdx.x == 0 && threadIdx.x < NC) {
+        float t = 0.f;
+        for (int n = 0; n < N; ++n) t += dy[(size_t)n * NC + threadIdx.x];
+        db[threadIdx.x] = t;
+    }
+}
+
+// loss = sum_n (logsumexp(l_n) - l_n[label]); dl = gscale*(softmax - onehot); pred = argmax
+__global__ __launch_bounds__(1024) void ce_sum_kernel(const float *__restrict__ logits,
+                                                      const int64_t *__restrict__ labels, int N,
+                                                      int NC, float gscale, float *__restrict__ loss,
+                                                      float *__restrict__ dlogits,
+                                                      int64_t *__restrict__ pred)
+{
+    __shared__ double s_loss[1024];
+    double local = 0.0;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const float *l = logits + (size_t)n * NC;
+        float m = l[0];
+        int am = 0;
+        for (int k = 1; k < NC; ++k)
+            if (l[k] > m) { m = l[k]; am = k; }
+        float se = 0.f;
+        for (int k = 0; k < NC; ++k) se += expf(l[k] - m);
+        const float lse = m + logf(se);
+        if (pred) pred[n] = am;
+        if (labels) {
+            const int lab = (int)labels[n];
+            local += (double)(lse - l[lab]);
+            if (dlogits)
+                for (int k = 0; k < NC; ++k)
+                    dlogits[(size_t)n * NC + k] = gscale * (expf(l[k] - lse) - (k == lab ? 1.f : 0.f));
+        }
+    }
+    s_loss[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_loss[threadIdx.x] += s_loss[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = (float)s_loss[0];
+}
+
+// torch.optim.Adam (non-amsgrad) single-tensor math on a flat parameter buffer
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   long long n, float lr, float beta1, float beta2,
+                                                   float eps, float weight_decay, float bc1,
+                                                   float bc2_sqrt)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float pv = p[i];
+        float gv = g[i] + weight_decay * pv;
+        const float mv = beta1 * m[i] + (1.f - beta1) * gv;
+        const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mv / denom);
+    }
+}
+
+// column sums of x [R, C] -> out [C] (deterministic; small R)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int ldx, int R,
+                                                     int C, float *__restrict__ out)
+{
+    __shared__ float s[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f;
+    if (c < C)
+        for (int r = ty; r < R; r += 4) a += x[(size_t)r * ldx + c];
+    s[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < C) out[c] = s[0][tx] + s[1][tx] + s[2][tx] + s[3][tx];
+}
+
+inline int ew_grid(long long total)
+{
+    long long g = cdivll(total, 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+COVA_API int cova_dropout_fwd(const float *x, int ldx, float *out, int ldo, uint8_t *mask,
+                              long long R, int C, float p, unsigned long long seed, int mask_given,
+                              void *stream)
+{
+    COVA_REQUIRE(x && out && mask && R > 0 && C > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(R * C)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, out, ldo, mask, R, C, p, seed, mask_given);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_dropout_bwd(const float *g, int ldg, const uint8_t *mask, float *dx, int ldx,
+                              long long R, int C, float p, void *stream)
+{
+    COVA_REQUIRE(g && mask && dx && R > 0 && C > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(R * C)), dim3(256), 0, (hipStream_t)stream, g,
+                       ldg, mask, dx, ldx, R, C, p);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_linear_small_fwd(const float *x, int ldx, const float *W, const float *b, float *y,
+                                   int N, int Cin, int NC, void *stream)
+{
+    COVA_REQUIRE(x && W && b && y && NC > 0 && NC <= MAXNC && Cin > 0);
+    if (N == 0) return COVA_OK;
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, W, b, y, N, Cin, NC);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_linear_small_bwd(const float *dy, const float *x, int ldx, const float *W,
+                                   float *dx, int lddx, float *dW, float *db, int N, int Cin, int NC,
+                                   void *stream)
+{
+    COVA_REQUIRE(dy && x && W && dx && dW && db && NC > 0 && NC <= MAXNC && Cin > 0 && N > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_small_bwd_x_kernel, dim3(ew_grid((long long)N * Cin)), dim3(256), 0, st,
+                       dy, W, dx, lddx, N, Cin, NC);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(linear_small_bwd_w_kernel, dim3(cdiv(Cin, 64)), dim3(256), 0, st, dy, x, ldx,
+                       dW, db, N, Cin, NC);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// labels / loss / dlogits / pred are each optional (NULL): pred-only = eval argmax
+COVA_API int cova_ce_sum(const float *logits, const int64_t *labels, int N, int NC, float gscale,
+                         float *loss, float *dlogits, int64_t *pred, void *stream)
+{
+    COVA_REQUIRE(logits && N > 0 && NC > 0);
+    hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, labels, N,
+                       NC, gscale, loss, dlogits, pred);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_adam_step(float *p, const float *g, float *m, float *v, long long n, int step,
+                            double lr, double beta1, double beta2, double eps, double weight_decay,
+                            void *stream)
+{
+    COVA_REQUIRE(p && g && m && v && n > 0 && step >= 1);
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1,
+                       bc2_sqrt);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream)
+{
+    COVA_REQUIRE(x && out && R > 0 && C > 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, R,
+                       C, out);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -1,0 +1,362 @@
+// RoIPool over the NHWC feature map, the positional (bbox) encoder input features, and the
+// graph-attention layer's sparse part (scores, masked softmax, neighbour gather) fwd + bwd.
+//
+// Reference: torchvision.ops.RoIPool as used at models.py:58,125 (algorithm restated in
+// oracle/roipool_ref.c), CoVA._get_bbox_features (models.py:129-148) and
+// GraphAttentionLayer.forward (models.py:171-212).
+//
+// GAT formulation: W_j is linear and bias-free, so W_j(h_pad[ctx]) == (W_j h)_pad[ctx]; the
+// dense projections Wh = h [W_i;W_j]^T are one GEMM per node (gemm.hip) and this file does the
+// O(N*K) part: e_ik = LeakyReLU(s_i + t_ctx(i,k)), s = a_i.Wh_i + b, t = a_j.Wh_j (t = 0 for the
+// -1 pad row), mask -> -9e15, softmax over the K slots, h'_i = sum_k alpha_ik Wh_j[ctx(i,k)].
+// One wavefront per node: the K <= 64 slots live in lanes for the softmax (shuffle
+// reductions), the D hidden channels live in lanes for the gather (256-byte coalesced rows).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ RoIPool
+// one wave per (roi, bin); lane = channel (C multiple of 64 handled by a loop)
+__global__ __launch_bounds__(256) void roipool_fwd_kernel(
+    const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int C, int H, int W,
+    int PH, int PW, float spatial_scale, float *__restrict__ out, int ld_out,
+    int32_t *__restrict__ argmax)
+{
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (task >= n_rois * PH * PW) return;
+    const int n = task / (PH * PW), bin = task - n * (PH * PW);
+    const int ph = bin / PW, pw = bin - ph * PW;
+    const float *roi = rois + 5 * n;
+    const int b = (int)roi[0];
+    const int rs_w = (int)roundf(roi[1] * spatial_scale);
+    const int rs_h = (int)roundf(roi[2] * spatial_scale);
+    const int re_w = (int)roundf(roi[3] * spatial_scale);
+    const int re_h = (int)roundf(roi[4] * spatial_scale);
+    const int roi_w = max(re_w - rs_w + 1, 1);
+    const int roi_h = max(re_h - rs_h + 1, 1);
+    const float bin_h = (float)roi_h / (float)PH;
+    const float bin_w = (float)roi_w / (float)PW;
+    int hstart = (int)floorf((float)ph * bin_h);
+    int hend = (int)ceilf((float)(ph + 1) * bin_h);
+    int wstart = (int)floorf((float)pw * bin_w);
+    int wend = (int)ceilf((float)(pw + 1) * bin_w);
+    hstart = min(max(hstart + rs_h, 0), H);
+    hend = min(max(hend + rs_h, 0), H);
+    wstart = min(max(wstart + rs_w, 0), W);
+    wend = min(max(wend + rs_w, 0), W);
+    const bool empty = (hend <= hstart) || (wend <= wstart);
+    const float *fb = feat + (size_t)b * H * W * C;
+    for (int c = lane; c < C; c += 64) {
+        float maxv = empty ? 0.f : -FLT_MAX;
+        int maxi = -1;
+        for (int h = hstart; h < hend; ++h)
+            for (int w = wstart; w < wend; ++w) {
+                const float v = fb[((size_t)h * W + w) * C + c];
+                if (v > maxv) { maxv = v; maxi = h * W + w; }
+            }
+        // reference layout [N, C, PH, PW] flattened per roi: c*(PH*PW) + bin  (models.py:125-127)
+        out[(size_t)n * ld_out + c * (PH * PW) + bin] = maxv;
+        argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = maxi;
+    }
+}
+
+__global__ __launch_bounds__(256) void roipool_bwd_kernel(
+    const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
+    const int32_t *__restrict__ argmax, int n_rois, int C, int H, int W, int PH, int PW,
+    float *__restrict__ gfeat)
+{
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (task >= n_rois * PH * PW) return;
+    const int n = task / (PH * PW), bin = task - n * (PH * PW);
+    const int b = (int)rois[5 * n];
+    float *gb = gfeat + (size_t)b * H * W * C;
+    for (int c = lane; c < C; c += 64) {
+        const int mi = argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin];
+        if (mi >= 0) atomicAdd(gb + (size_t)mi * C + c, gout[(size_t)n * ld_g + c * (PH * PW) + bin]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ bbox
+// raw = [x1, y1, w, h, w/h]; z = raw W^T + b  (models.py:134-144 up to the Linear)
+__global__ void bbox_linear_fwd_kernel(const float *__restrict__ bboxes,
+                                       const float *__restrict__ Wt /*[Hd,5]*/,
+                                       const float *__restrict__ bias, float *__restrict__ raw /*[N,5]*/,
+                                       float *__restrict__ z /*[N,Hd]*/, int N, int Hd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Hd) return;
+    const int n = i / Hd, j = i - n * Hd;
+    const float *bb = bboxes + 5 * n;
+    const float x1 = bb[1], y1 = bb[2];
+    const float w = bb[3] - x1, h = bb[4] - y1;
+    const float f[5] = {x1, y1, w, h, w / h};
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) raw[5 * n + k] = f[k];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc += f[k] * Wt[j * 5 + k];
+    z[i] = acc + bias[j];
+}
+
+// dW[j][k] = sum_n dz[n][j]*raw[n][k], db[j] = sum_n dz[n][j]; one block per j
+__global__ __launch_bounds__(256) void bbox_linear_bwd_kernel(const float *__restrict__ dz,
+                                                              const float *__restrict__ raw,
+                                                              float *__restrict__ dW,
+                                                              float *__restrict__ db, int N, int Hd)
+{
+    __shared__ float s[6][256];
+    const int j = blockIdx.x;
+    float a[6] = {0, 0, 0, 0, 0, 0};
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float g = dz[(size_t)n * Hd + j];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] += g * raw[5 * n + k];
+        a[5] += g;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k][threadIdx.x] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i) t += s[threadIdx.x][i];
+        if (threadIdx.x < 5) dW[j * 5 + threadIdx.x] = t;
+        else db[j] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------ GAT
+// s[n] = a[0:D].Wh[n][0:D] + b ; t[n] = a[D:2D].Wh[n][D:2D]       (one wave per node)
+__global__ __launch_bounds__(256) void gat_scores_kernel(const float *__restrict__ Wh, int ldw,
+                                                         const float *__restrict__ att_w,
+                                                         const float *__restrict__ att_b,
+                                                         float *__restrict__ s, float *__restrict__ t,
+                                                         int N, int D)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float *row = Wh + (size_t)n * ldw;
+    float a = 0.f, b = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        a += att_w[d] * row[d];
+        b += att_w[D + d] * row[D + d];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) { s[n] = a + att_b[0]; t[n] = b; }
+}
+
+__global__ __launch_bounds__(256) void gat_fwd_kernel(
+    const float *__restrict__ Wh, int ldw, const float *__restrict__ s, const float *__restrict__ t,
+    const int64_t *__restrict__ ctx, int N, int K, int D, float slope, float *__restrict__ attn,
+    float *__restrict__ hprime, int ldh)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float e = -INFINITY;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        const float u = s[n] + (j >= 0 ? t[j] : 0.f);
+        const float lr = u > 0.f ? u : slope * u;
+        e = j >= 0 ? lr : -9e15f;                          // models.py:202-203
+    }
+    const float m = wave_max(e);
+    const float p = lane < K ? expf(e - m) : 0.f;
+    const float denom = wave_sum(p);
+    const float alpha = p / denom;
+    if (lane < K) attn[(size_t)n * K + lane] = alpha;
+    const int jj = (int)j;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int jk = __shfl(jj, k, 64);
+            const float ak = __shfl(alpha, k, 64);
+            if (jk >= 0 && d < D) acc += ak * Wh[(size_t)jk * ldw + D + d];
+        }
+        if (d < D) hprime[(size_t)n * ldh + d] = acc;
+    }
+}
+
+// backward of the sparse part.  g = dL/dh' [N, D] (ld = ldg).
+//   dalpha_k = g . Wh_j[ctx_k];  de = alpha*(dalpha - sum alpha*dalpha) (0 on masked slots);
+//   du = de * LeakyReLU'(u);  ds_i = sum_k du_k;  dt[ctx_k] += du_k;
+//   dWh_i[i] = ds_i * a_i;  dWh_j[ctx_k] += alpha_k*g_i (+ dt_j*a_j added by gat_bwd_finish)
+// dWh [N, 2D] must be zeroed in its second half (and dt zeroed) before the launch.
+__global__ __launch_bounds__(256) void gat_bwd_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ Wh, int ldw,
+    const float *__restrict__ s, const float *__restrict__ t, const float *__restrict__ attn,
+    const int64_t *__restrict__ ctx, const float *__restrict__ att_w, int N, int K, int D,
+    float slope, float *__restrict__ dWh, int lddw, float *__restrict__ ds, float *__restrict__ dt)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float alpha = 0.f;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        alpha = attn[(size_t)n * K + lane];
+    }
+    const int jj = (int)j;
+    // dalpha for every slot: lanes over channels, one wave reduction per slot
+    float dalpha = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int jk = __shfl(jj, k, 64);
+        float part = 0.f;
+        if (jk >= 0)
+            for (int d = lane; d < D; d += 64)
+                part += g[(size_t)n * ldg + d] * Wh[(size_t)jk * ldw + D + d];
+        part = wave_sum(part);
+        if (lane == k) dalpha = part;
+    }
+    const float dot = wave_sum(alpha * dalpha);
+    float du = 0.f;
+    if (lane < K && jj >= 0) {
+        const float de = alpha * (dalpha - dot);
+        const float u = s[n] + t[jj];
+        du = de * (u > 0.f ? 1.f : slope);
+        atomicAdd(dt + jj, du);
+    }
+    const float dsn = wave_sum(du);
+    if (lane == 0) ds[n] = dsn;
+    for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
+    for (int k = 0; k < K; ++k) {
+        const int jk = __shfl(jj, k, 64);
+        const float ak = __shfl(alpha, k, 64);
+        if (jk < 0) continue;
+        for (int d = lane; d < D; d += 64)
+            atomicAdd(dWh + (size_t)jk * lddw + D + d, ak * g[(size_t)n * ldg + d]);
+    }
+}
+
+// dWh_j[n] += dt[n]*a_j  (elementwise), and the attention-vector gradients
+//   d att_w[d] = sum_n ds[n]*Wh[n][d] (d < D), sum_n dt[n]*Wh[n][d] (d >= D); d att_b = sum ds
+__global__ void gat_bwd_addt_kernel(float *__restrict__ dWh, int lddw, const float *__restrict__ dt,
+                                    const float *__restrict__ att_w, int N, int D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    dWh[(size_t)n * lddw + D + d] += dt[n] * att_w[D + d];
+}
+
+__global__ __launch_bounds__(256) void gat_bwd_att_kernel(const float *__restrict__ Wh, int ldw,
+                                                          const float *__restrict__ ds,
+                                                          const float *__restrict__ dt,
+                                                          float *__restrict__ d_att_w,
+                                                          float *__restrict__ d_att_b, int N, int D)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;     // 0 .. 2D (2D = bias column)
+    if (col > 2 * D) return;
+    float acc = 0.f;
+    if (col == 2 * D) {
+        for (int n = 0; n < N; ++n) acc += ds[n];
+        d_att_b[0] = acc;
+    } else {
+        const float *w = col < D ? ds : dt;
+        for (int n = 0; n < N; ++n) acc += w[n] * Wh[(size_t)n * ldw + col];
+        d_att_w[col] = acc;
+    }
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+// feat NHWC [B,H,W,C]; rois [N,5]; out row n at out + n*ld_out, C*PH*PW entries in the
+// reference's channel-major order; argmax [N, C*PH*PW] int32 (h*W + w, or -1)
+COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int C, int H, int W,
+                              int PH, int PW, float spatial_scale, float *out, int ld_out,
+                              int32_t *argmax, void *stream)
+{
+    COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && C > 0 && PH > 0 && PW > 0);
+    if (n_rois == 0) return COVA_OK;
+    hipLaunchKernelGGL(roipool_fwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
+                       (hipStream_t)stream, feat, rois, n_rois, C, H, W, PH, PW, spatial_scale, out,
+                       ld_out, argmax);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// gfeat NHWC [B,H,W,C] is zero-filled here, then receives scatter-adds
+COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
+                              int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
+                              void *stream)
+{
+    COVA_REQUIRE(gout && rois && argmax && gfeat && B > 0);
+    hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * H * W * C, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n_rois == 0) return COVA_OK;
+    hipLaunchKernelGGL(roipool_bwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, C, H, W, PH, PW, gfeat);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_bbox_linear_fwd(const float *bboxes, const float *W, const float *bias, float *raw,
+                                  float *z, int N, int Hd, void *stream)
+{
+    COVA_REQUIRE(bboxes && W && bias && raw && z && N >= 0 && Hd > 0);
+    if (N == 0) return COVA_OK;
+    hipLaunchKernelGGL(bbox_linear_fwd_kernel, dim3(cdiv(N * Hd, 256)), dim3(256), 0,
+                       (hipStream_t)stream, bboxes, W, bias, raw, z, N, Hd);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_bbox_linear_bwd(const float *dz, const float *raw, float *dW, float *db, int N,
+                                  int Hd, void *stream)
+{
+    COVA_REQUIRE(dz && raw && dW && db && Hd > 0);
+    hipLaunchKernelGGL(bbox_linear_bwd_kernel, dim3(Hd), dim3(256), 0, (hipStream_t)stream, dz, raw,
+                       dW, db, N, Hd);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// Wh [N, 2D] (ld = ldw): first D columns W_i h, last D columns W_j h.
+// Outputs: s, t [N]; attn [N, K]; hprime rows at hprime + n*ldh (D entries).
+COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const float *att_b,
+                          const int64_t *ctx, int N, int K, int D, float slope, float *s, float *t,
+                          float *attn, float *hprime, int ldh, void *stream)
+{
+    COVA_REQUIRE(Wh && att_w && att_b && ctx && s && t && attn && hprime && K > 0 && K <= 64 && D > 0);
+    if (N == 0) return COVA_OK;
+    hipLaunchKernelGGL(gat_scores_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh,
+                       ldw, att_w, att_b, s, t, N, D);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh, ldw,
+                       s, t, ctx, N, K, D, slope, attn, hprime, ldh);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// dWh [N, 2D] (ld = lddw) is fully written; ds, dt [N] scratch; d_att_w [2D], d_att_b [1]
+COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, const float *s,
+                          const float *t, const float *attn, const int64_t *ctx, const float *att_w,
+                          int N, int K, int D, float slope, float *dWh, int lddw, float *ds, float *dt,
+                          float *d_att_w, float *d_att_b, void *stream)
+{
+    COVA_REQUIRE(g && Wh && s && t && attn && ctx && att_w && dWh && ds && dt && d_att_w && d_att_b);
+    COVA_REQUIRE(K > 0 && K <= 64 && D > 0 && N > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dt, 0, sizeof(float) * (size_t)N, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset2DAsync(dWh + D, sizeof(float) * (size_t)lddw, 0, sizeof(float) * (size_t)D, (size_t)N, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gat_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
+                       ctx, att_w, N, K, D, slope, dWh, lddw, ds, dt);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_bwd_addt_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, st, dWh, lddw, dt,
+                       att_w, N, D);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_bwd_att_kernel, dim3(cdiv(2 * D + 1, 256)), dim3(256), 0, st, Wh, ldw, ds,
+                       dt, d_att_w, d_att_b, N, D);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -1,0 +1,381 @@
+"""Stage functions of the hot path: each composes C-ABI calls (libcova_hip.so) on device
+buffers owned by PyTorch.  No arithmetic of the path is done by torch operators here --
+torch only allocates HBM and provides the stream.
+
+Stages: conv stack R1, RoIPool R2, positional encoder R3, optional
+additional-feature BN R4, GAT G1-G6, decoder D, loss/predictions L/P, optimizer U.
+``params`` maps the reference's state_dict keys (weights.state_dict_spec) to device tensors.
+"""
+import torch
+
+from . import _lib
+from .weights import BACKBONE_CHANNELS as C64
+
+call, query = _lib.call, _lib.query
+BN_MOMENTUM, BN_EPS, LEAKY_SLOPE = 0.1, 1e-5, 0.2   # nn.BatchNorm defaults; models.py:156
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _check(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def feature_map_size(n):
+    """conv1 (7,2,3) then maxpool (3,2,1): models.py:53-56 does this with a dummy forward."""
+    return query("cova_conv_out_size", query("cova_conv_out_size", n, 7, 2, 3), 3, 2, 1)
+
+
+# ------------------------------------------------------------------------------- BatchNorm
+class BNState:
+    """scale/shift/mean/invstd of one BatchNorm application (+ what backward needs)."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "count", "C")
+
+
+def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
+              update_running=True):
+    st = BNState()
+    st.C, st.count = C, float(count)
+    st.scale, st.shift, st.mean, st.invstd = (_empty((C,), like) for _ in range(4))
+    g, b = params[prefix + "weight"], params[prefix + "bias"]
+    rm, rv = buffers[prefix + "running_mean"], buffers[prefix + "running_var"]
+    if training:
+        upd = update_running
+        call("cova_bn_finalize_fwd", partial, nparts, C, float(count), g, b, rm if upd else None,
+             rv if upd else None, BN_MOMENTUM, BN_EPS, st.scale, st.shift, st.mean, st.invstd)
+        if upd:
+            buffers[prefix + "num_batches_tracked"] += 1
+    else:
+        call("cova_bn_eval_params", g, b, rm, rv, BN_EPS, C, st.scale, st.shift, st.mean, st.invstd)
+    return st
+
+
+def colstats(x, ld, R, C):
+    n = query("cova_colreduce_num_chunks", R, C)
+    part = _empty((n, 2, C), x)
+    call("cova_colstats", x, ld, R, C, part)
+    return part, n
+
+
+def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=0):
+    """Returns (dgamma, dbeta); writes dz (and dres = relu-masked dout)."""
+    C = st.C
+    n = query("cova_colreduce_num_chunks", R, C)
+    part = _empty((n, 2, C), z)
+    call("cova_bn_bwd_reduce", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, R, C, part)
+    dgamma, dbeta, coef = _empty((C,), z), _empty((C,), z), _empty((2, C), z)
+    call("cova_bn_finalize_bwd", part, n, C, float(R), dgamma, dbeta, coef)
+    call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
+         lddz, dres, lddres, R, C)
+    return dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------- conv stack
+CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "convnet.4.1.conv2"]
+BN3_KEYS = ["convnet.4.0.bn1.", "convnet.4.0.bn2.", "convnet.4.1.bn1.", "convnet.4.1.bn2."]
+
+
+def convstack_fwd(images, params, buffers, training, save=True):
+    """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,64]  (models.py:49-51,125)."""
+    _check(images)
+    B, _, H, W = images.shape
+    H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
+    H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
+    sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2)}
+    w1k = _empty((148, 64), images)
+    call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
+    wf, wd = [], []
+    for k in CONV3_KEYS:
+        a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
+        call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
+        wf.append(a)
+        wd.append(b)
+    sv["wd"] = wd
+    # conv1 + bn1 + relu + maxpool
+    y1 = _empty((B, H1, W1, C64), images)
+    nt1 = query("cova_conv1_num_tiles", B, H, W)
+    part = _empty((nt1, 2, C64), images) if training else None
+    call("cova_conv1_fwd", images, w1k, y1, part, B, H, W)
+    bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1)
+    p1 = _empty((B, H2, W2, C64), images)
+    idx = _empty((B, H2, W2, C64), images, torch.uint8)
+    call("cova_bn_relu_maxpool_fwd", y1, bn1.scale, bn1.shift, p1, idx, B, H1, W1)
+    sv.update(y1=y1, bn1=bn1, idx=idx)
+    # layer1: two BasicBlocks
+    R = B * H2 * W2
+    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    x = p1
+    blocks = []
+    for blk in (0, 1):
+        part = _empty((nt, 2, C64), images) if training else None
+        z1 = _empty((B, H2, W2, C64), images)
+        call("cova_conv3x3_fwd", x, wf[2 * blk], None, z1, part, B, H2, W2)
+        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R)
+        a1 = _empty((B, H2, W2, C64), images)
+        call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
+        z2 = _empty((B, H2, W2, C64), images)
+        call("cova_conv3x3_fwd", a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
+        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R)
+        out = _empty((B, H2, W2, C64), images)
+        call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
+        blocks.append(dict(x=x, z1=z1, a1=a1, z2=z2, out=out, bna=bna, bnb=bnb))
+        x = out
+    sv["blocks"] = blocks
+    return x, (sv if save else None)
+
+
+def convstack_bwd(sv, dfeat):
+    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms."""
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    R = B * H2 * W2
+    grads = {}
+    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
+    dA = dfeat
+    for blk in (1, 0):
+        s = sv["blocks"][blk]
+        ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
+        # out = relu(bn2(z2) + x)
+        dz2, dres = torch.empty_like(dA), torch.empty_like(dA)
+        dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres, C64)
+        grads[BN3_KEYS[2 * blk + 1] + "weight"], grads[BN3_KEYS[2 * blk + 1] + "bias"] = dg, db
+        dw = _empty((64, 64, 3, 3), dfeat)
+        call("cova_conv3x3_wgrad", s["a1"], dz2, dw, ws3, B, H2, W2)
+        grads[kb + ".weight"] = dw
+        da1 = torch.empty_like(dA)
+        call("cova_conv3x3_fwd", dz2, sv["wd"][2 * blk + 1], None, da1, None, B, H2, W2)
+        # a1 = relu(bn1(z1))
+        dz1 = dz2   # reuse
+        dg, db = bn_backward(da1, C64, s["a1"], C64, s["z1"], C64, s["bna"], R, dz1, C64)
+        grads[BN3_KEYS[2 * blk] + "weight"], grads[BN3_KEYS[2 * blk] + "bias"] = dg, db
+        dw = _empty((64, 64, 3, 3), dfeat)
+        call("cova_conv3x3_wgrad", s["x"], dz1, dw, ws3, B, H2, W2)
+        grads[ka + ".weight"] = dw
+        dx = da1    # reuse
+        call("cova_conv3x3_fwd", dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
+        dA = dx
+    # maxpool + relu + bn1, then conv1's weight gradient
+    bn1 = sv["bn1"]
+    npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
+    part = _empty((npart, 2, C64), dfeat)
+    call("cova_bn_relu_maxpool_bwd_reduce", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
+         bn1.invstd, part, B, H1, W1)
+    dg, db, coef = _empty((C64,), dfeat), _empty((C64,), dfeat), _empty((2, C64), dfeat)
+    call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
+    grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
+    dy1 = torch.empty_like(sv["y1"])
+    call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
+         bn1.invstd, coef, dy1, B, H1, W1)
+    ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
+    dw1 = _empty((64, 3, 7, 7), dfeat)
+    call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
+    grads["convnet.0.weight"] = dw1
+    return grads
+
+
+# ------------------------------------------------------------------------------- RoIPool
+def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
+    _check(bboxes)
+    B, Hf, Wf, C = feat.shape
+    N = bboxes.shape[0]
+    PH, PW = roi_size
+    argmax = _empty((N, C * PH * PW), feat, torch.int32)
+    call("cova_roipool_fwd", feat, bboxes, N, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
+         argmax)
+    return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW))
+
+
+def roipool_bwd(sv, gout, ld_g):
+    B, Hf, Wf, C = sv["shape"]
+    PH, PW = sv["roi"]
+    gfeat = _empty((B, Hf, Wf, C), gout)
+    call("cova_roipool_bwd", gout, ld_g, sv["bboxes"], sv["argmax"], sv["bboxes"].shape[0], B, C, Hf,
+         Wf, PH, PW, gfeat)
+    return gfeat
+
+
+# ------------------------------------------------------------------------------- BN over [N, C]
+def bn1d_fwd(x, ldx, N, C, prefix, params, buffers, training, out, ldo, relu):
+    part, n = colstats(x, ldx, N, C) if training else (None, 0)
+    st = bn_params(prefix, params, buffers, C, x, training, part, n, N)
+    call("cova_bn_act_fwd", x, ldx, st.scale, st.shift, None, 0, out, ldo, N, C, 1 if relu else 0)
+    return st
+
+
+# ------------------------------------------------------------------------------- positional encoder
+def bbox_fwd(bboxes, params, buffers, training, out, ldo):
+    """models.py:129-148: [x1,y1,w,h,w/h] -> Linear(5,Hd) -> BatchNorm1d -> ReLU, written to out."""
+    N = bboxes.shape[0]
+    Hd = params["bbox_feat_encoder.0.weight"].shape[0]
+    raw, z = _empty((N, 5), bboxes), _empty((N, Hd), bboxes)
+    call("cova_bbox_linear_fwd", bboxes, params["bbox_feat_encoder.0.weight"],
+         params["bbox_feat_encoder.0.bias"], raw, z, N, Hd)
+    st = bn1d_fwd(z, Hd, N, Hd, "bbox_feat_encoder.1.", params, buffers, training, out, ldo, True)
+    return dict(raw=raw, z=z, st=st, N=N, Hd=Hd, out=out, ldo=ldo)
+
+
+def bbox_bwd(sv, gout, ldg):
+    N, Hd = sv["N"], sv["Hd"]
+    dz = _empty((N, Hd), gout)
+    dg, db = bn_backward(gout, ldg, sv["out"], sv["ldo"], sv["z"], Hd, sv["st"], N, dz, Hd)
+    dW, dbias = _empty((Hd, 5), gout), _empty((Hd,), gout)
+    call("cova_bbox_linear_bwd", dz, sv["raw"], dW, dbias, N, Hd)
+    return {"bbox_feat_encoder.0.weight": dW, "bbox_feat_encoder.0.bias": dbias,
+            "bbox_feat_encoder.1.weight": dg, "bbox_feat_encoder.1.bias": db}
+
+
+# ------------------------------------------------------------------------------- GAT
+def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
+    """models.py:171-212.  h rows at h + n*ldh (F values); hprime rows at hprime + n*ldo (D)."""
+    _check(ctx, torch.int64)
+    Wi, Wj = params[prefix + "W_i.weight"], params[prefix + "W_j.weight"]
+    aw, ab = params[prefix + "attention_layer.weight"], params[prefix + "attention_layer.bias"]
+    D, K = Wi.shape[0], ctx.shape[1]
+    Wh = _empty((N, 2 * D), h)
+    call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wi, F, Wh, 2 * D, None, 0)
+    call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wj, F, Wh[:, D:], 2 * D, None, 0)
+    s, t, attn = _empty((N,), h), _empty((N,), h), _empty((N, K), h)
+    call("cova_gat_fwd", Wh, 2 * D, aw, ab, ctx, N, K, D, LEAKY_SLOPE, s, t, attn, hprime, ldo)
+    return dict(h=h, ldh=ldh, N=N, F=F, D=D, K=K, ctx=ctx, Wh=Wh, s=s, t=t, attn=attn, prefix=prefix)
+
+
+def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh):
+    """g = dL/dh' (rows at g + n*ldg).  Writes / accumulates dL/dh into dh; returns param grads."""
+    N, F, D, K, prefix = sv["N"], sv["F"], sv["D"], sv["K"], sv["prefix"]
+    Wi, Wj = params[prefix + "W_i.weight"], params[prefix + "W_j.weight"]
+    aw = params[prefix + "attention_layer.weight"]
+    dWh = _empty((N, 2 * D), g)
+    ds, dt = _empty((N,), g), _empty((N,), g)
+    daw, dab = _empty((1, 2 * D), g), _empty((1,), g)
+    call("cova_gat_bwd", g, ldg, sv["Wh"], 2 * D, sv["s"], sv["t"], sv["attn"], sv["ctx"], aw, N, K, D,
+         LEAKY_SLOPE, dWh, 2 * D, ds, dt, daw, dab)
+    dWi, dWj = _empty((D, F), g), _empty((D, F), g)
+    call("cova_sgemm", 1, 0, D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
+    call("cova_sgemm", 1, 0, D, F, N, dWh[:, D:], 2 * D, sv["h"], sv["ldh"], dWj, F, None, 0)
+    call("cova_sgemm", 0, 0, N, F, D, dWh, 2 * D, Wi, F, dh, lddh, None, 1 if accumulate_dh else 0)
+    call("cova_sgemm", 0, 0, N, F, D, dWh[:, D:], 2 * D, Wj, F, dh, lddh, None, 1)
+    return {prefix + "W_i.weight": dWi, prefix + "W_j.weight": dWj,
+            prefix + "attention_layer.weight": daw, prefix + "attention_layer.bias": dab}
+
+
+# ------------------------------------------------------------------------------- decoder
+def dropout_fwd(x, ld, N, C, p, seed, mask=None):
+    out = _empty((N, C), x)
+    given = mask is not None
+    if not given:
+        mask = _empty((N, C), x, torch.uint8)
+    else:
+        _check(mask, torch.uint8)
+    call("cova_dropout_fwd", x, ld, out, C, mask, N, C, float(p), int(seed), 1 if given else 0)
+    return out, mask
+
+
+def decoder_fwd(x, N, T, params, buffers, training, p, seeds=(0, 0), masks=None):
+    """models.py:83-90 on the concatenated features x [N,T]: Dropout, Linear, BN1d, ReLU, Dropout,
+    Linear.  ``masks`` (two uint8 [N,T] keep-masks) override the generated ones (parity tests)."""
+    NC = params["decoder.5.weight"].shape[0]
+    drop = training and (p > 0 or masks is not None)
+    sv = dict(N=N, T=T, NC=NC, drop=drop, p=p)
+    xd, m1 = dropout_fwd(x, T, N, T, p, seeds[0], masks[0] if masks else None) if drop else (x, None)
+    z = _empty((N, T), x)
+    call("cova_sgemm", 0, 1, N, T, T, xd, T, params["decoder.1.weight"], T, z, T,
+         params["decoder.1.bias"], 0)
+    y = _empty((N, T), x)
+    st = bn1d_fwd(z, T, N, T, "decoder.2.", params, buffers, training, y, T, True)
+    yd, m2 = dropout_fwd(y, T, N, T, p, seeds[1], masks[1] if masks else None) if drop else (y, None)
+    logits = _empty((N, NC), x)
+    call("cova_linear_small_fwd", yd, T, params["decoder.5.weight"], params["decoder.5.bias"], logits,
+         N, T, NC)
+    sv.update(xd=xd, m1=m1, z=z, y=y, st=st, yd=yd, m2=m2)
+    return logits, sv
+
+
+def decoder_bwd(sv, dlogits, params):
+    """-> (dL/dx [N,T], param grads)."""
+    N, T, NC, p = sv["N"], sv["T"], sv["NC"], sv["p"]
+    _check(dlogits)
+    dyd = _empty((N, T), dlogits)
+    dW2, db2 = _empty((NC, T), dlogits), _empty((NC,), dlogits)
+    call("cova_linear_small_bwd", dlogits, sv["yd"], T, params["decoder.5.weight"], dyd, T, dW2, db2,
+         N, T, NC)
+    if sv["drop"]:
+        dy = _empty((N, T), dlogits)
+        call("cova_dropout_bwd", dyd, T, sv["m2"], dy, T, N, T, float(p))
+    else:
+        dy = dyd
+    dz = _empty((N, T), dlogits)
+    dg, db = bn_backward(dy, T, sv["y"], T, sv["z"], T, sv["st"], N, dz, T)
+    db1 = _empty((T,), dlogits)
+    call("cova_colsum", dz, T, N, T, db1)
+    dW1 = _empty((T, T), dlogits)
+    call("cova_sgemm", 1, 0, T, T, N, dz, T, sv["xd"], T, dW1, T, None, 0)
+    dxd = dy    # reuse
+    call("cova_sgemm", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dxd, T, None, 0)
+    if sv["drop"]:
+        dx = dyd    # reuse
+        call("cova_dropout_bwd", dxd, T, sv["m1"], dx, T, N, T, float(p))
+    else:
+        dx = dxd
+    grads = {"decoder.1.weight": dW1, "decoder.1.bias": db1, "decoder.2.weight": dg,
+             "decoder.2.bias": db, "decoder.5.weight": dW2, "decoder.5.bias": db2}
+    return dx, grads
+
+
+# ------------------------------------------------------------------------------- whole model
+def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_indices, training,
+              seeds=(0, 0), masks=None, save=True):
+    """CoVA.forward (models.py:94-122) -> (logits [N,n_classes], saved-for-backward or None)."""
+    N = bboxes.shape[0]
+    PH, PW = cfg["roi_output_size"]
+    n_vis = C64 * PH * PW
+    Hd, A = cfg["bbox_hidden_dim"], cfg["n_additional_feat"]
+    F = n_vis + Hd + A
+    D = cfg["hidden_dim"] if cfg["use_context"] else 0
+    T = F + D
+    feat, sv_conv = convstack_fwd(images, params, buffers, training, save)
+    comb = _empty((N, T), images)
+    scale = cfg.get("spatial_scale") or feat.shape[1] / images.shape[2]   # models.py:56
+    sv = dict(cfg=cfg, N=N, F=F, D=D, T=T, n_vis=n_vis, Hd=Hd, A=A, conv=sv_conv, comb=comb)
+    sv["roi"] = roipool_fwd(feat, bboxes, (PH, PW), scale, comb, T)
+    if Hd > 0:
+        sv["bbox"] = bbox_fwd(bboxes, params, buffers, training, comb[:, n_vis:], T)
+    if A > 0:
+        _check(additional_feats)
+        sv["addl_in"] = additional_feats
+        sv["addl"] = bn1d_fwd(additional_feats, A, N, A, "bn_additional_feat.", params, buffers,
+                              training, comb[:, n_vis + Hd:], T, False)
+    if D > 0:
+        sv["gat"] = gat_fwd(comb, T, N, F, context_indices, params, comb[:, F:], T)
+    logits, sv["dec"] = decoder_fwd(comb, N, T, params, buffers, training, cfg["drop_prob"], seeds,
+                                    masks)
+    return logits, (sv if save else None)
+
+
+def model_bwd(sv, dlogits, params):
+    """-> {state_dict key: gradient} for every trainable parameter."""
+    N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
+    dcomb, grads = decoder_bwd(sv["dec"], dlogits, params)
+    if D > 0:
+        grads.update(gat_bwd(sv["gat"], dcomb[:, F:], T, params, dcomb, T, True))
+    if A > 0:
+        st = sv["addl"]
+        dz = _empty((N, A), dcomb)
+        dg, db = bn_backward(dcomb[:, n_vis + Hd:], T, None, 0, sv["addl_in"], A, st, N, dz, A)
+        grads["bn_additional_feat.weight"], grads["bn_additional_feat.bias"] = dg, db
+    if Hd > 0:
+        grads.update(bbox_bwd(sv["bbox"], dcomb[:, n_vis:], T))
+    dfeat = roipool_bwd(sv["roi"], dcomb, T)
+    grads.update(convstack_bwd(sv["conv"], dfeat))
+    return grads
+
+
+def ce_sum(logits, labels, want_grad=True, gscale=1.0):
+    """CrossEntropyLoss(reduction='sum') + argmax (main.py:139, train.py:53,56)."""
+    N, NC = logits.shape
+    loss = _empty((1,), logits)
+    dl = _empty((N, NC), logits) if want_grad else None
+    pred = _empty((N,), logits, torch.int64)
+    call("cova_ce_sum", logits, labels, N, NC, float(gscale), loss, dl, pred)
+    return loss, dl, pred

@@ -1,0 +1,168 @@
+/*
+ * cova_hip.h -- C ABI of libcova_hip.so: the MI355X (gfx950) implementation of the CoVA
+ * forward/backward hot path.
+ *
+ * The reference (kevalmorabia97/CoVA-Web-Object-Detection) is pure Python: its hot path is
+ * `models.CoVA.forward` + autograd backward (models.py:94-122, train.py:47-60) and every kernel
+ * it runs comes from torch / torchvision.  It has no FFI of its own, so this boundary is what a
+ * native replacement of those torch/torchvision operator calls has to export (SURVEY.md
+ * section 8b): one entry point per fused stage of the path, each citing the reference call it
+ * replaces.  The reference-side binding is a ctypes stub; the host mirror of
+ * the reference's nn.Module surface lives in cova-web-object-detection_amd/models.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated; the library never allocates:
+ *     outputs and workspaces are caller-provided, sizes via the *_num_* / *_workspace_* queries;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
+ *     asynchronous on it, nothing synchronises, so calls are hipGraph-capturable;
+ *   - return value: 0 on success, a hipError_t value, or COVA_ERR_BAD_ARG (10001);
+ *   - all floating point data is IEEE fp32 (the reference computes in fp32), indices int64
+ *     as in the reference, RoIPool argmax int32;
+ *   - activations of the conv stack are NHWC ([B,H,W,64]; channel = fastest); the image is the
+ *     reference's NCHW [B,3,H,W]; dense matrices are row-major with a leading dimension `ld*`
+ *     counted in floats.
+ */
+#ifndef COVA_HIP_H
+#define COVA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVA_ERR_BAD_ARG 10001
+
+/* ------------------------------------------------------------------ conv stack (models.py:49-51)
+ * replaces: torchvision resnet18 children()[:-5] = nn.Conv2d(3,64,7,2,3), nn.BatchNorm2d(64),
+ * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
+ */
+int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
+
+/* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
+int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[148,64]*/, void *stream);
+int cova_conv3x3_prep_weights(const float *w_oihw /*[64,64,3,3]*/, float *w_fwd /*[9,64,64]*/,
+                              float *w_dgrad /*[9,64,64]*/, void *stream);
+
+/* nn.Conv2d(3,64,7,stride 2,pad 3,bias=False): img NCHW -> out NHWC [B,H1,W1,64].
+ * stat_part (nullable) [cova_conv1_num_tiles][2][64]: per-tile channel sum / sum of squares of
+ * the output (feeds cova_bn_finalize_fwd: train-mode BatchNorm2d statistics). */
+int cova_conv1_num_tiles(int B, int H, int W);
+int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part, int B, int H,
+                   int W, void *stream);
+/* gradient of conv1's weight (the image needs no gradient): dw OIHW [64,3,7,7] */
+int cova_conv1_wgrad_workspace_floats(int B, int H, int W);
+int cova_conv1_wgrad(const float *img, const float *dy /*NHWC*/, float *dw, float *ws, int B, int H,
+                     int W, void *stream);
+
+/* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC; with w_dgrad it is the data gradient.
+ * addend (nullable, NHWC) is added to the result (residual-branch gradient). */
+int cova_conv3x3_num_tiles(int B, int H, int W);
+int cova_conv3x3_fwd(const float *in, const float *w_t, const float *addend, float *out,
+                     float *stat_part, int B, int H, int W, void *stream);
+int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
+int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
+                       int H, int W, void *stream);
+
+/* ------------------------------------------------------------------ BatchNorm / ReLU / MaxPool
+ * replaces: nn.BatchNorm2d / nn.BatchNorm1d (train: batch statistics + running-stat update with
+ * momentum, unbiased running_var; eval: running statistics), nn.ReLU, the BasicBlock residual
+ * add and nn.MaxPool2d(3,2,1) -- models.py:49-51, :68, :73, :86 and their autograd. */
+int cova_colreduce_rows_per_chunk(long long R, int C);
+int cova_colreduce_num_chunks(long long R, int C);
+int cova_colstats(const float *x, int ldx, long long R, int C, float *partial /*[chunks,2,C]*/,
+                  void *stream);
+int cova_bn_finalize_fwd(const float *partial, int nparts, int C, double count, const float *gamma,
+                         const float *beta, float *running_mean /*nullable*/, float *running_var,
+                         float momentum, float eps, float *scale, float *shift, float *mean,
+                         float *invstd, void *stream);
+int cova_bn_eval_params(const float *gamma, const float *beta, const float *running_mean,
+                        const float *running_var, float eps, int C, float *scale, float *shift,
+                        float *mean /*nullable*/, float *invstd /*nullable*/, void *stream);
+int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const float *shift,
+                    const float *res /*nullable*/, int ldres, float *out, int ldo, long long R, int C,
+                    int relu, void *stream);
+int cova_bn_bwd_reduce(const float *dout, int ldd, const float *act /*nullable: relu mask source*/,
+                       int lda, const float *z, int ldz, const float *mean, const float *invstd,
+                       long long R, int C, float *partial /*[chunks,2,C]*/, void *stream);
+int cova_bn_finalize_bwd(const float *partial, int nparts, int C, double count,
+                         float *dgamma /*nullable*/, float *dbeta /*nullable*/, float *coef /*[2,C]*/,
+                         void *stream);
+int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int lda, const float *z, int ldz,
+                      const float *mean, const float *invstd, const float *scale, const float *coef,
+                      float *dz, int lddz, float *dres /*nullable*/, int lddres, long long R, int C,
+                      void *stream);
+int cova_bn_relu_maxpool_fwd(const float *y /*[B,H1,W1,64]*/, const float *scale, const float *shift,
+                             float *out /*[B,H2,W2,64]*/, uint8_t *idx, int B, int H1, int W1,
+                             void *stream);
+int cova_bn_relu_maxpool_bwd_num_partials(int B, int H1, int W1);
+int cova_bn_relu_maxpool_bwd_reduce(const float *dp, const uint8_t *idx, const float *y,
+                                    const float *scale, const float *shift, const float *mean,
+                                    const float *invstd, float *partial, int B, int H1, int W1,
+                                    void *stream);
+int cova_bn_relu_maxpool_bwd_apply(const float *dp, const uint8_t *idx, const float *y,
+                                   const float *scale, const float *shift, const float *mean,
+                                   const float *invstd, const float *coef, float *dz, int B, int H1,
+                                   int W1, void *stream);
+
+/* ------------------------------------------------------------------ RoIPool (models.py:58,125)
+ * replaces: torchvision.ops.RoIPool(output_size, spatial_scale)(feat, rois) and its backward.
+ * feat NHWC [B,H,W,C]; rois [N,5] = [batch_idx,x1,y1,x2,y2]; row n of the output (C*PH*PW
+ * values, index c*PH*PW + ph*PW + pw exactly like `.view(N, n_visual_feat)` at models.py:125-127)
+ * is written at out + n*ld_out so it can land directly in the concatenated feature matrix. */
+int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int C, int H, int W, int PH,
+                     int PW, float spatial_scale, float *out, int ld_out, int32_t *argmax,
+                     void *stream);
+int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
+                     int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
+                     void *stream);
+
+/* ------------------------------------------------------------------ positional encoder
+ * replaces: CoVA._get_bbox_features up to nn.Linear(5, Hd) (models.py:134-144):
+ * raw = [x1, y1, x2-x1, y2-y1, (x2-x1)/(y2-y1)], z = raw W^T + b */
+int cova_bbox_linear_fwd(const float *bboxes, const float *W /*[Hd,5]*/, const float *bias,
+                         float *raw /*[N,5]*/, float *z /*[N,Hd]*/, int N, int Hd, void *stream);
+int cova_bbox_linear_bwd(const float *dz, const float *raw, float *dW, float *db, int N, int Hd,
+                         void *stream);
+
+/* ------------------------------------------------------------------ dense layers
+ * replaces: nn.Linear forward/backward GEMMs (models.py:85,161-162): C (+)= op(A) op(B) (+ bias) */
+int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
+               int ldb, float *C, int ldc, const float *bias /*nullable [N]*/, int accumulate,
+               void *stream);
+
+/* ------------------------------------------------------------------ graph attention (models.py:171-212)
+ * replaces: GraphAttentionLayer.forward after the projections: gather, score, LeakyReLU, mask,
+ * softmax, weighted sum.  Wh [N,2D] = h [W_i;W_j]^T.  K <= 64. */
+int cova_gat_fwd(const float *Wh, int ldw, const float *att_w /*[2D]*/, const float *att_b /*[1]*/,
+                 const int64_t *ctx /*[N,K]*/, int N, int K, int D, float slope, float *s /*[N]*/,
+                 float *t /*[N]*/, float *attn /*[N,K]*/, float *hprime, int ldh, void *stream);
+int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, const float *s, const float *t,
+                 const float *attn, const int64_t *ctx, const float *att_w, int N, int K, int D,
+                 float slope, float *dWh /*[N,2D]*/, int lddw, float *ds /*[N]*/, float *dt /*[N]*/,
+                 float *d_att_w /*[2D]*/, float *d_att_b /*[1]*/, void *stream);
+
+/* ------------------------------------------------------------------ decoder tail, loss, optimizer
+ * replaces: nn.Dropout (models.py:84,88), nn.Linear(T, n_classes) (models.py:89),
+ * nn.CrossEntropyLoss(reduction="sum") + output.argmax(dim=1) (main.py:139, train.py:53,56),
+ * torch.optim.Adam(lr, weight_decay).step() (main.py:133-135, train.py:60). */
+int cova_dropout_fwd(const float *x, int ldx, float *out, int ldo, uint8_t *mask /*[R,C]*/,
+                     long long R, int C, float p, unsigned long long seed, int mask_given,
+                     void *stream);
+int cova_dropout_bwd(const float *g, int ldg, const uint8_t *mask, float *dx, int ldx, long long R,
+                     int C, float p, void *stream);
+int cova_linear_small_fwd(const float *x, int ldx, const float *W /*[NC,Cin]*/, const float *b,
+                          float *y /*[N,NC]*/, int N, int Cin, int NC, void *stream);
+int cova_linear_small_bwd(const float *dy, const float *x, int ldx, const float *W, float *dx,
+                          int lddx, float *dW, float *db, int N, int Cin, int NC, void *stream);
+int cova_ce_sum(const float *logits, const int64_t *labels /*nullable*/, int N, int NC, float gscale,
+                float *loss /*nullable [1]*/, float *dlogits /*nullable*/, int64_t *pred /*nullable*/,
+                void *stream);
+int cova_adam_step(float *p, const float *g, float *m, float *v, long long n, int step, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, void *stream);
+int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVA_HIP_H */

@@ -1,0 +1,70 @@
+"""CPU tests of the host logic: C-ABI library loads and exports every declared symbol, the
+drop-in module carries the reference's state_dict contract, and nothing falls back to CPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cova_web_object_detection_amd import _lib, synthetic, weights
+from cova_web_object_detection_amd.models import CoVA, GraphAttentionLayer
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), name
+    # pure host queries work without a GPU
+    assert _lib.query("cova_conv_out_size", 1280, 7, 2, 3) == 640
+    assert _lib.query("cova_conv_out_size", 640, 3, 2, 1) == 320
+    assert _lib.query("cova_conv3x3_num_tiles", 16, 320, 320) == 16 * 40 * 10
+
+
+def test_header_has_no_torch_types():
+    src = open(_lib.HEADER).read()
+    assert "torch" not in src.replace("torch.cuda.current_stream", "").replace("torch /", "").lower() \
+        or "at::" not in src
+    assert "at::Tensor" not in src and "#include <torch" not in src
+
+
+def test_module_state_dict_contract():
+    m = CoVA((3, 3), 1280, 4, True, 384, 32, 0, 0.2, None)
+    spec = weights.state_dict_spec()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _ in spec]
+    for k, shape in spec:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in m.parameters()) == 1616485
+    assert abs(m.roi_pool.spatial_scale - 0.25) < 1e-12
+    m.load_state_dict(weights.seeded_state_dict(3))
+    m2 = CoVA((3, 3), 1280, 4, True, 384, 32, 7, 0.2, None)      # CoVA++ branch
+    assert "bn_additional_feat.weight" in m2.state_dict() and m2.n_feat == 615
+
+
+def test_no_cpu_fallback():
+    m = CoVA((3, 3), 64, 4)
+    b = synthetic.make_batch(1, img_h=64, boxes_per_page=5, seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(b["images"], b["bboxes"], b["additional_feats"], b["context_indices"])
+    layer = GraphAttentionLayer(8, 4)
+    with pytest.raises(RuntimeError):
+        layer(torch.zeros(3, 8), torch.zeros(3, 2, dtype=torch.long))
+
+
+def test_synthetic_batch_contract():
+    b = synthetic.make_batch(3, img_h=32, boxes_per_page=[11, 40, 25], context_size=12, seed=5)
+    assert b["images"].shape == (3, 3, 32, 32) and b["bboxes"].shape == (76, 5)
+    assert b["context_indices"].shape == (76, 24) and b["context_indices"].dtype == torch.int64
+    ctx, idx = b["context_indices"].numpy(), b["bboxes"][:, 0].numpy()
+    for i in range(76):
+        nb = ctx[i][ctx[i] >= 0]
+        assert (idx[nb] == idx[i]).all()                 # neighbours never cross pages
+        assert i not in nb
+    for p in range(3):
+        lab = b["labels"][idx == p].numpy()
+        assert sorted(lab[lab > 0].tolist()) == [1, 2, 3]
+    b2 = synthetic.make_batch(3, img_h=32, boxes_per_page=[11, 40, 25], context_size=12, seed=5)
+    assert all(torch.equal(b[k], b2[k]) for k in b if torch.is_tensor(b[k]))

@@ -70,11 +70,11 @@ class _CoVAFn(torch.autograd.Function):
     """Whole forward pass as one autograd node: backward runs engine.model_bwd."""
 
     @staticmethod
-    def forward(ctx, model, images, bboxes, additional_feats, context_indices, *param_values):
+    def forward(ctx, model, need_grad, images, bboxes, additional_feats, context_indices,
+                *param_values):
         keys = model._param_keys
         params = dict(zip(keys, [p.detach() for p in param_values]))
         _, buffers = _named_tensors(model)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in param_values)
         seeds = model._next_dropout_seeds()
         logits, sv = engine.model_fwd(model._cfg, params, buffers, _f32c(images), _f32c(bboxes),
                                       _f32c(additional_feats), context_indices.contiguous(),
@@ -86,16 +86,15 @@ class _CoVAFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         grads = engine.model_bwd(ctx.sv, dlogits.contiguous(), ctx.params)
         ctx.sv = None
-        return (None, None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
+        return (None, None, None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
 
 class _VisualFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, images, bboxes, *param_values):
+    def forward(ctx, model, need_grad, images, bboxes, *param_values):
         keys = model._conv_keys
         params = dict(zip(keys, [p.detach() for p in param_values]))
         _, buffers = _named_tensors(model)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in param_values)
         images, bboxes = _f32c(images), _f32c(bboxes)
         feat, sv = engine.convstack_fwd(images, params, buffers, model.training, need_grad)
         out = torch.empty((bboxes.shape[0], model.n_visual_feat), device=images.device)
@@ -108,7 +107,7 @@ class _VisualFn(torch.autograd.Function):
     def backward(ctx, gout):
         gfeat = engine.roipool_bwd(ctx.rsv, gout.contiguous(), ctx.nv)
         grads = engine.convstack_bwd(ctx.sv, gfeat)
-        return (None, None, None) + tuple(grads.get(k) for k in ctx.keys)
+        return (None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
 
 class _BBoxFn(torch.autograd.Function):
@@ -289,12 +288,16 @@ class CoVA(nn.Module):
         if self.use_context and context_indices.shape[1] > 64:
             raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
         values = [p for _, p in self.named_parameters()]
-        return _CoVAFn.apply(self, images, bboxes, additional_feats, context_indices, *values)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
+        return _CoVAFn.apply(self, need_grad, images, bboxes, additional_feats, context_indices,
+                             *values)
 
     def _get_visual_features(self, images, bboxes):
         _require_cuda(images, bboxes)
         named = dict(self.named_parameters())
-        return _VisualFn.apply(self, images, bboxes, *[named[k] for k in self._conv_keys])
+        values = [named[k] for k in self._conv_keys]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
+        return _VisualFn.apply(self, need_grad, images, bboxes, *values)
 
     def _get_bbox_features(self, bboxes):
         """[x,y,w,h,asp_ratio] -> Linear -> BN -> ReLU (models.py:129-148)."""

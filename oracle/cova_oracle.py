@@ -57,7 +57,7 @@ def _fp(t):
 # --------------------------------------------------------------------------- RoIPool
 class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, rois, ph, pw, scale):
+    def forward(ctx, feat, rois, ph, pw, scale, forced_argmax=None):
         feat = feat.contiguous().float()
         rois = rois.contiguous().float()
         B, C, H, W = feat.shape
@@ -66,6 +66,8 @@ class _RoIPoolFn(torch.autograd.Function):
         arg = torch.empty((n, C, ph, pw), dtype=torch.int32)
         _lib().oracle_roipool_fwd(_fp(feat), _fp(rois), n, C, H, W, ph, pw,
                                   ctypes.c_float(scale), _fp(out), _fp(arg))
+        if forced_argmax is not None:      # route the gradient like the implementation under test
+            arg = forced_argmax.to(torch.int32).reshape(n, C, ph, pw).contiguous()
         ctx.save_for_backward(rois, arg)
         ctx.shape = (B, C, H, W, ph, pw)
         return out
@@ -78,13 +80,45 @@ class _RoIPoolFn(torch.autograd.Function):
         gin = torch.empty((B, C, H, W), dtype=torch.float32)
         _lib().oracle_roipool_bwd(_fp(grad_out), _fp(rois), _fp(arg), rois.shape[0], B, C, H, W,
                                   ph, pw, _fp(gin))
-        return gin, None, None, None, None
+        return gin, None, None, None, None, None
 
 
-def roi_pool(feat, rois, output_size, spatial_scale):
-    """feat [B,C,H,W], rois [N,5] -> [N,C,PH,PW]  (models.py:58,125)."""
+def roi_pool(feat, rois, output_size, spatial_scale, forced_argmax=None):
+    """feat [B,C,H,W], rois [N,5] -> [N,C,PH,PW]  (models.py:58,125).
+
+    ``forced_argmax`` ([N, C*PH*PW] flat h*W+w indices) overrides where backward routes the
+    gradient: fp32 implementations that sum in a different order legitimately disagree on
+    near-tied maxima, and gradient parity is only meaningful for identical routing."""
     return _RoIPoolFn.apply(feat, rois, int(output_size[0]), int(output_size[1]),
-                            float(spatial_scale))
+                            float(spatial_scale), forced_argmax)
+
+
+class _MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) (torchvision ResNet stem) with optionally forced argmax routing."""
+
+    @staticmethod
+    def forward(ctx, x, forced_idx=None):
+        out, idx = F.max_pool2d(x, kernel_size=3, stride=2, padding=1, return_indices=True)
+        ctx.save_for_backward(idx if forced_idx is None else forced_idx)
+        ctx.in_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.in_shape
+        gin = torch.zeros((B, C, H * W), dtype=g.dtype)
+        gin.scatter_add_(2, idx.reshape(B, C, -1), g.reshape(B, C, -1))
+        return gin.view(B, C, H, W), None
+
+
+def pool_window_pos_to_flat(idx_nhwc_u8, H1, W1):
+    """uint8 window positions (ky*3+kx, NHWC [B,H2,W2,C]) -> flat input indices NCHW [B,C,H2,W2]."""
+    pos = idx_nhwc_u8.permute(0, 3, 1, 2).long()
+    B, C, H2, W2 = pos.shape
+    oy = torch.arange(H2).view(1, 1, H2, 1)
+    ox = torch.arange(W2).view(1, 1, 1, W2)
+    return (2 * oy - 1 + pos // 3) * W1 + (2 * ox - 1 + pos % 3)
 
 
 def roi_pool_argmax(feat, rois, output_size, spatial_scale):
@@ -127,11 +161,11 @@ def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def convnet(images, sd, training):
+def convnet(images, sd, training, forced_pool_idx=None):
     """conv1 -> bn1 -> relu -> maxpool -> layer1 (models.py:49-51); [B,3,H,W] -> [B,64,H/4,W/4]."""
     x = F.conv2d(images, sd["convnet.0.weight"], None, stride=2, padding=3)
     x = F.relu(_bn(x, sd, "convnet.1.", training))
-    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = _MaxPool3x3s2Fn.apply(x, forced_pool_idx)
     for blk in (0, 1):
         p = "convnet.4.%d." % blk
         idt = x
@@ -178,7 +212,7 @@ def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False):
 
 
 def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training,
-            drop_masks=None, return_intermediates=False):
+            drop_masks=None, return_intermediates=False, routing=None):
     """CoVA.forward (models.py:94-122).  ``sd`` holds float32 CPU tensors keyed like the
     reference state_dict; BN buffers are updated in place when ``training``.
 
@@ -191,8 +225,10 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     img_h = images.shape[2]
     hf = feature_map_size(img_h)
     scale = hf / img_h                                      # models.py:56
-    feat = convnet(images, sd, training)
-    visual = roi_pool(feat, bboxes, roi, scale).reshape(bboxes.shape[0], -1)   # models.py:125
+    routing = routing or {}
+    feat = convnet(images, sd, training, routing.get("pool_idx"))
+    visual = roi_pool(feat, bboxes, roi, scale, routing.get("roi_argmax")).reshape(
+        bboxes.shape[0], -1)                                                   # models.py:125
     parts = [visual]
     if cfg.get("bbox_hidden_dim", 32) > 0:
         raw = bbox_features_raw(bboxes)
@@ -236,7 +272,7 @@ def param_keys(sd):
 
 
 def loss_and_grads(sd, images, bboxes, additional_feats, context_indices, labels, cfg,
-                   drop_masks=None):
+                   drop_masks=None, routing=None):
     """One train-mode forward + CE(sum) + backward (train.py:47-59).  Returns
     (loss, logits, grads{key: tensor}, sd_after) with BN running stats advanced in sd_after."""
     work = clone_state_dict(sd)
@@ -245,7 +281,7 @@ def loss_and_grads(sd, images, bboxes, additional_feats, context_indices, labels
         work[k] = work[k].clone().requires_grad_(True)
         leaves[k] = work[k]
     logits, inter = forward(work, images, bboxes, additional_feats, context_indices, cfg, True,
-                            drop_masks, return_intermediates=True)
+                            drop_masks, return_intermediates=True, routing=routing)
     loss = F.cross_entropy(logits, labels, reduction="sum")
     loss.backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)).detach().clone())

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 from cova_web_object_detection_amd import engine, synthetic, weights  # noqa: E402
 from cova_web_object_detection_amd.models import CoVA, GraphAttentionLayer  # noqa: E402
-from helpers import FULL_CASES, GOLDEN, check_grads, load_case, margins_ok  # noqa: E402
+from helpers import (FULL_CASES, GOLDEN, assert_routing_near_ties, check_grads, compare_grads,  # noqa: E402
+                     load_case, margins_ok, routing_from_saved)
 from oracle import cova_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
@@ -95,17 +96,32 @@ def test_full_model_matches_reference_fixture(name):
     m = build(cfg, img_h, sd)
     m.train()
     logits = m(*args)
+    routing = routing_from_saved(logits.grad_fn.sv)      # the HIP forward's max-pool / RoIPool routing
     loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
     loss.backward()
     assert relerr(logits.detach().cpu(), fx["train/logits"]) < 2e-4
     assert abs(loss.item() - float(fx["train/loss"])) <= 2e-4 * abs(float(fx["train/loss"]))
     grads = {k: p.grad for k, p in m.named_parameters()}
-    check_grads(fx, grads, rtol=2e-3)
-    for k, b in m.named_buffers():
+    # (1) heads do not depend on the routing: compare with the reference's gradients directly;
+    #     conv-stack gradients get a loose bound here (a single near-tie flip moves them by ~1e-3)
+    head = {k: v for k, v in fx.items() if not (k.startswith(("grad", "gradnorm", "gradsample"))
+                                                  and "/convnet." in k)}
+    check_grads(head, grads, rtol=2e-3)
+    conv_only = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample"))
+                 and "/convnet." in k}
+    check_grads(conv_only, grads, rtol=5e-2)
+    # (2) tight check of everything against the oracle forced to the same routing; the oracle
+    #     itself is pinned to the reference's gradients by tests/test_oracle_cpu.py
+    b = batch
+    _, _, grads_ref, after, inter = O.loss_and_grads(sd, b["images"], b["bboxes"], b["additional_feats"],
+                                                     b["context_indices"], b["labels"], cfg, None, routing)
+    compare_grads(grads, grads_ref, rtol=5e-4)
+    assert_routing_near_ties(routing, inter, b["bboxes"], (3, 3), m.roi_pool.spatial_scale)
+    for k, buf in m.named_buffers():
         if "buf/" + k in fx:
-            assert relerr(b.cpu(), fx["buf/" + k]) < 1e-4, k
+            assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k
         if k.endswith("num_batches_tracked"):
-            assert int(b) == 1
+            assert int(buf) == 1
 
 
 def test_fused_loss_and_engine_step_match_oracle():
@@ -119,22 +135,21 @@ def test_fused_loss_and_engine_step_match_oracle():
     N, T = 47, 576 + 32 + 96
     rs = np.random.RandomState(3)
     masks = [torch.from_numpy((rs.uniform(size=(N, T)) > 0.2).astype(np.uint8)) for _ in range(2)]
-    loss_ref, logits_ref, grads_ref, after, _ = O.loss_and_grads(
-        sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
-        batch["labels"], cfg, [m.float() for m in masks])
     params = {k: v.to(DEV) for k, v in sd.items() if k in O.param_keys(sd)}
     buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
     images, bboxes, addl, ctx = dev_batch(batch)
     logits, sv = engine.model_fwd(cfg, params, buffers, images, bboxes, addl, ctx, True,
                                   masks=[m.to(DEV) for m in masks])
     loss, dl, pred = engine.ce_sum(logits, batch["labels"].to(DEV))
+    routing = routing_from_saved(sv)
     grads = engine.model_bwd(sv, dl, params)
+    loss_ref, logits_ref, grads_ref, after, inter = O.loss_and_grads(
+        sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
+        batch["labels"], cfg, [m.float() for m in masks], routing)
+    assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
     assert relerr(logits.cpu(), logits_ref) < 2e-4
     assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
-    gscale = max(float(g.abs().max()) for g in grads_ref.values())
-    for k, g in grads_ref.items():
-        scale = max(float(g.abs().max()), 0.01 * gscale)
-        assert float((grads[k].cpu().view_as(g) - g).abs().max()) / scale < 2e-3, k
+    compare_grads(grads, grads_ref, rtol=5e-4)
     for k in buffers:
         if not k.endswith("num_batches_tracked"):
             assert relerr(buffers[k].cpu(), after[k]) < 1e-4, k

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Benchmark of the CoVA hot path on MI355X: webpages/s of one full training step
+(forward + CrossEntropy(sum) + backward + gradient all-reduce + Adam; train.py:42-60).
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic
+1280x1280 screenshots, 16 pages per GPU, 90 boxes per page, K = 24 DOM-window neighbours,
+ResNet-18 stem+layer1 representation network + 1-head GAT, Dropout p = 0.2, fp32.
+Inputs are device resident before the timed region.  N > 1: one process per GPU (launched by
+torch.distributed.run), every rank trains on its own 16 pages (weak scaling) and the flat
+6.5 MB gradient bucket is all-reduced over RCCL once per step.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     -- the dominant kernel (conv3x3 64->64 implicit GEMM on f32 MFMA): algorithmic
+                  FLOPs per launch / mean launch time measured with HIP events on the launching
+                  stream inside the timed steps, against the 157.3 TFLOP/s f32-MFMA peak.
+  cpu_baseline -- the CPU oracle (oracle/cova_oracle.py, a restatement of the reference's
+                  torch-CPU path) timed on this host on a bounded sample (2 pages per step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import cova_amd  # noqa: E402,F401
+from cova_web_object_detection_amd import _lib, synthetic, weights  # noqa: E402
+from cova_web_object_detection_amd.trainer import HotPathTrainer  # noqa: E402
+
+CFG = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
+           bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.2)
+IMG, PAGES_PER_GPU, BOXES, CS = 1280, 16, 90, 12
+PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-input MFMA
+CONV3_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
+
+
+def make_device_batch(seed, device, pages=PAGES_PER_GPU, img=IMG):
+    """Boxes / neighbour tables from the numpy generator; pixels drawn on the device (uniform
+    [0,1) like datasets.py:41-45's ToTensor output) to keep start-up short."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    images = torch.rand((pages, 3, img, img), generator=g, device=device, dtype=torch.float32)
+    boxes = synthetic.make_boxes_only(pages, img, img, BOXES, CS, seed)
+    out = {k: v.to(device) for k, v in boxes.items() if torch.is_tensor(v)}
+    out["images"] = images
+    return out
+
+
+def cpu_baseline(steps=2):
+    """Oracle train step (forward, CE-sum, backward, Adam) on the host cores, 2 pages per step."""
+    from oracle import cova_oracle as O
+    pages = 2
+    cfg = dict(CFG, drop_prob=0.0)      # oracle takes explicit masks; p=0 costs the same FLOPs
+    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(123, **wcfg)
+    boxes = synthetic.make_boxes_only(pages, IMG, IMG, BOXES, CS, 123)
+    images = torch.rand((pages, 3, IMG, IMG), generator=torch.Generator().manual_seed(123))
+    keys = O.param_keys(sd)
+    state = None
+
+    def one():
+        nonlocal sd, state
+        _, _, grads, after, _ = O.loss_and_grads(sd, images, boxes["bboxes"], boxes["additional_feats"],
+                                                 boxes["context_indices"], boxes["labels"], cfg, None)
+        new_p, state = O.adam_reference([sd[k] for k in keys], [grads[k] for k in keys], state)
+        for k, p in zip(keys, new_p):
+            after[k] = p
+        sd = after
+
+    one()                                # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(pages / dt, 4), "unit": "webpages/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d steps x %d pages of the same workload (1280x1280, 90 boxes, K=24), "
+                      "torch-CPU fp32 oracle incl. Adam, %.2f s/step" % (steps, pages, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(123, **wcfg)
+    trainer = HotPathTrainer(CFG, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank)
+    batch = make_device_batch(123 + rank, device, args.pages)
+    n_boxes = batch["bboxes"].shape[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    barrier()
+    _lib.PROFILE = {"cova_conv3x3_fwd": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.train_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.PROFILE["cova_conv3x3_fwd"]
+    _lib.PROFILE = None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = world * args.pages * args.steps / dt
+        conv_ms = sum(a.elapsed_time(b) for a, b in prof) / max(len(prof), 1)
+        flops = CONV3_FLOP_PER_PIXEL * args.pages * (IMG // 4) * (IMG // 4)
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        out = {
+            "metric": "webpages/sec fwd+bwd (90 bboxes, K=24)", "value": round(value, 3),
+            "unit": "webpages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 1280x1280 screenshots, %d pages/GPU, "
+                                   "%d boxes/page, K=%d, ResNet-18 stem+layer1 RN + 1-head GAT, "
+                                   "train step = fwd+CE+bwd+allreduce+Adam, dropout 0.2"
+                                   % (args.pages, BOXES, 2 * CS),
+                       "pages_per_gpu": args.pages, "global_pages": world * args.pages,
+                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world, "loss": round(loss_val, 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_kernel (fwd + dgrad launches)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
+                         "flop_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

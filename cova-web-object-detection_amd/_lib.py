@@ -76,12 +76,24 @@ def _arg(a):
     return a
 
 
+# Optional per-entry-point timing with HIP events on the launching stream (bench.py's roofline
+# leg): PROFILE = {entry point name: [(start_event, end_event), ...]}
+PROFILE = None
+
+
 def call(name, *args, stream=None):
     """Call a stream-taking entry point with tensors/None/scalars; raises on a non-zero status."""
     L = lib()
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
+    prof = PROFILE.get(name) if PROFILE is not None else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = L.fn[name](*[_arg(a) for a in args], stream)
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1))
     if rc != 0:
         raise CovaHipError("%s failed with status %d" % (name, rc))
 

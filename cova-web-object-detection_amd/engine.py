@@ -19,6 +19,15 @@ def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def _gbuf(gout, key, shape, like):
+    """Gradient destination: the caller's view (flat all-reduce bucket) or a fresh tensor."""
+    if gout is not None and key in gout:
+        g = gout[key]
+        assert g.numel() == int(torch.Size(shape).numel()) and g.is_contiguous(), key
+        return g
+    return _empty(shape, like)
+
+
 def _check(t, dtype=torch.float32):
     assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return t
@@ -60,13 +69,16 @@ def colstats(x, ld, R, C):
     return part, n
 
 
-def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=0):
+def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=0, gout=None,
+                prefix=None):
     """Returns (dgamma, dbeta); writes dz (and dres = relu-masked dout)."""
     C = st.C
     n = query("cova_colreduce_num_chunks", R, C)
     part = _empty((n, 2, C), z)
     call("cova_bn_bwd_reduce", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, R, C, part)
-    dgamma, dbeta, coef = _empty((C,), z), _empty((C,), z), _empty((2, C), z)
+    dgamma = _gbuf(gout, (prefix or "") + "weight", (C,), z)
+    dbeta = _gbuf(gout, (prefix or "") + "bias", (C,), z)
+    coef = _empty((2, C), z)
     call("cova_bn_finalize_bwd", part, n, C, float(R), dgamma, dbeta, coef)
     call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
          lddz, dres, lddres, R, C)
@@ -127,7 +139,7 @@ def convstack_fwd(images, params, buffers, training, save=True):
     return x, (sv if save else None)
 
 
-def convstack_bwd(sv, dfeat):
+def convstack_bwd(sv, dfeat, gout=None):
     """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
@@ -139,18 +151,20 @@ def convstack_bwd(sv, dfeat):
         ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
         # out = relu(bn2(z2) + x)
         dz2, dres = torch.empty_like(dA), torch.empty_like(dA)
-        dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres, C64)
+        dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres, C64,
+                             gout, BN3_KEYS[2 * blk + 1])
         grads[BN3_KEYS[2 * blk + 1] + "weight"], grads[BN3_KEYS[2 * blk + 1] + "bias"] = dg, db
-        dw = _empty((64, 64, 3, 3), dfeat)
+        dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
         call("cova_conv3x3_wgrad", s["a1"], dz2, dw, ws3, B, H2, W2)
         grads[kb + ".weight"] = dw
         da1 = torch.empty_like(dA)
         call("cova_conv3x3_fwd", dz2, sv["wd"][2 * blk + 1], None, da1, None, B, H2, W2)
         # a1 = relu(bn1(z1))
         dz1 = dz2   # reuse
-        dg, db = bn_backward(da1, C64, s["a1"], C64, s["z1"], C64, s["bna"], R, dz1, C64)
+        dg, db = bn_backward(da1, C64, s["a1"], C64, s["z1"], C64, s["bna"], R, dz1, C64, None, 0,
+                             gout, BN3_KEYS[2 * blk])
         grads[BN3_KEYS[2 * blk] + "weight"], grads[BN3_KEYS[2 * blk] + "bias"] = dg, db
-        dw = _empty((64, 64, 3, 3), dfeat)
+        dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
         call("cova_conv3x3_wgrad", s["x"], dz1, dw, ws3, B, H2, W2)
         grads[ka + ".weight"] = dw
         dx = da1    # reuse
@@ -162,14 +176,16 @@ def convstack_bwd(sv, dfeat):
     part = _empty((npart, 2, C64), dfeat)
     call("cova_bn_relu_maxpool_bwd_reduce", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
          bn1.invstd, part, B, H1, W1)
-    dg, db, coef = _empty((C64,), dfeat), _empty((C64,), dfeat), _empty((2, C64), dfeat)
+    dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
+    db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
+    coef = _empty((2, C64), dfeat)
     call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
     grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
     dy1 = torch.empty_like(sv["y1"])
     call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
          bn1.invstd, coef, dy1, B, H1, W1)
     ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
-    dw1 = _empty((64, 3, 7, 7), dfeat)
+    dw1 = _gbuf(gout, "convnet.0.weight", (64, 3, 7, 7), dfeat)
     call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
     grads["convnet.0.weight"] = dw1
     return grads
@@ -216,11 +232,13 @@ def bbox_fwd(bboxes, params, buffers, training, out, ldo):
     return dict(raw=raw, z=z, st=st, N=N, Hd=Hd, out=out, ldo=ldo)
 
 
-def bbox_bwd(sv, gout, ldg):
+def bbox_bwd(sv, g, ldg, gout=None):
     N, Hd = sv["N"], sv["Hd"]
-    dz = _empty((N, Hd), gout)
-    dg, db = bn_backward(gout, ldg, sv["out"], sv["ldo"], sv["z"], Hd, sv["st"], N, dz, Hd)
-    dW, dbias = _empty((Hd, 5), gout), _empty((Hd,), gout)
+    dz = _empty((N, Hd), g)
+    dg, db = bn_backward(g, ldg, sv["out"], sv["ldo"], sv["z"], Hd, sv["st"], N, dz, Hd, None, 0,
+                         gout, "bbox_feat_encoder.1.")
+    dW = _gbuf(gout, "bbox_feat_encoder.0.weight", (Hd, 5), g)
+    dbias = _gbuf(gout, "bbox_feat_encoder.0.bias", (Hd,), g)
     call("cova_bbox_linear_bwd", dz, sv["raw"], dW, dbias, N, Hd)
     return {"bbox_feat_encoder.0.weight": dW, "bbox_feat_encoder.0.bias": dbias,
             "bbox_feat_encoder.1.weight": dg, "bbox_feat_encoder.1.bias": db}
@@ -241,17 +259,19 @@ def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
     return dict(h=h, ldh=ldh, N=N, F=F, D=D, K=K, ctx=ctx, Wh=Wh, s=s, t=t, attn=attn, prefix=prefix)
 
 
-def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh):
+def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None):
     """g = dL/dh' (rows at g + n*ldg).  Writes / accumulates dL/dh into dh; returns param grads."""
     N, F, D, K, prefix = sv["N"], sv["F"], sv["D"], sv["K"], sv["prefix"]
     Wi, Wj = params[prefix + "W_i.weight"], params[prefix + "W_j.weight"]
     aw = params[prefix + "attention_layer.weight"]
     dWh = _empty((N, 2 * D), g)
     ds, dt = _empty((N,), g), _empty((N,), g)
-    daw, dab = _empty((1, 2 * D), g), _empty((1,), g)
+    daw = _gbuf(gout, prefix + "attention_layer.weight", (1, 2 * D), g)
+    dab = _gbuf(gout, prefix + "attention_layer.bias", (1,), g)
     call("cova_gat_bwd", g, ldg, sv["Wh"], 2 * D, sv["s"], sv["t"], sv["attn"], sv["ctx"], aw, N, K, D,
          LEAKY_SLOPE, dWh, 2 * D, ds, dt, daw, dab)
-    dWi, dWj = _empty((D, F), g), _empty((D, F), g)
+    dWi = _gbuf(gout, prefix + "W_i.weight", (D, F), g)
+    dWj = _gbuf(gout, prefix + "W_j.weight", (D, F), g)
     call("cova_sgemm", 1, 0, D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
     call("cova_sgemm", 1, 0, D, F, N, dWh[:, D:], 2 * D, sv["h"], sv["ldh"], dWj, F, None, 0)
     call("cova_sgemm", 0, 0, N, F, D, dWh, 2 * D, Wi, F, dh, lddh, None, 1 if accumulate_dh else 0)
@@ -292,12 +312,13 @@ def decoder_fwd(x, N, T, params, buffers, training, p, seeds=(0, 0), masks=None)
     return logits, sv
 
 
-def decoder_bwd(sv, dlogits, params):
+def decoder_bwd(sv, dlogits, params, gout=None):
     """-> (dL/dx [N,T], param grads)."""
     N, T, NC, p = sv["N"], sv["T"], sv["NC"], sv["p"]
     _check(dlogits)
     dyd = _empty((N, T), dlogits)
-    dW2, db2 = _empty((NC, T), dlogits), _empty((NC,), dlogits)
+    dW2 = _gbuf(gout, "decoder.5.weight", (NC, T), dlogits)
+    db2 = _gbuf(gout, "decoder.5.bias", (NC,), dlogits)
     call("cova_linear_small_bwd", dlogits, sv["yd"], T, params["decoder.5.weight"], dyd, T, dW2, db2,
          N, T, NC)
     if sv["drop"]:
@@ -306,10 +327,11 @@ def decoder_bwd(sv, dlogits, params):
     else:
         dy = dyd
     dz = _empty((N, T), dlogits)
-    dg, db = bn_backward(dy, T, sv["y"], T, sv["z"], T, sv["st"], N, dz, T)
-    db1 = _empty((T,), dlogits)
+    dg, db = bn_backward(dy, T, sv["y"], T, sv["z"], T, sv["st"], N, dz, T, None, 0, gout,
+                         "decoder.2.")
+    db1 = _gbuf(gout, "decoder.1.bias", (T,), dlogits)
     call("cova_colsum", dz, T, N, T, db1)
-    dW1 = _empty((T, T), dlogits)
+    dW1 = _gbuf(gout, "decoder.1.weight", (T, T), dlogits)
     call("cova_sgemm", 1, 0, T, T, N, dz, T, sv["xd"], T, dW1, T, None, 0)
     dxd = dy    # reuse
     call("cova_sgemm", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dxd, T, None, 0)
@@ -353,21 +375,23 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     return logits, (sv if save else None)
 
 
-def model_bwd(sv, dlogits, params):
-    """-> {state_dict key: gradient} for every trainable parameter."""
+def model_bwd(sv, dlogits, params, gout=None):
+    """-> {state_dict key: gradient} for every trainable parameter.  ``gout`` (optional) maps
+    keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket."""
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
-    dcomb, grads = decoder_bwd(sv["dec"], dlogits, params)
+    dcomb, grads = decoder_bwd(sv["dec"], dlogits, params, gout)
     if D > 0:
-        grads.update(gat_bwd(sv["gat"], dcomb[:, F:], T, params, dcomb, T, True))
+        grads.update(gat_bwd(sv["gat"], dcomb[:, F:], T, params, dcomb, T, True, gout))
     if A > 0:
         st = sv["addl"]
         dz = _empty((N, A), dcomb)
-        dg, db = bn_backward(dcomb[:, n_vis + Hd:], T, None, 0, sv["addl_in"], A, st, N, dz, A)
+        dg, db = bn_backward(dcomb[:, n_vis + Hd:], T, None, 0, sv["addl_in"], A, st, N, dz, A, None, 0,
+                             gout, "bn_additional_feat.")
         grads["bn_additional_feat.weight"], grads["bn_additional_feat.bias"] = dg, db
     if Hd > 0:
-        grads.update(bbox_bwd(sv["bbox"], dcomb[:, n_vis:], T))
+        grads.update(bbox_bwd(sv["bbox"], dcomb[:, n_vis:], T, gout))
     dfeat = roipool_bwd(sv["roi"], dcomb, T)
-    grads.update(convstack_bwd(sv["conv"], dfeat))
+    grads.update(convstack_bwd(sv["conv"], dfeat, gout))
     return grads
 
 

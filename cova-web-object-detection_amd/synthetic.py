@@ -39,20 +39,8 @@ def collate_context(per_page_ctx):
     return np.concatenate(outs, axis=0)
 
 
-def make_batch(n_pages, img_h=1280, img_w=None, boxes_per_page=90, context_size=12,
-               n_additional_feat=0, n_classes=4, seed=123, border_fraction=0.05,
-               device=None):
-    """Seeded synthetic batch (SURVEY.md section 8d).
-
-    ``boxes_per_page`` may be an int or a per-page sequence (ragged batches, 11..230 per
-    splits/bbox_stats.txt).  About ``border_fraction`` of the boxes cross the right/bottom
-    image border so that RoIPool clamping is exercised.
-    """
-    img_w = img_h if img_w is None else img_w
-    rs = np.random.RandomState(seed)
-    counts = [boxes_per_page] * n_pages if np.isscalar(boxes_per_page) else list(boxes_per_page)
-    assert len(counts) == n_pages
-    images = rs.random_sample((n_pages, 3, img_h, img_w)).astype(np.float32)
+def _draw_boxes(rs, counts, img_h, img_w, context_size, n_additional_feat, n_classes,
+                border_fraction):
     boxes, ctxs, labels = [], [], []
     for p, n in enumerate(counts):
         bw = rs.uniform(8, min(400, img_w), n)
@@ -71,14 +59,45 @@ def make_batch(n_pages, img_h=1280, img_w=None, boxes_per_page=90, context_size=
         labels.append(lab)
     n_total = sum(counts)
     addl = rs.standard_normal((n_total, n_additional_feat)).astype(np.float32)
-    batch = dict(
-        img_ids=np.arange(n_pages).astype(str),
-        images=torch.from_numpy(images),
+    return dict(
         bboxes=torch.from_numpy(np.concatenate(boxes, 0)),
         additional_feats=torch.from_numpy(addl),
         context_indices=torch.from_numpy(collate_context(ctxs)),
         labels=torch.from_numpy(np.concatenate(labels, 0)),
     )
+
+
+def _counts(n_pages, boxes_per_page):
+    counts = [boxes_per_page] * n_pages if np.isscalar(boxes_per_page) else list(boxes_per_page)
+    assert len(counts) == n_pages
+    return counts
+
+
+def make_boxes_only(n_pages, img_h, img_w, boxes_per_page=90, context_size=12, seed=123,
+                    n_additional_feat=0, n_classes=4, border_fraction=0.05):
+    """Everything of a batch except the pixels (bench.py draws those on the device)."""
+    rs = np.random.RandomState(seed)
+    return _draw_boxes(rs, _counts(n_pages, boxes_per_page), img_h, img_w, context_size,
+                       n_additional_feat, n_classes, border_fraction)
+
+
+def make_batch(n_pages, img_h=1280, img_w=None, boxes_per_page=90, context_size=12,
+               n_additional_feat=0, n_classes=4, seed=123, border_fraction=0.05,
+               device=None):
+    """Seeded synthetic batch (SURVEY.md section 8d).
+
+    ``boxes_per_page`` may be an int or a per-page sequence (ragged batches, 11..230 per
+    splits/bbox_stats.txt).  About ``border_fraction`` of the boxes cross the right/bottom
+    image border so that RoIPool clamping is exercised.
+    """
+    img_w = img_h if img_w is None else img_w
+    rs = np.random.RandomState(seed)
+    counts = _counts(n_pages, boxes_per_page)
+    images = rs.random_sample((n_pages, 3, img_h, img_w)).astype(np.float32)
+    batch = _draw_boxes(rs, counts, img_h, img_w, context_size, n_additional_feat, n_classes,
+                        border_fraction)
+    batch["img_ids"] = np.arange(n_pages).astype(str)
+    batch["images"] = torch.from_numpy(images)
     if device is not None:
         for k, v in batch.items():
             if torch.is_tensor(v):

@@ -1,0 +1,135 @@
+"""Training step of the hot path (train.py:42-60) as one object: forward, CE-sum, backward,
+data-parallel gradient exchange, Adam -- all device work through libcova_hip.so, the gradient
+exchange through torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
+
+Data parallelism: pages are independent units, so each rank takes whole
+pages; the model (1.6 M parameters) is replicated.  Every parameter lives in ONE flat fp32 buffer
+and every gradient in ONE flat bucket, so a step needs exactly one all-reduce (6.47 MB, latency
+bound on xGMI) and one Adam launch.  The loss is a SUM over boxes (main.py:139), so SUM-reduced
+gradients equal the single-device large-batch gradient except for BatchNorm, whose batch
+statistics stay per-rank (standard DDP behaviour; the reference has no SyncBN).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import engine
+from .weights import state_dict_spec
+
+_BUF_SUFFIX = ("running_mean", "running_var", "num_batches_tracked")
+
+
+def is_param_key(k):
+    return not k.endswith(_BUF_SUFFIX)
+
+
+class FlatBucket:
+    """One contiguous fp32 buffer with a named view per tensor (device agnostic)."""
+
+    def __init__(self, shapes, device):
+        self.offsets, n = OrderedDict(), 0
+        for k, shape in shapes.items():
+            numel = int(torch.Size(shape).numel())
+            self.offsets[k] = (n, numel, tuple(shape))
+            n += (numel + 3) // 4 * 4           # keep every view 16-byte aligned
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views = OrderedDict((k, self.flat[o:o + m].view(shape))
+                                 for k, (o, m, shape) in self.offsets.items())
+
+    def all_reduce_sum(self, group=None):
+        """One collective for the whole bucket."""
+        import torch.distributed as dist
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def shard_pages(n_pages, rank, world_size):
+    """Contiguous page range [lo, hi) of this rank (whole pages only)."""
+    base, rem = divmod(n_pages, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(batch, rank, world_size):
+    """Cut a collated batch (datasets.py:183-190 layout) into this rank's pages: boxes keep their
+    order, page indices and context indices are re-based to the shard."""
+    n_pages = batch["images"].shape[0]
+    lo, hi = shard_pages(n_pages, rank, world_size)
+    page = batch["bboxes"][:, 0]
+    sel = (page >= lo) & (page < hi)
+    first = int(torch.nonzero(sel)[0]) if bool(sel.any()) else 0
+    bb = batch["bboxes"][sel].clone()
+    bb[:, 0] -= lo
+    ctx = batch["context_indices"][sel].clone()
+    ctx[ctx >= 0] -= first
+    return dict(images=batch["images"][lo:hi].contiguous(), bboxes=bb,
+                additional_feats=batch["additional_feats"][sel].contiguous(),
+                context_indices=ctx, labels=batch["labels"][sel].contiguous())
+
+
+class HotPathTrainer:
+    """Owns flat parameters / gradients / Adam moments on one GPU and runs training steps."""
+
+    def __init__(self, cfg, state_dict, device, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.999),
+                 eps=1e-8, world_size=1, process_group=None, dropout_seed=123):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        spec = state_dict_spec(**{k: cfg[k] for k in ("roi_output_size", "n_classes", "use_context",
+                                                     "hidden_dim", "bbox_hidden_dim",
+                                                     "n_additional_feat")})
+        pshapes = OrderedDict((k, s) for k, s in spec if is_param_key(k))
+        self.pbucket = FlatBucket(pshapes, self.device)
+        self.gbucket = FlatBucket(pshapes, self.device)
+        self.params, self.grads = self.pbucket.views, self.gbucket.views
+        self.exp_avg = torch.zeros_like(self.pbucket.flat)
+        self.exp_avg_sq = torch.zeros_like(self.pbucket.flat)
+        self.buffers = {}
+        for k, _ in spec:
+            v = state_dict[k]
+            if is_param_key(k):
+                self.params[k].copy_(v)
+            else:
+                self.buffers[k] = v.clone().to(self.device)
+        self.hp = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        self.world_size, self.group = world_size, process_group
+        self.step_count, self.dropout_seed = 0, int(dropout_seed)
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for k in list(self.params) + list(self.buffers):
+            sd[k] = (self.params[k] if k in self.params else self.buffers[k]).detach().clone()
+        return sd
+
+    def forward_backward(self, batch, masks=None):
+        """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
+        self.step_count += 1
+        base = (self.dropout_seed * 0x9E3779B1 + 2 * self.step_count) & 0xFFFFFFFFFFFF
+        logits, sv = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],
+                                      batch["bboxes"], batch["additional_feats"],
+                                      batch["context_indices"], True, (base, base + 1), masks)
+        loss, dl, pred = engine.ce_sum(logits, batch["labels"])
+        engine.model_bwd(sv, dl, self.params, self.grads)
+        return loss, pred
+
+    def optimizer_step(self):
+        if self.world_size > 1:
+            self.gbucket.all_reduce_sum(self.group)
+        b1, b2 = self.hp["betas"]
+        engine.call("cova_adam_step", self.pbucket.flat, self.gbucket.flat, self.exp_avg,
+                    self.exp_avg_sq, self.pbucket.flat.numel(), self.step_count, self.hp["lr"], b1, b2,
+                    self.hp["eps"], self.hp["weight_decay"])
+
+    def train_step(self, batch, masks=None):
+        """optimizer.zero_grad(); forward; loss; backward; optimizer.step()  (train.py:45-60).
+        Gradients are fully overwritten each step, so zero_grad is implicit."""
+        loss, pred = self.forward_backward(batch, masks)
+        self.optimizer_step()
+        return loss, pred
+
+    @torch.no_grad()
+    def predict(self, batch):
+        """Eval-mode forward (running statistics) -> (logits, per-box argmax)."""
+        logits, _ = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],
+                                     batch["bboxes"], batch["additional_feats"],
+                                     batch["context_indices"], False, save=False)
+        _, _, pred = engine.ce_sum(logits, None, want_grad=False)
+        return logits, pred

@@ -94,6 +94,30 @@ __device__ __forceinline__ void combine_partials(const float *__restrict__ parti
         }
 }
 
+// Fold groups of `group` consecutive partial rows ([nparts][width] fp32) into one row each
+// (fp64 accumulation inside a group): a cheap, deterministic first reduction stage so that the
+// single-block finalize kernels never walk more than a few hundred rows.
+__global__ __launch_bounds__(256) void partials_fold_kernel(const float *__restrict__ partial,
+                                                            int nparts, int width, int group,
+                                                            float *__restrict__ out)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= width) return;
+    const int p0 = blockIdx.y * group;
+    int p1 = p0 + group;
+    if (p1 > nparts) p1 = nparts;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+        a0 += (double)partial[(size_t)p * width + col];
+        a1 += (double)partial[(size_t)(p + 1) * width + col];
+        a2 += (double)partial[(size_t)(p + 2) * width + col];
+        a3 += (double)partial[(size_t)(p + 3) * width + col];
+    }
+    for (; p < p1; ++p) a0 += (double)partial[(size_t)p * width + col];
+    out[(size_t)blockIdx.y * width + col] = (float)((a0 + a1) + (a2 + a3));
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(
     const float *__restrict__ partial, int nparts, int C, double count,
     const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -395,7 +419,7 @@ inline bool vec4_ok(const void *p, int ld)
 COVA_API int cova_colreduce_rows_per_chunk(long long R, int C)
 {
     const int rpb = 256 / pow2_cols_host(C);
-    long long rows = cdivll(R, 2048);
+    long long rows = cdivll(R, 1024);
     if (rows < 64) rows = 64;
     rows = cdivll(rows, rpb) * rpb;
     return (int)rows;
@@ -404,6 +428,18 @@ COVA_API int cova_colreduce_rows_per_chunk(long long R, int C)
 COVA_API int cova_colreduce_num_chunks(long long R, int C)
 {
     return (int)cdivll(R, cova_colreduce_rows_per_chunk(R, C));
+}
+
+// out [cdiv(nparts, group)][width] = sums of `group` consecutive rows of partial [nparts][width]
+COVA_API int cova_partials_fold(const float *partial, int nparts, int width, int group, float *out,
+                                void *stream)
+{
+    COVA_REQUIRE(partial && out && nparts > 0 && width > 0 && group > 0);
+    const dim3 grid(cdiv(width, 256), cdiv(nparts, group));
+    hipLaunchKernelGGL(partials_fold_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, nparts,
+                       width, group, out);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }
 
 // partial [num_chunks][2][C]: column sums and sums of squares of x [R, C] (ld = ldx)

@@ -173,6 +173,151 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// conv3x3 v2: persistent blocks, software-pipelined.
+//   * one block per CU walks tiles t = blockIdx.x, +gridDim.x, ...; while tile t computes, the
+//     halo'd input of tile t+grid is already in flight into registers (11 float4 per thread) and
+//     is written to LDS after the last tap -- global latency and most of the staging time
+//     disappear behind the MFMAs;
+//   * next-tap weights are fetched at the top of a tap and written to the other LDS buffer at
+//     its end (buffer parity runs across tiles: 9 taps per tile is odd);
+//   * LDS->register operand fragments are double buffered: step s+1 is read before the eight
+//     MFMAs of step s issue.
+// ------------------------------------------------------------------------------------
+namespace c3 {
+constexpr int NPRE = (PH * PW * 16 + THREADS - 1) / THREADS;     // 11 float4 per thread
+constexpr int RED_FLOATS = 8 * 128;                               // stats scratch
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
+    const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
+    float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
+    int ntiles)
+{
+    using namespace c3;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + RED_FLOATS];
+    float *s_in = lds;
+    float *s_w = lds + IN_FLOATS;
+    float *s_red = lds + LDS_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int pco = tid >> 4, pc4 = tid & 15;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    float4 pre[NPRE];
+    auto issue_tile_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+        const float *in_b = in + (size_t)b * H * W * 64;
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / PW, c = px - r * PW;
+            const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < PH * PW * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+            pre[it] = v;
+        }
+    };
+    auto write_tile_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            if (idx < PH * PW * 16)
+                *reinterpret_cast<float4 *>(s_in + (idx >> 4) * PSTR + (idx & 15) * 4) = pre[it];
+        }
+    };
+
+    issue_tile_loads(tile);
+    {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wt + pco * 64 + pc4 * 4);
+        const float4 w1 = *reinterpret_cast<const float4 *>(wt + (pco + 32) * 64 + pc4 * 4);
+        *reinterpret_cast<float4 *>(s_w + pco * PSTR + pc4 * 4) = w0;
+        *reinterpret_cast<float4 *>(s_w + (pco + 32) * PSTR + pc4 * 4) = w1;
+    }
+    write_tile_lds();
+    __syncthreads();
+
+    int wbuf = 0;      // LDS buffer holding the current tap's weights
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_tile_loads(next);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+        const float *a_tile = s_in + (wave * PW + li) * PSTR + kh2 * 4;
+        float4 a_cur = *reinterpret_cast<const float4 *>(a_tile);      // tap 0, step 0
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // next tap's weights (tap 8: tap 0 of the next tile) -> registers, early
+            const int ntap = tap == 8 ? 0 : tap + 1;
+            const float *wsrc = wt + (size_t)ntap * 4096;
+            const float4 wn0 = *reinterpret_cast<const float4 *>(wsrc + pco * 64 + pc4 * 4);
+            const float4 wn1 = *reinterpret_cast<const float4 *>(wsrc + (pco + 32) * 64 + pc4 * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const float *a_base = a_tile + (kh * PW + kw) * PSTR;
+            const float *b_base = s_w + wbuf * W_FLOATS + li * PSTR + kh2 * 4;
+            float4 b0_cur = *reinterpret_cast<const float4 *>(b_base);
+            float4 b1_cur = *reinterpret_cast<const float4 *>(b_base + 32 * PSTR);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float4 a_nxt, b0_nxt, b1_nxt;
+                if (s < 7) {
+                    a_nxt = *reinterpret_cast<const float4 *>(a_base + (s + 1) * 8);
+                    b0_nxt = *reinterpret_cast<const float4 *>(b_base + (s + 1) * 8);
+                    b1_nxt = *reinterpret_cast<const float4 *>(b_base + 32 * PSTR + (s + 1) * 8);
+                } else {
+                    // first A fragment of the next tap (input tile: independent of the barrier)
+                    const int t2 = tap == 8 ? 0 : tap + 1;
+                    const int kh_n = t2 / 3, kw_n = t2 - kh_n * 3;
+                    a_nxt = *reinterpret_cast<const float4 *>(a_tile + (kh_n * PW + kw_n) * PSTR);
+                    b0_nxt = b0_cur;
+                    b1_nxt = b1_cur;
+                }
+                acc0 = mfma32(a_cur.x, b0_cur.x, acc0);
+                acc1 = mfma32(a_cur.x, b1_cur.x, acc1);
+                acc0 = mfma32(a_cur.y, b0_cur.y, acc0);
+                acc1 = mfma32(a_cur.y, b1_cur.y, acc1);
+                acc0 = mfma32(a_cur.z, b0_cur.z, acc0);
+                acc1 = mfma32(a_cur.z, b1_cur.z, acc1);
+                acc0 = mfma32(a_cur.w, b0_cur.w, acc0);
+                acc1 = mfma32(a_cur.w, b1_cur.w, acc1);
+                a_cur = a_nxt;
+                b0_cur = b0_nxt;
+                b1_cur = b1_nxt;
+            }
+            float *wdst = s_w + (wbuf ^ 1) * W_FLOATS;
+            *reinterpret_cast<float4 *>(wdst + pco * PSTR + pc4 * 4) = wn0;
+            *reinterpret_cast<float4 *>(wdst + (pco + 32) * PSTR + pc4 * 4) = wn1;
+            wbuf ^= 1;
+            __syncthreads();
+        }
+
+        const int oy = y0 + wave;
+        float s0, s1, q0, q1;
+        epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W, oy < H,
+                             lane, s0, s1, q0, q1);
+        // every wave has finished reading s_in (barrier after tap 8): refill it for the next tile
+        if (has_next) write_tile_lds();
+        if (STATS) block_stats_reduce(s_red, stat_part, tile, tid, lane, wave, 8, s0, s1, q0, q1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // conv1: 7x7, stride 2, pad 3, 3 -> 64.  NCHW image -> NHWC activation.
 // K = 147 (+1 zero row) = 74 MFMA k-pairs.
 // ------------------------------------------------------------------------------------
@@ -249,6 +394,108 @@ __global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
     epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
                          oy < H1, lane, s0, s1, q0, q1);
     if (STATS) block_stats_reduce(s_in, stat_part, bid, tid, lane, wave, 8, s0, s1, q0, q1);
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 v2: persistent blocks (2 per CU); the 148x64 weight matrix stays resident in LDS for the
+// whole launch, the next tile's image patch is prefetched into registers during the MFMAs.
+// ------------------------------------------------------------------------------------
+namespace c1 {
+constexpr int PATCH = 3 * PR * 69;                                  // 4347 loaded floats
+constexpr int NPRE = (PATCH + THREADS - 1) / THREADS;               // 9 per thread
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
+    const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
+    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles)
+{
+    using namespace c1;
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS + 8 * 128];
+    float *s_in = lds;
+    float *s_w = lds + IN_FLOATS;
+    float *s_red = lds + IN_FLOATS + W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    float pre[NPRE];
+    auto issue_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+        const float *img_b = img + (size_t)b * 3 * H * W;
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            const int c = idx / (PR * 69);
+            const int rem = idx - c * (PR * 69);
+            const int r = rem / 69, j = rem - r * 69;
+            const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + j;
+            float v = 0.f;
+            if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = img_b[((size_t)c * H + gy) * W + gx];
+            pre[it] = v;
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            if (idx < PATCH) {
+                const int c = idx / (PR * 69);
+                const int rem = idx - c * (PR * 69);
+                const int r = rem / 69, j = rem - r * 69;
+                s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
+            }
+        }
+    };
+    issue_loads(tile);
+    for (int idx = tid; idx < W_FLOATS / 4; idx += THREADS)
+        reinterpret_cast<float4 *>(s_w)[idx] = reinterpret_cast<const float4 *>(wk)[idx];
+    write_lds();
+    __syncthreads();
+
+    const float *a_base = s_in + (2 * wave) * RSTR + li;
+    const float *b_base = s_w + kh2 * 64 + li;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_loads(next);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        float a_cur = a_base[kh2 ? tap_off(1) : tap_off(0)];
+        float b0_cur = b_base[0], b1_cur = b_base[32];
+#pragma unroll
+        for (int kk = 0; kk < 74; ++kk) {
+            const int kn = kk < 73 ? kk + 1 : kk;
+            const int off = kh2 ? tap_off(2 * kn + 1) : tap_off(2 * kn);
+            const float a_nxt = a_base[off];
+            const float b0_nxt = b_base[kn * 128];
+            const float b1_nxt = b_base[kn * 128 + 32];
+            acc0 = mfma32(a_cur, b0_cur, acc0);
+            acc1 = mfma32(a_cur, b1_cur, acc1);
+            a_cur = a_nxt;
+            b0_cur = b0_nxt;
+            b1_cur = b1_nxt;
+        }
+        const int oy = y0 + wave;
+        float s0, s1, q0, q1;
+        epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
+                             oy < H1, lane, s0, s1, q0, q1);
+        __syncthreads();                 // every wave is done reading the patch
+        if (has_next) write_lds();
+        if (STATS) block_stats_reduce(s_red, stat_part, tile, tid, lane, wave, 8, s0, s1, q0, q1);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -359,16 +606,152 @@ __global__ __launch_bounds__(wg3::THREADS) void conv3x3_wgrad_kernel(
         }
 }
 
-// sum partials and write dW in the reference's OIHW layout: dW[co][ci][kh][kw]
-__global__ void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts,
-                                            float *__restrict__ dw)
+// ------------------------------------------------------------------------------------
+// conv3x3 weight gradient v2: 12 waves per block.  Wave w owns tap row kh = w/4 (3 taps), output-
+// channel block w&1 and input-channel block (w>>1)&1 over ALL pixels of the tile: 3 accumulators
+// (48 registers) instead of 9, no duplicated partials, and three waves per SIMD to hide LDS
+// latency.  Tiles are 8x32 pixels; the next tile's halo'd activation tile and dz tile are
+// prefetched into registers while the current tile computes and are written to LDS afterwards.
+// ------------------------------------------------------------------------------------
+namespace wg3v2 {
+constexpr int TH = 8, TW = 32;
+constexpr int PH = TH + 2, PW = TW + 2;
+constexpr int A_FLOATS = PH * PW * 64;      // 21,760 floats = 87,040 B
+constexpr int DZ_FLOATS = TH * TW * 64;     // 16,384 floats = 65,536 B
+constexpr int THREADS = 768;
+constexpr int NPRE_A = (PH * PW * 16 + THREADS - 1) / THREADS;   // 8 float4
+constexpr int NPRE_D = (TH * TW * 16 + THREADS - 1) / THREADS;   // 6 float4
+}  // namespace wg3v2
+
+__global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
+    const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part,
+    int H, int W, int tiles_x, int tiles_y, int ntiles)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][co][ci]
-    if (idx >= 9 * 4096) return;
+    using namespace wg3v2;
+    __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + DZ_FLOATS];
+    float *s_a = lds;
+    float *s_dz = lds + A_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int cob = wave & 1, cib = (wave >> 1) & 1, trow = wave >> 2;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 pa[NPRE_A], pd[NPRE_D];
+    auto issue_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const float *act_b = act + (size_t)b * H * W * 64;
+        const float *dz_b = dz + (size_t)b * H * W * 64;
+#pragma unroll
+        for (int it = 0; it < NPRE_A; ++it) {
+            const int idx = tid + it * THREADS;
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / PW, c = px - r * PW;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < PH * PW * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+            pa[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NPRE_D; ++it) {
+            const int idx = tid + it * THREADS;
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / TW, c = px - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TH * TW * 16 && gy < H && gx < W)
+                v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+            pd[it] = v;
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPRE_A; ++it) {
+            const int idx = tid + it * THREADS;
+            if (idx < PH * PW * 16) *reinterpret_cast<float4 *>(s_a + idx * 4) = pa[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NPRE_D; ++it) {
+            const int idx = tid + it * THREADS;
+            if (idx < TH * TW * 16) *reinterpret_cast<float4 *>(s_dz + idx * 4) = pd[it];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        issue_loads(tile);
+        write_lds();
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_loads(next);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-pair t covers tile pixels 2t, 2t+1 (row = p>>5, col = p&31); this lane: p = 2t + kh2
+        const float *a_ptr = s_dz + kh2 * 64 + cob * 32 + li;
+        const float *b_ptr = s_a + (trow * PW + kh2) * 64 + cib * 32 + li;
+        float a_cur = a_ptr[0];
+        float b_cur0 = b_ptr[0], b_cur1 = b_ptr[64], b_cur2 = b_ptr[128];
+#pragma unroll 8
+        for (int t = 0; t < TH * TW / 2; ++t) {
+            // next k-pair (clamped on the last one; the extra read is unused)
+            const int tn = t + 1 < TH * TW / 2 ? t + 1 : t;
+            const int pn = 2 * tn;
+            const int rown = pn >> 5, coln = pn & 31;
+            const float a_nxt = a_ptr[(rown * TW + coln) * 64];
+            const float *bn = b_ptr + (rown * PW + coln) * 64;
+            const float b_nxt0 = bn[0], b_nxt1 = bn[64], b_nxt2 = bn[128];
+            acc[0] = mfma32(a_cur, b_cur0, acc[0]);
+            acc[1] = mfma32(a_cur, b_cur1, acc[1]);
+            acc[2] = mfma32(a_cur, b_cur2, acc[2]);
+            a_cur = a_nxt;
+            b_cur0 = b_nxt0;
+            b_cur1 = b_nxt1;
+            b_cur2 = b_nxt2;
+        }
+        __syncthreads();              // all waves done with this tile's LDS image
+        if (has_next) write_lds();
+        __syncthreads();
+    }
+    // one partial per block: part[block][tap][co][ci]
+    float *dst = part + (size_t)blockIdx.x * (9 * 4096);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob * 32 + mfma32_row(r, lane);
+            dst[(trow * 3 + kw) * 4096 + co * 64 + cib * 32 + li] = acc[kw][r];
+        }
+}
+
+// sum partials and write dW in the reference's OIHW layout: dW[co][ci][kh][kw].
+// block = 64 elements x 16 slices of the partial list, fp64 accumulation, fixed order.
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part,
+                                                                    int nparts,
+                                                                    float *__restrict__ dw)
+{
+    __shared__ double s_acc[16][64];
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;                    // over [tap][co][ci] = 36864
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * (9 * 4096) + idx];
-    const int tap = idx >> 12, co = (idx >> 6) & 63, ci = idx & 63;
-    dw[(co * 64 + ci) * 9 + tap] = (float)s;
+    for (int p = slice; p < nparts; p += 16) s += (double)part[(size_t)p * (9 * 4096) + idx];
+    s_acc[slice][tx] = s;
+    __syncthreads();
+    if (slice == 0) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
+        const int tap = idx >> 12, co = (idx >> 6) & 63, ci = idx & 63;
+        dw[(co * 64 + ci) * 9 + tap] = (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -464,18 +847,157 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_kernel(
             }
 }
 
-__global__ void conv1_wgrad_reduce_kernel(const float *__restrict__ part, int nparts,
-                                          float *__restrict__ dw)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [co][147]
-    if (idx >= 64 * 147) return;
-    const int co = idx / 147, k = idx - co * 147;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * (64 * 160) + co * 160 + k];
-    dw[idx] = (float)s;    // OIHW flattened: co*147 + c*49 + kh*7 + kw
+// conv1 weight gradient v2: wave w owns output-channel block w&1 and tile rows 2q, 2q+1
+// (q = w>>1): 5 accumulators (80 registers) over 64 pixels, four partials per block; the next
+// tile's dy tile and image patch are prefetched into registers during the MFMAs.
+namespace wg1 {
+constexpr int NPRE_D = (DY_FLOATS / 4 + THREADS - 1) / THREADS;    // 8 float4
 }
 
-inline int persistent_grid(int ntiles)
+__global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
+    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles)
+{
+    using namespace c1;
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS];
+    float *s_in = lds;
+    float *s_dy = lds + IN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int cob = wave & 1, q = wave >> 1;
+
+    int toff[5];
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb) {
+        const int k = tb * 32 + li;
+        toff[tb] = (k < 147) ? ((k / 49) * CSTR + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH +
+                                ((k % 7) >> 1))
+                             : 0;
+    }
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float pre[NPRE];
+    float4 pd[wg1::NPRE_D];
+    auto issue_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+        const int y0 = ty * wg1::TH, x0 = tx * wg1::TW;
+        const float *img_b = img + (size_t)b * 3 * H * W;
+        const float *dy_b = dy + (size_t)b * H1 * W1 * 64;
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            const int c = idx / (PR * 69);
+            const int rem = idx - c * (PR * 69);
+            const int r = rem / 69, j = rem - r * 69;
+            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
+            float v = 0.f;
+            if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = img_b[((size_t)c * H + gy) * W + gx];
+            pre[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < wg1::NPRE_D; ++it) {
+            const int idx = tid + it * THREADS;
+            const int px = idx >> 4, c4 = idx & 15;
+            const int r = px / wg1::TW, c = px - r * wg1::TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H1 && gx < W1)
+                v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
+            pd[it] = v;
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int idx = tid + it * THREADS;
+            if (idx < PATCH) {
+                const int c = idx / (PR * 69);
+                const int rem = idx - c * (PR * 69);
+                const int r = rem / 69, j = rem - r * 69;
+                s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < wg1::NPRE_D; ++it)
+            *reinterpret_cast<float4 *>(s_dy + (tid + it * THREADS) * 4) = pd[it];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        issue_loads(tile);
+        write_lds();
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_loads(next);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave: tile rows 2q, 2q+1; k-pair t -> pixels p = 2t + kh2 (row 2q + (p>>5), col p&31)
+        const float *a_ptr = s_dy + (2 * q * wg1::TW + kh2) * 64 + cob * 32 + li;
+        const float *b_ptr = s_in + (4 * q) * RSTR + kh2;
+        float a_cur = a_ptr[0];
+        float b_cur[5];
+#pragma unroll
+        for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_ptr[toff[tb]];
+#pragma unroll 4
+        for (int t = 0; t < 32; ++t) {
+            const int tn = t < 31 ? t + 1 : t;
+            const int pn = 2 * tn;
+            const int rown = pn >> 5, coln = pn & 31;
+            const float a_nxt = a_ptr[(rown * wg1::TW + coln) * 64];
+            const float *bn = b_ptr + (2 * rown) * RSTR + coln;
+            float b_nxt[5];
+#pragma unroll
+            for (int tb = 0; tb < 5; ++tb) b_nxt[tb] = bn[toff[tb]];
+#pragma unroll
+            for (int tb = 0; tb < 5; ++tb) acc[tb] = mfma32(a_cur, b_cur[tb], acc[tb]);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_nxt[tb];
+        }
+        __syncthreads();
+        if (has_next) write_lds();
+        __syncthreads();
+    }
+    // partial layout: part[(block*4 + q)][co 64][k 160]
+    float *dst = part + ((size_t)(blockIdx.x * 4 + q)) * (64 * 160);
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob * 32 + mfma32_row(r, lane);
+            dst[co * 160 + tb * 32 + li] = acc[tb][r];
+        }
+}
+
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *__restrict__ part,
+                                                                  int nparts, float *__restrict__ dw)
+{
+    __shared__ double s_acc[16][64];
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;                    // over [co][160]
+    double s = 0.0;
+    for (int p = slice; p < nparts; p += 16) s += (double)part[(size_t)p * (64 * 160) + idx];
+    s_acc[slice][tx] = s;
+    __syncthreads();
+    if (slice == 0) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
+        const int co = idx / 160, k = idx - co * 160;
+        if (k < 147) dw[co * 147 + k] = (float)t;           // OIHW: co*147 + c*49 + kh*7 + kw
+    }
+}
+
+extern int g_grid_cap;
+inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 {
     static int cus = 0;
     if (cus == 0) {
@@ -485,14 +1007,31 @@ inline int persistent_grid(int ntiles)
             cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    return ntiles < cus ? ntiles : cus;
+    int g = ntiles < cus * blocks_per_cu ? ntiles : cus * blocks_per_cu;
+    if (g_grid_cap > 0 && g > g_grid_cap) g = g_grid_cap;
+    return g;
 }
+
+int g_conv3x3_variant = 2;   // 1 = one block per tile, 2 = persistent + software pipelined
+int g_wgrad3_variant = 2;    // 1 = 8 waves x 9 taps, 2 = 12 waves x 3 taps + register prefetch
+int g_conv1_variant = 2;     // conv1 fwd + wgrad: 1 = v1, 2 = persistent + register prefetch
+int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
 
 }  // namespace
 
 // ====================================================================================
 // C ABI
 // ====================================================================================
+// tuning / A-B switches for benchmarking (key 1: conv3x3 fwd kernel variant)
+COVA_API int cova_set_option(int key, int value)
+{
+    if (key == 1) { g_conv3x3_variant = value; return COVA_OK; }
+    if (key == 2) { g_grid_cap = value; return COVA_OK; }
+    if (key == 3) { g_wgrad3_variant = value; return COVA_OK; }
+    if (key == 4) { g_conv1_variant = value; return COVA_OK; }
+    return COVA_ERR_BAD_ARG;
+}
+
 COVA_API int cova_conv_out_size(int in_size, int kernel, int stride, int pad)
 {
     return (in_size + 2 * pad - kernel) / stride + 1;
@@ -535,7 +1074,20 @@ COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *ad
 {
     COVA_REQUIRE(in && w_t && out && B > 0 && H > 0 && W > 0);
     const int tiles_x = cdiv(W, c3::TW), tiles_y = cdiv(H, c3::TH);
-    const dim3 grid(B * tiles_x * tiles_y), block(c3::THREADS);
+    const int ntiles = B * tiles_x * tiles_y;
+    const dim3 block(c3::THREADS);
+    if (g_conv3x3_variant == 2) {
+        const dim3 grid(persistent_grid(ntiles));
+        if (stat_part)
+            hipLaunchKernelGGL(conv3x3_c64_v2_kernel<true>, grid, block, 0, (hipStream_t)stream, in,
+                               w_t, addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles);
+        else
+            hipLaunchKernelGGL(conv3x3_c64_v2_kernel<false>, grid, block, 0, (hipStream_t)stream, in,
+                               w_t, addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
+    const dim3 grid(ntiles);
     if (stat_part)
         hipLaunchKernelGGL(conv3x3_c64_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,
                            addend, out, stat_part, H, W, tiles_x, tiles_y);
@@ -553,7 +1105,20 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
     COVA_REQUIRE(img && w_k && out && B > 0 && H > 0 && W > 0);
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, c1::TW), tiles_y = cdiv(H1, c1::TH);
-    const dim3 grid(B * tiles_x * tiles_y), block(c1::THREADS);
+    const dim3 block(c1::THREADS);
+    if (g_conv1_variant == 2) {
+        const int ntiles = B * tiles_x * tiles_y;
+        const dim3 pgrid(persistent_grid(ntiles, 2));
+        if (stat_part)
+            hipLaunchKernelGGL(conv1_7x7_v2_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img,
+                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles);
+        else
+            hipLaunchKernelGGL(conv1_7x7_v2_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img,
+                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
+    const dim3 grid(B * tiles_x * tiles_y);
     if (stat_part)
         hipLaunchKernelGGL(conv1_7x7_kernel<true>, grid, block, 0, (hipStream_t)stream, img, w_k,
                            out, stat_part, H, W, H1, W1, tiles_x, tiles_y);
@@ -566,7 +1131,7 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
 
 COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
 {
-    const int ntiles = B * cdiv(W, wg3::TW) * cdiv(H, wg3::TH);
+    const int ntiles = B * cdiv(W, wg3::TW) * cdiv(H, wg3::TH);   // v1 bound (>= v2's need)
     return persistent_grid(ntiles) * 2 * 9 * 4096;
 }
 
@@ -575,12 +1140,24 @@ COVA_API int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw, fl
                                 int H, int W, void *stream)
 {
     COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
+    if (g_wgrad3_variant == 2) {
+        const int tiles_x = cdiv(W, wg3v2::TW), tiles_y = cdiv(H, wg3v2::TH);
+        const int ntiles = B * tiles_x * tiles_y;
+        const int grid = persistent_grid(ntiles);
+        hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel, dim3(grid), dim3(wg3v2::THREADS), 0,
+                           (hipStream_t)stream, act, dz, ws, H, W, tiles_x, tiles_y, ntiles);
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 4096 / 64), dim3(1024), 0,
+                           (hipStream_t)stream, ws, grid, dw);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     const int tiles_x = cdiv(W, wg3::TW), tiles_y = cdiv(H, wg3::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(wg3::THREADS), 0, (hipStream_t)stream,
                        act, dz, ws, B, H, W, tiles_x, tiles_y);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(9 * 4096, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 4096 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 2, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -599,10 +1176,20 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
+    if (g_conv1_variant == 2) {
+        hipLaunchKernelGGL(conv1_wgrad_v2_kernel, dim3(grid), dim3(wg1::THREADS), 0,
+                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                           B * tiles_x * tiles_y);
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
+                           (hipStream_t)stream, ws, grid * 4, dw);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(grid), dim3(wg1::THREADS), 0, (hipStream_t)stream,
                        img, dy, ws, B, H, W, H1, W1, tiles_x, tiles_y);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(cdiv(64 * 147, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 8, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

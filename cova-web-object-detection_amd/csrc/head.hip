@@ -94,21 +94,21 @@ __global__ __launch_bounds__(256) void linear_small_bwd_x_kernel(const float *__
     }
 }
 
-// dW[k][c] = sum_n dy[n][k]*x[n][c]; block = 64 columns x 4 row slices; db by block 0
-__global__ __launch_bounds__(256) void linear_small_bwd_w_kernel(const float *__restrict__ dy,
-                                                                 const float *__restrict__ x, int ldx,
-                                                                 float *__restrict__ dW,
-                                                                 float *__restrict__ db, int N,
-                                                                 int Cin, int NC)
+// dW[k][c] = sum_n dy[n][k]*x[n][c]; block = 64 columns x 16 row slices; db by block 0
+__global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *__restrict__ dy,
+                                                                  const float *__restrict__ x, int ldx,
+                                                                  float *__restrict__ dW,
+                                                                  float *__restrict__ db, int N,
+                                                                  int Cin, int NC)
 {
-    __shared__ float s[4][MAXNC][64];
+    __shared__ float s[16][MAXNC][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     float acc[MAXNC];
 #pragma unroll
     for (int k = 0; k < MAXNC; ++k) acc[k] = 0.f;
     if (c < Cin)
-        for (int n = ty; n < N; n += 4) {
+        for (int n = ty; n < N; n += 16) {
             const float xv = x[(size_t)n * ldx + c];
 #pragma unroll
             for (int k = 0; k < MAXNC; ++k)
@@ -118,12 +118,15 @@ __global__ __launch_bounds__(256) void linear_small_bwd_w_kernel(const float *__
     for (int k = 0; k < MAXNC; ++k) s[ty][k][tx] = acc[k];
     __syncthreads();
     if (ty == 0 && c < Cin)
-        for (int k = 0; k < NC; ++k)
-            dW[(size_t)k * Cin + c] = s[0][k][tx] + s[1][k][tx] + s[2][k][tx] + s[3][k][tx];
-    if (blockIdx.x == 0 && threadIdx.x < NC) {
+        for (int k = 0; k < NC; ++k) {
+            float t = 0.f;
+            for (int j = 0; j < 16; ++j) t += s[j][k][tx];
+            dW[(size_t)k * Cin + c] = t;
+        }
+    if (blockIdx.x == 0 && ty == 1 && tx < NC) {
         float t = 0.f;
-        for (int n = 0; n < N; ++n) t += dy[(size_t)n * NC + threadIdx.x];
-        db[threadIdx.x] = t;
+        for (int n = 0; n < N; ++n) t += dy[(size_t)n * NC + tx];
+        db[tx] = t;
     }
 }
 
@@ -183,19 +186,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
-// column sums of x [R, C] -> out [C] (deterministic; small R)
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int ldx, int R,
-                                                     int C, float *__restrict__ out)
+// column sums of x [R, C] -> out [C] (deterministic; small R); 64 columns x 16 row slices
+__global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ x, int ldx, int R,
+                                                      int C, float *__restrict__ out)
 {
-    __shared__ float s[4][64];
+    __shared__ float s[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     float a = 0.f;
     if (c < C)
-        for (int r = ty; r < R; r += 4) a += x[(size_t)r * ldx + c];
+        for (int r = ty; r < R; r += 16) a += x[(size_t)r * ldx + c];
     s[ty][tx] = a;
     __syncthreads();
-    if (ty == 0 && c < C) out[c] = s[0][tx] + s[1][tx] + s[2][tx] + s[3][tx];
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+        for (int j = 0; j < 16; ++j) t += s[j][tx];
+        out[c] = t;
+    }
 }
 
 inline int ew_grid(long long total)
@@ -249,7 +256,7 @@ COVA_API int cova_linear_small_bwd(const float *dy, const float *x, int ldx, con
     hipLaunchKernelGGL(linear_small_bwd_x_kernel, dim3(ew_grid((long long)N * Cin)), dim3(256), 0, st,
                        dy, W, dx, lddx, N, Cin, NC);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(linear_small_bwd_w_kernel, dim3(cdiv(Cin, 64)), dim3(256), 0, st, dy, x, ldx,
+    hipLaunchKernelGGL(linear_small_bwd_w_kernel, dim3(cdiv(Cin, 64)), dim3(1024), 0, st, dy, x, ldx,
                        dW, db, N, Cin, NC);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -283,7 +290,7 @@ COVA_API int cova_adam_step(float *p, const float *g, float *m, float *v, long l
 COVA_API int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream)
 {
     COVA_REQUIRE(x && out && R > 0 && C > 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, R,
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, R,
                        C, out);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

@@ -50,11 +50,23 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     for (int c = lane; c < C; c += 64) {
         float maxv = empty ? 0.f : -FLT_MAX;
         int maxi = -1;
-        for (int h = hstart; h < hend; ++h)
-            for (int w = wstart; w < wend; ++w) {
-                const float v = fb[((size_t)h * W + w) * C + c];
-                if (v > maxv) { maxv = v; maxi = h * W + w; }
+        const int nw = wend - wstart;
+        for (int h = hstart; h < hend; ++h) {
+            const float *row = fb + ((size_t)h * W + wstart) * C + c;
+            int w = 0;
+            for (; w + 3 < nw; w += 4) {       // 4 loads in flight; compares in scan order
+                const float v0 = row[(size_t)w * C], v1 = row[(size_t)(w + 1) * C];
+                const float v2 = row[(size_t)(w + 2) * C], v3 = row[(size_t)(w + 3) * C];
+                if (v0 > maxv) { maxv = v0; maxi = h * W + wstart + w; }
+                if (v1 > maxv) { maxv = v1; maxi = h * W + wstart + w + 1; }
+                if (v2 > maxv) { maxv = v2; maxi = h * W + wstart + w + 2; }
+                if (v3 > maxv) { maxv = v3; maxi = h * W + wstart + w + 3; }
             }
+            for (; w < nw; ++w) {
+                const float v = row[(size_t)w * C];
+                if (v > maxv) { maxv = v; maxi = h * W + wstart + w; }
+            }
+        }
         // reference layout [N, C, PH, PW] flattened per roi: c*(PH*PW) + bin  (models.py:125-127)
         out[(size_t)n * ld_out + c * (PH * PW) + bin] = maxv;
         argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = maxi;
@@ -244,22 +256,30 @@ __global__ void gat_bwd_addt_kernel(float *__restrict__ dWh, int lddw, const flo
     dWh[(size_t)n * lddw + D + d] += dt[n] * att_w[D + d];
 }
 
-__global__ __launch_bounds__(256) void gat_bwd_att_kernel(const float *__restrict__ Wh, int ldw,
-                                                          const float *__restrict__ ds,
-                                                          const float *__restrict__ dt,
-                                                          float *__restrict__ d_att_w,
-                                                          float *__restrict__ d_att_b, int N, int D)
+// block = 64 columns x 16 row slices; column 2D is the bias (sum of ds)
+__global__ __launch_bounds__(1024) void gat_bwd_att_kernel(const float *__restrict__ Wh, int ldw,
+                                                           const float *__restrict__ ds,
+                                                           const float *__restrict__ dt,
+                                                           float *__restrict__ d_att_w,
+                                                           float *__restrict__ d_att_b, int N, int D)
 {
-    const int col = blockIdx.x * 256 + threadIdx.x;     // 0 .. 2D (2D = bias column)
-    if (col > 2 * D) return;
+    __shared__ float s_acc[16][64];
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;     // 0 .. 2D
     float acc = 0.f;
-    if (col == 2 * D) {
-        for (int n = 0; n < N; ++n) acc += ds[n];
-        d_att_b[0] = acc;
-    } else {
+    if (col < 2 * D) {
         const float *w = col < D ? ds : dt;
-        for (int n = 0; n < N; ++n) acc += w[n] * Wh[(size_t)n * ldw + col];
-        d_att_w[col] = acc;
+        for (int n = slice; n < N; n += 16) acc += w[n] * Wh[(size_t)n * ldw + col];
+    } else if (col == 2 * D) {
+        for (int n = slice; n < N; n += 16) acc += ds[n];
+    }
+    s_acc[slice][tx] = acc;
+    __syncthreads();
+    if (slice == 0 && col <= 2 * D) {
+        float t = 0.f;
+        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
+        if (col == 2 * D) d_att_b[0] = t;
+        else d_att_w[col] = t;
     }
 }
 
@@ -355,7 +375,7 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
     hipLaunchKernelGGL(gat_bwd_addt_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, st, dWh, lddw, dt,
                        att_w, N, D);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gat_bwd_att_kernel, dim3(cdiv(2 * D + 1, 256)), dim3(256), 0, st, Wh, ldw, ds,
+    hipLaunchKernelGGL(gat_bwd_att_kernel, dim3(cdiv(2 * D + 1, 64)), dim3(1024), 0, st, Wh, ldw, ds,
                        dt, d_att_w, d_att_b, N, D);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

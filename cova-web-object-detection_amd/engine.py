@@ -44,6 +44,19 @@ class BNState:
     __slots__ = ("scale", "shift", "mean", "invstd", "count", "C")
 
 
+FOLD_ABOVE, FOLD_GROUP = 256, 64
+
+
+def fold_partials(partial, nparts, width):
+    """Pre-reduce a long list of partial rows so the single-block finalize kernels stay short."""
+    while nparts > FOLD_ABOVE:
+        n2 = (nparts + FOLD_GROUP - 1) // FOLD_GROUP
+        out = _empty((n2, width), partial)
+        call("cova_partials_fold", partial, nparts, width, FOLD_GROUP, out)
+        partial, nparts = out, n2
+    return partial, nparts
+
+
 def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
               update_running=True):
     st = BNState()
@@ -53,6 +66,7 @@ def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0
     rm, rv = buffers[prefix + "running_mean"], buffers[prefix + "running_var"]
     if training:
         upd = update_running
+        partial, nparts = fold_partials(partial, nparts, 2 * C)
         call("cova_bn_finalize_fwd", partial, nparts, C, float(count), g, b, rm if upd else None,
              rv if upd else None, BN_MOMENTUM, BN_EPS, st.scale, st.shift, st.mean, st.invstd)
         if upd:
@@ -79,6 +93,7 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
     dgamma = _gbuf(gout, (prefix or "") + "weight", (C,), z)
     dbeta = _gbuf(gout, (prefix or "") + "bias", (C,), z)
     coef = _empty((2, C), z)
+    part, n = fold_partials(part, n, 2 * C)
     call("cova_bn_finalize_bwd", part, n, C, float(R), dgamma, dbeta, coef)
     call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
          lddz, dres, lddres, R, C)
@@ -179,6 +194,7 @@ def convstack_bwd(sv, dfeat, gout=None):
     dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
     db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
     coef = _empty((2, C64), dfeat)
+    part, npart = fold_partials(part, npart, 2 * C64)
     call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
     grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
     dy1 = torch.empty_like(sv["y1"])

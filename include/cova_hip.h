@@ -38,6 +38,8 @@ extern "C" {
  * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
+/* benchmarking switch (key 1 = conv3x3 kernel variant: 1 block-per-tile, 2 persistent pipelined) */
+int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
 int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[148,64]*/, void *stream);
@@ -68,6 +70,9 @@ int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, fl
  * replaces: nn.BatchNorm2d / nn.BatchNorm1d (train: batch statistics + running-stat update with
  * momentum, unbiased running_var; eval: running statistics), nn.ReLU, the BasicBlock residual
  * add and nn.MaxPool2d(3,2,1) -- models.py:49-51, :68, :73, :86 and their autograd. */
+/* deterministic pre-reduction of per-tile / per-chunk partial rows (fp64 inside a group) */
+int cova_partials_fold(const float *partial, int nparts, int width, int group, float *out,
+                       void *stream);
 int cova_colreduce_rows_per_chunk(long long R, int C);
 int cova_colreduce_num_chunks(long long R, int C);
 int cova_colstats(const float *x, int ldx, long long R, int C, float *partial /*[chunks,2,C]*/,

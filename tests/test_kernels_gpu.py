@@ -285,3 +285,75 @@ def test_adam_matches_torch():
         ref_p, state = O.adam_reference(ref_p, [gr], state)
         call("cova_adam_step", p, gr.to(DEV), m, v, n, step, 5e-4, 0.9, 0.999, 1e-8, 1e-3)
         close(p, ref_p[0], 1e-6, "adam step %d" % step)
+
+
+def test_conv3x3_persistent_multi_tile():
+    """More tiles than persistent blocks: exercises the cross-tile prefetch of the v2 kernel
+    (and, with a capped grid, many tiles per block) against the v1 kernel and torch-CPU."""
+    B, H, W = 3, 100, 200                      # 13 x 7 x 3 = 273 tiles > 256 CUs
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
+    call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
+    xg = nhwc(x)
+    ref = F.conv2d(x, w, padding=1)
+    nt = query("cova_conv3x3_num_tiles", B, H, W)
+    outs = []
+    for variant, cap in ((2, 0), (2, 7), (1, 0)):
+        query("cova_set_option", 1, variant)
+        query("cova_set_option", 2, cap)
+        out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_fwd", xg, wf, None, out, part, B, H, W)
+        close(nchw(out), ref, 1e-4, "conv3x3 v%d cap %d" % (variant, cap))
+        close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "stat sum")
+        outs.append((out, part))
+    query("cova_set_option", 1, 2)
+    query("cova_set_option", 2, 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])   # same summation order
+    assert torch.equal(outs[0][1], outs[2][1])
+
+
+def test_conv3x3_wgrad_variants_multi_tile():
+    B, H, W = 3, 100, 200
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 64, H, W, generator=g)
+    dz = torch.randn(B, 64, H, W, generator=g)
+    wr = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    (F.conv2d(x, wr, padding=1) * dz).sum().backward()
+    ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
+    for variant, cap in ((2, 0), (2, 5), (1, 0), (1, 5)):
+        query("cova_set_option", 3, variant)
+        query("cova_set_option", 2, cap)
+        dw = torch.zeros(64, 64, 3, 3, device=DEV)
+        call("cova_conv3x3_wgrad", nhwc(x), nhwc(dz), dw, ws, B, H, W)
+        close(dw, wr.grad, 2e-4, "conv3x3 wgrad v%d cap %d" % (variant, cap))
+    query("cova_set_option", 3, 2)
+    query("cova_set_option", 2, 0)
+
+
+def test_conv1_variants_multi_tile():
+    B, H, W = 2, 150, 330                     # 10 x 6 x 2 = 120 tiles; capped grid -> many per block
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(B, 3, H, W, generator=g)
+    wr = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x, wr, stride=2, padding=3)
+    H1, W1 = ref.shape[2], ref.shape[3]
+    dy = torch.randn(B, 64, H1, W1, generator=g)
+    (ref * dy).sum().backward()
+    wk = torch.empty(148, 64, device=DEV)
+    call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
+    nt = query("cova_conv1_num_tiles", B, H, W)
+    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
+    for variant, cap in ((2, 0), (2, 7), (1, 0), (1, 7)):
+        query("cova_set_option", 4, variant)
+        query("cova_set_option", 2, cap)
+        out, part = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+        call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
+        close(nchw(out), ref, 1e-4, "conv1 fwd v%d cap %d" % (variant, cap))
+        close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv1 sumsq")
+        dw = torch.zeros(64, 3, 7, 7, device=DEV)
+        call("cova_conv1_wgrad", x.to(DEV), nhwc(dy), dw, ws, B, H, W)
+        close(dw, wr.grad, 2e-4, "conv1 wgrad v%d cap %d" % (variant, cap))
+    query("cova_set_option", 4, 2)
+    query("cova_set_option", 2, 0)

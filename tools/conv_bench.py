@@ -1,0 +1,61 @@
+"""Micro-benchmark of the conv kernels at the bench workload size (B=16, 1280x1280 pages)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cova_amd  # noqa
+from cova_web_object_detection_amd import _lib
+call, query = _lib.call, _lib.query
+dev = "cuda:0"
+B, H, W = int(os.environ.get("B", 16)), 320, 320
+iters = 10
+
+
+def timeit(fn, n=iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+x = torch.randn(B, H, W, 64, device=dev)
+dz = torch.randn(B, H, W, 64, device=dev)
+w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+wf, wd = torch.empty(9, 64, 64, device=dev), torch.empty(9, 64, 64, device=dev)
+call("cova_conv3x3_prep_weights", w, wf, wd)
+out = torch.empty_like(x)
+part = torch.empty(query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)
+flop3 = 2 * 64 * 64 * 9 * B * H * W
+for variant in (1, 2):
+    query("cova_set_option", 1, variant)
+    for stats in (False, True):
+        t = timeit(lambda: call("cova_conv3x3_fwd", x, wf, None, out, part if stats else None, B, H, W))
+        print("conv3x3 fwd v%d stats=%d: %.3f ms  %.1f TF/s" % (variant, stats, t, flop3 / t / 1e9))
+ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=dev)
+dw = torch.empty(64, 64, 3, 3, device=dev)
+for variant in (1, 2):
+    query("cova_set_option", 3, variant)
+    t = timeit(lambda: call("cova_conv3x3_wgrad", x, dz, dw, ws, B, H, W))
+    print("conv3x3 wgrad v%d (+reduce): %.3f ms  %.1f TF/s" % (variant, t, flop3 / t / 1e9))
+img = torch.rand(B, 3, 1280, 1280, device=dev)
+w1 = torch.randn(64, 3, 7, 7, device=dev) * 0.1
+wk = torch.empty(148, 64, device=dev)
+call("cova_conv1_prep_weights", w1, wk)
+y1 = torch.empty(B, 640, 640, 64, device=dev)
+part1 = torch.empty(query("cova_conv1_num_tiles", B, 1280, 1280), 2, 64, device=dev)
+flop1 = 2 * 64 * 147 * B * 640 * 640
+for variant in (1, 2):
+    query("cova_set_option", 4, variant)
+    t = timeit(lambda: call("cova_conv1_fwd", img, wk, y1, part1, B, 1280, 1280))
+    print("conv1 fwd v%d: %.3f ms  %.1f TF/s" % (variant, t, flop1 / t / 1e9))
+ws1 = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, 1280, 1280), device=dev)
+dw1 = torch.empty(64, 3, 7, 7, device=dev)
+for variant in (1, 2):
+    query("cova_set_option", 4, variant)
+    t = timeit(lambda: call("cova_conv1_wgrad", img, y1, dw1, ws1, B, 1280, 1280))
+    print("conv1 wgrad v%d (+reduce): %.3f ms  %.1f TF/s" % (variant, t, flop1 / t / 1e9))

@@ -119,13 +119,13 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    _lib.PROFILE = {"cova_conv3x3_fwd": []}
+    _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": []}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    prof = _lib.PROFILE["cova_conv3x3_fwd"]
+    prof = _lib.PROFILE["cova_conv3x3_fwd"] + _lib.PROFILE["cova_conv3x3_dgrad_bnbwd"]
     _lib.PROFILE = None
     if world > 1:
         import torch.distributed as dist
@@ -151,7 +151,7 @@ def main():
                                    % (args.pages, BOXES, 2 * CS),
                        "pages_per_gpu": args.pages, "global_pages": world * args.pages,
                        "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world, "loss": round(loss_val, 3)},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_kernel (fwd + dgrad launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_v2_kernel (4 forward + 4 data-gradient launches per step)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),

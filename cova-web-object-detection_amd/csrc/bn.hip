@@ -94,6 +94,56 @@ __device__ __forceinline__ void combine_partials(const float *__restrict__ parti
         }
 }
 
+// C == 64, contiguous rows: float4 per thread, 16 rows per block pass (the NHWC activations).
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce64_kernel(
+    const float *__restrict__ x, const float *__restrict__ act, const float *__restrict__ z,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ partial,
+    long long R, int rows_per_chunk)
+{
+    __shared__ float s_s[16][64], s_q[16][64];
+    const int c4 = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float4 mu = make_float4(0, 0, 0, 0), is = mu;
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const float4 *>(mean + c4 * 4);
+        is = *reinterpret_cast<const float4 *>(invstd + c4 * 4);
+    }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = r0 + ty; r < r1; r += 16) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + r * 64 + c4 * 4);
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += vv[j]; q[j] += vv[j] * vv[j]; }
+        } else {
+            const float4 zz = *reinterpret_cast<const float4 *>(z + r * 64 + c4 * 4);
+            if (act != nullptr) {
+                const float4 a = *reinterpret_cast<const float4 *>(act + r * 64 + c4 * 4);
+                if (!(a.x > 0.f)) vv[0] = 0.f;
+                if (!(a.y > 0.f)) vv[1] = 0.f;
+                if (!(a.z > 0.f)) vv[2] = 0.f;
+                if (!(a.w > 0.f)) vv[3] = 0.f;
+            }
+            const float xh[4] = {(zz.x - mu.x) * is.x, (zz.y - mu.y) * is.y, (zz.z - mu.z) * is.z,
+                                 (zz.w - mu.w) * is.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += vv[j]; q[j] += vv[j] * xh[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_s[ty][c4 * 4 + j] = s[j]; s_q[ty][c4 * 4 + j] = q[j]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 16; ++r) { a += s_s[r][threadIdx.x]; b += s_q[r][threadIdx.x]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * 64 + threadIdx.x] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * 64 + threadIdx.x] = b;
+    }
+}
+
 // Fold groups of `group` consecutive partial rows ([nparts][width] fp32) into one row each
 // (fp64 accumulation inside a group): a cheap, deterministic first reduction stage so that the
 // single-block finalize kernels never walk more than a few hundred rows.
@@ -398,6 +448,56 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(
     }
 }
 
+// Window-based form of the PASS 0 reduction: every pooling window routes its gradient to exactly
+// one input pixel (its argmax), so sum_pixels dy = sum_windows dp*[bn(y_argmax) > 0] and likewise
+// for dy*xhat: one gather of y per (window, channel) instead of a sweep over the 4x larger input.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_win_kernel(
+    const float *__restrict__ dp, const uint8_t *__restrict__ idx, const float *__restrict__ y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ partial,
+    int B, int H1, int W1, int H2, int W2)
+{
+    __shared__ float s_s[16][64], s_q[16][64];
+    const int c4 = threadIdx.x & 15, prow = threadIdx.x >> 4;
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4 * 4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4 * 4);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const long long nwin = (long long)B * H2 * W2;
+    for (long long p = (long long)blockIdx.x * 16 + prow; p < nwin; p += (long long)gridDim.x * 16) {
+        const int ox = (int)(p % W2);
+        const long long pr = p / W2;
+        const int oy = (int)(pr % H2);
+        const int b = (int)(pr / H2);
+        const uchar4 id = *reinterpret_cast<const uchar4 *>(idx + (size_t)p * 64 + c4 * 4);
+        const float4 g = *reinterpret_cast<const float4 *>(dp + (size_t)p * 64 + c4 * 4);
+        const int pos[4] = {id.x, id.y, id.z, id.w};
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+        const float *yb = y + (size_t)b * H1 * W1 * 64 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ky = pos[j] / 3, kx = pos[j] - ky * 3;
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            const float yv = yb[((size_t)iy * W1 + ix) * 64 + j];
+            const float dy = (yv * scv[j] + shv[j] > 0.f) ? gv[j] : 0.f;
+            s[j] += dy;
+            q[j] += dy * ((yv - muv[j]) * isv[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_s[prow][c4 * 4 + j] = s[j]; s_q[prow][c4 * 4 + j] = q[j]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = 0.f, bq = 0.f;
+        for (int r = 0; r < 16; ++r) { a += s_s[r][threadIdx.x]; bq += s_q[r][threadIdx.x]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * 64 + threadIdx.x] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * 64 + threadIdx.x] = bq;
+    }
+}
+
 inline int ew_grid(long long total_threads)
 {
     long long g = cdivll(total_threads, 256);
@@ -419,7 +519,7 @@ inline bool vec4_ok(const void *p, int ld)
 COVA_API int cova_colreduce_rows_per_chunk(long long R, int C)
 {
     const int rpb = 256 / pow2_cols_host(C);
-    long long rows = cdivll(R, 1024);
+    long long rows = cdivll(R, 2048);
     if (rows < 64) rows = 64;
     rows = cdivll(rows, rpb) * rpb;
     return (int)rows;
@@ -448,6 +548,13 @@ COVA_API int cova_colstats(const float *x, int ldx, long long R, int C, float *p
     COVA_REQUIRE(x && partial && R > 0 && C > 0);
     const int rpc = cova_colreduce_rows_per_chunk(R, C);
     const dim3 grid((unsigned)cdivll(R, rpc), (unsigned)cdiv(C, pow2_cols_host(C)));
+    if (C == 64 && ldx == 64 && vec4_ok(x, ldx)) {
+        hipLaunchKernelGGL(colreduce64_kernel<0>, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, x,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, partial, R, rpc);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx,
                        (const float *)nullptr, 0, (const float *)nullptr, 0, (const float *)nullptr,
                        (const float *)nullptr, partial, R, C, rpc);
@@ -507,6 +614,13 @@ COVA_API int cova_bn_bwd_reduce(const float *dout, int ldd, const float *act, in
     COVA_REQUIRE(dout && z && mean && invstd && partial && R > 0 && C > 0);
     const int rpc = cova_colreduce_rows_per_chunk(R, C);
     const dim3 grid((unsigned)cdivll(R, rpc), (unsigned)cdiv(C, pow2_cols_host(C)));
+    if (C == 64 && ldd == 64 && ldz == 64 && (act == nullptr || lda == 64) && vec4_ok(dout, ldd) &&
+        vec4_ok(z, ldz) && vec4_ok(act, lda)) {
+        hipLaunchKernelGGL(colreduce64_kernel<1>, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, dout,
+                           act, z, mean, invstd, partial, R, rpc);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dout, ldd, act,
                        lda, z, ldz, mean, invstd, partial, R, C, rpc);
     COVA_LAUNCH_CHECK();
@@ -574,9 +688,9 @@ COVA_API int cova_bn_relu_maxpool_bwd_reduce(const float *dp, const uint8_t *idx
     COVA_REQUIRE(dp && idx && y && scale && shift && mean && invstd && partial);
     const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
     const int grid = cova_bn_relu_maxpool_bwd_num_partials(B, H1, W1);
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       dp, idx, y, scale, shift, mean, invstd, (const float *)nullptr,
-                       (float *)nullptr, partial, B, H1, W1, H2, W2);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_win_kernel, dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, dp, idx, y, scale, shift, mean, invstd, partial, B, H1, W1,
+                       H2, W2);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

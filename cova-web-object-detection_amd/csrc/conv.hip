@@ -19,15 +19,30 @@ namespace {
 // shared epilogue: one wave owns a 32(pixel) x 64(channel) output strip held in two
 // 32x32 accumulators (channel blocks 0 and 1).
 // ------------------------------------------------------------------------------------
+// BN-backward fusion (dgrad epilogue): the conv result is dL/d(post-ReLU activation); with
+// bn.act != nullptr the stored value becomes dy = result * (act > 0) and the accumulated sums are
+// (sum dy, sum dy * xhat), xhat = (z - mean) * invstd -- exactly what cova_bn_bwd_reduce computes,
+// without its three extra passes over HBM.
+struct BnBwdEpi {
+    const float *act, *z, *mean, *invstd;
+};
+
 __device__ __forceinline__ void epilogue_store_stats(const f32x16 &acc0, const f32x16 &acc1,
                                                      float *__restrict__ out,
                                                      const float *__restrict__ addend,
                                                      size_t pix_row_base, int x0, int W,
                                                      bool row_valid, int lane, float &s0,
-                                                     float &s1, float &q0, float &q1)
+                                                     float &s1, float &q0, float &q1,
+                                                     const BnBwdEpi bn = BnBwdEpi{nullptr, nullptr,
+                                                                                  nullptr, nullptr})
 {
     const int li = lane & 31;
     s0 = s1 = q0 = q1 = 0.f;
+    float mu0 = 0.f, mu1 = 0.f, is0 = 0.f, is1 = 0.f;
+    if (bn.act != nullptr) {
+        mu0 = bn.mean[li]; mu1 = bn.mean[32 + li];
+        is0 = bn.invstd[li]; is1 = bn.invstd[32 + li];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int px = mfma32_row(r, lane);
@@ -39,10 +54,21 @@ __device__ __forceinline__ void epilogue_store_stats(const f32x16 &acc0, const f
                 v0 += addend[o + li];
                 v1 += addend[o + 32 + li];
             }
-            out[o + li] = v0;
-            out[o + 32 + li] = v1;
-            s0 += v0; q0 += v0 * v0;
-            s1 += v1; q1 += v1 * v1;
+            if (bn.act != nullptr) {
+                if (!(bn.act[o + li] > 0.f)) v0 = 0.f;
+                if (!(bn.act[o + 32 + li] > 0.f)) v1 = 0.f;
+                const float xh0 = (bn.z[o + li] - mu0) * is0;
+                const float xh1 = (bn.z[o + 32 + li] - mu1) * is1;
+                out[o + li] = v0;
+                out[o + 32 + li] = v1;
+                s0 += v0; q0 += v0 * xh0;
+                s1 += v1; q1 += v1 * xh1;
+            } else {
+                out[o + li] = v0;
+                out[o + 32 + li] = v1;
+                s0 += v0; q0 += v0 * v0;
+                s1 += v1; q1 += v1 * v1;
+            }
         }
     }
     s0 += __shfl_xor(s0, 32, 64);
@@ -192,7 +218,7 @@ template <bool STATS>
 __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
     const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
-    int ntiles)
+    int ntiles, const BnBwdEpi bn)
 {
     using namespace c3;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + RED_FLOATS];
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
         const int oy = y0 + wave;
         float s0, s1, q0, q1;
         epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W, oy < H,
-                             lane, s0, s1, q0, q1);
+                             lane, s0, s1, q0, q1, bn);
         // every wave has finished reading s_in (barrier after tap 8): refill it for the next tile
         if (has_next) write_tile_lds();
         if (STATS) block_stats_reduce(s_red, stat_part, tile, tid, lane, wave, 8, s0, s1, q0, q1);
@@ -1069,6 +1095,39 @@ COVA_API int cova_conv1_prep_weights(const float *w_oihw, float *w_k, void *stre
 
 // in/out NHWC [B,H,W,64]; w_t [9][64][64]; addend (nullable) is added to the result;
 // stat_part (nullable): [cova_conv3x3_num_tiles][2][64] per-tile channel sum / sum of squares.
+static int launch_conv3x3(const float *in, const float *w_t, const float *addend, float *out,
+                          float *stat_part, int B, int H, int W, const BnBwdEpi bn, void *stream)
+{
+    const int tiles_x = cdiv(W, c3::TW), tiles_y = cdiv(H, c3::TH);
+    const int ntiles = B * tiles_x * tiles_y;
+    const dim3 block(c3::THREADS), grid(persistent_grid(ntiles));
+    if (stat_part)
+        hipLaunchKernelGGL(conv3x3_c64_v2_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+    else
+        hipLaunchKernelGGL(conv3x3_c64_v2_kernel<false>, grid, block, 0, (hipStream_t)stream, in, w_t,
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// Data gradient of conv3x3 fused with the ReLU mask and the BatchNorm-backward reduction of the
+// layer in FRONT of the conv (a = relu(bn(z)) was the conv's input):
+//   out = dy = (conv(dz, w_dgrad) + addend) * (act > 0)
+//   stat_part[tile] = (sum dy, sum dy * (z - mean) * invstd) per channel
+// replaces cova_conv3x3_fwd(dgrad) + cova_bn_bwd_reduce; follow with cova_bn_finalize_bwd and
+// cova_bn_bwd_apply(dout = dy, act = NULL).
+COVA_API int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float *addend,
+                                      const float *act, const float *z, const float *mean,
+                                      const float *invstd, float *dy, float *stat_part, int B,
+                                      int H, int W, void *stream)
+{
+    COVA_REQUIRE(dz && w_dgrad && act && z && mean && invstd && dy && stat_part && B > 0 && H > 0 &&
+                 W > 0);
+    return launch_conv3x3(dz, w_dgrad, addend, dy, stat_part, B, H, W, BnBwdEpi{act, z, mean, invstd},
+                          stream);
+}
+
 COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *addend, float *out,
                               float *stat_part, int B, int H, int W, void *stream)
 {
@@ -1076,17 +1135,9 @@ COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *ad
     const int tiles_x = cdiv(W, c3::TW), tiles_y = cdiv(H, c3::TH);
     const int ntiles = B * tiles_x * tiles_y;
     const dim3 block(c3::THREADS);
-    if (g_conv3x3_variant == 2) {
-        const dim3 grid(persistent_grid(ntiles));
-        if (stat_part)
-            hipLaunchKernelGGL(conv3x3_c64_v2_kernel<true>, grid, block, 0, (hipStream_t)stream, in,
-                               w_t, addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles);
-        else
-            hipLaunchKernelGGL(conv3x3_c64_v2_kernel<false>, grid, block, 0, (hipStream_t)stream, in,
-                               w_t, addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles);
-        COVA_LAUNCH_CHECK();
-        return COVA_OK;
-    }
+    if (g_conv3x3_variant == 2)
+        return launch_conv3x3(in, w_t, addend, out, stat_part, B, H, W,
+                              BnBwdEpi{nullptr, nullptr, nullptr, nullptr}, stream);
     const dim3 grid(ntiles);
     if (stat_part)
         hipLaunchKernelGGL(conv3x3_c64_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,

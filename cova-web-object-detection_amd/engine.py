@@ -154,36 +154,69 @@ def convstack_fwd(images, params, buffers, training, save=True):
     return x, (sv if save else None)
 
 
+def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
+    """Finalize + apply when the (sum dy, sum dy*xhat) partials were produced by a fused conv
+    epilogue and ``dy`` is already ReLU-masked."""
+    C = st.C
+    dgamma = _gbuf(gout, prefix + "weight", (C,), z)
+    dbeta = _gbuf(gout, prefix + "bias", (C,), z)
+    coef = _empty((2, C), z)
+    part, nparts = fold_partials(part, nparts, 2 * C)
+    call("cova_bn_finalize_bwd", part, nparts, C, float(R), dgamma, dbeta, coef)
+    call("cova_bn_bwd_apply", dy, C, None, 0, z, C, st.mean, st.invstd, st.scale, coef, dz, C, None, 0,
+         R, C)
+    return dgamma, dbeta
+
+
 def convstack_bwd(sv, dfeat, gout=None):
-    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms."""
+    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms.
+
+    The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
+    in front of them in their epilogue (cova_conv3x3_dgrad_bnbwd), so only the last block's bn2
+    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     grads = {}
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
-    dA = dfeat
+    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    dA, pend = dfeat, None          # pend: partials of the fused reduction for dA (already masked)
     for blk in (1, 0):
         s = sv["blocks"][blk]
         ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
-        # out = relu(bn2(z2) + x)
-        dz2, dres = torch.empty_like(dA), torch.empty_like(dA)
-        dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres, C64,
-                             gout, BN3_KEYS[2 * blk + 1])
-        grads[BN3_KEYS[2 * blk + 1] + "weight"], grads[BN3_KEYS[2 * blk + 1] + "bias"] = dg, db
+        pa, pb = BN3_KEYS[2 * blk], BN3_KEYS[2 * blk + 1]
+        # ---- out = relu(bn2(z2) + x)
+        dz2 = torch.empty_like(dA)
+        if pend is None:
+            dres = torch.empty_like(dA)
+            dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres,
+                                 C64, gout, pb)
+        else:
+            dres = dA                                 # masked dy doubles as the residual gradient
+            dg, db = bn_bwd_from_partials(pend, nt, dA, s["z2"], s["bnb"], R, dz2, gout, pb)
+        grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
         call("cova_conv3x3_wgrad", s["a1"], dz2, dw, ws3, B, H2, W2)
         grads[kb + ".weight"] = dw
-        da1 = torch.empty_like(dA)
-        call("cova_conv3x3_fwd", dz2, sv["wd"][2 * blk + 1], None, da1, None, B, H2, W2)
-        # a1 = relu(bn1(z1))
-        dz1 = dz2   # reuse
-        dg, db = bn_backward(da1, C64, s["a1"], C64, s["z1"], C64, s["bna"], R, dz1, C64, None, 0,
-                             gout, BN3_KEYS[2 * blk])
-        grads[BN3_KEYS[2 * blk] + "weight"], grads[BN3_KEYS[2 * blk] + "bias"] = dg, db
+        # ---- a1 = relu(bn1(z1)): dgrad of conv2 fused with bn1's mask + reduction
+        dy_a = torch.empty_like(dA)
+        part = _empty((nt, 2, C64), dfeat)
+        bna = s["bna"]
+        call("cova_conv3x3_dgrad_bnbwd", dz2, sv["wd"][2 * blk + 1], None, s["a1"], s["z1"], bna.mean,
+             bna.invstd, dy_a, part, B, H2, W2)
+        dz1 = dz2                                     # reuse
+        dg, db = bn_bwd_from_partials(part, nt, dy_a, s["z1"], bna, R, dz1, gout, pa)
+        grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
         call("cova_conv3x3_wgrad", s["x"], dz1, dw, ws3, B, H2, W2)
         grads[ka + ".weight"] = dw
-        dx = da1    # reuse
-        call("cova_conv3x3_fwd", dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
+        dx = dy_a                                     # reuse
+        if blk == 1:
+            prev = sv["blocks"][0]                    # this block's input is prev's relu(bn2 + x)
+            pend = _empty((nt, 2, C64), dfeat)
+            call("cova_conv3x3_dgrad_bnbwd", dz1, sv["wd"][2 * blk], dres, prev["out"], prev["z2"],
+                 prev["bnb"].mean, prev["bnb"].invstd, dx, pend, B, H2, W2)
+        else:
+            call("cova_conv3x3_fwd", dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
         dA = dx
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]

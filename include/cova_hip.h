@@ -62,6 +62,12 @@ int cova_conv1_wgrad(const float *img, const float *dy /*NHWC*/, float *dw, floa
 int cova_conv3x3_num_tiles(int B, int H, int W);
 int cova_conv3x3_fwd(const float *in, const float *w_t, const float *addend, float *out,
                      float *stat_part, int B, int H, int W, void *stream);
+/* data gradient fused with the ReLU mask + BatchNorm-backward reduction of the layer in front of
+ * the conv: out = dy = (conv(dz,w_dgrad) + addend) * (act > 0); stat_part[tile][2][64] =
+ * (sum dy, sum dy*xhat).  Follow with cova_bn_finalize_bwd + cova_bn_bwd_apply(dout=dy, act=NULL). */
+int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float *addend,
+                             const float *act, const float *z, const float *mean, const float *invstd,
+                             float *dy, float *stat_part, int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);

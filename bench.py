@@ -120,12 +120,20 @@ def main():
         trainer.train_step(batch)
     barrier()
     _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": []}
+    if os.environ.get("COVA_PROFILE_ALL"):          # per-entry-point HIP-event timing (diagnostic)
+        _lib.PROFILE = {name: [] for name in _lib.lib().protos}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.PROFILE["cova_conv3x3_fwd"] + _lib.PROFILE["cova_conv3x3_dgrad_bnbwd"]
+    if os.environ.get("COVA_PROFILE_ALL") and rank == 0:
+        rows = [(sum(a.elapsed_time(b) for a, b in v) / args.steps, len(v) // args.steps, k)
+                for k, v in _lib.PROFILE.items() if v]
+        for ms, n, k in sorted(rows, reverse=True):
+            print("%-36s %3d calls/step %8.3f ms/step" % (k, n, ms), file=sys.stderr)
+        print("sum %.3f ms/step" % sum(r[0] for r in rows), file=sys.stderr)
     _lib.PROFILE = None
     if world > 1:
         import torch.distributed as dist

@@ -354,18 +354,35 @@ constexpr int PCH = 36;                        // columns per parity plane (35 u
 constexpr int RSTR = 2 * PCH;                  // 72 floats per staged row (even | odd columns)
 constexpr int CSTR = PR * RSTR;                // 1512 floats per channel plane
 constexpr int IN_FLOATS = 3 * CSTR;            // 4536 floats
-constexpr int KROWS = 148;
-constexpr int W_FLOATS = KROWS * 64;           // 9472 floats
+// K ordering: 77 k-pairs (p, h) -> tap, chosen so that the two half-waves of an MFMA (h = lane>>5)
+// read LDS at a CONSTANT distance from each other within each of three sets; every operand read
+// is then `per-lane base + immediate` (no per-tap address registers):
+//   p =  0..48: (c=0, t=p)        | (c=1, t=p)          distance CSTR
+//   p = 49..69: (c=2, kh=j/7, kw) | (c=2, kh+4, kw)      distance 4*RSTR   (j = p-49, kh = 0..2)
+//   p = 70..76: (c=2, kh=3, kw)   | zero weight                            (kw = p-70)
+constexpr int NPAIR = 77;
+constexpr int KROWS = 2 * NPAIR;               // 154 weight rows (7 of them zero)
+constexpr int W_FLOATS = KROWS * 64;           // 9856 floats
 constexpr int THREADS = 512;
-// LDS offset of tap k = (c, kh, kw) relative to the lane's pixel origin
+__host__ __device__ constexpr int pair_tap(int p, int h)
+{
+    return p < 49 ? h * 49 + p
+                  : p < 70 ? 98 + ((p - 49) / 7 + 4 * h) * 7 + (p - 49) % 7
+                           : (h == 0 ? 98 + 21 + (p - 70) : -1);
+}
+// LDS offset of tap t = kh*7+kw inside one channel plane, relative to the lane's pixel origin
+__host__ __device__ constexpr int local_off(int t)
+{
+    return (t / 7) * RSTR + ((t % 7) & 1) * PCH + ((t % 7) >> 1);
+}
+// LDS offset of tap k = (c, kh, kw) relative to the lane's pixel origin (k < 0: any valid address)
 __host__ __device__ constexpr int tap_off(int k)
 {
-    return k >= 147 ? 0
-                    : (k / 49) * CSTR + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH + ((k % 7) >> 1);
+    return k < 0 ? 0 : (k / 49) * CSTR + local_off(k % 49);
 }
 }  // namespace c1
 
-// wk: [148][64] (k = c*49 + kh*7 + kw, row 147 = 0)
+// wk: [154][64], row 2p+h = weights of tap c1::pair_tap(p, h) (zero row if none)
 template <bool STATS>
 __global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
@@ -405,8 +422,8 @@ __global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
     const float *a_base = s_in + (2 * wave) * RSTR + li;   // output (row wave, col li) origin
     const float *b_base = s_w + kh2 * 64 + li;
 #pragma unroll
-    for (int kk = 0; kk < 74; ++kk) {
-        const int off = kh2 ? tap_off(2 * kk + 1) : tap_off(2 * kk);
+    for (int kk = 0; kk < NPAIR; ++kk) {
+        const int off = kh2 ? tap_off(pair_tap(kk, 1)) : tap_off(pair_tap(kk, 0));
         const float a = a_base[off];
         const float b0 = b_base[kk * 128];
         const float b1 = b_base[kk * 128 + 32];
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// conv1 v2: persistent blocks (2 per CU); the 148x64 weight matrix stays resident in LDS for the
+// conv1 v2: persistent blocks (2 per CU); the 154x64 weight matrix stays resident in LDS for the
 // whole launch, the next tile's image patch is prefetched into registers during the MFMAs.
 // ------------------------------------------------------------------------------------
 namespace c1 {
@@ -483,7 +500,10 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     write_lds();
     __syncthreads();
 
-    const float *a_base = s_in + (2 * wave) * RSTR + li;
+    const float *a_org = s_in + (2 * wave) * RSTR + li;          // this lane's output pixel
+    const float *a_set0 = a_org + kh2 * CSTR;                    // c=0 | c=1
+    const float *a_set1 = a_org + 2 * CSTR + kh2 * 4 * RSTR;     // c=2, kh | kh+4
+    const float *a_set2 = a_org + 2 * CSTR;                      // c=2, kh=3 | zero weight
     const float *b_base = s_w + kh2 * 64 + li;
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x;
@@ -498,20 +518,24 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        float a_cur = a_base[kh2 ? tap_off(1) : tap_off(0)];
-        float b0_cur = b_base[0], b1_cur = b_base[32];
+        // every LDS operand address is a per-lane base + a compile-time immediate (see pair_tap)
 #pragma unroll
-        for (int kk = 0; kk < 74; ++kk) {
-            const int kn = kk < 73 ? kk + 1 : kk;
-            const int off = kh2 ? tap_off(2 * kn + 1) : tap_off(2 * kn);
-            const float a_nxt = a_base[off];
-            const float b0_nxt = b_base[kn * 128];
-            const float b1_nxt = b_base[kn * 128 + 32];
-            acc0 = mfma32(a_cur, b0_cur, acc0);
-            acc1 = mfma32(a_cur, b1_cur, acc1);
-            a_cur = a_nxt;
-            b0_cur = b0_nxt;
-            b1_cur = b1_nxt;
+        for (int p = 0; p < 49; ++p) {
+            const float a = a_set0[local_off(p)];
+            acc0 = mfma32(a, b_base[p * 128], acc0);
+            acc1 = mfma32(a, b_base[p * 128 + 32], acc1);
+        }
+#pragma unroll
+        for (int j = 0; j < 21; ++j) {
+            const float a = a_set1[local_off(j)];
+            acc0 = mfma32(a, b_base[(49 + j) * 128], acc0);
+            acc1 = mfma32(a, b_base[(49 + j) * 128 + 32], acc1);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float a = a_set2[local_off(21 + j)];
+            acc0 = mfma32(a, b_base[(70 + j) * 128], acc0);
+            acc1 = mfma32(a, b_base[(70 + j) * 128 + 32], acc1);
         }
         const int oy = y0 + wave;
         float s0, s1, q0, q1;
@@ -542,10 +566,11 @@ __global__ void prep_w3x3_kernel(const float *__restrict__ w, float *__restrict_
 
 __global__ void prep_w7x7_kernel(const float *__restrict__ w, float *__restrict__ wk)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [148][64]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over [154][64]
     if (idx >= c1::W_FLOATS) return;
-    const int k = idx >> 6, co = idx & 63;
-    wk[idx] = (k < 147) ? w[co * 147 + k] : 0.f;             // w[co][c][kh][kw], k = c*49+kh*7+kw
+    const int row = idx >> 6, co = idx & 63;
+    const int tap = c1::pair_tap(row >> 1, row & 1);         // w[co][c][kh][kw], tap = c*49+kh*7+kw
+    wk[idx] = tap >= 0 ? w[co * 147 + tap] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1149,7 +1174,7 @@ COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *ad
     return COVA_OK;
 }
 
-// img NCHW [B,3,H,W]; w_k [148][64]; out NHWC [B,H1,W1,64]
+// img NCHW [B,3,H,W]; w_k [154][64]; out NHWC [B,H1,W1,64]
 COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part,
                             int B, int H, int W, void *stream)
 {

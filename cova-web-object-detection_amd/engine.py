@@ -112,7 +112,7 @@ def convstack_fwd(images, params, buffers, training, save=True):
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2)}
-    w1k = _empty((148, 64), images)
+    w1k = _empty((154, 64), images)
     call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
     wf, wd = [], []
     for k in CONV3_KEYS:

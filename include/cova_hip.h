@@ -42,7 +42,7 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
-int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[148,64]*/, void *stream);
+int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[154,64]*/, void *stream);
 int cova_conv3x3_prep_weights(const float *w_oihw /*[64,64,3,3]*/, float *w_fwd /*[9,64,64]*/,
                               float *w_dgrad /*[9,64,64]*/, void *stream);
 

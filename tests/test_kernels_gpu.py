@@ -89,7 +89,7 @@ def test_conv1_fwd_wgrad(B, H, W):
     g = torch.Generator().manual_seed(H + W)
     x = torch.rand(B, 3, H, W, generator=g)
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
-    wk = torch.empty(148, 64, device=DEV)
+    wk = torch.empty(154, 64, device=DEV)
     call("cova_conv1_prep_weights", w.to(DEV), wk)
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
     nt = query("cova_conv1_num_tiles", B, H, W)
@@ -341,7 +341,7 @@ def test_conv1_variants_multi_tile():
     H1, W1 = ref.shape[2], ref.shape[3]
     dy = torch.randn(B, 64, H1, W1, generator=g)
     (ref * dy).sum().backward()
-    wk = torch.empty(148, 64, device=DEV)
+    wk = torch.empty(154, 64, device=DEV)
     call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
     nt = query("cova_conv1_num_tiles", B, H, W)
     ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)

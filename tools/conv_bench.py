@@ -44,7 +44,7 @@ for variant in (1, 2):
     print("conv3x3 wgrad v%d (+reduce): %.3f ms  %.1f TF/s" % (variant, t, flop3 / t / 1e9))
 img = torch.rand(B, 3, 1280, 1280, device=dev)
 w1 = torch.randn(64, 3, 7, 7, device=dev) * 0.1
-wk = torch.empty(148, 64, device=dev)
+wk = torch.empty(154, 64, device=dev)
 call("cova_conv1_prep_weights", w1, wk)
 y1 = torch.empty(B, 640, 640, 64, device=dev)
 part1 = torch.empty(query("cova_conv1_num_tiles", B, 1280, 1280), 2, 64, device=dev)

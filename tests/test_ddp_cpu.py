@@ -1,0 +1,89 @@
+"""N > 1 path on CPU (gloo, world_size 2): page sharding, the flat gradient bucket and its single
+all-reduce.  The HIP kernels cannot run here, so each rank's local gradients come from the CPU
+oracle (test infrastructure); what is under test is the host logic of trainer.py that the GPU
+path uses unchanged (FlatBucket, shard_batch, all_reduce_sum)."""
+import os
+import socket
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import cova_amd  # noqa: E402,F401  (spawned workers re-import this module without conftest.py)
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cova_web_object_detection_amd import synthetic, weights
+from cova_web_object_detection_amd.trainer import FlatBucket, is_param_key, shard_batch, shard_pages
+from oracle import cova_oracle as O
+
+CFG = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=32,
+           bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_grads(batch):
+    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(9, **wcfg)
+    _, _, grads, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
+                                         batch["context_indices"], batch["labels"], CFG, None)
+    return sd, grads
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    full = synthetic.make_batch(4, img_h=64, boxes_per_page=[11, 20, 15, 30], context_size=4, seed=9)
+    shard = shard_batch(full, rank, world)
+    sd, grads = _local_grads(shard)
+    bucket = FlatBucket({k: tuple(v.shape) for k, v in sd.items() if is_param_key(k)}, "cpu")
+    for k, g in grads.items():
+        bucket.views[k].copy_(g)
+    bucket.all_reduce_sum()
+    torch.save({k: v.clone() for k, v in bucket.views.items()}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_shard_pages_and_rebase():
+    assert [shard_pages(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [shard_pages(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
+    full = synthetic.make_batch(4, img_h=32, boxes_per_page=[11, 20, 15, 30], context_size=4, seed=3)
+    s1 = shard_batch(full, 1, 2)
+    assert s1["images"].shape[0] == 2 and s1["bboxes"].shape[0] == 45
+    assert set(s1["bboxes"][:, 0].tolist()) == {0.0, 1.0}
+    ref = synthetic.collate_context([synthetic.context_window_indices(n, 4) for n in (15, 30)])
+    assert np.array_equal(s1["context_indices"].numpy(), ref)
+    assert torch.equal(s1["labels"], full["labels"][31:])
+
+
+def test_flat_bucket_views_alias_one_buffer():
+    shapes = {"a": (3, 5), "b": (7,), "c": (2, 2, 2)}
+    b = FlatBucket(shapes, "cpu")
+    b.views["b"].fill_(2.0)
+    assert b.flat.sum().item() == 14.0 and b.flat.numel() % 4 == 0
+    assert all(v.data_ptr() % 16 == 0 for v in b.views.values())
+
+
+@pytest.mark.timeout(300)
+def test_gloo_allreduce_of_flat_bucket_equals_sum_of_shard_gradients(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    full = synthetic.make_batch(4, img_h=64, boxes_per_page=[11, 20, 15, 30], context_size=4, seed=9)
+    expect = None
+    for r in range(world):
+        _, g = _local_grads(shard_batch(full, r, world))
+        expect = g if expect is None else {k: expect[k] + g[k] for k in g}
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world))
+    for k, v in expect.items():
+        assert torch.equal(r0[k], r1[k]), k                       # every rank holds the same sum
+        assert torch.allclose(r0[k], v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max()))), k  # thread-count dependent summation order

@@ -180,3 +180,52 @@ def test_module_surface_and_no_cpu_fallback():
     m2 = CoVA((3, 3), 64, 4, False, 384, 32, 0, 0.0, None).to(DEV)   # use_context=False branch
     out = m2(args[0], args[1], args[2], torch.empty((0, 0), dtype=torch.long, device=DEV))
     assert out.shape == (11, 4)
+
+
+def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
+    """The loop of train.py:42-60 (zero_grad, forward, CrossEntropyLoss(sum), backward,
+    torch.optim.Adam(lr 5e-4, weight_decay 1e-3) as in main.py:133-139) driving the drop-in module,
+    against (a) HotPathTrainer (fused CE + flat-buffer Adam kernel) and (b) the CPU oracle."""
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=64,
+               bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.0)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(31, logit_gain=2.0, **wcfg)
+    batch = synthetic.make_batch(2, img_h=64, boxes_per_page=[25, 14], context_size=12, seed=31)
+    args = dev_batch(batch)
+    labels = batch["labels"].to(DEV)
+    # (1) reference-style loop on the nn.Module
+    m = build(cfg, 64, sd)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, weight_decay=1e-3)
+    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m(*args)
+        pred = out.argmax(dim=1)
+        loss = crit(out, labels)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    # (2) fused trainer
+    tr = HotPathTrainer(cfg, sd, DEV)
+    dbatch = dict(images=args[0], bboxes=args[1], additional_feats=args[2], context_indices=args[3],
+                  labels=labels)
+    tlosses = [tr.train_step(dbatch)[0].item() for _ in range(3)]
+    for a, b in zip(losses, tlosses):
+        assert abs(a - b) <= 1e-3 * abs(a), (losses, tlosses)
+    tsd = tr.state_dict()
+    # Adam turns a ~0 gradient (round-off noise on shift-invariant parameters) into a +-lr step
+    # of arbitrary sign, so parameters can only be compared to within steps * lr; the loss
+    # trajectory above is the tight check.
+    for k, v in m.state_dict().items():
+        if v.dtype == torch.float32:
+            assert float((v - tsd[k]).abs().max()) <= 2 * 3 * 5e-4 + 1e-3 * float(v.abs().max()), k
+    # (3) first step vs the oracle (loss, and Adam's first update has magnitude ~lr everywhere)
+    loss_ref, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"],
+                                                    batch["additional_feats"], batch["context_indices"],
+                                                    batch["labels"], cfg, None)
+    assert abs(losses[0] - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    logits, pred = tr.predict(dbatch)
+    assert logits.shape == (39, 4) and torch.equal(pred, logits.argmax(1))

@@ -498,6 +498,87 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_win_kernel(
     }
 }
 
+// Quad form of the PASS 1 kernel: one thread per (pooling window, 4 channels) produces the 2x2 input
+// pixels (2oy..2oy+1, 2ox..2ox+1).  Those four pixels only receive gradient from the windows
+// (oy..oy+1, ox..ox+1), so 4 dp + 4 idx + 4 y loads (all independent) serve 4 outputs, instead of
+// up to 9 dependent loads per output pixel.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_quad_kernel(
+    const float *__restrict__ dp, const uint8_t *__restrict__ idx, const float *__restrict__ y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ coef, float *__restrict__ dz, int B, int H1, int W1, int H2, int W2)
+{
+    const int c4 = threadIdx.x & 15;
+    const float4 sc4 = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    const float4 sh4 = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+    const float4 mu4 = *reinterpret_cast<const float4 *>(mean + c4 * 4);
+    const float4 is4 = *reinterpret_cast<const float4 *>(invstd + c4 * 4);
+    const float4 k14 = *reinterpret_cast<const float4 *>(coef + c4 * 4);
+    const float4 k24 = *reinterpret_cast<const float4 *>(coef + 64 + c4 * 4);
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    const float k1[4] = {k14.x, k14.y, k14.z, k14.w}, k2[4] = {k24.x, k24.y, k24.z, k24.w};
+    const long long nwin = (long long)B * H2 * W2;
+    for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; p < nwin;
+         p += ((long long)gridDim.x * blockDim.x) >> 4) {
+        const int ox = (int)(p % W2);
+        const long long pr = p / W2;
+        const int oy = (int)(pr % H2);
+        const int b = (int)(pr / H2);
+        // the 2x2 windows (oy+i, ox+j)
+        float g[2][2][4];
+        int id[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = (oy + i < H2) && (ox + j < W2);
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                uchar4 iv = make_uchar4(255, 255, 255, 255);
+                if (ok) {
+                    const size_t o = (((size_t)b * H2 + oy + i) * W2 + ox + j) * 64 + c4 * 4;
+                    gv = *reinterpret_cast<const float4 *>(dp + o);
+                    iv = *reinterpret_cast<const uchar4 *>(idx + o);
+                }
+                g[i][j][0] = gv.x; g[i][j][1] = gv.y; g[i][j][2] = gv.z; g[i][j][3] = gv.w;
+                id[i][j][0] = iv.x; id[i][j][1] = iv.y; id[i][j][2] = iv.z; id[i][j][3] = iv.w;
+            }
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const int Y = 2 * oy + py;
+            if (Y >= H1) continue;
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int X = 2 * ox + px;
+                if (X >= W1) continue;
+                const size_t o = (((size_t)b * H1 + Y) * W1 + X) * 64 + c4 * 4;
+                const float4 yv4 = *reinterpret_cast<const float4 *>(y + o);
+                const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+                float out[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float dy = 0.f;
+                    // window rows: py == 0 -> (oy, ky=1); py == 1 -> (oy, ky=2), (oy+1, ky=0)
+#pragma unroll
+                    for (int i = 0; i <= py; ++i) {
+                        const int ky = py == 0 ? 1 : (i == 0 ? 2 : 0);
+#pragma unroll
+                        for (int j = 0; j <= px; ++j) {
+                            const int kx = px == 0 ? 1 : (j == 0 ? 2 : 0);
+                            if (id[i][j][c] == ky * 3 + kx) dy += g[i][j][c];
+                        }
+                    }
+                    const float t = yv[c] * sc[c] + sh[c];
+                    if (!(t > 0.f)) dy = 0.f;
+                    const float xh = (yv[c] - mu[c]) * is[c];
+                    out[c] = sc[c] * (dy - k1[c] - xh * k2[c]);
+                }
+                *reinterpret_cast<float4 *>(dz + o) = make_float4(out[0], out[1], out[2], out[3]);
+            }
+        }
+    }
+}
+
 inline int ew_grid(long long total_threads)
 {
     long long g = cdivll(total_threads, 256);
@@ -704,9 +785,9 @@ COVA_API int cova_bn_relu_maxpool_bwd_apply(const float *dp, const uint8_t *idx,
 {
     COVA_REQUIRE(dp && idx && y && scale && shift && mean && invstd && coef && dz);
     const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
-    const int grid = ew_grid((long long)B * H1 * W1 * 16);
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       dp, idx, y, scale, shift, mean, invstd, coef, dz, (float *)nullptr, B, H1, W1,
+    const int grid = ew_grid((long long)B * H2 * W2 * 16);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_quad_kernel, dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, dp, idx, y, scale, shift, mean, invstd, coef, dz, B, H1, W1,
                        H2, W2);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

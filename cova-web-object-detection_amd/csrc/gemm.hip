@@ -6,22 +6,73 @@
 //   C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 //   transA = 0: A is [M,K] (lda >= K);  transA = 1: A is stored [K,M] (lda >= M)
 //   transB = 0: B is [K,N] (ldb >= N);  transB = 1: B is stored [N,K] (ldb >= K)
-// Block tile 64x64, BK = 16, 4 waves (2x2), each wave one 32x32 accumulator.  LDS tiles are
-// k-major ([k][m]) so that MFMA operand reads are conflict-free ds_read_b32 across lanes.
+// Block tile 64x64, BK = 32, 4 waves (2x2), each wave one 32x32 accumulator.  LDS tiles are
+// k-major ([k][m]) so that MFMA operand reads are conflict-free ds_read_b32 across lanes; the
+// next k-tile is fetched into registers (2 x float4 per operand per thread) while the current one
+// feeds 16 MFMAs per wave.  ~3 GFLOP per call on this path: latency bound, not roofline relevant.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 65;   // +1 pad: transposing stores spread banks
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 68;
+
+// Fetch this thread's 8 elements of a (rows x BK) operand tile.
+//  k-contiguous storage (X[row][k]):   thread -> row = tid & 63, k = (tid >> 6) * 8 .. +7
+//  row-contiguous storage (X[k][row]): thread -> k = tid >> 3,   row = (tid & 7) * 8 .. +7
+template <bool KCONTIG>
+__device__ __forceinline__ void fetch8(const float *__restrict__ X, int ld, int row0, int nrows,
+                                       int k0, int K, int tid, bool vec_ok, float (&v)[8])
+{
+    if (KCONTIG) {
+        const int r = row0 + (tid & 63), k = k0 + (tid >> 6) * 8;
+        const float *p = X + (size_t)r * ld + k;
+        if (vec_ok && r < nrows && k + 7 < K) {
+            const float4 a = *reinterpret_cast<const float4 *>(p);
+            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r < nrows && k + j < K) ? p[j] : 0.f;
+        }
+    } else {
+        const int k = k0 + (tid >> 3), r = row0 + (tid & 7) * 8;
+        const float *p = X + (size_t)k * ld + r;
+        if (vec_ok && k < K && r + 7 < nrows) {
+            const float4 a = *reinterpret_cast<const float4 *>(p);
+            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (k < K && r + j < nrows) ? p[j] : 0.f;
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void stash8(float (*S)[LDT], int tid, const float (&v)[8])
+{
+    if (KCONTIG) {
+        const int r = tid & 63, k = (tid >> 6) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[k + j][r] = v[j];
+    } else {
+        const int k = tid >> 3, r = (tid & 7) * 8;
+        *reinterpret_cast<float4 *>(&S[k][r]) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(&S[k][r + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A, int lda,
                                                     const float *__restrict__ Bm, int ldb,
                                                     float *__restrict__ C, int ldc,
                                                     const float *__restrict__ bias, int M, int N,
-                                                    int K, int accumulate)
+                                                    int K, int accumulate, int vecA, int vecB)
 {
-    __shared__ float As[BK][LDT], Bs[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -30,51 +81,26 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // A tile: rows = m; stored k-contiguous unless transposed.  B tile: rows = n; stored
+    // k-contiguous when transB (B is [N,K]).
+    float va[8], vb[8];
+    fetch8<!TA>(A, lda, m0, M, 0, K, tid, vecA != 0, va);
+    fetch8<TB>(Bm, ldb, n0, N, 0, K, tid, vecB != 0, vb);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        // ---- stage A tile (BM x BK) as As[k][m]
-        if (!TA) {
-            const int r = tid >> 2, kq = (tid & 3) * 4;     // row r, 4 consecutive k
-            const int gm = m0 + r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gk = k0 + kq + j;
-                As[kq + j][r] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
-            }
-        } else {
-            const int kk = tid >> 4, mq = (tid & 15) * 4;   // k row kk, 4 consecutive m
-            const int gk = k0 + kk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gm = m0 + mq + j;
-                As[kk][mq + j] = (gm < M && gk < K) ? A[(size_t)gk * lda + gm] : 0.f;
-            }
-        }
-        // ---- stage B tile (BK x BN) as Bs[k][n]
-        if (TB) {
-            const int r = tid >> 2, kq = (tid & 3) * 4;     // n row r of stored [N,K]
-            const int gn = n0 + r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gk = k0 + kq + j;
-                Bs[kq + j][r] = (gn < N && gk < K) ? Bm[(size_t)gn * ldb + gk] : 0.f;
-            }
-        } else {
-            const int kk = tid >> 4, nq = (tid & 15) * 4;
-            const int gk = k0 + kk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + nq + j;
-                Bs[kk][nq + j] = (gn < N && gk < K) ? Bm[(size_t)gk * ldb + gn] : 0.f;
-            }
-        }
+        __syncthreads();                    // previous tile fully consumed
+        stash8<!TA>(As, tid, va);
+        stash8<TB>(Bs, tid, vb);
         __syncthreads();
+        if (k0 + BK < K) {                  // next tile in flight while this one computes
+            fetch8<!TA>(A, lda, m0, M, k0 + BK, K, tid, vecA != 0, va);
+            fetch8<TB>(Bm, ldb, n0, N, k0 + BK, K, tid, vecB != 0, vb);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const float a = As[2 * kk + kh2][wm * 32 + li];
             const float b = Bs[2 * kk + kh2][wn * 32 + li];
             acc = mfma32(a, b, acc);
         }
-        __syncthreads();
     }
     const int gn = n0 + wn * 32 + li;
     if (gn < N) {
@@ -92,6 +118,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A,
     }
 }
 
+inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
+
 }  // namespace
 
 COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda,
@@ -102,14 +130,15 @@ COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float
     if (M == 0 || N == 0) return COVA_OK;
     const dim3 grid(cdiv(N, BN), cdiv(M, BM)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const int va = vec_ok(A, lda), vb = vec_ok(B, ldb);
     if (!transA && !transB)
-        hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
+        hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
     else if (!transA && transB)
-        hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
+        hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
     else if (transA && !transB)
-        hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
+        hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
     else
-        hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
+        hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -112,6 +112,30 @@ class _MaxPool3x3s2Fn(torch.autograd.Function):
         return gin.view(B, C, H, W), None
 
 
+class _ReluFn(torch.autograd.Function):
+    """ReLU whose BACKWARD gate can be forced (forward is always relu(x)).
+
+    A ReLU gate is a discrete decision: two fp32 implementations that sum in different orders
+    disagree on it whenever the pre-activation is within round-off of zero (a handful of the ~1e7
+    gates of a batch).  Gradient parity is only meaningful for identical decisions, so the tests
+    hand the gates taken by the implementation under test to the oracle's backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, forced_gate=None):
+        gate = (x > 0) if forced_gate is None else forced_gate.to(torch.bool)
+        ctx.save_for_backward(gate)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        return g * gate.to(g.dtype), None
+
+
+def _relu(x, routing, key):
+    return _ReluFn.apply(x, routing.get(key) if routing else None)
+
+
 def pool_window_pos_to_flat(idx_nhwc_u8, H1, W1):
     """uint8 window positions (ky*3+kx, NHWC [B,H2,W2,C]) -> flat input indices NCHW [B,C,H2,W2]."""
     pos = idx_nhwc_u8.permute(0, 3, 1, 2).long()
@@ -161,19 +185,21 @@ def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def convnet(images, sd, training, forced_pool_idx=None):
-    """conv1 -> bn1 -> relu -> maxpool -> layer1 (models.py:49-51); [B,3,H,W] -> [B,64,H/4,W/4]."""
+def convnet(images, sd, training, routing=None):
+    """conv1 -> bn1 -> relu -> maxpool -> layer1 (models.py:49-51); [B,3,H,W] -> [B,64,H/4,W/4].
+    ``routing`` (tests only): forced max-pool indices / ReLU gates for the backward pass."""
+    routing = routing or {}
     x = F.conv2d(images, sd["convnet.0.weight"], None, stride=2, padding=3)
-    x = F.relu(_bn(x, sd, "convnet.1.", training))
-    x = _MaxPool3x3s2Fn.apply(x, forced_pool_idx)
+    x = _relu(_bn(x, sd, "convnet.1.", training), routing, "gate_bn1")
+    x = _MaxPool3x3s2Fn.apply(x, routing.get("pool_idx"))
     for blk in (0, 1):
         p = "convnet.4.%d." % blk
         idt = x
         y = F.conv2d(x, sd[p + "conv1.weight"], None, stride=1, padding=1)
-        y = F.relu(_bn(y, sd, p + "bn1.", training))
+        y = _relu(_bn(y, sd, p + "bn1.", training), routing, "gate_a1_%d" % blk)
         y = F.conv2d(y, sd[p + "conv2.weight"], None, stride=1, padding=1)
         y = _bn(y, sd, p + "bn2.", training)
-        x = F.relu(y + idt)
+        x = _relu(y + idt, routing, "gate_out_%d" % blk)
     return x
 
 
@@ -226,14 +252,14 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     hf = feature_map_size(img_h)
     scale = hf / img_h                                      # models.py:56
     routing = routing or {}
-    feat = convnet(images, sd, training, routing.get("pool_idx"))
+    feat = convnet(images, sd, training, routing)
     visual = roi_pool(feat, bboxes, roi, scale, routing.get("roi_argmax")).reshape(
         bboxes.shape[0], -1)                                                   # models.py:125
     parts = [visual]
     if cfg.get("bbox_hidden_dim", 32) > 0:
         raw = bbox_features_raw(bboxes)
         z = F.linear(raw, sd["bbox_feat_encoder.0.weight"], sd["bbox_feat_encoder.0.bias"])
-        parts.append(F.relu(_bn(z, sd, "bbox_feat_encoder.1.", training)))
+        parts.append(_relu(_bn(z, sd, "bbox_feat_encoder.1.", training), routing, "gate_bbox"))
     else:
         parts.append(bboxes[:, :0])
     if cfg.get("n_additional_feat", 0) > 0:
@@ -253,7 +279,7 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     if training and drop_masks is not None:
         x = x * drop_masks[0] / (1.0 - p)
     x = F.linear(x, sd["decoder.1.weight"], sd["decoder.1.bias"])
-    x = F.relu(_bn(x, sd, "decoder.2.", training))
+    x = _relu(_bn(x, sd, "decoder.2.", training), routing, "gate_dec")
     if training and drop_masks is not None:
         x = x * drop_masks[1] / (1.0 - p)
     logits = F.linear(x, sd["decoder.5.weight"], sd["decoder.5.bias"])

@@ -115,9 +115,9 @@ def test_full_model_matches_reference_fixture(name):
     b = batch
     _, _, grads_ref, after, inter = O.loss_and_grads(sd, b["images"], b["bboxes"], b["additional_feats"],
                                                      b["context_indices"], b["labels"], cfg, None, routing)
-    # 2e-3: max-pool / RoIPool routing is forced, but ReLU gates of pre-activations within ~1e-6
-    # of zero can still open on one side only (a handful of the ~1e6 gates per batch)
-    compare_grads(grads, grads_ref, rtol=2e-3)
+    # every discrete decision of the HIP forward (max-pool / RoIPool argmax, ReLU gates) is forced
+    # in the oracle's backward, so what remains is fp32 round-off: 2e-4 of each tensor's scale
+    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
     assert_routing_near_ties(routing, inter, b["bboxes"], (3, 3), m.roi_pool.spatial_scale)
     for k, buf in m.named_buffers():
         if "buf/" + k in fx:
@@ -151,7 +151,7 @@ def test_fused_loss_and_engine_step_match_oracle():
     assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
     assert relerr(logits.cpu(), logits_ref) < 2e-4
     assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
-    compare_grads(grads, grads_ref, rtol=2e-3)
+    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
     for k in buffers:
         if not k.endswith("num_batches_tracked"):
             assert relerr(buffers[k].cpu(), after[k]) < 1e-4, k
@@ -219,9 +219,12 @@ def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
     # Adam turns a ~0 gradient (round-off noise on shift-invariant parameters) into a +-lr step
     # of arbitrary sign, so parameters can only be compared to within steps * lr; the loss
     # trajectory above is the tight check.
-    for k, v in m.state_dict().items():
-        if v.dtype == torch.float32:
-            assert float((v - tsd[k]).abs().max()) <= 2 * 3 * 5e-4 + 1e-3 * float(v.abs().max()), k
+    # (running statistics are not compared: they integrate the +-lr noise of the zero-gradient
+    # parameters, e.g. gat.W_i, through the forward pass)
+    bad = {k: float((v - tsd[k]).abs().max()) for k, v in m.named_parameters()
+           if float((v - tsd[k]).abs().max()) > 2 * 3 * 5e-4 + 1e-3 * float(v.abs().max())}
+    assert not bad, bad
+    assert all(torch.isfinite(v).all() for v in tsd.values())
     # (3) first step vs the oracle (loss, and Adam's first update has magnitude ~lr everywhere)
     loss_ref, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"],
                                                     batch["additional_feats"], batch["context_indices"],

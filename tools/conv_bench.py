@@ -36,7 +36,12 @@ for variant in (1, 2):
     for stats in (False, True):
         t = timeit(lambda: call("cova_conv3x3_fwd", x, wf, None, out, part if stats else None, B, H, W))
         print("conv3x3 fwd v%d stats=%d: %.3f ms  %.1f TF/s" % (variant, stats, t, flop3 / t / 1e9))
+sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+mean, invstd = torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5
+t = timeit(lambda: call("cova_conv3x3_dgrad_bnbwd", dz, wd, x, x, dz, mean, invstd, out, part, B, H, W))
+print("conv3x3 dgrad_bnbwd (+addend, act): %.3f ms  %.1f TF/s" % (t, flop3 / t / 1e9))
 ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=dev)
+
 dw = torch.empty(64, 64, 3, 3, device=dev)
 for variant in (1, 2):
     query("cova_set_option", 3, variant)

@@ -7,13 +7,14 @@ from cova_web_object_detection_amd import engine, synthetic, weights
 from oracle import cova_oracle as O
 
 img_h = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-boxes = [40, 23]
+boxes = [int(b) for b in os.environ.get("BOXES", "40,23").split(",")]
+seed = int(os.environ.get("SEED", 123))
 dev = "cuda:0"
 cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
            bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.0)
 wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
-sd = weights.seeded_state_dict(123, logit_gain=4.0, **wcfg)
-batch = synthetic.make_batch(2, img_h=img_h, boxes_per_page=boxes, context_size=12, seed=123)
+sd = weights.seeded_state_dict(seed, logit_gain=4.0, **wcfg)
+batch = synthetic.make_batch(len(boxes), img_h=img_h, boxes_per_page=boxes, context_size=12, seed=seed)
 keys = O.param_keys(sd)
 loss_ref, logits_ref, grads_ref, _, _ = O.loss_and_grads(
     sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
@@ -29,6 +30,13 @@ for trial in range(2):
     args = [batch[k].to(dev) for k in ("images", "bboxes", "additional_feats", "context_indices")]
     logits, sv = engine.model_fwd(cfg, params, buffers, *args, True)
     loss, dl, pred = engine.ce_sum(logits, batch["labels"].to(dev))
+    if trial == 0 and os.environ.get("FORCED"):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from helpers import routing_from_saved
+        routing = routing_from_saved(sv)
+        loss_ref, logits_ref, grads_ref, _, _ = O.loss_and_grads(
+            sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
+            batch["labels"], cfg, None, routing)
     grads = engine.model_bwd(sv, dl, params)
     gscale = max(float(g.abs().max()) for g in grads_ref.values())
     print("trial", trial, "loss", loss.item(), float(loss_ref), "gscale", gscale)

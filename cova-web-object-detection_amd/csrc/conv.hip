@@ -228,7 +228,11 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh2 = lane >> 5;
     const int pco = tid >> 4, pc4 = tid & 15;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order, speed only), so give
+    // each XCD a contiguous run of tiles per round -- neighbouring tiles then share halo rows in
+    // one L2 instead of fetching them through eight.
     int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
 
     float4 pre[NPRE];

@@ -218,8 +218,10 @@ template <bool STATS>
 __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
     const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
-    int ntiles, const BnBwdEpi bn)
+    int ntiles, const BnBwdEpi bn, int abl)
 {
+    // abl: ablation mask for tools/conv_bench.py (0 in production): 1 no epilogue, 2 no LDS refill,
+    // 4 no input prefetch loads, 8 no weight restaging, 16 no per-tap barrier
     using namespace c3;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + RED_FLOATS];
     float *s_in = lds;
@@ -236,22 +238,24 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
     if (tile >= ntiles) return;
 
     float4 pre[NPRE];
+    // slot `it` of the halo'd input tile of tile t (tile coordinates passed in as scalars)
+    auto issue_slot = [&](int it, const float *in_b, int ty, int tx) {
+        const int idx = tid + it * THREADS;
+        const int px = idx >> 4, c4 = idx & 15;
+        const int r = px / PW, c = px - r * PW;
+        const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < PH * PW * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+        pre[it] = v;
+    };
     auto issue_tile_loads = [&](int t) {
         const int tx = t % tiles_x;
         const int ty = (t / tiles_x) % tiles_y;
         const int b = t / (tiles_x * tiles_y);
         const float *in_b = in + (size_t)b * H * W * 64;
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
-            const int idx = tid + it * THREADS;
-            const int px = idx >> 4, c4 = idx & 15;
-            const int r = px / PW, c = px - r * PW;
-            const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < PH * PW * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-            pre[it] = v;
-        }
+        for (int it = 0; it < NPRE; ++it) issue_slot(it, in_b, ty, tx);
     };
     auto write_tile_lds = [&]() {
 #pragma unroll
@@ -280,8 +284,12 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
         const int y0 = ty * TH, x0 = tx * TW;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
-        if (has_next) issue_tile_loads(next);
-        __builtin_amdgcn_sched_barrier(0);
+        // The next tile's input is fetched in slices spread over taps 0..5 (two slots per tap, issued
+        // AFTER that tap's weight loads): HBM sees a steady stream instead of a 23 MB burst from all
+        // CUs at once, and the end-of-tap wait for the weights (vmcnt is FIFO) never has to wait for
+        // input slots younger than one tap.
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const float *nin_b = in + (size_t)(next / (tiles_x * tiles_y)) * H * W * 64;
 
         f32x16 acc0, acc1;
 #pragma unroll
@@ -289,13 +297,20 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
 
         const float *a_tile = s_in + (wave * PW + li) * PSTR + kh2 * 4;
         float4 a_cur = *reinterpret_cast<const float4 *>(a_tile);      // tap 0, step 0
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // next tap's weights (tap 8: tap 0 of the next tile) -> registers, early
             const int ntap = tap == 8 ? 0 : tap + 1;
             const float *wsrc = wt + (size_t)ntap * 4096;
-            const float4 wn0 = *reinterpret_cast<const float4 *>(wsrc + pco * 64 + pc4 * 4);
-            const float4 wn1 = *reinterpret_cast<const float4 *>(wsrc + (pco + 32) * 64 + pc4 * 4);
+            float4 wn0 = make_float4(0, 0, 0, 0), wn1 = wn0;
+            if (!(abl & 8)) {
+                wn0 = *reinterpret_cast<const float4 *>(wsrc + pco * 64 + pc4 * 4);
+                wn1 = *reinterpret_cast<const float4 *>(wsrc + (pco + 32) * 64 + pc4 * 4);
+            }
+            if (has_next && !(abl & 4)) {
+                if (2 * tap < NPRE) issue_slot(2 * tap, nin_b, nty, ntx);
+                if (2 * tap + 1 < NPRE) issue_slot(2 * tap + 1, nin_b, nty, ntx);
+            }
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - kh * 3;
             const float *a_base = a_tile + (kh * PW + kw) * PSTR;
@@ -329,19 +344,26 @@ __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
                 b0_cur = b0_nxt;
                 b1_cur = b1_nxt;
             }
-            float *wdst = s_w + (wbuf ^ 1) * W_FLOATS;
-            *reinterpret_cast<float4 *>(wdst + pco * PSTR + pc4 * 4) = wn0;
-            *reinterpret_cast<float4 *>(wdst + (pco + 32) * PSTR + pc4 * 4) = wn1;
-            wbuf ^= 1;
-            __syncthreads();
+            if (!(abl & 8)) {
+                float *wdst = s_w + (wbuf ^ 1) * W_FLOATS;
+                *reinterpret_cast<float4 *>(wdst + pco * PSTR + pc4 * 4) = wn0;
+                *reinterpret_cast<float4 *>(wdst + (pco + 32) * PSTR + pc4 * 4) = wn1;
+                wbuf ^= 1;
+            }
+            if (!(abl & 16)) __syncthreads();
         }
 
         const int oy = y0 + wave;
-        float s0, s1, q0, q1;
-        epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W, oy < H,
-                             lane, s0, s1, q0, q1, bn);
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        if (abl & 1) {
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+        } else {
+            epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W,
+                                 oy < H, lane, s0, s1, q0, q1, bn);
+        }
+        if (abl & 16) __syncthreads();
         // every wave has finished reading s_in (barrier after tap 8): refill it for the next tile
-        if (has_next) write_tile_lds();
+        if (has_next && !(abl & 2)) write_tile_lds();
         if (STATS) block_stats_reduce(s_red, stat_part, tile, tid, lane, wave, 8, s0, s1, q0, q1);
         __syncthreads();
     }
@@ -468,23 +490,23 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     if (tile >= ntiles) return;
 
     float pre[NPRE];
+    auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
+        const int idx = tid + it * THREADS;
+        const int c = idx / (PR * 69);
+        const int rem = idx - c * (PR * 69);
+        const int r = rem / 69, j = rem - r * 69;
+        const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + j;
+        float v = 0.f;
+        if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = img_b[((size_t)c * H + gy) * W + gx];
+        pre[it] = v;
+    };
     auto issue_loads = [&](int t) {
         const int tx = t % tiles_x;
         const int ty = (t / tiles_x) % tiles_y;
         const int b = t / (tiles_x * tiles_y);
-        const float *img_b = img + (size_t)b * 3 * H * W;
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
-            const int idx = tid + it * THREADS;
-            const int c = idx / (PR * 69);
-            const int rem = idx - c * (PR * 69);
-            const int r = rem / 69, j = rem - r * 69;
-            const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + j;
-            float v = 0.f;
-            if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = img_b[((size_t)c * H + gy) * W + gx];
-            pre[it] = v;
-        }
+        for (int it = 0; it < NPRE; ++it) issue_slot(it, img + (size_t)b * 3 * H * W, ty, tx);
     };
     auto write_lds = [&]() {
 #pragma unroll
@@ -516,8 +538,9 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         const int y0 = ty * TH, x0 = tx * TW;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
-        if (has_next) issue_loads(next);
-        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's 9 patch slots are issued one every 5 k-pairs inside the MFMA loop
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const float *nimg = img + (size_t)(next / (tiles_x * tiles_y)) * 3 * H * W;
 
         f32x16 acc0, acc1;
 #pragma unroll
@@ -525,6 +548,7 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         // every LDS operand address is a per-lane base + a compile-time immediate (see pair_tap)
 #pragma unroll
         for (int p = 0; p < 49; ++p) {
+            if (p % 5 == 0 && p / 5 < NPRE && has_next) issue_slot(p / 5, nimg, nty, ntx);
             const float a = a_set0[local_off(p)];
             acc0 = mfma32(a, b_base[p * 128], acc0);
             acc1 = mfma32(a, b_base[p * 128 + 32], acc1);
@@ -680,7 +704,7 @@ constexpr int NPRE_D = (TH * TW * 16 + THREADS - 1) / THREADS;   // 6 float4
 
 __global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
     const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part,
-    int H, int W, int tiles_x, int tiles_y, int ntiles)
+    int H, int W, int tiles_x, int tiles_y, int ntiles, int abl)
 {
     using namespace wg3v2;
     __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + DZ_FLOATS];
@@ -697,26 +721,19 @@ __global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     float4 pa[NPRE_A], pd[NPRE_D];
-    auto issue_loads = [&](int t) {
-        const int tx = t % tiles_x;
-        const int ty = (t / tiles_x) % tiles_y;
-        const int b = t / (tiles_x * tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
-        const float *act_b = act + (size_t)b * H * W * 64;
-        const float *dz_b = dz + (size_t)b * H * W * 64;
-#pragma unroll
-        for (int it = 0; it < NPRE_A; ++it) {
-            const int idx = tid + it * THREADS;
+    // slot s < NPRE_A: activation halo tile; s >= NPRE_A: dz tile (tile origin y0, x0 of batch b)
+    auto issue_slot = [&](int s, const float *act_b, const float *dz_b, int y0, int x0) {
+        if (s < NPRE_A) {
+            const int idx = tid + s * THREADS;
             const int px = idx >> 4, c4 = idx & 15;
             const int r = px / PW, c = px - r * PW;
             const int gy = y0 + r - 1, gx = x0 + c - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < PH * PW * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-            pa[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < NPRE_D; ++it) {
+            pa[s] = v;
+        } else {
+            const int it = s - NPRE_A;
             const int idx = tid + it * THREADS;
             const int px = idx >> 4, c4 = idx & 15;
             const int r = px / TW, c = px - r * TW;
@@ -726,6 +743,14 @@ __global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
                 v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
             pd[it] = v;
         }
+    };
+    auto issue_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+#pragma unroll
+        for (int s = 0; s < NPRE_A + NPRE_D; ++s)
+            issue_slot(s, act + (size_t)b * H * W * 64, dz + (size_t)b * H * W * 64, ty * TH, tx * TW);
     };
     auto write_lds = [&]() {
 #pragma unroll
@@ -749,32 +774,43 @@ __global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
     for (; tile < ntiles; tile += gridDim.x) {
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
-        if (has_next) issue_loads(next);
-        __builtin_amdgcn_sched_barrier(0);
+        // next tile's coordinates; its 14 prefetch slots are issued one per 8 k-pairs inside the
+        // MFMA loop, so the address arithmetic and the loads overlap with the matrix pipe instead
+        // of forming a load-issue phase at the head of every tile
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const int nb = next / (tiles_x * tiles_y);
+        const float *nact = act + (size_t)nb * H * W * 64;
+        const float *ndz = dz + (size_t)nb * H * W * 64;
         // k-pair t covers tile pixels 2t, 2t+1 (row = p>>5, col = p&31); this lane: p = 2t + kh2
         const float *a_ptr = s_dz + kh2 * 64 + cob * 32 + li;
         const float *b_ptr = s_a + (trow * PW + kh2) * 64 + cib * 32 + li;
         float a_cur = a_ptr[0];
         float b_cur0 = b_ptr[0], b_cur1 = b_ptr[64], b_cur2 = b_ptr[128];
-#pragma unroll 8
-        for (int t = 0; t < TH * TW / 2; ++t) {
-            // next k-pair (clamped on the last one; the extra read is unused)
-            const int tn = t + 1 < TH * TW / 2 ? t + 1 : t;
-            const int pn = 2 * tn;
-            const int rown = pn >> 5, coln = pn & 31;
-            const float a_nxt = a_ptr[(rown * TW + coln) * 64];
-            const float *bn = b_ptr + (rown * PW + coln) * 64;
-            const float b_nxt0 = bn[0], b_nxt1 = bn[64], b_nxt2 = bn[128];
-            acc[0] = mfma32(a_cur, b_cur0, acc[0]);
-            acc[1] = mfma32(a_cur, b_cur1, acc[1]);
-            acc[2] = mfma32(a_cur, b_cur2, acc[2]);
-            a_cur = a_nxt;
-            b_cur0 = b_nxt0;
-            b_cur1 = b_nxt1;
-            b_cur2 = b_nxt2;
+#pragma unroll
+        for (int tt = 0; tt < TH * TW / 16; ++tt) {
+            if (tt < NPRE_A + NPRE_D && has_next && !(abl & 4))
+                issue_slot(tt, nact, ndz, nty * TH, ntx * TW);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = tt * 8 + u;
+                // next k-pair (clamped on the last one; the extra read is unused)
+                const int tn = t + 1 < TH * TW / 2 ? t + 1 : t;
+                const int pn = 2 * tn;
+                const int rown = pn >> 5, coln = pn & 31;
+                const float a_nxt = a_ptr[(rown * TW + coln) * 64];
+                const float *bn = b_ptr + (rown * PW + coln) * 64;
+                const float b_nxt0 = bn[0], b_nxt1 = bn[64], b_nxt2 = bn[128];
+                acc[0] = mfma32(a_cur, b_cur0, acc[0]);
+                acc[1] = mfma32(a_cur, b_cur1, acc[1]);
+                acc[2] = mfma32(a_cur, b_cur2, acc[2]);
+                a_cur = a_nxt;
+                b_cur0 = b_nxt0;
+                b_cur1 = b_nxt1;
+                b_cur2 = b_nxt2;
+            }
         }
         __syncthreads();              // all waves done with this tile's LDS image
-        if (has_next) write_lds();
+        if (has_next && !(abl & 2)) write_lds();
         __syncthreads();
     }
     // one partial per block: part[block][tap][co][ci]
@@ -937,16 +973,10 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 
     float pre[NPRE];
     float4 pd[wg1::NPRE_D];
-    auto issue_loads = [&](int t) {
-        const int tx = t % tiles_x;
-        const int ty = (t / tiles_x) % tiles_y;
-        const int b = t / (tiles_x * tiles_y);
-        const int y0 = ty * wg1::TH, x0 = tx * wg1::TW;
-        const float *img_b = img + (size_t)b * 3 * H * W;
-        const float *dy_b = dy + (size_t)b * H1 * W1 * 64;
-#pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
-            const int idx = tid + it * THREADS;
+    // slot s < NPRE: image patch element; s >= NPRE: float4 of the dy tile
+    auto issue_slot = [&](int s, const float *img_b, const float *dy_b, int y0, int x0) {
+        if (s < NPRE) {
+            const int idx = tid + s * THREADS;
             const int c = idx / (PR * 69);
             const int rem = idx - c * (PR * 69);
             const int r = rem / 69, j = rem - r * 69;
@@ -954,10 +984,9 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             float v = 0.f;
             if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = img_b[((size_t)c * H + gy) * W + gx];
-            pre[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < wg1::NPRE_D; ++it) {
+            pre[s] = v;
+        } else {
+            const int it = s - NPRE;
             const int idx = tid + it * THREADS;
             const int px = idx >> 4, c4 = idx & 15;
             const int r = px / wg1::TW, c = px - r * wg1::TW;
@@ -967,6 +996,15 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
                 v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
             pd[it] = v;
         }
+    };
+    auto issue_loads = [&](int t) {
+        const int tx = t % tiles_x;
+        const int ty = (t / tiles_x) % tiles_y;
+        const int b = t / (tiles_x * tiles_y);
+#pragma unroll
+        for (int s = 0; s < NPRE + wg1::NPRE_D; ++s)
+            issue_slot(s, img + (size_t)b * 3 * H * W, dy + (size_t)b * H1 * W1 * 64, ty * wg1::TH,
+                       tx * wg1::TW);
     };
     auto write_lds = [&]() {
 #pragma unroll
@@ -993,8 +1031,11 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
     for (; tile < ntiles; tile += gridDim.x) {
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
-        if (has_next) issue_loads(next);
-        __builtin_amdgcn_sched_barrier(0);
+        // next tile's 17 prefetch slots: one per k-pair inside the MFMA loop
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const int nb = next / (tiles_x * tiles_y);
+        const float *nimg = img + (size_t)nb * 3 * H * W;
+        const float *ndy = dy + (size_t)nb * H1 * W1 * 64;
         // this wave: tile rows 2q, 2q+1; k-pair t -> pixels p = 2t + kh2 (row 2q + (p>>5), col p&31)
         const float *a_ptr = s_dy + (2 * q * wg1::TW + kh2) * 64 + cob * 32 + li;
         const float *b_ptr = s_in + (4 * q) * RSTR + kh2;
@@ -1002,8 +1043,10 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         float b_cur[5];
 #pragma unroll
         for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_ptr[toff[tb]];
-#pragma unroll 4
+#pragma unroll
         for (int t = 0; t < 32; ++t) {
+            if (t < NPRE + wg1::NPRE_D && has_next)
+                issue_slot(t, nimg, ndy, nty * wg1::TH, ntx * wg1::TW);
             const int tn = t < 31 ? t + 1 : t;
             const int pn = 2 * tn;
             const int rown = pn >> 5, coln = pn & 31;
@@ -1070,6 +1113,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 int g_conv3x3_variant = 2;   // 1 = one block per tile, 2 = persistent + software pipelined
 int g_wgrad3_variant = 2;    // 1 = 8 waves x 9 taps, 2 = 12 waves x 3 taps + register prefetch
 int g_conv1_variant = 2;     // conv1 fwd + wgrad: 1 = v1, 2 = persistent + register prefetch
+int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
 
 }  // namespace
@@ -1084,6 +1128,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
     if (key == 3) { g_wgrad3_variant = value; return COVA_OK; }
     if (key == 4) { g_conv1_variant = value; return COVA_OK; }
+    if (key == 5) { g_ablate = value; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1132,10 +1177,10 @@ static int launch_conv3x3(const float *in, const float *w_t, const float *addend
     const dim3 block(c3::THREADS), grid(persistent_grid(ntiles));
     if (stat_part)
         hipLaunchKernelGGL(conv3x3_c64_v2_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn, g_ablate);
     else
         hipLaunchKernelGGL(conv3x3_c64_v2_kernel<false>, grid, block, 0, (hipStream_t)stream, in, w_t,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn, g_ablate);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -1225,7 +1270,7 @@ COVA_API int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw, fl
         const int ntiles = B * tiles_x * tiles_y;
         const int grid = persistent_grid(ntiles);
         hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel, dim3(grid), dim3(wg3v2::THREADS), 0,
-                           (hipStream_t)stream, act, dz, ws, H, W, tiles_x, tiles_y, ntiles);
+                           (hipStream_t)stream, act, dz, ws, H, W, tiles_x, tiles_y, ntiles, g_ablate);
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 4096 / 64), dim3(1024), 0,
                            (hipStream_t)stream, ws, grid, dw);

@@ -173,6 +173,10 @@ int cova_adam_step(float *p, const float *g, float *m, float *v, long long n, in
                    double beta1, double beta2, double eps, double weight_decay, void *stream);
 int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream);
 
+/* ------------------------------------------------------------------ diagnostics (bench tools only)
+ * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */
+int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

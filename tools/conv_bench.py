@@ -23,6 +23,11 @@ def timeit(fn, n=iters):
     return e0.elapsed_time(e1) / n
 
 
+scratch = torch.zeros(16, device=dev)
+for blocks in (256, 512):
+    iters = 4000
+    t = timeit(lambda: call("cova_probe_mfma_f32", scratch, blocks, iters), 5)
+    print("MFMA f32 32x32x2 probe, %d blocks x 8 waves: %.3f ms  %.1f TF/s" % (blocks, t, blocks * 8 * iters * 16 * 4096 / t / 1e9))
 x = torch.randn(B, H, W, 64, device=dev)
 dz = torch.randn(B, H, W, 64, device=dev)
 w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
@@ -36,6 +41,14 @@ for variant in (1, 2):
     for stats in (False, True):
         t = timeit(lambda: call("cova_conv3x3_fwd", x, wf, None, out, part if stats else None, B, H, W))
         print("conv3x3 fwd v%d stats=%d: %.3f ms  %.1f TF/s" % (variant, stats, t, flop3 / t / 1e9))
+query("cova_set_option", 1, 2)
+for abl, what in ((0, "full"), (1, "no epilogue"), (2, "no LDS refill"), (4, "no prefetch loads"), (8, "no weight restage"),
+                  (16, "no tap barrier"), (6, "no refill+prefetch"), (7, "no epi+refill+prefetch"), (15, "MFMA + LDS reads + barriers"),
+                  (31, "MFMA + LDS reads only")):
+    query("cova_set_option", 5, abl)
+    t = timeit(lambda: call("cova_conv3x3_fwd", x, wf, None, out, None, B, H, W))
+    print("ablation %2d %-28s: %.3f ms  %.1f TF/s" % (abl, what, t, flop3 / t / 1e9))
+query("cova_set_option", 5, 0)
 sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
 mean, invstd = torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5
 t = timeit(lambda: call("cova_conv3x3_dgrad_bnbwd", dz, wd, x, x, dz, mean, invstd, out, part, B, H, W))
@@ -43,6 +56,12 @@ print("conv3x3 dgrad_bnbwd (+addend, act): %.3f ms  %.1f TF/s" % (t, flop3 / t /
 ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=dev)
 
 dw = torch.empty(64, 64, 3, 3, device=dev)
+query("cova_set_option", 3, 2)
+for abl, what in ((0, "full"), (2, "no LDS refill"), (4, "no prefetch loads"), (6, "no refill+prefetch")):
+    query("cova_set_option", 5, abl)
+    t = timeit(lambda: call("cova_conv3x3_wgrad", x, dz, dw, ws, B, H, W))
+    print("wgrad ablation %2d %-22s: %.3f ms  %.1f TF/s" % (abl, what, t, flop3 / t / 1e9))
+query("cova_set_option", 5, 0)
 for variant in (1, 2):
     query("cova_set_option", 3, variant)
     t = timeit(lambda: call("cova_conv3x3_wgrad", x, dz, dw, ws, B, H, W))

@@ -477,7 +477,8 @@ constexpr int NPRE = (PATCH + THREADS - 1) / THREADS;               // 9 per thr
 template <bool STATS>
 __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
-    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles)
+    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
+    int abl)
 {
     using namespace c1;
     __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS + 8 * 128];
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         // every LDS operand address is a per-lane base + a compile-time immediate (see pair_tap)
 #pragma unroll
         for (int p = 0; p < 49; ++p) {
-            if (p % 5 == 0 && p / 5 < NPRE && has_next) issue_slot(p / 5, nimg, nty, ntx);
+            if (p % 5 == 0 && p / 5 < NPRE && has_next && !(abl & 4)) issue_slot(p / 5, nimg, nty, ntx);
             const float a = a_set0[local_off(p)];
             acc0 = mfma32(a, b_base[p * 128], acc0);
             acc1 = mfma32(a, b_base[p * 128 + 32], acc1);
@@ -566,11 +567,14 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
             acc1 = mfma32(a, b_base[(70 + j) * 128 + 32], acc1);
         }
         const int oy = y0 + wave;
-        float s0, s1, q0, q1;
-        epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
-                             oy < H1, lane, s0, s1, q0, q1);
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        if (abl & 1)
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+        else
+            epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
+                                 oy < H1, lane, s0, s1, q0, q1);
         __syncthreads();                 // every wave is done reading the patch
-        if (has_next) write_lds();
+        if (has_next && !(abl & 2)) write_lds();
         if (STATS) block_stats_reduce(s_red, stat_part, tile, tid, lane, wave, 8, s0, s1, q0, q1);
         __syncthreads();
     }
@@ -1236,10 +1240,10 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
         const dim3 pgrid(persistent_grid(ntiles, 2));
         if (stat_part)
             hipLaunchKernelGGL(conv1_7x7_v2_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img,
-                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles);
+                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
         else
             hipLaunchKernelGGL(conv1_7x7_v2_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img,
-                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles);
+                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
         COVA_LAUNCH_CHECK();
         return COVA_OK;
     }

@@ -73,6 +73,12 @@ call("cova_conv1_prep_weights", w1, wk)
 y1 = torch.empty(B, 640, 640, 64, device=dev)
 part1 = torch.empty(query("cova_conv1_num_tiles", B, 1280, 1280), 2, 64, device=dev)
 flop1 = 2 * 64 * 147 * B * 640 * 640
+query("cova_set_option", 4, 2)
+for abl, what in ((0, "full"), (1, "no epilogue"), (2, "no LDS refill"), (4, "no prefetch loads"), (7, "MFMA + LDS reads")):
+    query("cova_set_option", 5, abl)
+    t = timeit(lambda: call("cova_conv1_fwd", img, wk, y1, part1, B, 1280, 1280))
+    print("conv1 fwd ablation %2d %-20s: %.3f ms  %.1f TF/s" % (abl, what, t, flop1 / t / 1e9))
+query("cova_set_option", 5, 0)
 for variant in (1, 2):
     query("cova_set_option", 4, variant)
     t = timeit(lambda: call("cova_conv1_fwd", img, wk, y1, part1, B, 1280, 1280))

@@ -205,6 +205,42 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ 
     }
 }
 
+// Evaluation decision of train.py:131-154: for every page and every class column, the (page-local)
+// indices of the k boxes with the highest score, best first.  One wave per (page, class); ties go
+// to the lower box index.  page_start [n_pages+1] = box offsets of the pages in the flat batch.
+__global__ __launch_bounds__(256) void page_class_topk_kernel(const float *__restrict__ logits,
+                                                              const int64_t *__restrict__ page_start,
+                                                              int n_pages, int NC, int k,
+                                                              int64_t *__restrict__ out)
+{
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (task >= n_pages * NC) return;
+    const int page = task / NC, c = task - page * NC;
+    const int lo = (int)page_start[page], hi = (int)page_start[page + 1];
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    for (int j = 0; j < k; ++j) {
+        // best (value, lowest index) strictly after (prev_v, prev_i) in the order (v desc, i asc)
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int n = lo + lane; n < hi; n += 64) {
+            const float v = logits[(size_t)n * NC + c];
+            const int i = n - lo;
+            const bool after = (v < prev_v) || (v == prev_v && i > prev_i);
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) out[((size_t)page * NC + c) * k + j] = (bi == 0x7fffffff) ? -1 : bi;
+        prev_v = bv;
+        prev_i = bi;
+    }
+}
+
 inline int ew_grid(long long total)
 {
     long long g = cdivll(total, 256);
@@ -292,6 +328,19 @@ COVA_API int cova_colsum(const float *x, int ldx, int R, int C, float *out, void
     COVA_REQUIRE(x && out && R > 0 && C > 0);
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, R,
                        C, out);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// out [n_pages, NC, k] int64: page-local box indices of the k highest logits per class, best first
+// (-1 when the page has fewer than k boxes).  replaces the per-page python loop + argsort of
+// train.py:131-153.
+COVA_API int cova_page_class_topk(const float *logits, const int64_t *page_start, int n_pages, int NC,
+                                  int k, int64_t *out, void *stream)
+{
+    COVA_REQUIRE(logits && page_start && out && n_pages > 0 && NC > 0 && k > 0);
+    hipLaunchKernelGGL(page_class_topk_kernel, dim3(cdiv(n_pages * NC, 4)), dim3(256), 0,
+                       (hipStream_t)stream, logits, page_start, n_pages, NC, k, out);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

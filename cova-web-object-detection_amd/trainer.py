@@ -126,6 +126,22 @@ class HotPathTrainer:
         return loss, pred
 
     @torch.no_grad()
+    def evaluate(self, batch, page_start, k=1):
+        """Eval-mode decisions of train.py:131-154 for one batch.  ``page_start`` int64 [n_pages+1]
+        box offsets.  Returns (topk [n_pages, n_classes, k] page-local box indices, best first;
+        correct [n_pages, n_classes-1] bool = the labelled box of class c is among the top k)."""
+        logits, _ = self.predict(batch)
+        n_pages, nc = page_start.numel() - 1, logits.shape[1]
+        topk = torch.empty((n_pages, nc, k), dtype=torch.int64, device=logits.device)
+        engine.call("cova_page_class_topk", logits, page_start.contiguous(), n_pages, nc, k, topk)
+        labels, correct = batch["labels"], []
+        for c in range(1, nc):          # one labelled box per class and page (README.md:17)
+            pos = torch.nonzero(labels == c).view(-1)
+            true_local = pos - page_start[:-1]
+            correct.append((topk[:, c, :] == true_local.view(-1, 1)).any(dim=1))
+        return topk, torch.stack(correct, dim=1)
+
+    @torch.no_grad()
     def predict(self, batch):
         """Eval-mode forward (running statistics) -> (logits, per-box argmax)."""
         logits, _ = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],

@@ -172,6 +172,10 @@ int cova_ce_sum(const float *logits, const int64_t *labels /*nullable*/, int N, 
 int cova_adam_step(float *p, const float *g, float *m, float *v, long long n, int step, double lr,
                    double beta1, double beta2, double eps, double weight_decay, void *stream);
 int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream);
+/* evaluation decision (train.py:131-153): per page and class column, page-local indices of the k
+ * highest-scoring boxes, best first; page_start [n_pages+1] are box offsets; out [n_pages,NC,k] */
+int cova_page_class_topk(const float *logits, const int64_t *page_start, int n_pages, int NC, int k,
+                         int64_t *out, void *stream);
 
 /* ------------------------------------------------------------------ diagnostics (bench tools only)
  * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */

@@ -232,3 +232,53 @@ def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
     assert abs(losses[0] - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
     logits, pred = tr.predict(dbatch)
     assert logits.shape == (39, 4) and torch.equal(pred, logits.argmax(1))
+
+
+def test_eval_decision_kernel_matches_reference_rule():
+    """cova_page_class_topk against the reference's evaluate_model output (golden/evaluate.npz) and
+    against torch.argsort on random logits with ragged pages, incl. k larger than a page."""
+    from cova_web_object_detection_amd import _lib
+    fx = np.load(GOLDEN + "/evaluate.npz")
+    logits = torch.from_numpy(fx["logits"]).to(DEV)
+    pages = fx["bboxes"][:, 0].astype(np.int64)
+    counts = np.bincount(pages)
+    start = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)])).to(DEV)
+    labels = torch.from_numpy(fx["labels"])
+    for k in (1, 3):
+        out = torch.empty((len(counts), 4, k), dtype=torch.int64, device=DEV)
+        _lib.call("cova_page_class_topk", logits, start, len(counts), 4, k, out)
+        out = out.cpu()
+        acc = np.zeros((len(counts), 3), dtype=np.int32)
+        for p in range(len(counts)):
+            lab = labels[pages == p]
+            o = logits.cpu()[pages == p]
+            ref = torch.argsort(o, dim=0, descending=True)[:k]          # [k, 4], best first
+            assert torch.equal(out[p].t(), ref)                           # no ties in random logits
+            for c in (1, 2, 3):
+                acc[p, c - 1] = int(int(torch.nonzero(lab == c)[0]) in out[p, c].tolist())
+        assert np.array_equal(acc, fx["img_acc_k%d" % k][:, 1:])          # reference's own decisions
+    # k larger than the page: padded with -1, prefix still sorted
+    small = torch.randn(5, 4, device=DEV)
+    st = torch.tensor([0, 2, 5], device=DEV)
+    out = torch.empty((2, 4, 4), dtype=torch.int64, device=DEV)
+    _lib.call("cova_page_class_topk", small, st, 2, 4, 4, out)
+    assert (out[0, :, 2:] == -1).all() and (out[1, :, 3:] == -1).all() and (out[0, :, :2] >= 0).all()
+
+
+def test_trainer_evaluate_matches_oracle_decision_rule():
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=64,
+               bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.2)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(41, logit_gain=3.0, **wcfg)
+    counts = [25, 11, 40]
+    batch = synthetic.make_batch(3, img_h=64, boxes_per_page=counts, context_size=12, seed=41)
+    dbatch = {k: v.to(DEV) for k, v in batch.items() if torch.is_tensor(v)}
+    tr = HotPathTrainer(cfg, sd, DEV)
+    start = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), device=DEV)
+    for k in (1, 3):
+        topk, correct = tr.evaluate(dbatch, start, k)
+        logits, _ = tr.predict(dbatch)
+        ref = np.asarray(O.eval_accuracy(logits.cpu(), batch["bboxes"], batch["labels"], 4, k))
+        assert np.array_equal(correct.cpu().numpy().astype(np.int64), ref)
+        assert topk.shape == (3, 4, k)

@@ -282,3 +282,55 @@ def test_trainer_evaluate_matches_oracle_decision_rule():
         ref = np.asarray(O.eval_accuracy(logits.cpu(), batch["bboxes"], batch["labels"], 4, k))
         assert np.array_equal(correct.cpu().numpy().astype(np.int64), ref)
         assert topk.shape == (3, 4, k)
+
+
+@pytest.mark.parametrize("K", [2, 64])
+def test_gat_extreme_neighbour_counts(K):
+    rs = np.random.RandomState(K)
+    N, Fd, D = 70, 48, 24
+    sd = {"gat.W_i.weight": torch.from_numpy(rs.uniform(-0.3, 0.3, (D, Fd)).astype(np.float32)),
+          "gat.W_j.weight": torch.from_numpy(rs.uniform(-0.3, 0.3, (D, Fd)).astype(np.float32)),
+          "gat.attention_layer.weight": torch.from_numpy(rs.uniform(-0.5, 0.5, (1, 2 * D)).astype(np.float32)),
+          "gat.attention_layer.bias": torch.from_numpy(rs.uniform(-0.5, 0.5, (1,)).astype(np.float32))}
+    h = torch.from_numpy(rs.standard_normal((N, Fd)).astype(np.float32))
+    ctx = torch.from_numpy(synthetic.context_window_indices(N, K // 2))
+    layer = GraphAttentionLayer(Fd, D)
+    layer.load_state_dict({k[4:]: v for k, v in sd.items()})
+    layer = layer.to(DEV)
+    hg = h.to(DEV).requires_grad_(True)
+    hp, attn = layer(hg, ctx.to(DEV), return_attn_wts=True)
+    hr = h.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hp_ref, attn_ref = O.gat(hr, ctx, sdr, return_attn_wts=True)
+    assert relerr(hp.detach().cpu(), hp_ref.detach()) < 1e-5 and relerr(attn.cpu(), attn_ref.detach()) < 1e-5
+    g = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32))
+    (hp * g.to(DEV)).sum().backward()
+    (hp_ref * g).sum().backward()
+    assert relerr(hg.grad.cpu(), hr.grad) < 1e-4
+    for k, p in layer.named_parameters():
+        ref = sdr["gat." + k].grad
+        assert float((p.grad.cpu() - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1e-3), k
+    with pytest.raises(ValueError):
+        layer(hg, torch.zeros((N, 65), dtype=torch.long, device=DEV))
+
+
+@pytest.mark.parametrize("use_context,boxes", [(False, [7, 30]), (True, [3, 4]), (True, [230])])
+def test_small_and_ragged_batches_match_oracle_forward(use_context, boxes):
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=use_context, hidden_dim=48,
+               bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.0)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(len(boxes) * 13 + boxes[0], logit_gain=2.0, **wcfg)
+    batch = synthetic.make_batch(len(boxes), img_h=64, boxes_per_page=boxes, context_size=12, seed=boxes[0])
+    if not use_context:
+        batch["context_indices"] = torch.empty((0, 0), dtype=torch.long)
+    m = build(cfg, 64, sd)
+    args = dev_batch(batch)
+    for training in (False, True):
+        m.train(training)
+        with torch.no_grad():
+            got = m(*args)
+        ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"], batch["additional_feats"],
+                        batch["context_indices"], cfg, training, None)
+        assert relerr(got.cpu(), ref) < 2e-4, (training, relerr(got.cpu(), ref))
+    empty = m(args[0], args[1][:0], args[2][:0], args[3][:0] if use_context else args[3])
+    assert empty.shape == (0, 4)

@@ -1122,6 +1122,9 @@ int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many t
 
 }  // namespace
 
+// shared with conv_wino.hip (same shared object; hidden visibility)
+int cova_internal_persistent_grid(int ntiles) { return persistent_grid(ntiles); }
+
 // ====================================================================================
 // C ABI
 // ====================================================================================

@@ -101,6 +101,23 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 
 
 # ------------------------------------------------------------------------------- conv stack
+# 3x3 convolutions (forward + data gradient): Winograd F(2x2,3x3) kernel (2.25x fewer MFMAs, same
+# fp32 error) or the direct implicit-GEMM kernel.  The weight gradient always uses the direct form.
+USE_WINOGRAD = True
+
+
+def conv3x3(x, wts, addend, out, part, B, H, W, bn=None):
+    """wts = (direct layout, winograd layout) of either the forward or the dgrad weights.
+    bn = (act, z, mean, invstd): fused ReLU mask + BatchNorm-backward sums in the epilogue."""
+    if USE_WINOGRAD:
+        a, z, m, i = bn if bn is not None else (None, None, None, None)
+        call("cova_conv3x3_wino", x, wts[1], addend, a, z, m, i, out, part, B, H, W)
+    elif bn is not None:
+        call("cova_conv3x3_dgrad_bnbwd", x, wts[0], addend, bn[0], bn[1], bn[2], bn[3], out, part, B, H, W)
+    else:
+        call("cova_conv3x3_fwd", x, wts[0], addend, out, part, B, H, W)
+
+
 CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "convnet.4.1.conv2"]
 BN3_KEYS = ["convnet.4.0.bn1.", "convnet.4.0.bn2.", "convnet.4.1.bn1.", "convnet.4.1.bn2."]
 
@@ -116,10 +133,16 @@ def convstack_fwd(images, params, buffers, training, save=True):
     call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
     wf, wd = [], []
     for k in CONV3_KEYS:
-        a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
-        call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
-        wf.append(a)
-        wd.append(b)
+        if USE_WINOGRAD:
+            a, b = _empty((16, 16, 4, 64), images), _empty((16, 16, 4, 64), images)
+            call("cova_conv3x3_prep_weights_wino", params[k + ".weight"], a, b)
+            wf.append((None, a))
+            wd.append((None, b))
+        else:
+            a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
+            call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
+            wf.append((a, None))
+            wd.append((b, None))
     sv["wd"] = wd
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
@@ -139,12 +162,12 @@ def convstack_fwd(images, params, buffers, training, save=True):
     for blk in (0, 1):
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
-        call("cova_conv3x3_fwd", x, wf[2 * blk], None, z1, part, B, H2, W2)
+        conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
         bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R)
         a1 = _empty((B, H2, W2, C64), images)
         call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
         z2 = _empty((B, H2, W2, C64), images)
-        call("cova_conv3x3_fwd", a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
+        conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
         bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R)
         out = _empty((B, H2, W2, C64), images)
         call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
@@ -201,8 +224,8 @@ def convstack_bwd(sv, dfeat, gout=None):
         dy_a = torch.empty_like(dA)
         part = _empty((nt, 2, C64), dfeat)
         bna = s["bna"]
-        call("cova_conv3x3_dgrad_bnbwd", dz2, sv["wd"][2 * blk + 1], None, s["a1"], s["z1"], bna.mean,
-             bna.invstd, dy_a, part, B, H2, W2)
+        conv3x3(dz2, sv["wd"][2 * blk + 1], None, dy_a, part, B, H2, W2,
+                (s["a1"], s["z1"], bna.mean, bna.invstd))
         dz1 = dz2                                     # reuse
         dg, db = bn_bwd_from_partials(part, nt, dy_a, s["z1"], bna, R, dz1, gout, pa)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
@@ -213,10 +236,10 @@ def convstack_bwd(sv, dfeat, gout=None):
         if blk == 1:
             prev = sv["blocks"][0]                    # this block's input is prev's relu(bn2 + x)
             pend = _empty((nt, 2, C64), dfeat)
-            call("cova_conv3x3_dgrad_bnbwd", dz1, sv["wd"][2 * blk], dres, prev["out"], prev["z2"],
-                 prev["bnb"].mean, prev["bnb"].invstd, dx, pend, B, H2, W2)
+            conv3x3(dz1, sv["wd"][2 * blk], dres, dx, pend, B, H2, W2,
+                    (prev["out"], prev["z2"], prev["bnb"].mean, prev["bnb"].invstd))
         else:
-            call("cova_conv3x3_fwd", dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
+            conv3x3(dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
         dA = dx
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]

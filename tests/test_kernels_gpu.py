@@ -384,3 +384,44 @@ def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     call("cova_conv3x3_dgrad_bnbwd", dz, wd, add, act, z, mean, invstd, dy, part, B, H, W)
     assert torch.equal(dy, plain * (act > 0))
     close(part.sum(0), part_ref.sum(0), 1e-5, "fused bn-bwd sums")
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
+def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap):
+    """Winograd F(2x2,3x3) kernel: forward (+statistics), data gradient (+addend) and the fused
+    ReLU-mask / BN-backward epilogue against torch-CPU and the direct kernel."""
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    dz = torch.randn(B, 64, H, W, generator=g)
+    add = torch.randn(B, 64, H, W, generator=g)
+    uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
+    call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
+    query("cova_set_option", 2, cap)
+    try:
+        nt = query("cova_conv3x3_num_tiles", B, H, W)
+        out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_wino", nhwc(x), uf, None, None, None, None, None, out, part, B, H, W)
+        ref = F.conv2d(x, w, padding=1)
+        close(nchw(out), ref, 1e-4, "winograd fwd")
+        close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "winograd stat sum")
+        close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "winograd stat sumsq")
+        xr = x.clone().requires_grad_(True)
+        (F.conv2d(xr, w, padding=1) * dz).sum().backward()
+        dx = torch.zeros(B, H, W, 64, device=DEV)
+        call("cova_conv3x3_wino", nhwc(dz), ud, nhwc(add), None, None, None, None, dx, None, B, H, W)
+        close(nchw(dx), xr.grad + add, 1e-4, "winograd dgrad")
+        # fused epilogue == direct kernel's fused epilogue
+        act = nhwc(torch.relu(torch.randn(B, 64, H, W, generator=g)))
+        z = nhwc(torch.randn(B, 64, H, W, generator=g))
+        mean, invstd = torch.randn(64, generator=g).to(DEV) * 0.2, (torch.rand(64, generator=g) + 0.5).to(DEV)
+        wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
+        call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
+        dy_d, part_d = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_dgrad_bnbwd", nhwc(dz), wd, nhwc(add), act, z, mean, invstd, dy_d, part_d, B, H, W)
+        dy_w, part_w = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_wino", nhwc(dz), ud, nhwc(add), act, z, mean, invstd, dy_w, part_w, B, H, W)
+        close(dy_w, dy_d, 1e-5, "winograd fused dy")
+        close(part_w.sum(0), part_d.sum(0), 1e-4, "winograd fused sums")
+    finally:
+        query("cova_set_option", 2, 0)

@@ -41,6 +41,11 @@ for variant in (1, 2):
     for stats in (False, True):
         t = timeit(lambda: call("cova_conv3x3_fwd", x, wf, None, out, part if stats else None, B, H, W))
         print("conv3x3 fwd v%d stats=%d: %.3f ms  %.1f TF/s" % (variant, stats, t, flop3 / t / 1e9))
+uf, ud = torch.empty(16, 16, 4, 64, device=dev), torch.empty(16, 16, 4, 64, device=dev)
+call("cova_conv3x3_prep_weights_wino", w, uf, ud)
+for stats in (False, True):
+    t = timeit(lambda: call("cova_conv3x3_wino", x, uf, None, None, None, None, None, out, part if stats else None, B, H, W))
+    print("conv3x3 WINOGRAD fwd stats=%d: %.3f ms  %.1f TF/s (direct-equivalent)" % (stats, t, flop3 / t / 1e9))
 query("cova_set_option", 1, 2)
 for abl, what in ((0, "full"), (1, "no epilogue"), (2, "no LDS refill"), (4, "no prefetch loads"), (8, "no weight restage"),
                   (16, "no tap barrier"), (6, "no refill+prefetch"), (7, "no epi+refill+prefetch"), (15, "MFMA + LDS reads + barriers"),

@@ -186,8 +186,8 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             for (int p = 0; p < 16; ++p) {
                 const float b0 = bp[p * (4 * UROW)];
                 const float b1 = bp[p * (4 * UROW) + 16];
-                acc[0][p] = mfma16(V[p], b0, acc[0][p]);
-                acc[1][p] = mfma16(V[p], b1, acc[1][p]);
+                acc[0][p] = mfma16(b0, V[p], acc[0][p]);      // D[co][tile] += U[co][ci] * V[ci][tile]
+                acc[1][p] = mfma16(b1, V[p], acc[1][p]);
             }
             // (5) input transform of the NEXT chunk (for s = 15: chunk 0 of the next tile, whose
             //     planes were refilled at chunk 2 of this tile) -- overlaps the MFMAs in flight
@@ -201,19 +201,20 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
         }
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.
-        // lane holds, for q = 0..3: tile (lane>>4)*4 + q of tile row tb, channel cbp*32 + c2*16 + ti
-        float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
-        float mu[2] = {0.f, 0.f}, is[2] = {0.f, 0.f};
-        if (bn.z != nullptr) {
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                mu[c2] = bn.mean[cbp * 32 + c2 * 16 + ti];
-                is[c2] = bn.invstd[cbp * 32 + c2 * 16 + ti];
-            }
-        }
+        // D layout (rows = co, cols = tiles): this lane holds, for c2 = 0..1 and q = 0..3, channel
+        // cbp*32 + c2*16 + kq*4 + q of Winograd tile (tb, ti) -- four consecutive channels per
+        // pixel, so every epilogue access is a float4.
+        float ssum[2][4], ssq[2][4];
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-            const int co = cbp * 32 + c2 * 16 + ti;
+            const int co = cbp * 32 + c2 * 16 + kq * 4;
+            float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = mu4;
+            if (bn.z != nullptr) {
+                mu4 = *reinterpret_cast<const float4 *>(bn.mean + co);
+                is4 = *reinterpret_cast<const float4 *>(bn.invstd + co);
+            }
+            const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+            float y[2][2][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float s0[4], s1[4];
@@ -224,47 +225,64 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
                     s0[bcol] = m0 + m1 + m2;
                     s1[bcol] = m1 - m2 - m3;
                 }
-                const float y[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]},
-                                       {s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]}};
-                const int tcol = (lane >> 4) * 4 + q;
+                y[0][0][q] = s0[0] + s0[1] + s0[2];
+                y[0][1][q] = s0[1] - s0[2] - s0[3];
+                y[1][0][q] = s1[0] + s1[1] + s1[2];
+                y[1][1][q] = s1[1] - s1[2] - s1[3];
+                ssum[c2][q] = 0.f;
+                ssq[c2][q] = 0.f;
+            }
 #pragma unroll
-                for (int yy = 0; yy < 2; ++yy) {
-                    const int oy = y0 + 2 * tb + yy;
+            for (int yy = 0; yy < 2; ++yy) {
+                const int oy = y0 + 2 * tb + yy;
 #pragma unroll
-                    for (int xx = 0; xx < 2; ++xx) {
-                        const int ox = x0 + 2 * tcol + xx;
-                        if (oy < H && ox < W) {
-                            const size_t o = (((size_t)b * H + oy) * W + ox) * 64 + co;
-                            float v = y[yy][xx];
-                            if (addend != nullptr) v += addend[o];
-                            if (bn.z != nullptr) {
-                                if (!(bn.act[o] > 0.f)) v = 0.f;
-                                const float xh = (bn.z[o] - mu[c2]) * is[c2];
-                                ssum[c2] += v;
-                                ssq[c2] += v * xh;
-                            } else {
-                                ssum[c2] += v;
-                                ssq[c2] += v * v;
-                            }
-                            out[o] = v;
+                for (int xx = 0; xx < 2; ++xx) {
+                    const int ox = x0 + 2 * ti + xx;
+                    if (oy < H && ox < W) {
+                        const size_t o = (((size_t)b * H + oy) * W + ox) * 64 + co;
+                        float v[4] = {y[yy][xx][0], y[yy][xx][1], y[yy][xx][2], y[yy][xx][3]};
+                        if (addend != nullptr) {
+                            const float4 ad = *reinterpret_cast<const float4 *>(addend + o);
+                            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
                         }
+                        if (bn.z != nullptr) {
+                            const float4 a4 = *reinterpret_cast<const float4 *>(bn.act + o);
+                            const float4 z4 = *reinterpret_cast<const float4 *>(bn.z + o);
+                            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (!(av[q] > 0.f)) v[q] = 0.f;
+                                ssum[c2][q] += v[q];
+                                ssq[c2][q] += v[q] * ((zv[q] - mu[q]) * is[q]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { ssum[c2][q] += v[q]; ssq[c2][q] += v[q] * v[q]; }
+                        }
+                        *reinterpret_cast<float4 *>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
         }
         if (STATS) {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                ssum[c2] += __shfl_xor(ssum[c2], 16, 64);
-                ssum[c2] += __shfl_xor(ssum[c2], 32, 64);
-                ssq[c2] += __shfl_xor(ssq[c2], 16, 64);
-                ssq[c2] += __shfl_xor(ssq[c2], 32, 64);
-            }
-            if (lane < 16) {       // s_red[wave][0..31] sums, [32..63] sums of squares (32 channels)
-                s_red[wave * 64 + lane] = ssum[0];
-                s_red[wave * 64 + 16 + lane] = ssum[1];
-                s_red[wave * 64 + 32 + lane] = ssq[0];
-                s_red[wave * 64 + 48 + lane] = ssq[1];
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        ssum[c2][q] += __shfl_xor(ssum[c2][q], o, 64);
+                        ssq[c2][q] += __shfl_xor(ssq[c2][q], o, 64);
+                    }
+                }
+            if (ti == 0) {         // s_red[wave][0..31] sums, [32..63] sums of squares (32 channels)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s_red[wave * 64 + c2 * 16 + kq * 4 + q] = ssum[c2][q];
+                        s_red[wave * 64 + 32 + c2 * 16 + kq * 4 + q] = ssq[c2][q];
+                    }
             }
             __syncthreads();
             if (tid < 128) {

@@ -22,7 +22,10 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + SOURCES + ["-o", LIB_PATH]
+           "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+    if os.environ.get("COVA_ABLATE"):          # tools/conv_bench.py ablation study builds
+        cmd.append("-DCOVA_ABLATE=1")
+    cmd += SOURCES + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

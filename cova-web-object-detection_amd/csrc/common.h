@@ -21,6 +21,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (!(cond)) return COVA_ERR_BAD_ARG;       \
     } while (0)
 
+// Ablation switches of the conv kernels (tools/conv_bench.py) exist only in builds made with
+// -DCOVA_ABLATE; in the production library the mask folds to 0 and the branches disappear.
+#ifdef COVA_ABLATE
+#define COVA_ABL(x) (x)
+#else
+#define COVA_ABL(x) 0
+#endif
+
 #define COVA_API extern "C" __attribute__((visibility("default")))
 
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 FMA chain.

@@ -218,8 +218,9 @@ template <bool STATS>
 __global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_v2_kernel(
     const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
-    int ntiles, const BnBwdEpi bn, int abl)
+    int ntiles, const BnBwdEpi bn, int abl_arg)
 {
+    const int abl = COVA_ABL(abl_arg);
     // abl: ablation mask for tools/conv_bench.py (0 in production): 1 no epilogue, 2 no LDS refill,
     // 4 no input prefetch loads, 8 no weight restaging, 16 no per-tap barrier
     using namespace c3;
@@ -478,8 +479,9 @@ template <bool STATS>
 __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
     float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
-    int abl)
+    int abl_arg)
 {
+    const int abl = COVA_ABL(abl_arg);
     using namespace c1;
     __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS + 8 * 128];
     float *s_in = lds;
@@ -708,8 +710,9 @@ constexpr int NPRE_D = (TH * TW * 16 + THREADS - 1) / THREADS;   // 6 float4
 
 __global__ __launch_bounds__(wg3v2::THREADS) void conv3x3_wgrad_v2_kernel(
     const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part,
-    int H, int W, int tiles_x, int tiles_y, int ntiles, int abl)
+    int H, int W, int tiles_x, int tiles_y, int ntiles, int abl_arg)
 {
+    const int abl = COVA_ABL(abl_arg);
     using namespace wg3v2;
     __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + DZ_FLOATS];
     float *s_a = lds;
@@ -1124,6 +1127,7 @@ int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many t
 
 // shared with conv_wino.hip (same shared object; hidden visibility)
 int cova_internal_persistent_grid(int ntiles) { return persistent_grid(ntiles); }
+int cova_internal_ablate() { return g_ablate; }
 
 // ====================================================================================
 // C ABI

@@ -16,9 +16,9 @@
 //     adds for the 16 positions -- no transformed-input buffer exists anywhere;
 //   * the input tile lives in LDS channel-major [ci][341 px] (odd pixel stride => the stride-2 tile
 //     walk and the 4 channels of a k-step hit 32 distinct banks);
-//   * the transformed weights U[chunk s][pos][ci 4][co 64] (prepared once per step) stream through a
-//     double-buffered 2 x 20 KB LDS ring, one 4-channel chunk per barrier; rows are padded to 80
-//     floats so that the 4 channels of a B-operand read fall on different banks.
+//   * the transformed weights U[chunk s][ci 4][co 64][pos 16] (prepared once per step) stream through
+//     a double-buffered 2 x 20 KB LDS ring, one 4-channel chunk per barrier; a lane's 16 positions
+//     are contiguous (4 ds_read_b128 per channel block), rows padded to 20 floats (conflict free).
 // Per tile: 16 chunks x (16 A reads + 32 adds + 32 B reads + 32 MFMAs) per wave.
 #include "common.h"
 
@@ -33,8 +33,8 @@ constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
 constexpr int NPIX = PH * PW;                 // 340
 constexpr int PIXS = 341;                     // odd channel-plane stride
 constexpr int IN_FLOATS = 64 * PIXS;          // 21,824 floats = 87.3 KB
-constexpr int UROW = 80;                      // padded co row
-constexpr int UCH = 16 * 4 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
+constexpr int UROW = 20;                      // one (ci, co) row = 16 positions + 4 pad floats
+constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
 constexpr int UCH_G = 16 * 4 * 64;            // 4,096 floats per chunk in global memory
 constexpr int THREADS = 512;
 constexpr int RED_FLOATS = 8 * 64;
@@ -78,8 +78,11 @@ template <bool STATS>
 __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     const float *__restrict__ in, const float *__restrict__ ug, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
-    int ntiles, const BnBwdEpiW bn)
+    int ntiles, const BnBwdEpiW bn, int abl_arg)
 {
+    const int abl = COVA_ABL(abl_arg);
+    // abl (tools/conv_bench.py only, 0 in production): 1 no epilogue, 2 no refill stores,
+    // 4 no refill loads, 8 no weight restaging, 16 no per-chunk barrier, 32 no input transform
     using namespace wn;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *s_in = lds;
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 
     // transformed-weight chunk s: 1024 float4 in global memory, 2 per thread
     auto u_lds_off = [&](int f) {            // float4 index -> LDS float offset inside a chunk
-        const int flat = f * 4;
-        return (flat >> 8) * (4 * UROW) + ((flat >> 6) & 3) * UROW + (flat & 63);
+        const int flat = f * 4;                 // global chunk layout [k 4][co 64][pos 16]
+        return (flat >> 4) * UROW + (flat & 15);
     };
     const int uo0 = u_lds_off(tid), uo1 = u_lds_off(tid + THREADS);
 
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 
     int ubuf = 0;
     const float *a_lane = s_in + kq * PIXS + (2 * tb) * PW + 2 * ti;      // this lane's patch origin
-    const float *b_lane = s_u + kq * UROW + cbp * 32 + ti;
+    const float *b_lane = s_u + (kq * 64 + cbp * 32 + ti) * UROW;   // row (ci kq, co cbp*32 + ti)
     float V[16];
     wino_input_transform(a_lane, V);                                       // chunk 0 of the first tile
     for (; tile < ntiles; tile += gridDim.x) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 #pragma unroll 1
         for (int s = 0; s < 16; ++s) {
             // (1) refill: planes consumed two chunks ago <- data of the tile after theirs
-            if (ring2_plane >= 0 && tid < NPIX) {
+            if (ring2_plane >= 0 && tid < NPIX && !(abl & 2)) {
                 float *dst = s_in + (size_t)ring2_plane * PIXS + rpx;
                 dst[0] = ring2.x;
                 dst[PIXS] = ring2.y;
@@ -172,32 +175,45 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             ring2_plane = ring1_plane;
             // (2) fetch this chunk's planes for the next tile (zero outside the image)
             ring1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nload) ring1 = *reinterpret_cast<const float4 *>(nsrc + 4 * s);
+            if (nload && !(abl & 4)) ring1 = *reinterpret_cast<const float4 *>(nsrc + 4 * s);
             ring1_plane = has_next ? 4 * s : -1;
             // (3) next chunk of transformed weights (chunk 0 again for the next tile)
             const int ns = (s + 1) & 15;
-            const float4 un0 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid];
-            const float4 un1 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid + THREADS];
+            float4 un0 = make_float4(0, 0, 0, 0), un1 = un0;
+            if (!(abl & 8)) {
+                un0 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid];
+                un1 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid + THREADS];
+            }
             __builtin_amdgcn_sched_barrier(0);
 
             // (4) 32 MFMAs of this chunk
+            // the 16 positions of a (ci, co) pair are contiguous: 4 ds_read_b128 per channel block
             const float *bp = b_lane + ubuf * UCH;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const float b0 = bp[p * (4 * UROW)];
-                const float b1 = bp[p * (4 * UROW) + 16];
-                acc[0][p] = mfma16(b0, V[p], acc[0][p]);      // D[co][tile] += U[co][ci] * V[ci][tile]
-                acc[1][p] = mfma16(b1, V[p], acc[1][p]);
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const float4 u0 = *reinterpret_cast<const float4 *>(bp + p4 * 4);
+                const float4 u1 = *reinterpret_cast<const float4 *>(bp + 16 * UROW + p4 * 4);
+                // D[co][tile] += U[co][ci] * V[ci][tile]
+                acc[0][p4 * 4 + 0] = mfma16(u0.x, V[p4 * 4 + 0], acc[0][p4 * 4 + 0]);
+                acc[1][p4 * 4 + 0] = mfma16(u1.x, V[p4 * 4 + 0], acc[1][p4 * 4 + 0]);
+                acc[0][p4 * 4 + 1] = mfma16(u0.y, V[p4 * 4 + 1], acc[0][p4 * 4 + 1]);
+                acc[1][p4 * 4 + 1] = mfma16(u1.y, V[p4 * 4 + 1], acc[1][p4 * 4 + 1]);
+                acc[0][p4 * 4 + 2] = mfma16(u0.z, V[p4 * 4 + 2], acc[0][p4 * 4 + 2]);
+                acc[1][p4 * 4 + 2] = mfma16(u1.z, V[p4 * 4 + 2], acc[1][p4 * 4 + 2]);
+                acc[0][p4 * 4 + 3] = mfma16(u0.w, V[p4 * 4 + 3], acc[0][p4 * 4 + 3]);
+                acc[1][p4 * 4 + 3] = mfma16(u1.w, V[p4 * 4 + 3], acc[1][p4 * 4 + 3]);
             }
             // (5) input transform of the NEXT chunk (for s = 15: chunk 0 of the next tile, whose
             //     planes were refilled at chunk 2 of this tile) -- overlaps the MFMAs in flight
-            wino_input_transform(a_lane + (4 * ns) * PIXS, V);
+            if (!(abl & 32)) wino_input_transform(a_lane + (4 * ns) * PIXS, V);
             // (6) publish the next weight chunk
-            float *ud = s_u + (ubuf ^ 1) * UCH;
-            *reinterpret_cast<float4 *>(ud + uo0) = un0;
-            *reinterpret_cast<float4 *>(ud + uo1) = un1;
-            ubuf ^= 1;
-            __syncthreads();
+            if (!(abl & 8)) {
+                float *ud = s_u + (ubuf ^ 1) * UCH;
+                *reinterpret_cast<float4 *>(ud + uo0) = un0;
+                *reinterpret_cast<float4 *>(ud + uo1) = un1;
+                ubuf ^= 1;
+            }
+            if (!(abl & 16)) __syncthreads();
         }
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.
@@ -205,6 +221,17 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
         // cbp*32 + c2*16 + kq*4 + q of Winograd tile (tb, ti) -- four consecutive channels per
         // pixel, so every epilogue access is a float4.
         float ssum[2][4], ssq[2][4];
+        if (abl & 16) __syncthreads();
+        if (abl & 1) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(acc[c2][p]));
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ssum[c2][q] = 0.f; ssq[c2][q] = 0.f; }
+        } else
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int co = cbp * 32 + c2 * 16 + kq * 4;
@@ -298,15 +325,15 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     }
 }
 
-// U[s][pos = a*4+b][k][co] = (G g G^T)[a][b] for input channel 4s+k.
+// U[s][k][co][pos = a*4+b] = (G g G^T)[a][b] for input channel 4s+k.
 //  fwd:   g = w[co][ci][:, :]
 //  dgrad: output channel = ci, input channel = co, g = w[co][ci] rotated by 180 degrees
 __global__ void prep_wino_kernel(const float *__restrict__ w, float *__restrict__ u_fwd,
                                  float *__restrict__ u_dgrad)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;    // over [s 16][pos 16][k 4][o 64]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;    // over [s 16][k 4][o 64][pos 16]
     if (idx >= 16 * 16 * 4 * 64) return;
-    const int o = idx & 63, k = (idx >> 6) & 3, pos = (idx >> 8) & 15, s = idx >> 12;
+    const int pos = idx & 15, o = (idx >> 4) & 63, k = (idx >> 10) & 3, s = idx >> 12;
     const int c = 4 * s + k, a = pos >> 2, bb = pos & 3;
     const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
     float uf = 0.f, ud = 0.f;
@@ -325,8 +352,9 @@ __global__ void prep_wino_kernel(const float *__restrict__ w, float *__restrict_
 }  // namespace
 
 extern int cova_internal_persistent_grid(int ntiles);
+extern int cova_internal_ablate();
 
-// u_fwd / u_dgrad: [16][16][4][64] floats each (65,536)
+// u_fwd / u_dgrad: [16 chunks][4 ci][64 co][16 positions] floats each (65,536)
 COVA_API int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_dgrad,
                                             void *stream)
 {
@@ -353,10 +381,12 @@ COVA_API int cova_conv3x3_wino(const float *in, const float *u, const float *add
     const BnBwdEpiW bn{act, z, mean, invstd};
     if (stat_part)
         hipLaunchKernelGGL(conv3x3_c64_wino_kernel<true>, grid, block, 0, (hipStream_t)stream, in, u,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn,
+                           cova_internal_ablate());
     else
         hipLaunchKernelGGL(conv3x3_c64_wino_kernel<false>, grid, block, 0, (hipStream_t)stream, in, u,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn);
+                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn,
+                           cova_internal_ablate());
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

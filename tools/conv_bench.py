@@ -46,6 +46,13 @@ call("cova_conv3x3_prep_weights_wino", w, uf, ud)
 for stats in (False, True):
     t = timeit(lambda: call("cova_conv3x3_wino", x, uf, None, None, None, None, None, out, part if stats else None, B, H, W))
     print("conv3x3 WINOGRAD fwd stats=%d: %.3f ms  %.1f TF/s (direct-equivalent)" % (stats, t, flop3 / t / 1e9))
+for abl, what in ((0, "full"), (1, "no epilogue"), (2, "no refill stores"), (6, "no refill loads+stores"), (8, "no weight restage"),
+                  (16, "no chunk barrier"), (32, "no input transform"), (7, "no epi+refill"), (15, "MFMA+LDS+transform+barriers"),
+                  (63, "MFMA + B reads only")):
+    query("cova_set_option", 5, abl)
+    t = timeit(lambda: call("cova_conv3x3_wino", x, uf, None, None, None, None, None, out, None, B, H, W))
+    print("WINO ablation %2d %-30s: %.3f ms  %.1f TF/s" % (abl, what, t, flop3 / t / 1e9))
+query("cova_set_option", 5, 0)
 query("cova_set_option", 1, 2)
 for abl, what in ((0, "full"), (1, "no epilogue"), (2, "no LDS refill"), (4, "no prefetch loads"), (8, "no weight restage"),
                   (16, "no tap barrier"), (6, "no refill+prefetch"), (7, "no epi+refill+prefetch"), (15, "MFMA + LDS reads + barriers"),

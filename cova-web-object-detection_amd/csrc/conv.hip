@@ -1268,7 +1268,7 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
 COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
 {
     const int ntiles = B * cdiv(W, wg3::TW) * cdiv(H, wg3::TH);   // v1 bound (>= v2's need)
-    return persistent_grid(ntiles) * 2 * 9 * 4096;
+    return persistent_grid(ntiles) * 2 * 9 * 4096 + 16 * 4096;   // + Q buffer of the Winograd form
 }
 
 // act, dz NHWC [B,H,W,64]; dw OIHW [64,64,3,3]; ws >= cova_conv3x3_wgrad_workspace_floats

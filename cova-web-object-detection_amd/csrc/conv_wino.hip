@@ -390,3 +390,239 @@ COVA_API int cova_conv3x3_wino(const float *in, const float *u, const float *add
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+// ====================================================================================
+// Winograd weight gradient:  dW = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G
+// For each of the 16 transform positions a GEMM  Q[pos][co][ci] = sum_tiles Wd[pos][tile][co] *
+// V[pos][tile][ci]  (K = number of 2x2 tiles = pixels/4): 4*64*64 MACs per pixel instead of 9*64*64.
+// Persistent 512-thread blocks, 8x32-pixel tiles (64 Winograd tiles).  Wave w owns transform row
+// a = w>>1 and the two columns b = 2*(w&1), +1 for the whole 64x64 (co, ci) plane: 8 accumulators
+// of v_mfma_f32_32x32x2_f32.  Both MFMA operands are formed on the fly from the NHWC tiles in LDS
+// (lanes over channels: conflict-free ds_read_b32): per k-pair 8 reads of dY (shared by the two
+// columns) + 12 reads of the input patch (3 columns x 2 rows x 2 channel blocks) + 32 FMAs for
+// 8 MFMAs.  The tiles are refilled band by band (2 input rows + 2 dY rows per tile row, one
+// barrier each) with the next tile's data fetched during the MFMAs.
+// ====================================================================================
+namespace {
+
+namespace wgw {
+constexpr int TH = 8, TW = 32, PH = 10, PW = 34;
+constexpr int D_FLOATS = PH * PW * 64;       // 21,760 floats
+constexpr int DY_FLOATS = TH * TW * 64;      // 16,384 floats
+constexpr int THREADS = 512;
+}  // namespace wgw
+
+__global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
+    const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part, int H, int W,
+    int tiles_x, int tiles_y, int ntiles)
+{
+    using namespace wgw;
+    __shared__ __attribute__((aligned(16))) float lds[D_FLOATS + DY_FLOATS];
+    float *s_d = lds;
+    float *s_dy = lds + D_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh2 = lane >> 5;
+    // per-wave (uniform) transform coefficients
+    const int a = wave >> 1, pair = wave & 1;
+    // B^T row a = sr1 * e[r1] + sr2 * e[r2]
+    const int r1 = a == 0 ? 0 : 1, r2 = a == 3 ? 3 : 2;
+    const float sr1 = a == 2 ? -1.f : 1.f, sr2 = (a == 0 || a == 3) ? -1.f : 1.f;
+    // the two columns b0 = 2*pair, b1 = b0+1 read input columns c0, c0+1, c0+2
+    const int c0 = pair;                         // pair 0: cols 0,1,2 ; pair 1: cols 1,2,3
+    const float vc[2][3] = {{pair == 0 ? 1.f : -1.f, pair == 0 ? 0.f : 1.f, pair == 0 ? -1.f : 0.f},
+                            {pair == 0 ? 0.f : 1.f, pair == 0 ? 1.f : 0.f, pair == 0 ? 1.f : -1.f}};
+    // A (4x2) rows: (1,0) (1,1) (1,-1) (0,-1)
+    const float cy0 = a == 3 ? 0.f : 1.f, cy1 = a == 0 ? 0.f : (a == 1 ? 1.f : -1.f);
+    const float cx[2][2] = {{pair == 0 ? 1.f : 1.f, pair == 0 ? 0.f : -1.f},       // b0 = 0 | 2
+                            {pair == 0 ? 1.f : 0.f, pair == 0 ? 1.f : -1.f}};      // b1 = 1 | 3
+
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    f32x16 acc[2][2][2];        // [column e][co block][ci block]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
+
+    // fetch helpers: float4 slot `idx` of input rows [row0, row0+nrows) / dy rows of tile (ty, tx, b)
+    auto load_d = [&](const float *act_b, int ty, int tx, int row0, int idx) {
+        const int px = idx >> 4, c4 = idx & 15;
+        const int r = row0 + px / PW, c = px % PW;
+        const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+        return v;
+    };
+    auto load_dy = [&](const float *dz_b, int ty, int tx, int row0, int idx) {
+        const int px = idx >> 4, c4 = idx & 15;
+        const int r = row0 + px / TW, c = px % TW;
+        const int gy = ty * TH + r, gx = tx * TW + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < H && gx < W)
+            v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
+        return v;
+    };
+
+    if (tile < ntiles) {      // first tile: everything
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const float *act_b = act + (size_t)b * H * W * 64, *dz_b = dz + (size_t)b * H * W * 64;
+#pragma unroll 1
+        for (int idx = tid; idx < PH * PW * 16; idx += THREADS)
+            *reinterpret_cast<float4 *>(s_d + idx * 4) = load_d(act_b, ty, tx, 0, idx);
+#pragma unroll 1
+        for (int idx = tid; idx < TH * TW * 16; idx += THREADS)
+            *reinterpret_cast<float4 *>(s_dy + idx * 4) = load_dy(dz_b, ty, tx, 0, idx);
+    }
+    __syncthreads();
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const int nb = next / (tiles_x * tiles_y);
+        const float *nact = act + (size_t)nb * H * W * 64, *ndz = dz + (size_t)nb * H * W * 64;
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            // band tr of the NEXT tile: input rows 2tr, 2tr+1 (+ rows 8, 9 with the last band) and dY
+            // rows 2tr, 2tr+1; fetched now, written after this tile row's barrier
+            constexpr int kMaxD = 5, kDy = 2;
+            const int nd_rows = tr == 3 ? 4 : 2;
+            float4 rd[kMaxD], rdy[kDy];
+            if (has_next) {
+#pragma unroll
+                for (int k = 0; k < kMaxD; ++k) {
+                    const int idx = tid + k * THREADS;
+                    if (idx < nd_rows * PW * 16) rd[k] = load_d(nact, nty, ntx, 2 * tr, idx);
+                }
+#pragma unroll
+                for (int k = 0; k < kDy; ++k) rdy[k] = load_dy(ndz, nty, ntx, 2 * tr, tid + k * THREADS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- 8 k-pairs: tiles (tr, 2t + kh2)
+            const float *dyb = s_dy + ((2 * tr) * TW + 2 * kh2) * 64 + li;
+            const float *db = s_d + ((2 * tr) * PW + 2 * kh2 + c0) * 64 + li;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float wd[2][2], vv[2][2];       // [column e][channel block]
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const float *p = dyb + (4 * t) * 64 + blk * 32;          // tile col 2t+kh2 -> px 4t+2kh2
+                    const float y00 = p[0], y01 = p[64], y10 = p[TW * 64], y11 = p[TW * 64 + 64];
+                    const float top0 = cx[0][0] * y00 + cx[0][1] * y01, bot0 = cx[0][0] * y10 + cx[0][1] * y11;
+                    const float top1 = cx[1][0] * y00 + cx[1][1] * y01, bot1 = cx[1][0] * y10 + cx[1][1] * y11;
+                    wd[0][blk] = cy0 * top0 + cy1 * bot0;
+                    wd[1][blk] = cy0 * top1 + cy1 * bot1;
+                    const float *q = db + (4 * t) * 64 + blk * 32;
+                    float rc[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        rc[j] = sr1 * q[(r1 * PW + j) * 64] + sr2 * q[(r2 * PW + j) * 64];
+                    vv[0][blk] = vc[0][0] * rc[0] + vc[0][1] * rc[1] + vc[0][2] * rc[2];
+                    vv[1][blk] = vc[1][0] * rc[0] + vc[1][1] * rc[1] + vc[1][2] * rc[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[e][i][j] = mfma32(wd[e][i], vv[e][j], acc[e][i][j]);
+            }
+            __syncthreads();          // everyone is done with this band
+            if (has_next) {
+#pragma unroll
+                for (int k = 0; k < kMaxD; ++k) {
+                    const int idx = tid + k * THREADS;
+                    if (idx < nd_rows * PW * 16)
+                        *reinterpret_cast<float4 *>(s_d + (2 * tr) * PW * 64 + idx * 4) = rd[k];
+                }
+#pragma unroll
+                for (int k = 0; k < kDy; ++k)
+                    *reinterpret_cast<float4 *>(s_dy + (2 * tr) * TW * 64 + (tid + k * THREADS) * 4) = rdy[k];
+            }
+        }
+        __syncthreads();              // the refilled tile is complete before the next tile starts
+    }
+    // partial: part[block][pos = a*4 + b][co][ci]
+    float *dst = part + (size_t)blockIdx.x * (16 * 4096);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int pos = a * 4 + 2 * pair + e;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[pos * 4096 + (i * 32 + mfma32_row(r, lane)) * 64 + j * 32 + li] = acc[e][i][j][r];
+    }
+}
+
+// sum the per-block partials (fp64) : q[16*4096]
+__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float *__restrict__ part,
+                                                                 int nparts, float *__restrict__ q)
+{
+    __shared__ double s_acc[16][64];
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;
+    double s = 0.0;
+    for (int p = slice; p < nparts; p += 16) s += (double)part[(size_t)p * (16 * 4096) + idx];
+    s_acc[slice][tx] = s;
+    __syncthreads();
+    if (slice == 0) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
+        q[idx] = (float)t;
+    }
+}
+
+// dW[co][ci][r][t] = sum_{a,b} G[a][r] * Q[a*4+b][co][ci] * G[b][t]   (OIHW)
+__global__ void wgrad_wino_final_kernel(const float *__restrict__ q, float *__restrict__ dw)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over [co][ci]
+    if (idx >= 4096) return;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float Q[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Q[p] = q[p * 4096 + idx];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) s += G[a][r] * G[b][t] * Q[a * 4 + b];
+            dw[idx * 9 + r * 3 + t] = s;
+        }
+}
+
+}  // namespace
+
+// act, dz NHWC [B,H,W,64]; dw OIHW [64,64,3,3]; ws >= (grid*16*4096 + 16*4096) floats, which
+// cova_conv3x3_wgrad_workspace_floats covers
+COVA_API int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw, float *ws, int B,
+                                     int H, int W, void *stream)
+{
+    COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
+    const int tiles_x = cdiv(W, wgw::TW), tiles_y = cdiv(H, wgw::TH);
+    const int ntiles = B * tiles_x * tiles_y;
+    const int grid = cova_internal_persistent_grid(ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(grid), dim3(wgw::THREADS), 0, st, act, dz, ws, H,
+                       W, tiles_x, tiles_y, ntiles);
+    COVA_LAUNCH_CHECK();
+    float *q = ws + (size_t)grid * (16 * 4096);
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(16 * 4096 / 64), dim3(1024), 0, st, ws, grid, q);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_wino_final_kernel, dim3(16), dim3(256), 0, st, q, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -101,8 +101,8 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 
 
 # ------------------------------------------------------------------------------- conv stack
-# 3x3 convolutions (forward + data gradient): Winograd F(2x2,3x3) kernel (2.25x fewer MFMAs, same
-# fp32 error) or the direct implicit-GEMM kernel.  The weight gradient always uses the direct form.
+# 3x3 convolutions (forward, data gradient, weight gradient): Winograd F(2x2,3x3) kernels (2.25x
+# fewer MFMAs, same fp32 error) or the direct implicit-GEMM kernels.
 USE_WINOGRAD = True
 
 
@@ -201,6 +201,7 @@ def convstack_bwd(sv, dfeat, gout=None):
     R = B * H2 * W2
     grads = {}
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
+    WGRAD3 = "cova_conv3x3_wgrad_wino" if USE_WINOGRAD else "cova_conv3x3_wgrad"
     nt = query("cova_conv3x3_num_tiles", B, H2, W2)
     dA, pend = dfeat, None          # pend: partials of the fused reduction for dA (already masked)
     for blk in (1, 0):
@@ -218,7 +219,7 @@ def convstack_bwd(sv, dfeat, gout=None):
             dg, db = bn_bwd_from_partials(pend, nt, dA, s["z2"], s["bnb"], R, dz2, gout, pb)
         grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
-        call("cova_conv3x3_wgrad", s["a1"], dz2, dw, ws3, B, H2, W2)
+        call(WGRAD3, s["a1"], dz2, dw, ws3, B, H2, W2)
         grads[kb + ".weight"] = dw
         # ---- a1 = relu(bn1(z1)): dgrad of conv2 fused with bn1's mask + reduction
         dy_a = torch.empty_like(dA)
@@ -230,7 +231,7 @@ def convstack_bwd(sv, dfeat, gout=None):
         dg, db = bn_bwd_from_partials(part, nt, dy_a, s["z1"], bna, R, dz1, gout, pa)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
-        call("cova_conv3x3_wgrad", s["x"], dz1, dw, ws3, B, H2, W2)
+        call(WGRAD3, s["x"], dz1, dw, ws3, B, H2, W2)
         grads[ka + ".weight"] = dw
         dx = dy_a                                     # reuse
         if blk == 1:

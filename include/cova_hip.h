@@ -75,6 +75,8 @@ int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_d
 int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,
                       const float *z, const float *mean, const float *invstd, float *out,
                       float *stat_part, int B, int H, int W, void *stream);
+int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
+                            int H, int W, void *stream);   /* Winograd form of cova_conv3x3_wgrad */
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);

@@ -425,3 +425,20 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap):
         close(part_w.sum(0), part_d.sum(0), 1e-4, "winograd fused sums")
     finally:
         query("cova_set_option", 2, 0)
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
+def test_conv3x3_winograd_wgrad(B, H, W, cap):
+    g = torch.Generator().manual_seed(H + W + B)
+    x = torch.randn(B, 64, H, W, generator=g)
+    dz = torch.randn(B, 64, H, W, generator=g)
+    wr = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    (F.conv2d(x, wr, padding=1) * dz).sum().backward()
+    ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
+    query("cova_set_option", 2, cap)
+    try:
+        dw = torch.zeros(64, 64, 3, 3, device=DEV)
+        call("cova_conv3x3_wgrad_wino", nhwc(x), nhwc(dz), dw, ws, B, H, W)
+        close(dw, wr.grad, 2e-4, "winograd wgrad")
+    finally:
+        query("cova_set_option", 2, 0)

@@ -74,6 +74,8 @@ for abl, what in ((0, "full"), (2, "no LDS refill"), (4, "no prefetch loads"), (
     t = timeit(lambda: call("cova_conv3x3_wgrad", x, dz, dw, ws, B, H, W))
     print("wgrad ablation %2d %-22s: %.3f ms  %.1f TF/s" % (abl, what, t, flop3 / t / 1e9))
 query("cova_set_option", 5, 0)
+t = timeit(lambda: call("cova_conv3x3_wgrad_wino", x, dz, dw, ws, B, H, W))
+print("conv3x3 WINOGRAD wgrad (+reduce): %.3f ms  %.1f TF/s (direct-equivalent)" % (t, flop3 / t / 1e9))
 for variant in (1, 2):
     query("cova_set_option", 3, variant)
     t = timeit(lambda: call("cova_conv3x3_wgrad", x, dz, dw, ws, B, H, W))

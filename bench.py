@@ -172,9 +172,9 @@ def main():
                          "executed_frac": round(achieved / 2.25 / PEAK_F32_MFMA_TFLOPS, 4),
                          # HBM bytes per forward launch from PMC (separate --pmc FETCH_SIZE /
                          # WRITE_SIZE passes, FETCH doubled per the gfx950 correction):
-                         # 2*224 MiB + 403 MiB, profiles/r01_pmc_conv_kernels_isolated.txt;
+                         # 2*232.7 MiB + 408.3 MiB, profiles/r01_pmc_conv_kernels_isolated.txt;
                          # algorithmic = 2 * 419.4 MB (one read + one write of [16,320,320,64] f32)
-                         "traffic": 892e6 * args.pages / 16, "traffic_unit": "B/launch",
+                         "traffic": 916e6 * args.pages / 16, "traffic_unit": "B/launch",
                          "algorithmic_bytes": 2 * 4 * 64 * args.pages * (IMG // 4) * (IMG // 4),
                          "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
                          "flop_per_launch": flops},

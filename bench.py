@@ -119,7 +119,8 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": [], "cova_conv3x3_wino": []}
+    _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": [], "cova_conv3x3_wino": [],
+                    "cova_conv3x3_wino_pro": []}
     if os.environ.get("COVA_PROFILE_ALL"):          # per-entry-point HIP-event timing (diagnostic)
         _lib.PROFILE = {name: [] for name in _lib.lib().protos}
     t0 = time.perf_counter()
@@ -128,7 +129,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = (_lib.PROFILE["cova_conv3x3_fwd"] + _lib.PROFILE["cova_conv3x3_dgrad_bnbwd"] +
-            _lib.PROFILE["cova_conv3x3_wino"])
+            _lib.PROFILE["cova_conv3x3_wino"] + _lib.PROFILE["cova_conv3x3_wino_pro"])
     if os.environ.get("COVA_PROFILE_ALL") and rank == 0:
         rows = [(sum(a.elapsed_time(b) for a, b in v) / args.steps, len(v) // args.steps, k)
                 for k, v in _lib.PROFILE.items() if v]

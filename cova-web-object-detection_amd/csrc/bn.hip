@@ -230,6 +230,29 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(
     }
 }
 
+// finalize_bwd that also emits the affine form of the apply step,
+//   dz = scale*(dy - c1 - xhat*c2) = A*dy + B*z + C,   abc = [3][C] = A | B | C,
+// for the convolutions that apply it on load (cova_conv3x3_wino_pro / _wgrad_wino_pro).
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_abc_kernel(
+    const float *__restrict__ partial, int nparts, int C, double count,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ scale, float *__restrict__ abc)
+{
+    __shared__ double s_a[1024], s_b[1024];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double s1, s2;
+    combine_partials(partial, nparts, C, c, slice, s_a, s_b, s1, s2);
+    if (slice == 0 && c < C) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        const double c1 = s1 / count, c2 = s2 / count;
+        const double sc = scale[c], is = invstd[c], mu = mean[c];
+        abc[c] = (float)sc;
+        abc[C + c] = (float)(-sc * is * c2);
+        abc[2 * C + c] = (float)(sc * (mu * is * c2 - c1));
+    }
+}
+
 // out = act(z*scale + shift (+ res));  V = vector width (1 or 4)
 template <int V>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float y = v[j] * sc[j] + sh[j];
+            float y = fmaf(sc[j], v[j], sh[j]);      // same form as the conv prologues
             if (res) y += rr[j];
             if (relu) y = y > 0.f ? y : 0.f;
             v[j] = y;
@@ -715,6 +738,21 @@ COVA_API int cova_bn_finalize_bwd(const float *partial, int nparts, int C, doubl
     COVA_REQUIRE(partial && coef && nparts > 0 && C > 0);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
                        partial, nparts, C, count, dgamma, dbeta, coef);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// BN backward, stage 2 in affine form: dgamma, dbeta (nullable) and abc [3][C] with
+// dz = abc[0]*dy + abc[1]*z + abc[2]  (applied on load by the *_pro convolutions)
+COVA_API int cova_bn_finalize_bwd_abc(const float *partial, int nparts, int C, double count,
+                                      float *dgamma, float *dbeta, const float *mean,
+                                      const float *invstd, const float *scale, float *abc,
+                                      void *stream)
+{
+    COVA_REQUIRE(partial && mean && invstd && scale && abc && nparts > 0 && C > 0);
+    hipLaunchKernelGGL(bn_finalize_bwd_abc_kernel, dim3(cdiv(C, 64)), dim3(1024), 0,
+                       (hipStream_t)stream, partial, nparts, C, count, dgamma, dbeta, mean, invstd,
+                       scale, abc);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -24,8 +24,21 @@
 
 namespace {
 
+// ReLU mask + BatchNorm-backward sums in the epilogue.  The mask is act > 0, or, when the
+// activation was never materialised (act == nullptr), fma(msc, z, msh) > 0 -- the same expression
+// the affine-on-load prologue evaluates, so both sides take identical decisions.
 struct BnBwdEpiW {
-    const float *act, *z, *mean, *invstd;
+    const float *act, *z, *mean, *invstd, *msc, *msh;
+};
+
+// Affine-on-load prologue: the conv input is  f(A[c]*in + B[c]*in2 + C[c])  (f = ReLU or identity),
+// zero outside the image.  Covers (a) a BatchNorm+ReLU folded into the consuming conv
+// (A = scale, B = 0, C = shift, relu) and (b) the BatchNorm-backward "apply" folded into the
+// consumers of dz:  dz = scale*(dy - c1 - xhat*c2) = A*dy + B*z + C.
+struct ProIn {
+    const float *abc;      // [3][64] = A | B | C, or nullptr
+    const float *in2;      // second tensor (same NHWC shape as the input) or nullptr (B ignored)
+    int relu;
 };
 
 namespace wn {
@@ -37,6 +50,9 @@ constexpr int UROW = 20;                      // one (ci, co) row = 16 positions
 constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
 constexpr int UCH_G = 16 * 4 * 64;            // 4,096 floats per chunk in global memory
 constexpr int THREADS = 512;
+// L2 prefetch of the epilogue operands during the chunk loop: measured 4% slower (the extra
+// in-order loads delay the weight-chunk waits), kept for experiments only
+constexpr bool PREFETCH_EPI = false;
 constexpr int RED_FLOATS = 8 * 64;
 constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.3 KB
 }  // namespace wn
@@ -74,23 +90,48 @@ __device__ __forceinline__ void wino_input_transform(const float *__restrict__ a
     }
 }
 
-template <bool STATS>
+// BN: 0 = plain epilogue, 1 = ReLU mask from z (fma(msc, z, msh) > 0) + BatchNorm-backward sums,
+//     2 = ReLU mask from the materialised activation + BatchNorm-backward sums
+template <bool STATS, bool PRO, bool ADD, int BN>
 __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     const float *__restrict__ in, const float *__restrict__ ug, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
-    int ntiles, const BnBwdEpiW bn, int abl_arg)
+    int ntiles, const BnBwdEpiW bn, const ProIn pro, int abl_arg)
 {
     const int abl = COVA_ABL(abl_arg);
     // abl (tools/conv_bench.py only, 0 in production): 1 no epilogue, 2 no refill stores,
-    // 4 no refill loads, 8 no weight restaging, 16 no per-chunk barrier, 32 no input transform
+    // 4 no refill loads, 8 no weight restaging, 16 no per-chunk barrier, 32 no input transform,
+    // 64 no statistics reduction, 128 no epilogue operand loads, 256 no output stores,
+    // 512 no L2 prefetch of the epilogue operands
     using namespace wn;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 192];
     float *s_in = lds;
     float *s_u = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + 2 * UCH;
+    float *s_pro = lds + LDS_FLOATS;               // A | B | C per channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tb = wave & 3, cbp = wave >> 2;
     const int ti = lane & 15, kq = lane >> 4;
+    const bool pro2 = PRO && pro.in2 != nullptr;
+    if (PRO) {
+        if (tid < 192) s_pro[tid] = pro.abc[tid];
+        __syncthreads();
+    }
+    // staged value of an in-image element: f(A*v + B*w + C) on 4 consecutive channels c..c+3
+    auto pro_apply = [&](float4 v, float4 w, int c) {
+        const float4 A = *reinterpret_cast<const float4 *>(s_pro + c);
+        const float4 Bc = *reinterpret_cast<const float4 *>(s_pro + 64 + c);
+        const float4 Cc = *reinterpret_cast<const float4 *>(s_pro + 128 + c);
+        float4 r;
+        r.x = fmaf(A.x, v.x, pro2 ? fmaf(Bc.x, w.x, Cc.x) : Cc.x);
+        r.y = fmaf(A.y, v.y, pro2 ? fmaf(Bc.y, w.y, Cc.y) : Cc.y);
+        r.z = fmaf(A.z, v.z, pro2 ? fmaf(Bc.z, w.z, Cc.z) : Cc.z);
+        r.w = fmaf(A.w, v.w, pro2 ? fmaf(Bc.w, w.w, Cc.w) : Cc.w);
+        if (pro.relu) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        }
+        return r;
+    };
 
     int tile = blockIdx.x;       // XCD-aware order (see conv.hip)
     if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -106,15 +147,21 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     // ---- first tile: whole halo'd input tile, channel-major in LDS
     {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const float *in_b = in + (size_t)b * H * W * 64;
 #pragma unroll 1
         for (int idx = tid; idx < NPIX * 16; idx += THREADS) {
             const int px = idx >> 4, c = (idx & 15) * 4;
             const int r = px / PW, cc = px - r * PW;
             const int gy = ty * TH + r - 1, gx = tx * TW + cc - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t o = ((size_t)b * H * W + (size_t)gy * W + gx) * 64 + c;
+                v = *reinterpret_cast<const float4 *>(in + o);
+                if (PRO) {
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pro2) w = *reinterpret_cast<const float4 *>(pro.in2 + o);
+                    v = pro_apply(v, w, c);
+                }
+            }
             s_in[(c + 0) * PIXS + px] = v.x;
             s_in[(c + 1) * PIXS + px] = v.y;
             s_in[(c + 2) * PIXS + px] = v.z;
@@ -129,13 +176,22 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 
     // Streaming refill: chunk s of a tile reads only channel planes 4s..4s+3, so once its barrier
     // has passed those planes are dead and are overwritten with the NEXT tile's data two chunks
-    // later (loaded into a 2-deep register ring in between).  The tile buffer is therefore refilled
-    // during the MFMAs, 4 planes per chunk: no tile-sized prefetch registers, no refill phase
-    // between tiles, and HBM sees a perfectly steady stream.  Thread px (< 340) owns pixel px.
+    // later.  The tile buffer is therefore refilled during the MFMAs, 4 planes per chunk: no
+    // tile-sized prefetch registers, no refill phase between tiles, and HBM sees a perfectly steady
+    // stream.  Thread px (< 340) owns pixel px.  Two register rings (even / odd chunks) hold the
+    // data in flight, so a load has two full chunks (~3 us) to land before it is needed.
+    // Every global load in the loop is unconditional (clamped address, value discarded when not
+    // needed): a load inside a branch would force s_waitcnt vmcnt(0) at the next counted wait.
+    struct Ring {
+        float4 v, w;        // planes 4s..4s+3 of the next tile's pixel (w: second input of PRO)
+        int plane;          // first plane, or -1: nothing to write
+        bool in;            // pixel lies inside the image
+        float pf;           // landing register of the epilogue-operand prefetch (value unused)
+    };
     const int rpx = tid < NPIX ? tid : 0;
     const int rrow = rpx / PW, rcol = rpx - rrow * PW;
-    float4 ring1 = make_float4(0.f, 0.f, 0.f, 0.f), ring2 = ring1;   // loaded 1 / 2 steps ago
-    int ring1_plane = -1, ring2_plane = -1;                            // -1: nothing to write
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Ring ringA{zero4, zero4, -1, false, 0.f}, ringB{zero4, zero4, -1, false, 0.f};
 
     int ubuf = 0;
     const float *a_lane = s_in + kq * PIXS + (2 * tb) * PW + 2 * ti;      // this lane's patch origin
@@ -147,13 +203,31 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
         const int ty = (tile / tiles_x) % tiles_y;
         const int b = tile / (tiles_x * tiles_y);
         const int y0 = ty * TH, x0 = tx * TW;
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
+        const bool has_next = tile + gridDim.x < ntiles;
+        const int next = has_next ? tile + gridDim.x : tile;       // always a valid tile
         const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
-        const float *nin_b = in + (size_t)(next / (tiles_x * tiles_y)) * H * W * 64;
         const int ngy = nty * TH + rrow - 1, ngx = ntx * TW + rcol - 1;
         const bool nload = has_next && tid < NPIX && ngy >= 0 && ngy < H && ngx >= 0 && ngx < W;
-        const float *nsrc = nin_b + ((size_t)ngy * W + ngx) * 64;
+        const size_t noff = (size_t)(next / (tiles_x * tiles_y)) * H * W * 64 +
+                            ((size_t)min(max(ngy, 0), H - 1) * W + min(max(ngx, 0), W - 1)) * 64;
+        const float *nsrc = in + noff;
+        const float *nsrc2 = pro2 ? pro.in2 + noff : in + noff;
+        const size_t img = (size_t)b * H * W * 64;
+
+        // Epilogue operands (addend / z / activation): every chunk each wave touches one dword in
+        // 4 of the 64 128-byte lines of its output region (2 rows x 32 pixels x 32 channels) per
+        // tensor, so that the epilogue finds them in L2 instead of waiting for HBM.
+        constexpr int NPF = PREFETCH_EPI ? (ADD ? 1 : 0) + (BN != 0 ? 1 : 0) + (BN == 2 ? 1 : 0) : 0;
+        const float *pf_base = in;
+        if (NPF > 0) {
+            const float *t0 = ADD ? addend : bn.z;
+            const float *t1 = ADD ? (BN != 0 ? bn.z : addend) : (BN == 2 ? bn.act : bn.z);
+            const float *t2 = BN == 2 ? bn.act : t0;
+            const int g = lane >> 2;
+            pf_base = (g == 1 && NPF > 1) ? t1 : ((g == 2 && NPF > 2) ? t2 : t0);
+            pf_base += img + cbp * 32;
+        }
+        const int pf_li = (lane < 4 * NPF) ? (lane & 3) : 0;
 
         f32x4 acc[2][16];
 #pragma unroll
@@ -161,28 +235,39 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 #pragma unroll
             for (int p = 0; p < 16; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-        for (int s = 0; s < 16; ++s) {
+        auto chunk = [&](const int s, Ring &ring) {
             // (1) refill: planes consumed two chunks ago <- data of the tile after theirs
-            if (ring2_plane >= 0 && tid < NPIX && !(abl & 2)) {
-                float *dst = s_in + (size_t)ring2_plane * PIXS + rpx;
-                dst[0] = ring2.x;
-                dst[PIXS] = ring2.y;
-                dst[2 * PIXS] = ring2.z;
-                dst[3 * PIXS] = ring2.w;
+            if (ring.plane >= 0 && tid < NPIX && !(abl & 2)) {
+                float4 v = zero4;
+                if (ring.in) v = PRO ? pro_apply(ring.v, ring.w, ring.plane) : ring.v;
+                float *dst = s_in + (size_t)ring.plane * PIXS + rpx;
+                dst[0] = v.x;
+                dst[PIXS] = v.y;
+                dst[2 * PIXS] = v.z;
+                dst[3 * PIXS] = v.w;
             }
-            ring2 = ring1;
-            ring2_plane = ring1_plane;
-            // (2) fetch this chunk's planes for the next tile (zero outside the image)
-            ring1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nload && !(abl & 4)) ring1 = *reinterpret_cast<const float4 *>(nsrc + 4 * s);
-            ring1_plane = has_next ? 4 * s : -1;
-            // (3) next chunk of transformed weights (chunk 0 again for the next tile)
+            // (2) next chunk of transformed weights (chunk 0 again for the next tile).  Issued FIRST:
+            //     vmcnt retires in order, so the wait for these (end of this chunk) must not have
+            //     the long-latency HBM loads below in front of it.
             const int ns = (s + 1) & 15;
-            float4 un0 = make_float4(0, 0, 0, 0), un1 = un0;
+            float4 un0 = zero4, un1 = zero4;
             if (!(abl & 8)) {
                 un0 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid];
                 un1 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid + THREADS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) fetch this chunk's planes for the next tile; consumed two chunks from now
+            if (!(abl & 4)) {
+                ring.v = *reinterpret_cast<const float4 *>(nsrc + 4 * s);
+                if (pro2) ring.w = *reinterpret_cast<const float4 *>(nsrc2 + 4 * s);
+            }
+            ring.plane = has_next ? 4 * s : -1;
+            ring.in = nload;
+            if (NPF > 0 && !(abl & 512)) {
+                const int line = s * 4 + pf_li;
+                const int prow = min(y0 + 2 * tb + (line >> 5), H - 1), pcol = min(x0 + (line & 31), W - 1);
+                asm volatile("" ::"v"(ring.pf));          // the load of two chunks ago has long landed
+                ring.pf = pf_base[(size_t)(unsigned)((prow * W + pcol) * 64)];
             }
             __builtin_amdgcn_sched_barrier(0);
 
@@ -214,6 +299,11 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
                 ubuf ^= 1;
             }
             if (!(abl & 16)) __syncthreads();
+        };
+#pragma unroll 1
+        for (int s2 = 0; s2 < 8; ++s2) {
+            chunk(2 * s2, ringA);
+            chunk(2 * s2 + 1, ringB);
         }
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.
@@ -231,67 +321,128 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { ssum[c2][q] = 0.f; ssq[c2][q] = 0.f; }
-        } else
+        } else {
+            // (a) output transform of both channel groups: the 128 accumulator registers die here
+            float y[2][4][4];                      // [c2][pixel = yy*2 + xx][q]
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int co = cbp * 32 + c2 * 16 + kq * 4;
-            float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = mu4;
-            if (bn.z != nullptr) {
-                mu4 = *reinterpret_cast<const float4 *>(bn.mean + co);
-                is4 = *reinterpret_cast<const float4 *>(bn.invstd + co);
-            }
-            const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-            float y[2][2][4];
+            for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s0[4], s1[4];
+                for (int q = 0; q < 4; ++q) {
+                    float s0[4], s1[4];
 #pragma unroll
-                for (int bcol = 0; bcol < 4; ++bcol) {
-                    const float m0 = acc[c2][0 * 4 + bcol][q], m1 = acc[c2][1 * 4 + bcol][q];
-                    const float m2 = acc[c2][2 * 4 + bcol][q], m3 = acc[c2][3 * 4 + bcol][q];
-                    s0[bcol] = m0 + m1 + m2;
-                    s1[bcol] = m1 - m2 - m3;
+                    for (int bcol = 0; bcol < 4; ++bcol) {
+                        const float m0 = acc[c2][0 * 4 + bcol][q], m1 = acc[c2][1 * 4 + bcol][q];
+                        const float m2 = acc[c2][2 * 4 + bcol][q], m3 = acc[c2][3 * 4 + bcol][q];
+                        s0[bcol] = m0 + m1 + m2;
+                        s1[bcol] = m1 - m2 - m3;
+                    }
+                    y[c2][0][q] = s0[0] + s0[1] + s0[2];
+                    y[c2][1][q] = s0[1] - s0[2] - s0[3];
+                    y[c2][2][q] = s1[0] + s1[1] + s1[2];
+                    y[c2][3][q] = s1[1] - s1[2] - s1[3];
+                    ssum[c2][q] = 0.f;
+                    ssq[c2][q] = 0.f;
                 }
-                y[0][0][q] = s0[0] + s0[1] + s0[2];
-                y[0][1][q] = s0[1] - s0[2] - s0[3];
-                y[1][0][q] = s1[0] + s1[1] + s1[2];
-                y[1][1][q] = s1[1] - s1[2] - s1[3];
-                ssum[c2][q] = 0.f;
-                ssq[c2][q] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+            // (b) every epilogue operand (2 channel groups x 4 pixels x up to 3 tensors, float4 each)
+            //     is requested before the first one is used -- one memory round trip per tile --
+            //     and nothing is conditional (out-of-image pixels read a clamped address and are
+            //     discarded), so the waits are counted instead of s_waitcnt vmcnt(0).
+            int co0 = cbp * 32 + kq * 4;
+            asm volatile("" : "+v"(co0));      // keeps the per-channel constant loads out of the main loop
+            // wave-uniform image base + 32-bit in-image element offsets (scalar-base addressing)
+            const float *add_b = addend + img, *z_b = bn.z + img, *act_b = bn.act + img;
+            float *out_b = out + img;
+            bool ok[4];
+            unsigned off[4], offc[4];
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const int oy = y0 + 2 * tb + (pq >> 1), ox = x0 + 2 * ti + (pq & 1);
+                ok[pq] = oy < H && ox < W;
+                off[pq] = (unsigned)((oy * W + ox) * 64 + co0);
+                offc[pq] = (unsigned)((min(oy, H - 1) * W + min(ox, W - 1)) * 64 + co0);
             }
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                const int oy = y0 + 2 * tb + yy;
-#pragma unroll
-                for (int xx = 0; xx < 2; ++xx) {
-                    const int ox = x0 + 2 * ti + xx;
-                    if (oy < H && ox < W) {
-                        const size_t o = (((size_t)b * H + oy) * W + ox) * 64 + co;
-                        float v[4] = {y[yy][xx][0], y[yy][xx][1], y[yy][xx][2], y[yy][xx][3]};
-                        if (addend != nullptr) {
-                            const float4 ad = *reinterpret_cast<const float4 *>(addend + o);
-                            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                        }
-                        if (bn.z != nullptr) {
-                            const float4 a4 = *reinterpret_cast<const float4 *>(bn.act + o);
-                            const float4 z4 = *reinterpret_cast<const float4 *>(bn.z + o);
-                            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (!(av[q] > 0.f)) v[q] = 0.f;
-                                ssum[c2][q] += v[q];
-                                ssq[c2][q] += v[q] * ((zv[q] - mu[q]) * is[q]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { ssum[c2][q] += v[q]; ssq[c2][q] += v[q] * v[q]; }
-                        }
-                        *reinterpret_cast<float4 *>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            struct Ops {
+                float4 ad[4], z4[4], a4[4], mu4, is4, sc4, sh4;
+            };
+            auto load_ops = [&](const int c2, Ops &o) {
+                o.mu4 = o.is4 = o.sc4 = o.sh4 = zero4;
+                if (BN != 0) {
+                    o.mu4 = *reinterpret_cast<const float4 *>(bn.mean + co0 + c2 * 16);
+                    o.is4 = *reinterpret_cast<const float4 *>(bn.invstd + co0 + c2 * 16);
+                    if (BN == 1) {
+                        o.sc4 = *reinterpret_cast<const float4 *>(bn.msc + co0 + c2 * 16);
+                        o.sh4 = *reinterpret_cast<const float4 *>(bn.msh + co0 + c2 * 16);
                     }
                 }
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    o.ad[pq] = o.a4[pq] = o.z4[pq] = zero4;
+                    const size_t e = (size_t)(offc[pq] + c2 * 16);
+                    if (ADD && !(abl & 128)) o.ad[pq] = *reinterpret_cast<const float4 *>(add_b + e);
+                    if (BN != 0 && !(abl & 128)) o.z4[pq] = *reinterpret_cast<const float4 *>(z_b + e);
+                    if (BN == 2 && !(abl & 128)) o.a4[pq] = *reinterpret_cast<const float4 *>(act_b + e);
+                }
+            };
+            // (c) addend, ReLU mask, BatchNorm-backward sums (or plain statistics); result in place
+            auto finish = [&](const int c2, const Ops &o) {
+                const float mu[4] = {o.mu4.x, o.mu4.y, o.mu4.z, o.mu4.w};
+                const float is[4] = {o.is4.x, o.is4.y, o.is4.z, o.is4.w};
+                const float msc[4] = {o.sc4.x, o.sc4.y, o.sc4.z, o.sc4.w};
+                const float msh[4] = {o.sh4.x, o.sh4.y, o.sh4.z, o.sh4.w};
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    const float adv[4] = {o.ad[pq].x, o.ad[pq].y, o.ad[pq].z, o.ad[pq].w};
+                    const float zv[4] = {o.z4[pq].x, o.z4[pq].y, o.z4[pq].z, o.z4[pq].w};
+                    const float aa[4] = {o.a4[pq].x, o.a4[pq].y, o.a4[pq].z, o.a4[pq].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = y[c2][pq][q] + adv[q];
+                        if (BN != 0) {
+                            const float av = BN == 2 ? aa[q] : fmaf(msc[q], zv[q], msh[q]);
+                            if (!(av > 0.f) || !ok[pq]) v = 0.f;
+                            ssum[c2][q] += v;
+                            ssq[c2][q] += v * ((zv[q] - mu[q]) * is[q]);
+                        } else {
+                            if (!ok[pq]) v = 0.f;
+                            ssum[c2][q] += v;
+                            ssq[c2][q] += v * v;
+                        }
+                        y[c2][pq][q] = v;
+                    }
+                }
+            };
+            constexpr int NT = (ADD ? 1 : 0) + (BN != 0 ? 1 : 0) + (BN == 2 ? 1 : 0);
+            if (NT <= 1) {              // everything in flight at once: one round trip
+                Ops o0, o1;
+                load_ops(0, o0);
+                load_ops(1, o1);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(0, o0);
+                finish(1, o1);
+            } else {                    // one channel group at a time (registers): two round trips
+                Ops o;
+                load_ops(0, o);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(0, o);
+                __builtin_amdgcn_sched_barrier(0);
+                load_ops(1, o);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(1, o);
+            }
+            // (d) the eight stores last, so that no load ever waits behind a (conditional) store
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(abl & 256)) {
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq)
+                        if (ok[pq])
+                            *reinterpret_cast<float4 *>(out_b + (size_t)(off[pq] + c2 * 16)) =
+                                make_float4(y[c2][pq][0], y[c2][pq][1], y[c2][pq][2], y[c2][pq][3]);
             }
         }
-        if (STATS) {
+        if (STATS && !(abl & 64)) {
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -368,6 +519,61 @@ COVA_API int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, f
 // Same contract as cova_conv3x3_fwd / cova_conv3x3_dgrad_bnbwd (stat_part is indexed by the
 // 8x32 tiles of cova_conv3x3_num_tiles), with Winograd-transformed weights `u`.
 // act/z/mean/invstd may all be NULL (plain conv, statistics = sum / sum of squares).
+struct WinoArgs {
+    const float *in, *u, *addend;
+    float *out, *stat_part;
+    int H, W, tiles_x, tiles_y, ntiles;
+    BnBwdEpiW bn;
+    ProIn pro;
+    int abl;
+    dim3 grid;
+    hipStream_t st;
+};
+
+template <bool STATS, bool PRO, bool ADD, int BN>
+static void launch_wino_variant(const WinoArgs &a)
+{
+    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<STATS, PRO, ADD, BN>), a.grid, dim3(wn::THREADS), 0, a.st,
+                       a.in, a.u, a.addend, a.out, a.stat_part, a.H, a.W, a.tiles_x, a.tiles_y, a.ntiles,
+                       a.bn, a.pro, a.abl);
+}
+
+template <bool STATS, int BN>
+static void launch_wino_epi(const WinoArgs &a)
+{
+    const bool p = a.pro.abc != nullptr, ad = a.addend != nullptr;
+    if (p && ad) launch_wino_variant<STATS, true, true, BN>(a);
+    else if (p) launch_wino_variant<STATS, true, false, BN>(a);
+    else if (ad) launch_wino_variant<STATS, false, true, BN>(a);
+    else launch_wino_variant<STATS, false, false, BN>(a);
+}
+
+static int launch_wino(const float *in, const float *u, const float *addend, const BnBwdEpiW bn,
+                       const ProIn pro, float *out, float *stat_part, int B, int H, int W, void *stream)
+{
+    WinoArgs a;
+    a.in = in; a.u = u; a.addend = addend; a.out = out; a.stat_part = stat_part;
+    a.H = H; a.W = W;
+    a.tiles_x = cdiv(W, wn::TW); a.tiles_y = cdiv(H, wn::TH);
+    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.bn = bn; a.pro = pro;
+    a.abl = cova_internal_ablate();
+    a.grid = dim3(cova_internal_persistent_grid(a.ntiles));
+    a.st = (hipStream_t)stream;
+    // 32-bit in-image offsets in the epilogue
+    COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));
+    const int mode = bn.z == nullptr ? 0 : (bn.act == nullptr ? 1 : 2);    // BN epilogues need stat_part
+    if (mode == 1) launch_wino_epi<true, 1>(a);
+    else if (mode == 2) launch_wino_epi<true, 2>(a);
+    else if (stat_part) launch_wino_epi<true, 0>(a);
+    else launch_wino_epi<false, 0>(a);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// Same contract as cova_conv3x3_fwd / cova_conv3x3_dgrad_bnbwd (stat_part is indexed by the
+// 8x32 tiles of cova_conv3x3_num_tiles), with Winograd-transformed weights `u`.
+// act/z/mean/invstd may all be NULL (plain conv, statistics = sum / sum of squares).
 COVA_API int cova_conv3x3_wino(const float *in, const float *u, const float *addend,
                                const float *act, const float *z, const float *mean,
                                const float *invstd, float *out, float *stat_part, int B, int H, int W,
@@ -375,20 +581,26 @@ COVA_API int cova_conv3x3_wino(const float *in, const float *u, const float *add
 {
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((z == nullptr) || (act && mean && invstd && stat_part));
-    const int tiles_x = cdiv(W, wn::TW), tiles_y = cdiv(H, wn::TH);
-    const int ntiles = B * tiles_x * tiles_y;
-    const dim3 grid(cova_internal_persistent_grid(ntiles)), block(wn::THREADS);
-    const BnBwdEpiW bn{act, z, mean, invstd};
-    if (stat_part)
-        hipLaunchKernelGGL(conv3x3_c64_wino_kernel<true>, grid, block, 0, (hipStream_t)stream, in, u,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn,
-                           cova_internal_ablate());
-    else
-        hipLaunchKernelGGL(conv3x3_c64_wino_kernel<false>, grid, block, 0, (hipStream_t)stream, in, u,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y, ntiles, bn,
-                           cova_internal_ablate());
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    return launch_wino(in, u, addend, BnBwdEpiW{act, z, mean, invstd, nullptr, nullptr},
+                       ProIn{nullptr, nullptr, 0}, out, stat_part, B, H, W, stream);
+}
+
+// cova_conv3x3_wino whose input is  f(A[c]*in + B[c]*in2 + C[c])  applied on load (f = ReLU if
+// pro_relu, identity otherwise; zero padding stays zero).  pro_abc = [3][64] floats (A | B | C);
+// in2 may be NULL (then B is ignored).  Folds a BatchNorm+ReLU, or the BatchNorm-backward apply
+// dz = A*dy + B*z + C, into the convolution that consumes it.  In the epilogue the ReLU mask may
+// come from z itself (act == NULL): fma(mask_scale, z, mask_shift) > 0.
+COVA_API int cova_conv3x3_wino_pro(const float *in, const float *in2, const float *pro_abc,
+                                   int pro_relu, const float *u, const float *addend,
+                                   const float *act, const float *mask_scale,
+                                   const float *mask_shift, const float *z, const float *mean,
+                                   const float *invstd, float *out, float *stat_part, int B, int H,
+                                   int W, void *stream)
+{
+    COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
+    COVA_REQUIRE((z == nullptr) || ((act || (mask_scale && mask_shift)) && mean && invstd && stat_part));
+    return launch_wino(in, u, addend, BnBwdEpiW{act, z, mean, invstd, mask_scale, mask_shift},
+                       ProIn{pro_abc, pro_abc ? in2 : nullptr, pro_relu}, out, stat_part, B, H, W, stream);
 }
 
 // ====================================================================================
@@ -412,15 +624,38 @@ constexpr int DY_FLOATS = TH * TW * 64;      // 16,384 floats
 constexpr int THREADS = 512;
 }  // namespace wgw
 
+// PROA: the activation operand is f(A*act + C) on load (BatchNorm+ReLU never materialised);
+// PROD: the gradient operand is A*dz + B*dz2 + C on load (BatchNorm-backward apply folded in).
+template <bool PROA, bool PROD>
 __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
     const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part, int H, int W,
-    int tiles_x, int tiles_y, int ntiles)
+    int tiles_x, int tiles_y, int ntiles, const ProIn proa, const ProIn prod)
 {
     using namespace wgw;
-    __shared__ __attribute__((aligned(16))) float lds[D_FLOATS + DY_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[D_FLOATS + DY_FLOATS + 384];
     float *s_d = lds;
     float *s_dy = lds + D_FLOATS;
+    float *s_pa = lds + D_FLOATS + DY_FLOATS;      // A | B | C of the activation prologue
+    float *s_pd = s_pa + 192;                      // A | B | C of the gradient prologue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (PROA || PROD) {
+        if (PROA && tid < 192) s_pa[tid] = proa.abc[tid];
+        if (PROD && tid >= 192 && tid < 384) s_pd[tid - 192] = prod.abc[tid - 192];
+        __syncthreads();
+    }
+    auto affine = [&](const float *tab, float4 v, float4 w, int c, int relu, bool useb) {
+        const float4 A = *reinterpret_cast<const float4 *>(tab + c);
+        const float4 Bc = *reinterpret_cast<const float4 *>(tab + 64 + c);
+        const float4 Cc = *reinterpret_cast<const float4 *>(tab + 128 + c);
+        float4 r;      // same expression as the forward prologue (identical ReLU decisions)
+        r.x = fmaf(A.x, v.x, useb ? fmaf(Bc.x, w.x, Cc.x) : Cc.x);
+        r.y = fmaf(A.y, v.y, useb ? fmaf(Bc.y, w.y, Cc.y) : Cc.y);
+        r.z = fmaf(A.z, v.z, useb ? fmaf(Bc.z, w.z, Cc.z) : Cc.z);
+        r.w = fmaf(A.w, v.w, useb ? fmaf(Bc.w, w.w, Cc.w) : Cc.w);
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        return r;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int li = lane & 31, kh2 = lane >> 5;
     // per-wave (uniform) transform coefficients
     const int a = wave >> 1, pair = wave & 1;
@@ -449,35 +684,53 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
 
-    // fetch helpers: float4 slot `idx` of input rows [row0, row0+nrows) / dy rows of tile (ty, tx, b)
-    auto load_d = [&](const float *act_b, int ty, int tx, int row0, int idx) {
+    // fetch helpers: float4 slot `idx` of input rows [row0, ...) / dy rows of tile (ty, tx) of batch
+    // image b_off (element offset); `ok` = inside the image, v2 = second tensor of the prologue
+    auto load_d = [&](size_t b_off, int ty, int tx, int row0, int idx, float4 &v, bool &ok) {
         const int px = idx >> 4, c4 = idx & 15;
         const int r = row0 + px / PW, c = px % PW;
         const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-        return v;
+        v = zero4;
+        ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (ok) v = *reinterpret_cast<const float4 *>(act + b_off + ((size_t)gy * W + gx) * 64 + c4 * 4);
     };
-    auto load_dy = [&](const float *dz_b, int ty, int tx, int row0, int idx) {
+    auto load_dy = [&](size_t b_off, int ty, int tx, int row0, int idx, float4 &v, float4 &v2, bool &ok) {
         const int px = idx >> 4, c4 = idx & 15;
         const int r = row0 + px / TW, c = px % TW;
         const int gy = ty * TH + r, gx = tx * TW + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy < H && gx < W)
-            v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-        return v;
+        v = zero4;
+        v2 = zero4;
+        ok = gy < H && gx < W;
+        if (ok) {
+            const size_t o = b_off + ((size_t)gy * W + gx) * 64 + c4 * 4;
+            v = *reinterpret_cast<const float4 *>(dz + o);
+            if (PROD && prod.in2 != nullptr) v2 = *reinterpret_cast<const float4 *>(prod.in2 + o);
+        }
+    };
+    auto fin_d = [&](float4 v, bool ok, int idx) {      // value stored to LDS for an input slot
+        return (PROA && ok) ? affine(s_pa, v, zero4, (idx & 15) * 4, proa.relu, false) : v;
+    };
+    auto fin_dy = [&](float4 v, float4 v2, bool ok, int idx) {
+        return (PROD && ok) ? affine(s_pd, v, v2, (idx & 15) * 4, prod.relu, prod.in2 != nullptr) : v;
     };
 
     if (tile < ntiles) {      // first tile: everything
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const float *act_b = act + (size_t)b * H * W * 64, *dz_b = dz + (size_t)b * H * W * 64;
+        const size_t b_off = (size_t)b * H * W * 64;
 #pragma unroll 1
-        for (int idx = tid; idx < PH * PW * 16; idx += THREADS)
-            *reinterpret_cast<float4 *>(s_d + idx * 4) = load_d(act_b, ty, tx, 0, idx);
+        for (int idx = tid; idx < PH * PW * 16; idx += THREADS) {
+            float4 v;
+            bool ok;
+            load_d(b_off, ty, tx, 0, idx, v, ok);
+            *reinterpret_cast<float4 *>(s_d + idx * 4) = fin_d(v, ok, idx);
+        }
 #pragma unroll 1
-        for (int idx = tid; idx < TH * TW * 16; idx += THREADS)
-            *reinterpret_cast<float4 *>(s_dy + idx * 4) = load_dy(dz_b, ty, tx, 0, idx);
+        for (int idx = tid; idx < TH * TW * 16; idx += THREADS) {
+            float4 v, v2;
+            bool ok;
+            load_dy(b_off, ty, tx, 0, idx, v, v2, ok);
+            *reinterpret_cast<float4 *>(s_dy + idx * 4) = fin_dy(v, v2, ok, idx);
+        }
     }
     __syncthreads();
 
@@ -485,23 +738,24 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
-        const int nb = next / (tiles_x * tiles_y);
-        const float *nact = act + (size_t)nb * H * W * 64, *ndz = dz + (size_t)nb * H * W * 64;
+        const size_t nb_off = (size_t)(next / (tiles_x * tiles_y)) * H * W * 64;
 #pragma unroll
         for (int tr = 0; tr < 4; ++tr) {
             // band tr of the NEXT tile: input rows 2tr, 2tr+1 (+ rows 8, 9 with the last band) and dY
             // rows 2tr, 2tr+1; fetched now, written after this tile row's barrier
             constexpr int kMaxD = 5, kDy = 2;
             const int nd_rows = tr == 3 ? 4 : 2;
-            float4 rd[kMaxD], rdy[kDy];
+            float4 rd[kMaxD], rdy[kDy], rdy2[kDy];
+            bool okd[kMaxD], okdy[kDy];
             if (has_next) {
 #pragma unroll
                 for (int k = 0; k < kMaxD; ++k) {
                     const int idx = tid + k * THREADS;
-                    if (idx < nd_rows * PW * 16) rd[k] = load_d(nact, nty, ntx, 2 * tr, idx);
+                    if (idx < nd_rows * PW * 16) load_d(nb_off, nty, ntx, 2 * tr, idx, rd[k], okd[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < kDy; ++k) rdy[k] = load_dy(ndz, nty, ntx, 2 * tr, tid + k * THREADS);
+                for (int k = 0; k < kDy; ++k)
+                    load_dy(nb_off, nty, ntx, 2 * tr, tid + k * THREADS, rdy[k], rdy2[k], okdy[k]);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- 8 k-pairs: tiles (tr, 2t + kh2)
@@ -540,11 +794,13 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
                 for (int k = 0; k < kMaxD; ++k) {
                     const int idx = tid + k * THREADS;
                     if (idx < nd_rows * PW * 16)
-                        *reinterpret_cast<float4 *>(s_d + (2 * tr) * PW * 64 + idx * 4) = rd[k];
+                        *reinterpret_cast<float4 *>(s_d + (2 * tr) * PW * 64 + idx * 4) =
+                            fin_d(rd[k], okd[k], idx);
                 }
 #pragma unroll
                 for (int k = 0; k < kDy; ++k)
-                    *reinterpret_cast<float4 *>(s_dy + (2 * tr) * TW * 64 + (tid + k * THREADS) * 4) = rdy[k];
+                    *reinterpret_cast<float4 *>(s_dy + (2 * tr) * TW * 64 + (tid + k * THREADS) * 4) =
+                        fin_dy(rdy[k], rdy2[k], okdy[k], tid + k * THREADS);
             }
         }
         __syncthreads();              // the refilled tile is complete before the next tile starts
@@ -606,18 +862,26 @@ __global__ void wgrad_wino_final_kernel(const float *__restrict__ q, float *__re
 
 }  // namespace
 
-// act, dz NHWC [B,H,W,64]; dw OIHW [64,64,3,3]; ws >= (grid*16*4096 + 16*4096) floats, which
-// cova_conv3x3_wgrad_workspace_floats covers
-COVA_API int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw, float *ws, int B,
-                                     int H, int W, void *stream)
+static int launch_wgrad_wino(const float *act, const float *dz, float *dw, float *ws, int B, int H, int W,
+                             const ProIn proa, const ProIn prod, void *stream)
 {
-    COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
     const int tiles_x = cdiv(W, wgw::TW), tiles_y = cdiv(H, wgw::TH);
     const int ntiles = B * tiles_x * tiles_y;
     const int grid = cova_internal_persistent_grid(ntiles);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(grid), dim3(wgw::THREADS), 0, st, act, dz, ws, H,
-                       W, tiles_x, tiles_y, ntiles);
+    const dim3 g(grid), blk(wgw::THREADS);
+    if (proa.abc && prod.abc)
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<true, true>), g, blk, 0, st, act, dz, ws, H, W,
+                           tiles_x, tiles_y, ntiles, proa, prod);
+    else if (proa.abc)
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<true, false>), g, blk, 0, st, act, dz, ws, H, W,
+                           tiles_x, tiles_y, ntiles, proa, prod);
+    else if (prod.abc)
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<false, true>), g, blk, 0, st, act, dz, ws, H, W,
+                           tiles_x, tiles_y, ntiles, proa, prod);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<false, false>), g, blk, 0, st, act, dz, ws, H, W,
+                           tiles_x, tiles_y, ntiles, proa, prod);
     COVA_LAUNCH_CHECK();
     float *q = ws + (size_t)grid * (16 * 4096);
     hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(16 * 4096 / 64), dim3(1024), 0, st, ws, grid, q);
@@ -625,4 +889,25 @@ COVA_API int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *d
     hipLaunchKernelGGL(wgrad_wino_final_kernel, dim3(16), dim3(256), 0, st, q, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
+}
+
+// act, dz NHWC [B,H,W,64]; dw OIHW [64,64,3,3]; ws >= (grid*16*4096 + 16*4096) floats, which
+// cova_conv3x3_wgrad_workspace_floats covers
+COVA_API int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw, float *ws, int B,
+                                     int H, int W, void *stream)
+{
+    COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
+    return launch_wgrad_wino(act, dz, dw, ws, B, H, W, ProIn{nullptr, nullptr, 0},
+                             ProIn{nullptr, nullptr, 0}, stream);
+}
+
+// Same with operands transformed on load: activation = f(A*act + C) (act_abc [3,64], B row ignored;
+// NULL = plain), gradient = A*dz + B*dz2 + C (dz_abc [3,64], dz2 nullable; NULL = plain).
+COVA_API int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc, int act_relu,
+                                         const float *dz, const float *dz2, const float *dz_abc,
+                                         float *dw, float *ws, int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
+    return launch_wgrad_wino(act, dz, dw, ws, B, H, W, ProIn{act_abc, nullptr, act_relu},
+                             ProIn{dz_abc, dz2, 0}, stream);
 }

@@ -28,7 +28,125 @@ __global__ __launch_bounds__(512) void mfma_f32_probe_kernel(float *out, int ite
         for (int r = 0; r < 16; ++r) s += acc[t][r];
     if (s == 123.456f) out[0] = s;      // keeps the chain live, practically never true
 }
+// Mixed probe: blocks [0, mfma_blocks) run the MFMA loop, the remaining blocks stream `buf`
+// (float4 loads, grid-stride) -- both kinds co-resident on every CU.  Answers whether MFMA issue and
+// HBM streaming overlap on this chip or add up (power / fabric coupling).
+__global__ __launch_bounds__(512) void mix_probe_kernel(float *out, const float4 *buf, long long n4,
+                                                        int mfma_blocks, int iters, int passes,
+                                                        float a0, float b0)
+{
+    if ((int)blockIdx.x < mfma_blocks) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = (float)(t + r);
+        float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 - (threadIdx.x & 3) * 1e-3f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma32(a, b, acc[0]);
+                acc[1] = mfma32(b, a, acc[1]);
+                acc[2] = mfma32(a, a, acc[2]);
+                acc[3] = mfma32(b, b, acc[3]);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[t][r];
+        if (s == 123.456f) out[0] = s;
+    } else {
+        const long long nb = gridDim.x - mfma_blocks, bid = blockIdx.x - mfma_blocks;
+        float s = 0.f;
+        for (int p = 0; p < passes; ++p)
+            for (long long i = bid * 512 + threadIdx.x; i < n4; i += nb * 512) {
+                const float4 v = buf[i];
+                s += v.x + v.y + v.z + v.w;
+            }
+        if (s == 123.456f) out[1] = s;
+    }
+}
+// Same-wave probe: every wave interleaves its MFMA chain with `loads_per_iter` independent float4
+// loads per 16 MFMAs (consumed four iterations later) -- the conv kernels' structure in miniature.
+template <int LPI>
+__global__ __launch_bounds__(512) void mfma_load_probe_kernel(float *out, const float4 *buf, long long n4,
+                                                              int iters, float a0, float b0)
+{
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = (float)(t + r);
+    float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 - (threadIdx.x & 3) * 1e-3f;
+    const long long stride = (long long)gridDim.x * 512;
+    long long idx = (long long)blockIdx.x * 512 + threadIdx.x;
+    float4 ring[4][LPI > 0 ? LPI : 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < (LPI > 0 ? LPI : 1); ++j) ring[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < LPI; ++j) {
+                s += ring[k][j].x + ring[k][j].w;
+                ring[k][j] = buf[idx];
+                idx += stride;
+                if (idx >= n4) idx -= n4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma32(a, b, acc[0]);
+                acc[1] = mfma32(b, a, acc[1]);
+                acc[2] = mfma32(a, a, acc[2]);
+                acc[3] = mfma32(b, b, acc[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    if (s == 123.456f) out[0] = s;
+}
 }  // namespace
+
+// blocks x 8 waves; per wave iters*16 MFMAs and iters*loads_per_iter float4 loads per lane
+COVA_API int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blocks, int iters,
+                                  int loads_per_iter, void *stream)
+{
+    COVA_REQUIRE(scratch && buf && blocks > 0 && iters > 0 && n4 > 0);
+    const float4 *b4 = reinterpret_cast<const float4 *>(buf);
+    hipStream_t st = (hipStream_t)stream;
+    if (loads_per_iter == 0)
+        hipLaunchKernelGGL(mfma_load_probe_kernel<0>, dim3(blocks), dim3(512), 0, st, scratch, b4, n4, iters, 0.999f, 1.001f);
+    else if (loads_per_iter == 1)
+        hipLaunchKernelGGL(mfma_load_probe_kernel<1>, dim3(blocks), dim3(512), 0, st, scratch, b4, n4, iters, 0.999f, 1.001f);
+    else if (loads_per_iter == 2)
+        hipLaunchKernelGGL(mfma_load_probe_kernel<2>, dim3(blocks), dim3(512), 0, st, scratch, b4, n4, iters, 0.999f, 1.001f);
+    else
+        return COVA_ERR_BAD_ARG;
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// mfma_blocks x (iters*16 MFMAs per wave)  +  stream_blocks streaming n4 float4 `passes` times
+COVA_API int cova_probe_mix(float *scratch, const float *buf, long long n4, int mfma_blocks,
+                            int stream_blocks, int iters, int passes, void *stream)
+{
+    COVA_REQUIRE(scratch && buf && mfma_blocks >= 0 && stream_blocks >= 0 && mfma_blocks + stream_blocks > 0);
+    hipLaunchKernelGGL(mix_probe_kernel, dim3(mfma_blocks + stream_blocks), dim3(512), 0,
+                       (hipStream_t)stream, scratch, reinterpret_cast<const float4 *>(buf), n4,
+                       mfma_blocks, iters, passes, 0.999f, 1.001f);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
 
 // launches `blocks` x 512 threads; every wave issues iters*16 MFMAs (each 4096 FLOP)
 COVA_API int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream)

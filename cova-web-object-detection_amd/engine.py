@@ -6,6 +6,8 @@ Stages: conv stack R1, RoIPool R2, positional encode
 additional-feature BN R4, GAT G1-G6, decoder D, loss/predictions L/P, optimizer U.
 ``params`` maps the reference's state_dict keys (weights.state_dict_spec) to device tensors.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -41,7 +43,7 @@ def feature_map_size(n):
 # ------------------------------------------------------------------------------- BatchNorm
 class BNState:
     """scale/shift/mean/invstd of one BatchNorm application (+ what backward needs)."""
-    __slots__ = ("scale", "shift", "mean", "invstd", "count", "C")
+    __slots__ = ("scale", "shift", "mean", "invstd", "count", "C", "abc")
 
 
 FOLD_ABOVE, FOLD_GROUP = 256, 64
@@ -61,7 +63,9 @@ def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0
               update_running=True):
     st = BNState()
     st.C, st.count = C, float(count)
-    st.scale, st.shift, st.mean, st.invstd = (_empty((C,), like) for _ in range(4))
+    st.abc = _empty((3, C), like)               # scale | (unused) | shift: the prologue's A | B | C
+    st.scale, st.shift = st.abc[0], st.abc[2]
+    st.mean, st.invstd = _empty((C,), like), _empty((C,), like)
     g, b = params[prefix + "weight"], params[prefix + "bias"]
     rm, rv = buffers[prefix + "running_mean"], buffers[prefix + "running_var"]
     if training:
@@ -104,6 +108,10 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 # 3x3 convolutions (forward, data gradient, weight gradient): Winograd F(2x2,3x3) kernels (2.25x
 # fewer MFMAs, same fp32 error) or the direct implicit-GEMM kernels.
 USE_WINOGRAD = True
+# With the Winograd kernels, BatchNorm+ReLU between the two convs of a BasicBlock and the
+# BatchNorm-backward "apply" passes are evaluated on load inside the consuming convolutions
+# (cova_conv3x3_wino_pro / cova_conv3x3_wgrad_wino_pro): a1 and dz are never written to HBM.
+FUSE_AFFINE = os.environ.get("COVA_FUSE_AFFINE", "1") != "0"
 
 
 def conv3x3(x, wts, addend, out, part, B, H, W, bn=None):
@@ -164,10 +172,15 @@ def convstack_fwd(images, params, buffers, training, save=True):
         z1 = _empty((B, H2, W2, C64), images)
         conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
         bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R)
-        a1 = _empty((B, H2, W2, C64), images)
-        call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
         z2 = _empty((B, H2, W2, C64), images)
-        conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
+        if USE_WINOGRAD and FUSE_AFFINE:            # a1 = relu(bn1(z1)) formed on load
+            a1 = None
+            call("cova_conv3x3_wino_pro", z1, None, bna.abc, 1, wf[2 * blk + 1][1], None, None, None,
+                 None, None, None, None, z2, part, B, H2, W2)
+        else:
+            a1 = _empty((B, H2, W2, C64), images)
+            call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
+            conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
         bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R)
         out = _empty((B, H2, W2, C64), images)
         call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
@@ -175,6 +188,17 @@ def convstack_fwd(images, params, buffers, training, save=True):
         x = out
     sv["blocks"] = blocks
     return x, (sv if save else None)
+
+
+def block_a1(blk):
+    """a1 = relu(bn1(z1)) of a BasicBlock; materialised on demand when the fused path skipped it
+    (same fma expression as the conv prologue, so ReLU decisions are identical)."""
+    if blk["a1"] is not None:
+        return blk["a1"]
+    z1, bna = blk["z1"], blk["bna"]
+    a1 = torch.empty_like(z1)
+    call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, z1.numel() // C64, C64, 1)
+    return a1
 
 
 def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
@@ -191,15 +215,74 @@ def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
     return dgamma, dbeta
 
 
-def convstack_bwd(sv, dfeat, gout=None):
-    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms.
+def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
+    """(dgamma, dbeta, abc) with dz = abc[0]*dy + abc[1]*z + abc[2] (applied on load downstream)."""
+    C = st.C
+    dgamma = _gbuf(gout, prefix + "weight", (C,), like)
+    dbeta = _gbuf(gout, prefix + "bias", (C,), like)
+    abc = _empty((3, C), like)
+    part, nparts = fold_partials(part, nparts, 2 * C)
+    call("cova_bn_finalize_bwd_abc", part, nparts, C, float(R), dgamma, dbeta, st.mean, st.invstd,
+         st.scale, abc)
+    return dgamma, dbeta, abc
 
-    The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
-    in front of them in their epilogue (cova_conv3x3_dgrad_bnbwd), so only the last block's bn2
-    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass."""
+
+def _layer1_bwd_fused(sv, dfeat, gout, grads):
+    """Backward of the two BasicBlocks with every BatchNorm-backward apply (except the one fed by
+    RoIPool's scatter) and both a1 = relu(bn1(z1)) recomputations folded into the Winograd kernels.
+    Returns the gradient w.r.t. the max-pool output."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    grads = {}
+    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
+    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    dA, pend = dfeat, None
+    for blk in (1, 0):
+        s = sv["blocks"][blk]
+        ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
+        pa, pb = BN3_KEYS[2 * blk], BN3_KEYS[2 * blk + 1]
+        bna, bnb = s["bna"], s["bnb"]
+        # ---- out = relu(bn2(z2) + x): dz2 = abc_b . (dres, z2); dres = masked incoming gradient
+        if pend is None:
+            dres, dz2 = torch.empty_like(dA), torch.empty_like(dA)
+            dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, bnb, R, dz2, C64, dres, C64,
+                                 gout, pb)
+            g_in, g_in2, g_abc = dz2, None, None
+        else:
+            dres = dA
+            dg, db, g_abc = _bn_abc_from_partials(pend, nt, bnb, R, gout, pb, dfeat)
+            g_in, g_in2 = dA, s["z2"]
+        grads[pb + "weight"], grads[pb + "bias"] = dg, db
+        dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
+        call("cova_conv3x3_wgrad_wino_pro", s["z1"], bna.abc, 1, g_in, g_in2, g_abc, dw, ws3, B, H2, W2)
+        grads[kb + ".weight"] = dw
+        # ---- dgrad of conv2 with bn1's ReLU mask (recomputed from z1) + backward sums in the epilogue
+        dy_a = torch.empty_like(dA)
+        part = _empty((nt, 2, C64), dfeat)
+        call("cova_conv3x3_wino_pro", g_in, g_in2, g_abc, 0, sv["wd"][2 * blk + 1][1], None, None,
+             bna.scale, bna.shift, s["z1"], bna.mean, bna.invstd, dy_a, part, B, H2, W2)
+        dg, db, abc_a = _bn_abc_from_partials(part, nt, bna, R, gout, pa, dfeat)
+        grads[pa + "weight"], grads[pa + "bias"] = dg, db
+        dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
+        call("cova_conv3x3_wgrad_wino_pro", s["x"], None, 0, dy_a, s["z1"], abc_a, dw, ws3, B, H2, W2)
+        grads[ka + ".weight"] = dw
+        # ---- dgrad of conv1 (+ residual gradient); for block 1 the epilogue prepares block 0's bn2
+        dx = torch.empty_like(dA)
+        if blk == 1:
+            prev = sv["blocks"][0]
+            pend = _empty((nt, 2, C64), dfeat)
+            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres,
+                 prev["out"], None, None, prev["z2"], prev["bnb"].mean, prev["bnb"].invstd, dx, pend,
+                 B, H2, W2)
+        else:
+            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
+                 None, None, None, None, None, dx, None, B, H2, W2)
+        dA = dx
+    return dA
+
+
+def _layer1_bwd_unfused(sv, dfeat, gout, grads):
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
     WGRAD3 = "cova_conv3x3_wgrad_wino" if USE_WINOGRAD else "cova_conv3x3_wgrad"
     nt = query("cova_conv3x3_num_tiles", B, H2, W2)
@@ -242,6 +325,20 @@ def convstack_bwd(sv, dfeat, gout=None):
         else:
             conv3x3(dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
         dA = dx
+    return dA
+
+
+def convstack_bwd(sv, dfeat, gout=None):
+    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms.
+
+    The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
+    in front of them in their epilogue (cova_conv3x3_dgrad_bnbwd), so only the last block's bn2
+    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass."""
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    R = B * H2 * W2
+    grads = {}
+    fused = USE_WINOGRAD and FUSE_AFFINE and sv["blocks"][0]["a1"] is None
+    dA = (_layer1_bwd_fused if fused else _layer1_bwd_unfused)(sv, dfeat, gout, grads)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
     npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)

@@ -75,8 +75,23 @@ int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_d
 int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,
                       const float *z, const float *mean, const float *invstd, float *out,
                       float *stat_part, int B, int H, int W, void *stream);
+/* input transformed on load: f(A[c]*in + B[c]*in2 + C[c]), f = ReLU if pro_relu; pro_abc [3,64]
+ * (nullable = plain input); in2 nullable (B ignored).  Folds BatchNorm+ReLU (models.py:49-51 via
+ * torchvision BasicBlock bn1/relu), or the BatchNorm-backward apply, into the consuming conv.
+ * Epilogue mask: act > 0, or fma(mask_scale, z, mask_shift) > 0 when act == NULL. */
+int cova_conv3x3_wino_pro(const float *in, const float *in2 /*nullable*/,
+                          const float *pro_abc /*nullable*/, int pro_relu, const float *u,
+                          const float *addend /*nullable*/, const float *act /*nullable*/,
+                          const float *mask_scale /*nullable*/, const float *mask_shift /*nullable*/,
+                          const float *z /*nullable*/, const float *mean /*nullable*/,
+                          const float *invstd /*nullable*/, float *out, float *stat_part /*nullable*/,
+                          int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                             int H, int W, void *stream);   /* Winograd form of cova_conv3x3_wgrad */
+int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc /*nullable*/, int act_relu,
+                                const float *dz, const float *dz2 /*nullable*/,
+                                const float *dz_abc /*nullable*/, float *dw, float *ws, int B, int H,
+                                int W, void *stream);
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);
@@ -108,6 +123,10 @@ int cova_bn_bwd_reduce(const float *dout, int ldd, const float *act /*nullable: 
 int cova_bn_finalize_bwd(const float *partial, int nparts, int C, double count,
                          float *dgamma /*nullable*/, float *dbeta /*nullable*/, float *coef /*[2,C]*/,
                          void *stream);
+/* same + the apply step in affine form: dz = abc[0]*dy + abc[1]*z + abc[2]; abc [3,C] */
+int cova_bn_finalize_bwd_abc(const float *partial, int nparts, int C, double count,
+                             float *dgamma /*nullable*/, float *dbeta /*nullable*/, const float *mean,
+                             const float *invstd, const float *scale, float *abc, void *stream);
 int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int lda, const float *z, int ldz,
                       const float *mean, const float *invstd, const float *scale, const float *coef,
                       float *dz, int lddz, float *dres /*nullable*/, int lddres, long long R, int C,
@@ -189,6 +208,12 @@ int cova_page_class_topk(const float *logits, const int64_t *page_start, int n_p
 /* ------------------------------------------------------------------ diagnostics (bench tools only)
  * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */
 int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream);
+/* same-wave probe: per wave iters*16 MFMAs interleaved with iters*loads_per_iter (0..2) float4 loads per lane */
+int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blocks, int iters,
+                         int loads_per_iter, void *stream);
+/* mixed probe: mfma_blocks MFMA blocks + stream_blocks blocks streaming buf (n4 float4, `passes` times) */
+int cova_probe_mix(float *scratch, const float *buf, long long n4, int mfma_blocks, int stream_blocks,
+                   int iters, int passes, void *stream);
 
 #ifdef __cplusplus
 }

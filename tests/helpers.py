@@ -68,6 +68,7 @@ def routing_from_saved(sv):
     of the ~1e5 routing decisions per batch); gradient parity is asserted for identical routing
     and the disagreements themselves are asserted to be near-ties (assert_routing_near_ties)."""
     from oracle import cova_oracle as O
+    from cova_web_object_detection_amd import engine as E
     B, H, W, H1, W1, H2, W2 = sv["conv"]["dims"]
     r = {"roi_argmax": sv["roi"]["argmax"].cpu(),
          "pool_idx": O.pool_window_pos_to_flat(sv["conv"]["idx"].cpu(), H1, W1)}
@@ -77,7 +78,7 @@ def routing_from_saved(sv):
     bn1 = conv["bn1"]
     r["gate_bn1"] = nchw(conv["y1"] * bn1.scale + bn1.shift > 0)
     for i, blk in enumerate(conv["blocks"]):
-        r["gate_a1_%d" % i] = nchw(blk["a1"] > 0)
+        r["gate_a1_%d" % i] = nchw(E.block_a1(blk) > 0)
         r["gate_out_%d" % i] = nchw(blk["out"] > 0)
     n_vis, hd = sv["n_vis"], sv["Hd"]
     if hd > 0:

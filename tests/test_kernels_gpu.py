@@ -442,3 +442,74 @@ def test_conv3x3_winograd_wgrad(B, H, W, cap):
         close(dw, wr.grad, 2e-4, "winograd wgrad")
     finally:
         query("cova_set_option", 2, 0)
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
+def test_conv3x3_winograd_affine_on_load(B, H, W, cap):
+    """cova_conv3x3_wino_pro == cova_conv3x3_wino on a pre-transformed input (bit-exact: the
+    prologue evaluates the same fma as cova_bn_act_fwd), for BatchNorm+ReLU on load, the
+    BatchNorm-backward apply on load, and the z-derived ReLU mask in the epilogue."""
+    g = torch.Generator().manual_seed(7 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x, x2 = nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W))
+    add = nhwc(rnd(B, 64, H, W))
+    w = rnd(64, 64, 3, 3) * 0.05
+    abc = rnd(3, 64).to(DEV)
+    uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
+    call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
+    nt = query("cova_conv3x3_num_tiles", B, H, W)
+    R = B * H * W
+    query("cova_set_option", 2, cap)
+    try:
+        # (a) relu(A*x + C) on load, with statistics
+        a1 = torch.empty_like(x)
+        call("cova_bn_act_fwd", x, 64, abc[0], abc[2], None, 0, a1, 64, R, 64, 1)
+        ref, pref = torch.empty_like(x), torch.empty(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_wino", a1, uf, None, None, None, None, None, ref, pref, B, H, W)
+        out, part = torch.empty_like(x), torch.empty(nt, 2, 64, device=DEV)
+        call("cova_conv3x3_wino_pro", x, None, abc, 1, uf, None, None, None, None, None, None, None,
+             out, part, B, H, W)
+        assert torch.equal(out, ref) and torch.equal(part, pref)
+        # (b) A*x + B*x2 + C on load (no relu), addend, epilogue mask from z
+        pre = torch.addcmul(torch.addcmul(abc[2].expand_as(x), x2, abc[1]), x, abc[0])
+        z = nhwc(rnd(B, 64, H, W))
+        msc, msh = rnd(64).to(DEV), rnd(64).to(DEV) * 0.3
+        act = torch.empty_like(z)
+        call("cova_bn_act_fwd", z, 64, msc, msh, None, 0, act, 64, R, 64, 1)
+        mean, invstd = rnd(64).to(DEV) * 0.2, (torch.rand(64, generator=g) + 0.5).to(DEV)
+        call("cova_conv3x3_wino", pre, ud, add, act, z, mean, invstd, ref, pref, B, H, W)
+        call("cova_conv3x3_wino_pro", x, x2, abc, 0, ud, add, None, msc, msh, z, mean, invstd, out,
+             part, B, H, W)
+        assert torch.equal(out == 0, ref == 0), "ReLU mask from z differs from the materialised one"
+        close(out, ref, 2e-6, "affine-on-load dgrad")
+        close(part.sum(0), pref.sum(0), 1e-5, "affine-on-load sums")
+        # (c) no prologue through the _pro entry point, no statistics
+        call("cova_conv3x3_wino", x, uf, add, None, None, None, None, ref, None, B, H, W)
+        call("cova_conv3x3_wino_pro", x, None, None, 0, uf, add, None, None, None, None, None, None, out,
+             None, B, H, W)
+        assert torch.equal(out, ref)
+    finally:
+        query("cova_set_option", 2, 0)
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
+def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
+    g = torch.Generator().manual_seed(3 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x, dy, z = nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W))
+    abc_a, abc_d = rnd(3, 64).to(DEV), rnd(3, 64).to(DEV)
+    R = B * H * W
+    a1 = torch.empty_like(x)
+    call("cova_bn_act_fwd", x, 64, abc_a[0], abc_a[2], None, 0, a1, 64, R, 64, 1)
+    dz = torch.addcmul(torch.addcmul(abc_d[2].expand_as(dy), z, abc_d[1]), dy, abc_d[0])
+    ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
+    query("cova_set_option", 2, cap)
+    try:
+        ref, dw = torch.zeros(64, 64, 3, 3, device=DEV), torch.zeros(64, 64, 3, 3, device=DEV)
+        for (pa, pd) in [(True, True), (True, False), (False, True), (False, False)]:
+            call("cova_conv3x3_wgrad_wino", a1 if pa else x, dz if pd else dy, ref, ws, B, H, W)
+            call("cova_conv3x3_wgrad_wino_pro", x, abc_a if pa else None, 1, dy, z if pd else None,
+                 abc_d if pd else None, dw, ws, B, H, W)
+            close(dw, ref, 2e-6, "wgrad affine-on-load %s %s" % (pa, pd))
+    finally:
+        query("cova_set_option", 2, 0)

@@ -1,14 +1,19 @@
-"""Per-kernel average of one PMC counter from a rocprofv3 rocpd database (values in KiB for
-FETCH_SIZE / WRITE_SIZE).  Usage: rocpd_pmc.py <db> [<db> ...]"""
+"""Per-kernel average of PMC counters from a rocprofv3 rocpd database.
+Usage: rocpd_pmc.py [--raw] <db> [<db> ...]   (default: values shown /1024, i.e. MB for *_SIZE)"""
 import sqlite3
 import sys
 
-for path in sys.argv[1:]:
+args = sys.argv[1:]
+raw = "--raw" in args
+args = [a for a in args if a != "--raw"]
+for path in args:
     db = sqlite3.connect(path)
     rows = db.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from "
-                      "counters_collection group by kernel_name, counter_name order by sum(value) desc").fetchall()
+                      "counters_collection group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
     print("# %s" % path)
-    print("%-60s %-12s %6s %14s %12s" % ("kernel", "counter", "calls", "avg_MB", "avg_us"))
-    for n, c, k, v, d in rows[:24]:
-        n = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
-        print("%-60s %-12s %6d %14.1f %12.1f" % (n, c, k, v / 1024.0, d / 1e3))
+    print("%-50s %-34s %6s %16s %12s" % ("kernel", "counter", "calls", "avg" if raw else "avg/1024", "avg_us"))
+    for n, c, k, v, d in rows:
+        n = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:50]
+        if raw and ("wino" not in n and "conv" not in n):
+            continue
+        print("%-50s %-34s %6d %16.1f %12.1f" % (n, c, k, v if raw else v / 1024.0, d / 1e3))

@@ -344,3 +344,55 @@ COVA_API int cova_page_class_topk(const float *logits, const int64_t *page_start
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Attention export (extract_attn_wts_and_visualize.py:104-135): one row per box,
+//   [x, y, w, h, label, K x (x, y, w, h) of the context boxes (zeros for -1 pads), K attention weights]
+// The caller keeps the rows with label > 0 and writes them with np.savetxt(fmt="%.3f").
+namespace {
+__global__ __launch_bounds__(256) void attn_export_rows_kernel(
+    const float *__restrict__ bboxes, const long long *__restrict__ ctx,
+    const float *__restrict__ attn, const long long *__restrict__ labels, int N, int K,
+    float *__restrict__ out)
+{
+    const int width = 5 + 5 * K;
+    const long long total = (long long)N * width;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / width), c = (int)(t - (long long)i * width);
+        float v;
+        if (c < 4) {
+            const float *b = bboxes + (size_t)i * 5 + 1;
+            v = c < 2 ? b[c] : b[c] - b[c - 2];
+        } else if (c == 4) {
+            v = (float)labels[i];
+        } else if (c < 5 + 4 * K) {
+            const int k = (c - 5) >> 2, j = (c - 5) & 3;
+            const long long n = ctx[(size_t)i * K + k];
+            if (n < 0) {
+                v = 0.f;
+            } else {
+                const float *b = bboxes + (size_t)n * 5 + 1;
+                v = j < 2 ? b[j] : b[j] - b[j - 2];
+            }
+        } else {
+            v = attn[(size_t)i * K + (c - 5 - 4 * K)];
+        }
+        out[t] = v;
+    }
+}
+}  // namespace
+
+// out [N, 5 + 5K]
+COVA_API int cova_attn_export_rows(const float *bboxes, const long long *ctx, const float *attn,
+                                   const long long *labels, int N, int K, float *out, void *stream)
+{
+    COVA_REQUIRE(bboxes && ctx && attn && labels && out && N >= 0 && K > 0);
+    if (N == 0) return COVA_OK;
+    long long g = ((long long)N * (5 + 5 * K) + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(attn_export_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       bboxes, ctx, attn, labels, N, K, out);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -205,6 +205,20 @@ int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream)
 int cova_page_class_topk(const float *logits, const int64_t *page_start, int n_pages, int NC, int k,
                          int64_t *out, void *stream);
 
+/* ---- device-side input pipeline --------------------------------------
+ * ToTensor of datasets.py:41-45,96-97: u8 [B,H,W,3] -> f32 [B,3,H,W], value/255 (bit-exact) */
+int cova_images_u8_to_f32(const uint8_t *u8_nhwc, float *f32_nchw, int B, int H, int W, void *stream);
+/* WebDataset.__getitem__ box part + custom_collate_fn (datasets.py:110-128,159-178):
+ * rows [N,5] = x,y,w,h,label of B pages back to back, page_offsets int32 [B+1] (device) ->
+ * bboxes [N,5] = page,x1,y1,x2,y2; labels [N] i64; ctx [N,2*context_size] i64 batch-global ids, -1 pads */
+int cova_collate_boxes(const float *rows, const int *page_offsets, int B, int N, int context_size,
+                       float *bboxes, long long *labels, long long *ctx /*nullable if context_size==0*/,
+                       void *stream);
+/* attention export rows (extract_attn_wts_and_visualize.py:104-135): out [N, 5+5K] =
+ * x,y,w,h,label, K x (x,y,w,h) of the context boxes (0 for pads), K attention weights */
+int cova_attn_export_rows(const float *bboxes, const long long *ctx, const float *attn,
+                          const long long *labels, int N, int K, float *out, void *stream);
+
 /* ------------------------------------------------------------------ diagnostics (bench tools only)
  * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */
 int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream);

@@ -363,3 +363,47 @@ def eval_accuracy(logits, bboxes, labels, n_classes, k=1):
             row.append(1 if true_box in topk[:, c] else 0)
         res.append(row)
     return res
+
+
+# ------------------------------------------------------------------ input pipeline (section 8f.1)
+def collate_reference(u8_pages, rows_per_page, context_size):
+    """CPU restatement of WebDataset.__getitem__ (tensor part, datasets.py:94-132, sampling
+    fraction 1) + custom_collate_fn (datasets.py:159-190).
+
+    u8_pages: uint8 [B,H,W,3] (what PIL yields for an RGB page); rows_per_page: list of float32
+    [n,5] = x,y,w,h,label (np.loadtxt of bboxes/*.csv, datasets.py:52-60).
+    Pinned against tests/golden/collate_raw.npz (output of the reference's own code)."""
+    images = torch.from_numpy(np.ascontiguousarray(u8_pages)).permute(0, 3, 1, 2).float().div(255)
+    boxes, ctxs, labels, seen = [], [], [], 0
+    for p, rows in enumerate(rows_per_page):
+        rows = np.asarray(rows, dtype=np.float32).reshape(-1, 5)
+        n = rows.shape[0]
+        labels.append(torch.from_numpy(rows[:, -1].astype(np.int64)))      # datasets.py:112
+        b = torch.from_numpy(rows[:, :-1].copy())
+        b[:, 2:] += b[:, :2]                                               # datasets.py:115
+        boxes.append(torch.cat((torch.full((n, 1), float(p)), b), dim=1))  # datasets.py:172-174
+        ctx = np.full((n, 2 * context_size), -1, dtype=np.int64)
+        for i in range(n):                                                 # datasets.py:121-128
+            c = list(range(max(0, i - context_size), i)) + \
+                list(range(i + 1, min(n, i + context_size + 1)))
+            ctx[i, :len(c)] = c
+        ctx[ctx != -1] += seen                                             # datasets.py:175
+        seen += n
+        ctxs.append(torch.from_numpy(ctx))
+    return dict(images=images, bboxes=torch.cat(boxes), labels=torch.cat(labels),
+                context_indices=torch.cat(ctxs),
+                additional_feats=torch.empty((seen, 0), dtype=torch.float32))
+
+
+# ------------------------------------------------------------------ attention export (section 8f.3)
+def attention_rows(bboxes, context_indices, labels, attn):
+    """Rows written by extract_attn_wts_and_visualize.py:104-135 (before np.savetxt):
+    [x, y, w, h, label, K x (x,y,w,h) of the context boxes (zeros for -1), K attention weights]
+    for the boxes with label > 0.  Pinned against tests/golden/attn_export.npz."""
+    N = bboxes.shape[0]
+    coords = bboxes[:, 1:].clone()
+    coords[:, 2:] -= coords[:, :2]
+    padded = torch.cat((coords, torch.zeros(1, 4)), dim=0)
+    ctx_coords = padded[context_indices.view(-1)].view(N, -1)      # -1 selects the zero row
+    sel = labels > 0
+    return torch.cat((coords[sel], labels[sel].float().view(-1, 1), ctx_coords[sel], attn[sel]), dim=1)

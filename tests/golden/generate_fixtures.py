@@ -172,6 +172,75 @@ def case_collate():
     print("collate ok", tuple(ctx.shape))
 
 
+def case_collate_raw():
+    """Same as case_collate but the fixture also holds the RAW inputs (uint8 HWC pixels, the
+    x,y,w,h,label rows as np.loadtxt returns them), for the device-side input pipeline."""
+    from PIL import Image
+    rs = np.random.RandomState(12)
+    counts, cs, H, W = [7, 40, 2, 13], 5, 24, 36
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(d + "/imgs")
+        os.makedirs(d + "/bboxes")
+        ids, u8, rows = [], [], []
+        for p, n in enumerate(counts):
+            img = (rs.uniform(0, 256, (H, W, 3))).astype(np.uint8)
+            Image.fromarray(img).save("%s/imgs/%d.png" % (d, p))
+            u8.append(img)
+            xywh = rs.uniform(1, 12, (n, 4)).astype(np.float32)
+            lab = np.zeros((n, 1), dtype=np.float32)
+            lab[:min(3, n), 0] = [1, 2, 3][:min(3, n)]
+            np.savetxt("%s/bboxes/%d.csv" % (d, p), np.concatenate([xywh, lab], 1), delimiter=",",
+                       header="x,y,w,h,label", comments="", fmt="%.6f")
+            rows.append(np.loadtxt("%s/bboxes/%d.csv" % (d, p), delimiter=",", skiprows=1,
+                                   dtype="float32").reshape(n, 5))          # datasets.py:52-60
+            ids.append(str(p))
+        ds = ref_datasets.WebDataset(d, ids, cs, False, 1)
+        items = [ds[i] for i in range(len(ids))]
+        img_ids, images, bboxes, addl, ctx, labels = ref_datasets.custom_collate_fn(items)
+    np.savez_compressed(os.path.join(HERE, "collate_raw.npz"), counts=np.asarray(counts),
+                        context_size=cs, u8_pages=np.stack(u8), rows=np.concatenate(rows, 0),
+                        images=images.numpy(), bboxes=bboxes.numpy(), context_indices=ctx.numpy(),
+                        labels=labels.numpy())
+    print("collate_raw ok", tuple(images.shape), tuple(ctx.shape))
+
+
+def case_attn_export():
+    """The attention dump of extract_attn_wts_and_visualize.py:104-135 (the statements between the
+    batch upload and np.savetxt, executed on the reference model) for the inputs of cova_h64_n11."""
+    fx = np.load(os.path.join(HERE, "cova_h64_n11.npz"))
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True,
+               hidden_dim=int(fx["meta/hidden_dim"]), bbox_hidden_dim=int(fx["meta/bbox_hidden_dim"]),
+               n_additional_feat=int(fx["meta/n_additional_feat"]), drop_prob=0.0)
+    wcfg = {k: cfg[k] for k in ("roi_output_size", "n_classes", "use_context", "hidden_dim",
+                                "bbox_hidden_dim", "n_additional_feat")}
+    sd = weights.seeded_state_dict(int(fx["meta/seed"]), logit_gain=float(fx["meta/logit_gain"]), **wcfg)
+    batch = synthetic.make_batch(int(fx["meta/n_pages"]), img_h=int(fx["meta/img_h"]),
+                                 boxes_per_page=[int(b) for b in fx["meta/boxes"]],
+                                 context_size=int(fx["meta/context_size"]),
+                                 n_additional_feat=cfg["n_additional_feat"], seed=int(fx["meta/seed"]))
+    model = build_ref_model(cfg, int(fx["meta/img_h"]), sd)
+    model.eval()
+    images, bboxes, additional_feats = batch["images"], batch["bboxes"], batch["additional_feats"]
+    context_indices, labels = batch["context_indices"], batch["labels"]
+    N = bboxes.shape[0]
+    with torch.no_grad():
+        bbox_coords = bboxes[:, 1:].clone()
+        bbox_coords[:, 2:] -= bbox_coords[:, :2]
+        bbox_coords_padded = torch.cat((bbox_coords, torch.zeros(4).view(1, -1)), dim=0)
+        context_bbox_coords = bbox_coords_padded[context_indices.view(-1)].view(N, -1)
+        visual_feats = model._get_visual_features(images, bboxes)
+        bbox_feats = model._get_bbox_features(bboxes)
+        addl = model.bn_additional_feat(additional_feats)
+        own_features = torch.cat((visual_feats, bbox_feats, addl), dim=1)
+        _, attention_wts = model.gat(own_features, context_indices, return_attn_wts=True)
+    sel = labels > 0
+    dump_obj = torch.cat((bbox_coords[sel], labels[sel].float().view(-1, 1), context_bbox_coords[sel],
+                          attention_wts[sel]), dim=1).numpy()
+    np.savez_compressed(os.path.join(HERE, "attn_export.npz"), rows=dump_obj,
+                        source=np.asarray("cova_h64_n11"))
+    print("attn_export ok", dump_obj.shape)
+
+
 def case_evaluate():
     """train.evaluate_model's per-page / per-class decision (train.py:131-154) on fixed logits."""
     rs = np.random.RandomState(5)
@@ -202,8 +271,14 @@ def case_evaluate():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:           # e.g. `generate_fixtures.py case_collate_raw case_attn_export`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     case_gat()
     case_collate()
+    case_collate_raw()
+    case_attn_export()
     case_evaluate()
     # full model: img_H 64/128 keeps inputs regenerable from seeds and outputs small
     case_full_model("cova_h64_n11", 1, 64, 11, 12, seed=101, hidden_dim=64, bbox_hidden_dim=16)

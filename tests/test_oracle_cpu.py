@@ -108,3 +108,30 @@ def test_full_model_oracle_matches_reference(name):
     check_grads(fx, grads, rtol=1e-3)
     for k in [k for k in fx if k.startswith("buf/")]:
         assert np.allclose(after[k[4:]].numpy(), fx[k], atol=1e-6, rtol=1e-5), k
+
+
+def test_collate_restatement_matches_reference_on_raw_inputs():
+    """oracle.collate_reference (ToTensor + __getitem__ box part + custom_collate_fn) is pinned by
+    the reference's own output on uint8 pages / csv rows (tests/golden/collate_raw.npz)."""
+    fx = np.load(GOLDEN + "/collate_raw.npz")
+    rows = np.split(fx["rows"], np.cumsum(fx["counts"])[:-1])
+    got = O.collate_reference(fx["u8_pages"], rows, int(fx["context_size"]))
+    for k in ("images", "bboxes", "labels", "context_indices"):
+        assert np.array_equal(got[k].numpy(), fx[k]), k
+    assert got["additional_feats"].shape == (fx["rows"].shape[0], 0)
+
+
+def test_attention_rows_restatement_matches_reference_dump():
+    """oracle.attention_rows on the oracle's own eval forward == the reference's dump
+    (extract_attn_wts_and_visualize.py:104-135) within fp32 round-off of the attention weights;
+    the geometric / integer columns are exact."""
+    fx = np.load(GOLDEN + "/attn_export.npz")
+    _, cfg, sd, batch = load_case(str(fx["source"]))
+    _, inter = O.forward(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
+                         batch["context_indices"], cfg, training=False, return_intermediates=True)
+    rows = O.attention_rows(batch["bboxes"], batch["context_indices"], batch["labels"], inter["attn"])
+    ref = fx["rows"]
+    assert rows.shape == ref.shape
+    K = batch["context_indices"].shape[1]
+    assert np.array_equal(rows[:, :5 + 4 * K].numpy(), ref[:, :5 + 4 * K])
+    np.testing.assert_allclose(rows[:, 5 + 4 * K:].numpy(), ref[:, 5 + 4 * K:], atol=1e-6)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     // abl (tools/conv_bench.py only, 0 in production): 1 no epilogue, 2 no refill stores,
     // 4 no refill loads, 8 no weight restaging, 16 no per-chunk barrier, 32 no input transform,
     // 64 no statistics reduction, 128 no epilogue operand loads, 256 no output stores,
-    // 512 no L2 prefetch of the epilogue operands
+    // 512 no L2 prefetch of the epilogue operands, 1024 no MFMA/VALU/LDS interleave hints
     using namespace wn;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 192];
     float *s_in = lds;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     int ubuf = 0;
     const float *a_lane = s_in + kq * PIXS + (2 * tb) * PW + 2 * ti;      // this lane's patch origin
     const float *b_lane = s_u + (kq * 64 + cbp * 32 + ti) * UROW;   // row (ci kq, co cbp*32 + ti)
-    float V[16];
+    float V[16], V1[16];            // transformed input of the even / odd chunk (double buffer)
     wino_input_transform(a_lane, V);                                       // chunk 0 of the first tile
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 #pragma unroll
             for (int p = 0; p < 16; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        auto chunk = [&](const int s, Ring &ring) {
+        auto chunk = [&](const int s, Ring &ring, const float (&V)[16], float (&Vn)[16]) {
             // (1) refill: planes consumed two chunks ago <- data of the tile after theirs
             if (ring.plane >= 0 && tid < NPIX && !(abl & 2)) {
                 float4 v = zero4;
@@ -289,8 +289,24 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
                 acc[1][p4 * 4 + 3] = mfma16(u1.w, V[p4 * 4 + 3], acc[1][p4 * 4 + 3]);
             }
             // (5) input transform of the NEXT chunk (for s = 15: chunk 0 of the next tile, whose
-            //     planes were refilled at chunk 2 of this tile) -- overlaps the MFMAs in flight
-            if (!(abl & 32)) wino_input_transform(a_lane + (4 * ns) * PIXS, V);
+            //     planes were refilled at chunk 2 of this tile) into the other V buffer.  The asm
+            //     uses pin it inside this chunk (LLVM otherwise sinks it below the barrier, next to
+            //     its first use, where both waves of a SIMD run it with the matrix pipe idle) and the
+            //     group barriers weave its 8 LDS reads and 32 adds between the MFMAs.
+            if (!(abl & 32)) {
+                wino_input_transform(a_lane + (4 * ns) * PIXS, Vn);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(Vn[k]));
+            }
+            if (!(abl & 1024)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // DS read: first operands
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // VALU
+                }
+            }
             // (6) publish the next weight chunk
             if (!(abl & 8)) {
                 float *ud = s_u + (ubuf ^ 1) * UCH;
@@ -298,12 +314,13 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
                 *reinterpret_cast<float4 *>(ud + uo1) = un1;
                 ubuf ^= 1;
             }
+            __builtin_amdgcn_sched_barrier(0);      // nothing of this chunk sinks below its barrier
             if (!(abl & 16)) __syncthreads();
         };
 #pragma unroll 1
         for (int s2 = 0; s2 < 8; ++s2) {
-            chunk(2 * s2, ringA);
-            chunk(2 * s2 + 1, ringB);
+            chunk(2 * s2, ringA, V, V1);
+            chunk(2 * s2 + 1, ringB, V1, V);
         }
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.

@@ -6,6 +6,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define COVA_OK 0
 #define COVA_ERR_BAD_ARG 10001

@@ -635,6 +635,7 @@ COVA_API int cova_conv3x3_wino_pro(const float *in, const float *in2, const floa
 namespace {
 
 namespace wgw {
+constexpr bool WG_PIPE = true;
 constexpr int TH = 8, TW = 32, PH = 10, PW = 34;
 constexpr int D_FLOATS = PH * PW * 64;       // 21,760 floats
 constexpr int DY_FLOATS = TH * TW * 64;      // 16,384 floats
@@ -676,17 +677,25 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
     const int li = lane & 31, kh2 = lane >> 5;
     // per-wave (uniform) transform coefficients
     const int a = wave >> 1, pair = wave & 1;
-    // B^T row a = sr1 * e[r1] + sr2 * e[r2]
+    // Operand formation with as few vector-ALU instructions as possible (on gfx950 the f32 MFMA and
+    // the VALU share the issue slot: measured, their times add up).  Everything is evaluated on
+    // f32x2 = (channel block 0, channel block 1) pairs (v_pk_fma_f32 / v_pk_add_f32) and the +-1 / 0
+    // transform coefficients are wave-uniform scalars; row / column choices live in the LDS
+    // addresses.  Three sign flips are left to wgrad_wino_final_kernel (wino_wgrad_sign):
+    //   A dY A^T row a:  R_j = y[i0][j] + sa * y[1][j]      i0 = (a == 3), sa = 0, +1, -1, 0   (a = 3 flipped)
+    //   columns b0, b1:  wd0 = R_0 + al * R_1,  wd1 = be * R_0 + R_1                           (b = 3 flipped)
+    //   B^T d B  row a:  u = q[r1] + sr * q[r2]             (a = 2 flipped: d1 - d2 instead of d2 - d1)
+    //   columns b0, b1:  vv0 = u[X] - u[Z],  vv1 = u[P] + sc * u[Q]
+    const int i0 = a == 3 ? 1 : 0;
+    const float sa = a == 1 ? 1.f : (a == 2 ? -1.f : 0.f);
+    const float al = pair == 0 ? 0.f : -1.f, be = pair == 0 ? 1.f : 0.f;
     const int r1 = a == 0 ? 0 : 1, r2 = a == 3 ? 3 : 2;
-    const float sr1 = a == 2 ? -1.f : 1.f, sr2 = (a == 0 || a == 3) ? -1.f : 1.f;
-    // the two columns b0 = 2*pair, b1 = b0+1 read input columns c0, c0+1, c0+2
-    const int c0 = pair;                         // pair 0: cols 0,1,2 ; pair 1: cols 1,2,3
-    const float vc[2][3] = {{pair == 0 ? 1.f : -1.f, pair == 0 ? 0.f : 1.f, pair == 0 ? -1.f : 0.f},
-                            {pair == 0 ? 0.f : 1.f, pair == 0 ? 1.f : 0.f, pair == 0 ? 1.f : -1.f}};
-    // A (4x2) rows: (1,0) (1,1) (1,-1) (0,-1)
-    const float cy0 = a == 3 ? 0.f : 1.f, cy1 = a == 0 ? 0.f : (a == 1 ? 1.f : -1.f);
-    const float cx[2][2] = {{pair == 0 ? 1.f : 1.f, pair == 0 ? 0.f : -1.f},       // b0 = 0 | 2
-                            {pair == 0 ? 1.f : 0.f, pair == 0 ? 1.f : -1.f}};      // b1 = 1 | 3
+    const float sr = a == 1 ? 1.f : -1.f;
+    const int cX = pair == 0 ? 0 : 2, cZ = pair == 0 ? 2 : 1, cP = 1, cQ = pair == 0 ? 2 : 3;
+    const float sc = pair == 0 ? 1.f : -1.f;
+    // the coefficients as VGPR pairs, so that the compiler keeps the packed forms
+    f32x2 sa2 = {sa, sa}, al2 = {al, al}, be2 = {be, be}, sr2 = {sr, sr}, sc2 = {sc, sc};
+    asm volatile("" : "+v"(sa2), "+v"(al2), "+v"(be2), "+v"(sr2), "+v"(sc2));
 
     int tile = blockIdx.x;
     if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -731,6 +740,18 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
         return (PROD && ok) ? affine(s_pd, v, v2, (idx & 15) * 4, prod.relu, prod.in2 != nullptr) : v;
     };
 
+    // LDS pixel layout: channel c = blk*32 + l sits at float 2*l + blk, so that a lane's two channel
+    // blocks are ONE ds_read_b64 with a 16-bit immediate offset (no per-read address arithmetic).
+    // A staged float4 (channels 4k..4k+3 of one block) becomes two ds_write2_b32.
+    auto stage4 = [&](float *tile_base, int idx, float4 v) {
+        const int px = idx >> 4, c = (idx & 15) * 4;
+        float *dst = tile_base + px * 64 + ((c & 31) << 1) + (c >> 5);
+        dst[0] = v.x;
+        dst[2] = v.y;
+        dst[4] = v.z;
+        dst[6] = v.w;
+    };
+
     if (tile < ntiles) {      // first tile: everything
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const size_t b_off = (size_t)b * H * W * 64;
@@ -739,14 +760,14 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
             float4 v;
             bool ok;
             load_d(b_off, ty, tx, 0, idx, v, ok);
-            *reinterpret_cast<float4 *>(s_d + idx * 4) = fin_d(v, ok, idx);
+            stage4(s_d, idx, fin_d(v, ok, idx));
         }
 #pragma unroll 1
         for (int idx = tid; idx < TH * TW * 16; idx += THREADS) {
             float4 v, v2;
             bool ok;
             load_dy(b_off, ty, tx, 0, idx, v, v2, ok);
-            *reinterpret_cast<float4 *>(s_dy + idx * 4) = fin_dy(v, v2, ok, idx);
+            stage4(s_dy, idx, fin_dy(v, v2, ok, idx));
         }
     }
     __syncthreads();
@@ -776,34 +797,79 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- 8 k-pairs: tiles (tr, 2t + kh2)
-            const float *dyb = s_dy + ((2 * tr) * TW + 2 * kh2) * 64 + li;
-            const float *db = s_d + ((2 * tr) * PW + 2 * kh2 + c0) * 64 + li;
+            const float *dyb = s_dy + ((2 * tr) * TW + 2 * kh2) * 64 + 2 * li;
+            const float *db = s_d + ((2 * tr) * PW + 2 * kh2) * 64 + 2 * li;
+            // Software pipeline over the 8 k-pairs of the band: the 20 LDS reads of pair t+1 are
+            // issued before the 8 MFMAs of pair t and its ~40 FMAs are woven between them, so the
+            // matrix pipe is not left idle while a wave forms its operands.
+            struct Raw {
+                f32x2 y[4], q[8];               // dY: (i0,0) (i0,1) (1,0) (1,1); input: rows r1, r2 x cols X Z P Q
+            };
+            auto pair2 = [&](const float *p) { return *reinterpret_cast<const f32x2 *>(p); };   // both channel blocks
+            auto read_ops = [&](const int t, Raw &r) {
+                const float *p = dyb + (4 * t) * 64;                          // tile col 2t+kh2 -> px 4t+2kh2
+                r.y[0] = pair2(p + i0 * TW * 64);
+                r.y[1] = pair2(p + i0 * TW * 64 + 64);
+                r.y[2] = pair2(p + TW * 64);
+                r.y[3] = pair2(p + TW * 64 + 64);
+                const float *q = db + (4 * t) * 64;
+                r.q[0] = pair2(q + (r1 * PW + cX) * 64);
+                r.q[1] = pair2(q + (r1 * PW + cZ) * 64);
+                r.q[2] = pair2(q + (r1 * PW + cP) * 64);
+                r.q[3] = pair2(q + (r1 * PW + cQ) * 64);
+                r.q[4] = pair2(q + (r2 * PW + cX) * 64);
+                r.q[5] = pair2(q + (r2 * PW + cZ) * 64);
+                r.q[6] = pair2(q + (r2 * PW + cP) * 64);
+                r.q[7] = pair2(q + (r2 * PW + cQ) * 64);
+            };
+            auto form_ops = [&](const Raw &r, float (&wd)[2][2], float (&vv)[2][2]) {   // [column e][channel block]
+                // `keep` = empty asm on the 64-bit pair: stops LLVM from splitting the packed op into
+                // two scalar ones when its halves are consumed separately (by the MFMAs)
+                auto keep = [](f32x2 x) { asm("" : "+v"(x)); return x; };
+                const f32x2 R0 = keep(sa2 * r.y[2] + r.y[0]), R1 = keep(sa2 * r.y[3] + r.y[1]);
+                const f32x2 w0 = keep(al2 * R1 + R0), w1 = keep(be2 * R0 + R1);
+                const f32x2 u10 = keep(r.q[0] - r.q[1]), u20 = keep(r.q[4] - r.q[5]);
+                const f32x2 u11 = keep(sc2 * r.q[3] + r.q[2]), u21 = keep(sc2 * r.q[7] + r.q[6]);
+                const f32x2 v0 = keep(sr2 * u20 + u10), v1 = keep(sr2 * u21 + u11);
+                wd[0][0] = w0.x; wd[0][1] = w0.y; wd[1][0] = w1.x; wd[1][1] = w1.y;
+                vv[0][0] = v0.x; vv[0][1] = v0.y; vv[1][0] = v1.x; vv[1][1] = v1.y;
+            };
+            float wd[2][2][2], vv[2][2][2];     // double buffered operands
+            {
+                Raw r;
+                read_ops(0, r);
+                form_ops(r, wd[0], vv[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                float wd[2][2], vv[2][2];       // [column e][channel block]
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const float *p = dyb + (4 * t) * 64 + blk * 32;          // tile col 2t+kh2 -> px 4t+2kh2
-                    const float y00 = p[0], y01 = p[64], y10 = p[TW * 64], y11 = p[TW * 64 + 64];
-                    const float top0 = cx[0][0] * y00 + cx[0][1] * y01, bot0 = cx[0][0] * y10 + cx[0][1] * y11;
-                    const float top1 = cx[1][0] * y00 + cx[1][1] * y01, bot1 = cx[1][0] * y10 + cx[1][1] * y11;
-                    wd[0][blk] = cy0 * top0 + cy1 * bot0;
-                    wd[1][blk] = cy0 * top1 + cy1 * bot1;
-                    const float *q = db + (4 * t) * 64 + blk * 32;
-                    float rc[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        rc[j] = sr1 * q[(r1 * PW + j) * 64] + sr2 * q[(r2 * PW + j) * 64];
-                    vv[0][blk] = vc[0][0] * rc[0] + vc[0][1] * rc[1] + vc[0][2] * rc[2];
-                    vv[1][blk] = vc[1][0] * rc[0] + vc[1][1] * rc[1] + vc[1][2] * rc[2];
-                }
+                const int cur = t & 1;
+                Raw r;
+                if (t < 7) read_ops(t + 1, r);
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[e][i][j] = mfma32(wd[e][i], vv[e][j], acc[e][i][j]);
+                            acc[e][i][j] = mfma32(wd[cur][e][i], vv[cur][e][j], acc[e][i][j]);
+                if (t < 7) {
+                    form_ops(r, wd[cur ^ 1], vv[cur ^ 1]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wd[cur ^ 1][e][i]), "v"(vv[cur ^ 1][e][i]));
+                    if (WG_PIPE) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // LDS reads of pair t+1
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // packed FMAs of pair t+1
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();          // everyone is done with this band
             if (has_next) {
@@ -811,13 +877,12 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
                 for (int k = 0; k < kMaxD; ++k) {
                     const int idx = tid + k * THREADS;
                     if (idx < nd_rows * PW * 16)
-                        *reinterpret_cast<float4 *>(s_d + (2 * tr) * PW * 64 + idx * 4) =
-                            fin_d(rd[k], okd[k], idx);
+                        stage4(s_d + (2 * tr) * PW * 64, idx, fin_d(rd[k], okd[k], idx));
                 }
 #pragma unroll
                 for (int k = 0; k < kDy; ++k)
-                    *reinterpret_cast<float4 *>(s_dy + (2 * tr) * TW * 64 + (tid + k * THREADS) * 4) =
-                        fin_dy(rdy[k], rdy2[k], okdy[k], tid + k * THREADS);
+                    stage4(s_dy + (2 * tr) * TW * 64, tid + k * THREADS,
+                           fin_dy(rdy[k], rdy2[k], okdy[k], tid + k * THREADS));
             }
         }
         __syncthreads();              // the refilled tile is complete before the next tile starts
@@ -863,7 +928,12 @@ __global__ void wgrad_wino_final_kernel(const float *__restrict__ q, float *__re
     const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
     float Q[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) Q[p] = q[p * 4096 + idx];
+    for (int p = 0; p < 16; ++p) {
+        // sign flips left open by the operand formation of conv3x3_wgrad_wino_kernel
+        const int a = p >> 2, b = p & 3;
+        const float sgn = ((a == 3) != (b == 3)) != (a == 2) ? -1.f : 1.f;
+        Q[p] = sgn * q[p * 4096 + idx];
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll

@@ -115,7 +115,77 @@ __global__ __launch_bounds__(512) void mfma_load_probe_kernel(float *out, const 
         for (int r = 0; r < 16; ++r) s += acc[t][r];
     if (s == 123.456f) out[0] = s;
 }
+// MFMA chain with VPM independent VALU FMAs issued after every MFMA (same wave): do the vector ALU
+// and the matrix pipe overlap, or do their issue cycles add up?
+template <int VPM>
+__global__ __launch_bounds__(512) void mfma_valu_probe_kernel(float *out, int iters, float a0, float b0)
+{
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{(float)t, 1.f, 2.f, 3.f};
+    float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 - (threadIdx.x & 3) * 1e-3f;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = a * (k + 1);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u & 7], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < VPM; ++k) v[(u + k) & 7] = fmaf(v[(u + k) & 7], b, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    if (s == 123.456f) out[0] = s;
+}
+
+// VALU only (same FMA stream, no MFMA) for reference
+template <int VPM>
+__global__ __launch_bounds__(512) void valu_probe_kernel(float *out, int iters, float a0, float b0)
+{
+    float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 - (threadIdx.x & 3) * 1e-3f;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = a * (k + 1);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int k = 0; k < VPM; ++k) v[(u + k) & 7] = fmaf(v[(u + k) & 7], b, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    if (s == 123.456f) out[0] = s;
+}
 }  // namespace
+
+// blocks x 8 waves, per wave iters*16 v_mfma_f32_16x16x4_f32, each followed by valu_per_mfma
+// independent v_fma_f32 (0, 2, 4 or 6); mfma == 0 runs the VALU stream alone
+COVA_API int cova_probe_mfma_valu(float *scratch, int blocks, int iters, int valu_per_mfma, int mfma,
+                                  void *stream)
+{
+    COVA_REQUIRE(scratch && blocks > 0 && iters > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(blocks), b(512);
+#define COVA_PV(N)                                                                                   \
+    if (valu_per_mfma == N) {                                                                        \
+        if (mfma) hipLaunchKernelGGL(mfma_valu_probe_kernel<N>, g, b, 0, st, scratch, iters, 0.999f, 1.001f); \
+        else hipLaunchKernelGGL(valu_probe_kernel<N>, g, b, 0, st, scratch, iters, 0.999f, 1.001f);  \
+    }
+    COVA_PV(0) COVA_PV(2) COVA_PV(4) COVA_PV(6)
+#undef COVA_PV
+    COVA_REQUIRE(valu_per_mfma == 0 || valu_per_mfma == 2 || valu_per_mfma == 4 || valu_per_mfma == 6);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
 
 // blocks x 8 waves; per wave iters*16 MFMAs and iters*loads_per_iter float4 loads per lane
 COVA_API int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blocks, int iters,

@@ -222,6 +222,8 @@ int cova_attn_export_rows(const float *bboxes, const long long *ctx, const float
 /* ------------------------------------------------------------------ diagnostics (bench tools only)
  * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */
 int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream);
+/* MFMA (16x16x4 f32) chain with valu_per_mfma (0,2,4,6) independent FMAs after each MFMA; mfma=0: VALU only */
+int cova_probe_mfma_valu(float *scratch, int blocks, int iters, int valu_per_mfma, int mfma, void *stream);
 /* same-wave probe: per wave iters*16 MFMAs interleaved with iters*loads_per_iter (0..2) float4 loads per lane */
 int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blocks, int iters,
                          int loads_per_iter, void *stream);

@@ -46,3 +46,20 @@ for lpi in (0, 1, 2):
     t = run2(lpi, ITERS)
     gb = 256 * 512 * 16 * ITERS * lpi / 1e9
     print("same-wave: %d float4 loads per 16 MFMAs: %.2f ms  %.1f TF/s  %.2f TB/s" % (lpi, t, 256 * 8 * ITERS * 16 * 4096 / t / 1e9, gb / t))
+
+
+def run3(vpm, mfma, iters=8000):
+    fn = lambda: _lib.call("cova_probe_mfma_valu", scratch, 256, iters, vpm, mfma)
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+for vpm in (0, 2, 4, 6):
+    tm = run3(vpm, 1)
+    tv = run3(vpm, 0) if vpm else 0.0
+    print("MFMA 16x16x4 + %d FMAs each: %.2f ms (%.1f TF/s MFMA) ; the FMAs alone %.2f ms" % (vpm, tm, 256 * 8 * 8000 * 16 * 2048 / tm / 1e9, tv))

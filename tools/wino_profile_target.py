@@ -23,6 +23,20 @@ fns = {
     "full": lambda: call("cova_conv3x3_wino", x, ud, add, x2, z, mean, invstd, out, part, B, H, W),
     "pro": lambda: call("cova_conv3x3_wino_pro", x, x2, abc, 0, ud, N, N, N, N, N, N, N, out, N, B, H, W),
 }
+ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=dev)
+dw = torch.empty(64, 64, 3, 3, device=dev)
+fns["wgrad"] = lambda: call("cova_conv3x3_wgrad_wino", x, x2, dw, ws, B, H, W)
+fns["wgrad_pro"] = lambda: call("cova_conv3x3_wgrad_wino_pro", x, abc, 1, x2, z, abc, dw, ws, B, H, W)
+img = torch.rand(B, 3, 1280, 1280, device=dev)
+w1 = torch.randn(64, 3, 7, 7, device=dev) * 0.1
+wk = torch.empty(154, 64, device=dev)
+call("cova_conv1_prep_weights", w1, wk)
+y1 = torch.empty(B, 640, 640, 64, device=dev)
+part1 = torch.empty(query("cova_conv1_num_tiles", B, 1280, 1280), 2, 64, device=dev)
+ws1 = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, 1280, 1280), device=dev)
+dw1 = torch.empty(64, 3, 7, 7, device=dev)
+fns["conv1"] = lambda: call("cova_conv1_fwd", img, wk, y1, part1, B, 1280, 1280)
+fns["conv1_wgrad"] = lambda: call("cova_conv1_wgrad", img, y1, dw1, ws1, B, 1280, 1280)
 for _ in range(int(os.environ.get("N", 6))):
     fns[mode]()
 torch.cuda.synchronize()

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
-    float *__restrict__ out, uint8_t *__restrict__ idx, int B, int H1, int W1, int H2, int W2)
+    float *__restrict__ out, uint8_t *__restrict__ idx, float *__restrict__ ymax, int B, int H1, int W1,
+    int H2, int W2)
 {
     const long long total = (long long)B * H2 * W2 * 16;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c4 * 4);
         const float4 sh = *reinterpret_cast<const float4 *>(shift + c4 * 4);
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float my[4] = {0.f, 0.f, 0.f, 0.f};          // raw conv output at the arg-max position
         int mi[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -362,18 +364,20 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
                 if (ix < 0 || ix >= W1) continue;
                 const float4 v = *reinterpret_cast<const float4 *>(
                     y + (((size_t)b * H1 + iy) * W1 + ix) * 64 + c4 * 4);
-                float t[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z,
-                              v.w * sc.w + sh.w};
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                float t[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z),
+                              fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = t[j] > 0.f ? t[j] : 0.f;
-                    if (a > m[j]) { m[j] = a; mi[j] = ky * 3 + kx; }
+                    if (a > m[j]) { m[j] = a; mi[j] = ky * 3 + kx; my[j] = vv[j]; }
                 }
             }
         }
         const size_t o = (((size_t)b * H2 + oy) * W2 + ox) * 64 + c4 * 4;
         *reinterpret_cast<float4 *>(out + o) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<uchar4 *>(idx + o) = make_uchar4(mi[0], mi[1], mi[2], mi[3]);
+        if (ymax != nullptr) *reinterpret_cast<float4 *>(ymax + o) = make_float4(my[0], my[1], my[2], my[3]);
     }
 }
 
@@ -779,13 +783,17 @@ COVA_API int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int
 }
 
 // y NHWC [B,H1,W1,64] raw conv1 output -> out NHWC [B,H2,W2,64], idx uint8 same shape
+// ymax (nullable): the raw y at each window's arg-max, [B,H2,W2,64]; with it the BatchNorm-backward
+// sums of this layer can be taken in the epilogue of the convolution that produces the pooled
+// gradient (mask = fma(scale, ymax, shift) > 0) instead of by cova_bn_relu_maxpool_bwd_reduce
 COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const float *shift,
-                                      float *out, uint8_t *idx, int B, int H1, int W1, void *stream)
+                                      float *out, uint8_t *idx, float *ymax, int B, int H1, int W1,
+                                      void *stream)
 {
     COVA_REQUIRE(y && scale && shift && out && idx && B > 0 && H1 > 0 && W1 > 0);
     const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_grid((long long)B * H2 * W2 * 16)),
-                       dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, B, H1, W1, H2, W2);
+                       dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B, H1, W1, H2, W2);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -123,10 +123,30 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
             for (int j = 0; j < 16; ++j) t += s[j][k][tx];
             dW[(size_t)k * Cin + c] = t;
         }
-    if (blockIdx.x == 0 && ty == 1 && tx < NC) {
-        float t = 0.f;
-        for (int n = 0; n < N; ++n) t += dy[(size_t)n * NC + tx];
-        db[tx] = t;
+    if (blockIdx.x == 0) {                  // db[k] = sum_n dy[n][k]: all 1024 threads, LDS tree
+        __syncthreads();
+        float pk[MAXNC];
+#pragma unroll
+        for (int k = 0; k < MAXNC; ++k) pk[k] = 0.f;
+        for (int n = threadIdx.x; n < N; n += 1024)
+#pragma unroll
+            for (int k = 0; k < MAXNC; ++k)
+                if (k < NC) pk[k] += dy[(size_t)n * NC + k];
+#pragma unroll
+        for (int k = 0; k < MAXNC; ++k) s[ty][k][tx] = pk[k];
+        __syncthreads();
+        if (ty == 0)
+            for (int k = 0; k < NC; ++k) {
+                float t = 0.f;
+                for (int j = 0; j < 16; ++j) t += s[j][k][tx];
+                s[0][k][tx] = t;
+            }
+        __syncthreads();
+        if (threadIdx.x < NC) {
+            float t = 0.f;
+            for (int j = 0; j < 64; ++j) t += s[0][threadIdx.x][j];
+            db[threadIdx.x] = t;
+        }
     }
 }
 

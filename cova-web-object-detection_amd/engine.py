@@ -160,8 +160,10 @@ def convstack_fwd(images, params, buffers, training, save=True):
     bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1)
     p1 = _empty((B, H2, W2, C64), images)
     idx = _empty((B, H2, W2, C64), images, torch.uint8)
-    call("cova_bn_relu_maxpool_fwd", y1, bn1.scale, bn1.shift, p1, idx, B, H1, W1)
-    sv.update(y1=y1, bn1=bn1, idx=idx)
+    # ymax = y1 at each window's arg-max: lets the last data-gradient conv take bn1's backward sums
+    ymax = _empty((B, H2, W2, C64), images) if (training and save and USE_WINOGRAD and FUSE_AFFINE) else None
+    call("cova_bn_relu_maxpool_fwd", y1, bn1.scale, bn1.shift, p1, idx, ymax, B, H1, W1)
+    sv.update(y1=y1, bn1=bn1, idx=idx, ymax=ymax)
     # layer1: two BasicBlocks
     R = B * H2 * W2
     nt = query("cova_conv3x3_num_tiles", B, H2, W2)
@@ -273,6 +275,12 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads):
             call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres,
                  prev["out"], None, None, prev["z2"], prev["bnb"].mean, prev["bnb"].invstd, dx, pend,
                  B, H2, W2)
+        elif sv.get("ymax") is not None:
+            # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
+            bn1 = sv["bn1"]
+            sv["pool_part"] = _empty((nt, 2, C64), dfeat)
+            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
+                 bn1.scale, bn1.shift, sv["ymax"], bn1.mean, bn1.invstd, dx, sv["pool_part"], B, H2, W2)
         else:
             call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
                  None, None, None, None, None, dx, None, B, H2, W2)
@@ -341,10 +349,13 @@ def convstack_bwd(sv, dfeat, gout=None):
     dA = (_layer1_bwd_fused if fused else _layer1_bwd_unfused)(sv, dfeat, gout, grads)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
-    npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
-    part = _empty((npart, 2, C64), dfeat)
-    call("cova_bn_relu_maxpool_bwd_reduce", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
-         bn1.invstd, part, B, H1, W1)
+    if fused and sv.get("pool_part") is not None:
+        part, npart = sv["pool_part"], query("cova_conv3x3_num_tiles", B, H2, W2)
+    else:
+        npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
+        part = _empty((npart, 2, C64), dfeat)
+        call("cova_bn_relu_maxpool_bwd_reduce", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
+             bn1.invstd, part, B, H1, W1)
     dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
     db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
     coef = _empty((2, C64), dfeat)

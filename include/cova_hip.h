@@ -132,8 +132,9 @@ int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int lda, con
                       float *dz, int lddz, float *dres /*nullable*/, int lddres, long long R, int C,
                       void *stream);
 int cova_bn_relu_maxpool_fwd(const float *y /*[B,H1,W1,64]*/, const float *scale, const float *shift,
-                             float *out /*[B,H2,W2,64]*/, uint8_t *idx, int B, int H1, int W1,
-                             void *stream);
+                             float *out /*[B,H2,W2,64]*/, uint8_t *idx,
+                             float *ymax /*nullable [B,H2,W2,64]: raw y at the arg-max*/, int B, int H1,
+                             int W1, void *stream);
 int cova_bn_relu_maxpool_bwd_num_partials(int B, int H1, int W1);
 int cova_bn_relu_maxpool_bwd_reduce(const float *dp, const uint8_t *idx, const float *y,
                                     const float *scale, const float *shift, const float *mean,

@@ -124,7 +124,7 @@ def test_bn_pool_full_size_properties():
     H2 = W2 = 320
     p = torch.empty(B, H2, W2, 64, device=DEV)
     idx = torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
-    call("cova_bn_relu_maxpool_fwd", y, st.scale, st.shift, p, idx, B, H1, W1)
+    call("cova_bn_relu_maxpool_fwd", y, st.scale, st.shift, p, idx, None, B, H1, W1)
     for (y0, x0, h, w) in [(0, 0, 20, 24), (300, 296, 20, 24), (100, 0, 9, 33)]:
         ys, ye, xs, xe = max(2 * y0 - 1, 0), min(2 * (y0 + h) , H1), max(2 * x0 - 1, 0), min(2 * (x0 + w), W1)
         crop = torch.relu(out[0, ys:ye, xs:xe]).permute(2, 0, 1).unsqueeze(0).cpu()

@@ -167,8 +167,10 @@ def test_bn_relu_maxpool(B, H1, W1):
     st = engine.bn_params("bn.", params, buffers, 64, yg, True, part, n, B * H1 * W1)
     out = torch.empty(B, H2, W2, 64, device=DEV)
     idx = torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
-    call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, out, idx, B, H1, W1)
+    ymax = torch.empty_like(out)
+    call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, out, idx, ymax, B, H1, W1)
     close(nchw(out), ref, 1e-5, "maxpool fwd")
+    close(torch.relu(ymax * st.scale + st.shift), out, 1e-6, "arg-max pre-activation")
     npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
     bpart = torch.empty(npart, 2, 64, device=DEV)
     dpg = nhwc(dp)

@@ -90,6 +90,58 @@ __global__ __launch_bounds__(256) void roipool_bwd_kernel(
     }
 }
 
+// RoIPool backward fused with the ReLU mask and the BatchNorm-backward sums of the layer that produced
+// the feature map (out = relu(bn(z) + residual)):  g' = g * (act[pos] > 0) is scattered, and
+// (sum g', sum g' * xhat(z[pos])) are accumulated per channel -- both are linear in the scattered
+// contributions, so they can be taken here instead of by a pass over the dense gradient map.
+// Tasks (box, bin) are assigned to waves by a fixed grid-stride rule: the partial sums are deterministic.
+__global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
+    const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
+    const int32_t *__restrict__ argmax, int n_rois, int C, int H, int W, int PH, int PW,
+    const float *__restrict__ act, const float *__restrict__ z, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ gfeat, float *__restrict__ partial)
+{
+    constexpr int MAXCB = 4;                      // C <= 256
+    __shared__ float s_red[4][2][64 * MAXCB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ntask = n_rois * PH * PW, ncb = C / 64;
+    float su[MAXCB], sq[MAXCB], mu[MAXCB], is[MAXCB];
+#pragma unroll
+    for (int k = 0; k < MAXCB; ++k) {
+        su[k] = sq[k] = 0.f;
+        mu[k] = k < ncb ? mean[k * 64 + lane] : 0.f;
+        is[k] = k < ncb ? invstd[k * 64 + lane] : 0.f;
+    }
+    for (int task = blockIdx.x * 4 + wave; task < ntask; task += gridDim.x * 4) {
+        const int n = task / (PH * PW), bin = task - n * (PH * PW);
+        const size_t boff = (size_t)(int)rois[5 * n] * H * W * C;
+#pragma unroll
+        for (int k = 0; k < MAXCB; ++k) {
+            if (k >= ncb) break;
+            const int c = k * 64 + lane;
+            const int mi = argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin];
+            if (mi < 0) continue;
+            const size_t pos = boff + (size_t)mi * C + c;
+            float g = gout[(size_t)n * ld_g + c * (PH * PW) + bin];
+            if (!(act[pos] > 0.f)) g = 0.f;
+            atomicAdd(gfeat + pos, g);
+            su[k] += g;
+            sq[k] += g * ((z[pos] - mu[k]) * is[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXCB; ++k) {
+        s_red[wave][0][k * 64 + lane] = su[k];
+        s_red[wave][1][k * 64 + lane] = sq[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        partial[((size_t)blockIdx.x * 2 + which) * C + c] =
+            (s_red[0][which][c] + s_red[1][which][c]) + (s_red[2][which][c] + s_red[3][which][c]);
+    }
+}
+
 // ------------------------------------------------------------------------------------ bbox
 // raw = [x1, y1, w, h, w/h]; z = raw W^T + b  (models.py:134-144 up to the Linear)
 __global__ void bbox_linear_fwd_kernel(const float *__restrict__ bboxes,
@@ -314,6 +366,32 @@ COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, co
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_bwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, C, H, W, PH, PW, gfeat);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW)
+{
+    int g = cdiv(n_rois * PH * PW, 4);
+    if (g > 1024) g = 1024;
+    return g < 1 ? 1 : g;
+}
+
+// cova_roipool_bwd whose scattered gradient is masked by act > 0 and which also emits the
+// BatchNorm-backward partial sums [num_partials][2][C] of (g', g' * (z - mean) * invstd); C % 64 == 0,
+// C <= 256.  gfeat (zero-filled here) then holds the ReLU-masked gradient.
+COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
+                                 int n_rois, int B, int C, int H, int W, int PH, int PW,
+                                 const float *act, const float *z, const float *mean,
+                                 const float *invstd, float *gfeat, float *partial, void *stream)
+{
+    COVA_REQUIRE(gout && rois && argmax && act && z && mean && invstd && gfeat && partial && B > 0);
+    COVA_REQUIRE(C % 64 == 0 && C <= 256);
+    hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * H * W * C, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const int grid = cova_roipool_bwd_bn_num_partials(n_rois, PH, PW);
+    hipLaunchKernelGGL(roipool_bwd_bn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gout, ld_g,
+                       rois, argmax, n_rois, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

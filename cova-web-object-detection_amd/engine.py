@@ -229,7 +229,7 @@ def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
     return dgamma, dbeta, abc
 
 
-def _layer1_bwd_fused(sv, dfeat, gout, grads):
+def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     """Backward of the two BasicBlocks with every BatchNorm-backward apply (except the one fed by
     RoIPool's scatter) and both a1 = relu(bn1(z1)) recomputations folded into the Winograd kernels.
     Returns the gradient w.r.t. the max-pool output."""
@@ -237,7 +237,11 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads):
     R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
     nt = query("cova_conv3x3_num_tiles", B, H2, W2)
-    dA, pend = dfeat, None
+    # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
+    # the last bn2 were taken by cova_roipool_bwd_bn
+    dA, pend, npend = dfeat, None, nt
+    if head_part is not None:
+        pend, npend = head_part
     for blk in (1, 0):
         s = sv["blocks"][blk]
         ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
@@ -251,7 +255,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads):
             g_in, g_in2, g_abc = dz2, None, None
         else:
             dres = dA
-            dg, db, g_abc = _bn_abc_from_partials(pend, nt, bnb, R, gout, pb, dfeat)
+            dg, db, g_abc = _bn_abc_from_partials(pend, npend, bnb, R, gout, pb, dfeat)
             g_in, g_in2 = dA, s["z2"]
         grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
@@ -271,7 +275,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads):
         dx = torch.empty_like(dA)
         if blk == 1:
             prev = sv["blocks"][0]
-            pend = _empty((nt, 2, C64), dfeat)
+            pend, npend = _empty((nt, 2, C64), dfeat), nt
             call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres,
                  prev["out"], None, None, prev["z2"], prev["bnb"].mean, prev["bnb"].invstd, dx, pend,
                  B, H2, W2)
@@ -336,7 +340,7 @@ def _layer1_bwd_unfused(sv, dfeat, gout, grads):
     return dA
 
 
-def convstack_bwd(sv, dfeat, gout=None):
+def convstack_bwd(sv, dfeat, gout=None, head_part=None):
     """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms.
 
     The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
@@ -346,7 +350,11 @@ def convstack_bwd(sv, dfeat, gout=None):
     R = B * H2 * W2
     grads = {}
     fused = USE_WINOGRAD and FUSE_AFFINE and sv["blocks"][0]["a1"] is None
-    dA = (_layer1_bwd_fused if fused else _layer1_bwd_unfused)(sv, dfeat, gout, grads)
+    if fused:
+        dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
+    else:
+        assert head_part is None
+        dA = _layer1_bwd_unfused(sv, dfeat, gout, grads)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
     if fused and sv.get("pool_part") is not None:
@@ -391,6 +399,21 @@ def roipool_bwd(sv, gout, ld_g):
     call("cova_roipool_bwd", gout, ld_g, sv["bboxes"], sv["argmax"], sv["bboxes"].shape[0], B, C, Hf,
          Wf, PH, PW, gfeat)
     return gfeat
+
+
+def roipool_bwd_bn(sv, gout, ld_g, last_block):
+    """RoIPool backward that also applies the ReLU mask of the feature map's producer
+    (out = relu(bn2(z2) + x)) and takes bn2's backward sums -> (masked gradient, (partials, count))."""
+    B, Hf, Wf, C = sv["shape"]
+    PH, PW = sv["roi"]
+    n = sv["bboxes"].shape[0]
+    gfeat = _empty((B, Hf, Wf, C), gout)
+    npart = query("cova_roipool_bwd_bn_num_partials", n, PH, PW)
+    part = _empty((npart, 2, C), gout)
+    bnb = last_block["bnb"]
+    call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
+         last_block["out"], last_block["z2"], bnb.mean, bnb.invstd, gfeat, part)
+    return gfeat, (part, npart)
 
 
 # ------------------------------------------------------------------------------- BN over [N, C]
@@ -571,8 +594,13 @@ def model_bwd(sv, dlogits, params, gout=None):
         grads["bn_additional_feat.weight"], grads["bn_additional_feat.bias"] = dg, db
     if Hd > 0:
         grads.update(bbox_bwd(sv["bbox"], dcomb[:, n_vis:], T, gout))
-    dfeat = roipool_bwd(sv["roi"], dcomb, T)
-    grads.update(convstack_bwd(sv["conv"], dfeat, gout))
+    conv = sv["conv"]
+    if USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None and N > 0:
+        dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["blocks"][1])
+        grads.update(convstack_bwd(conv, dfeat, gout, head_part))
+    else:
+        dfeat = roipool_bwd(sv["roi"], dcomb, T)
+        grads.update(convstack_bwd(conv, dfeat, gout))
     return grads
 
 

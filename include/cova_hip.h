@@ -156,6 +156,13 @@ int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int C, in
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                      int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
                      void *stream);
+/* same, fused with the ReLU mask (act > 0) and the BatchNorm-backward partial sums of the layer that
+ * produced the map: gfeat = masked gradient, partial [cova_roipool_bwd_bn_num_partials][2][C] */
+int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW);
+int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
+                        int n_rois, int B, int C, int H, int W, int PH, int PW, const float *act,
+                        const float *z, const float *mean, const float *invstd, float *gfeat,
+                        float *partial, void *stream);
 
 /* ------------------------------------------------------------------ positional encoder
  * replaces: CoVA._get_bbox_features up to nn.Linear(5, Hd) (models.py:134-144):

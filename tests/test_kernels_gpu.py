@@ -208,6 +208,20 @@ def test_roipool_matches_oracle_bit_exact():
     gfeat = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, gfeat)
     close(nchw(gfeat), gref, 1e-5, "roipool bwd")
+    # fused variant: ReLU mask of the map's producer + BatchNorm-backward sums
+    act = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
+    z = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
+    mean = torch.from_numpy(rs.standard_normal(C).astype(np.float32)).to(DEV) * 0.2
+    invstd = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).to(DEV)
+    npart = query("cova_roipool_bwd_bn_num_partials", n, 3, 3)
+    part = torch.empty(npart, 2, C, device=DEV)
+    gmask = torch.empty(B, H, W, C, device=DEV)
+    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, act, z, mean,
+         invstd, gmask, part)
+    ref_masked = gfeat * (act > 0)
+    close(gmask, ref_masked, 1e-5, "roipool bwd masked")
+    close(part[:, 0].sum(0), ref_masked.sum((0, 1, 2)), 1e-4, "roipool bwd sum dy")
+    close(part[:, 1].sum(0), (ref_masked * ((z - mean) * invstd)).sum((0, 1, 2)), 1e-4, "roipool bwd sum dy*xhat")
 
 
 def test_bbox_linear():

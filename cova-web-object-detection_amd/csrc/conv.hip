@@ -952,11 +952,26 @@ namespace wg1 {
 constexpr int NPRE_D = (DY_FLOATS / 4 + THREADS - 1) / THREADS;    // 8 float4
 }
 
+// POOL: the gradient operand is not read but rebuilt while staging (the BatchNorm+ReLU+MaxPool
+// backward "apply" pass folded in):  dy1 = A*g + B*y1 + C  per channel, where g routes the pooled
+// gradient dp (already ReLU-masked) to each window's arg-max (idx).  The tile is staged as B*y1 + C
+// and each thread then scatters its share of the 5x17 pooling windows that can reach the tile with
+// LDS float atomics (A*dp to the arg-max pixel): dy1 (1.68 GB at the bench size) is never written.
+struct PoolBwd {
+    const float *dp;          // [B,H2,W2,64] pooled gradient, ReLU mask already applied
+    const uint8_t *idx;       // [B,H2,W2,64] arg-max position ky*3+kx inside the 3x3/s2 window
+    const float *abc;         // [3][64] A | B | C
+    int H2, W2;
+};
+
+template <bool POOL>
 __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
     const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles)
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
 {
     using namespace c1;
+    constexpr int NPOOL = POOL ? 3 : 0;           // (window, 4-channel group) items per thread: 5*17*16 = 1360
+    constexpr int WIN_W = wg1::TW / 2 + 1, WIN_ITEMS = (wg1::TH / 2 + 1) * WIN_W * 16;
     __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS];
     float *s_in = lds;
     float *s_dy = lds + IN_FLOATS;
@@ -980,9 +995,36 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 
     float pre[NPRE];
     float4 pd[wg1::NPRE_D];
-    // slot s < NPRE: image patch element; s >= NPRE: float4 of the dy tile
-    auto issue_slot = [&](int s, const float *img_b, const float *dy_b, int y0, int x0) {
-        if (s < NPRE) {
+    bool pd_in[wg1::NPRE_D];                      // POOL: pixel inside the map
+    float4 pdp[POOL ? 3 : 1];
+    uint32_t pix[POOL ? 3 : 1];
+    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA, cC = cA;      // this thread's 4 channels
+    if (POOL) {
+        const int c4 = tid & 15;
+        cA = *reinterpret_cast<const float4 *>(pool.abc + c4 * 4);
+        cB = *reinterpret_cast<const float4 *>(pool.abc + 64 + c4 * 4);
+        cC = *reinterpret_cast<const float4 *>(pool.abc + 128 + c4 * 4);
+    }
+    // slot s < NPRE: image patch element; then NPRE_D float4 of the dy (POOL: y1) tile; then NPOOL
+    // (window, channel group) items of the pooled gradient
+    auto issue_slot = [&](int s, const float *img_b, const float *dy_b, int y0, int x0, int b) {
+        if (s >= NPRE + wg1::NPRE_D) {
+            if (POOL) {
+                const int k = s - NPRE - wg1::NPRE_D;
+                const int item = tid + k * THREADS;
+                const int wr = item / (WIN_W * 16), wc = (item >> 4) % WIN_W;
+                const int ph = (y0 >> 1) + wr, pw = (x0 >> 1) + wc;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint32_t code = 0;
+                if (item < WIN_ITEMS && ph < pool.H2 && pw < pool.W2) {
+                    const size_t o = (((size_t)b * pool.H2 + ph) * pool.W2 + pw) * 64 + (tid & 15) * 4;
+                    v = *reinterpret_cast<const float4 *>(pool.dp + o);
+                    code = *reinterpret_cast<const uint32_t *>(pool.idx + o);
+                }
+                pdp[k] = v;
+                pix[k] = code;
+            }
+        } else if (s < NPRE) {
             const int idx = tid + s * THREADS;
             const int c = idx / (PR * 69);
             const int rem = idx - c * (PR * 69);
@@ -999,9 +1041,10 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             const int r = px / wg1::TW, c = px - r * wg1::TW;
             const int gy = y0 + r, gx = x0 + c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H1 && gx < W1)
-                v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
+            const bool in = gy < H1 && gx < W1;
+            if (in) v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
             pd[it] = v;
+            pd_in[it] = in;
         }
     };
     auto issue_loads = [&](int t) {
@@ -1009,9 +1052,9 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         const int ty = (t / tiles_x) % tiles_y;
         const int b = t / (tiles_x * tiles_y);
 #pragma unroll
-        for (int s = 0; s < NPRE + wg1::NPRE_D; ++s)
+        for (int s = 0; s < NPRE + wg1::NPRE_D + NPOOL; ++s)
             issue_slot(s, img + (size_t)b * 3 * H * W, dy + (size_t)b * H1 * W1 * 64, ty * wg1::TH,
-                       tx * wg1::TW);
+                       tx * wg1::TW, b);
     };
     auto write_lds = [&]() {
 #pragma unroll
@@ -1025,14 +1068,44 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             }
         }
 #pragma unroll
-        for (int it = 0; it < wg1::NPRE_D; ++it)
-            *reinterpret_cast<float4 *>(s_dy + (tid + it * THREADS) * 4) = pd[it];
+        for (int it = 0; it < wg1::NPRE_D; ++it) {
+            float4 v = pd[it];
+            if (POOL) {                                                   // B*y1 + C, 0 outside the map
+                v.x = pd_in[it] ? fmaf(cB.x, v.x, cC.x) : 0.f;
+                v.y = pd_in[it] ? fmaf(cB.y, v.y, cC.y) : 0.f;
+                v.z = pd_in[it] ? fmaf(cB.z, v.z, cC.z) : 0.f;
+                v.w = pd_in[it] ? fmaf(cB.w, v.w, cC.w) : 0.f;
+            }
+            *reinterpret_cast<float4 *>(s_dy + (tid + it * THREADS) * 4) = v;
+        }
+    };
+    // POOL: route A*dp of this thread's windows to their arg-max pixels inside the staged tile
+    auto scatter_pool = [&]() {
+        const float av[4] = {cA.x, cA.y, cA.z, cA.w};
+#pragma unroll
+        for (int k = 0; k < NPOOL; ++k) {
+            const int item = tid + k * THREADS;
+            const int wr = item / (WIN_W * 16), wc = (item >> 4) % WIN_W;
+            const float g[4] = {pdp[k].x, pdp[k].y, pdp[k].z, pdp[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int code = (pix[k] >> (8 * j)) & 255;
+                const int ky = (code * 11) >> 5, kx = code - 3 * ky;      // code / 3, code % 3 for code < 9
+                const int r = 2 * wr - 1 + ky, c = 2 * wc - 1 + kx;       // tile-relative (tile origin is even)
+                if (g[j] != 0.f && r >= 0 && r < wg1::TH && c >= 0 && c < wg1::TW)
+                    atomicAdd(s_dy + (r * wg1::TW + c) * 64 + (tid & 15) * 4 + j, av[j] * g[j]);
+            }
+        }
     };
 
     int tile = blockIdx.x;
     if (tile < ntiles) {
         issue_loads(tile);
         write_lds();
+        if (POOL) {
+            __syncthreads();
+            scatter_pool();
+        }
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -1052,8 +1125,8 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_ptr[toff[tb]];
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
-            if (t < NPRE + wg1::NPRE_D && has_next)
-                issue_slot(t, nimg, ndy, nty * wg1::TH, ntx * wg1::TW);
+            if (t < NPRE + wg1::NPRE_D + NPOOL && has_next)
+                issue_slot(t, nimg, ndy, nty * wg1::TH, ntx * wg1::TW, nb);
             const int tn = t < 31 ? t + 1 : t;
             const int pn = 2 * tn;
             const int rown = pn >> 5, coln = pn & 31;
@@ -1070,6 +1143,10 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         }
         __syncthreads();
         if (has_next) write_lds();
+        if (POOL) {
+            __syncthreads();
+            if (has_next) scatter_pool();
+        }
         __syncthreads();
     }
     // partial layout: part[(block*4 + q)][co 64][k 160]
@@ -1304,6 +1381,29 @@ COVA_API int cova_conv1_wgrad_workspace_floats(int B, int H, int W)
     return persistent_grid(cova_conv1_num_tiles(B, H, W)) * 8 * 64 * 160;
 }
 
+// conv1 weight gradient with the BatchNorm+ReLU+MaxPool backward apply folded into its operand:
+//   dy1 = abc[0]*route(dp, idx) + abc[1]*y1 + abc[2]   (what cova_bn_relu_maxpool_bwd_apply would write)
+// y1 NHWC [B,H1,W1,64] = conv1 output; dp NHWC [B,H2,W2,64] pooled gradient with the ReLU mask already
+// applied; idx = arg-max codes of cova_bn_relu_maxpool_fwd; abc [3,64] from cova_bn_finalize_bwd_abc.
+COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const float *dp,
+                                      const uint8_t *idx, const float *abc, float *dw, float *ws,
+                                      int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(img && y1 && dp && idx && abc && dw && ws && B > 0 && H > 0 && W > 0);
+    const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
+    const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
+    const int grid = persistent_grid(B * tiles_x * tiles_y);
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
+                       (hipStream_t)stream, ws, grid * 4, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
 // img NCHW [B,3,H,W]; dy NHWC [B,H1,W1,64]; dw OIHW [64,3,7,7]
 COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, float *ws, int B, int H,
                               int W, void *stream)
@@ -1313,9 +1413,9 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
     if (g_conv1_variant == 2) {
-        hipLaunchKernelGGL(conv1_wgrad_v2_kernel, dim3(grid), dim3(wg1::THREADS), 0,
+        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
                            (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y);
+                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                            (hipStream_t)stream, ws, grid * 4, dw);

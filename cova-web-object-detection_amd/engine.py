@@ -366,16 +366,24 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None):
              bn1.invstd, part, B, H1, W1)
     dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
     db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
-    coef = _empty((2, C64), dfeat)
     part, npart = fold_partials(part, npart, 2 * C64)
-    call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
-    grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
-    dy1 = torch.empty_like(sv["y1"])
-    call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
-         bn1.invstd, coef, dy1, B, H1, W1)
     ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
     dw1 = _gbuf(gout, "convnet.0.weight", (64, 3, 7, 7), dfeat)
-    call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
+    if fused and sv.get("pool_part") is not None:
+        # dA is already ReLU-masked (epilogue of the last data-gradient conv): the pooling/BN backward
+        # apply is folded into conv1's weight-gradient kernel, dy1 is never written
+        abc = _empty((3, C64), dfeat)
+        call("cova_bn_finalize_bwd_abc", part, npart, C64, float(B * H1 * W1), dg, db, bn1.mean,
+             bn1.invstd, bn1.scale, abc)
+        call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
+    else:
+        coef = _empty((2, C64), dfeat)
+        call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
+        dy1 = torch.empty_like(sv["y1"])
+        call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
+             bn1.invstd, coef, dy1, B, H1, W1)
+        call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
+    grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
     grads["convnet.0.weight"] = dw1
     return grads
 

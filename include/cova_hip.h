@@ -56,6 +56,11 @@ int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_p
 int cova_conv1_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv1_wgrad(const float *img, const float *dy /*NHWC*/, float *dw, float *ws, int B, int H,
                      int W, void *stream);
+/* same with the BatchNorm+ReLU+MaxPool backward apply folded into the gradient operand:
+ * dy1 = abc[0]*route(dp, idx) + abc[1]*y1 + abc[2]; dp [B,H2,W2,64] already ReLU-masked */
+int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const float *dp, const uint8_t *idx,
+                             const float *abc, float *dw, float *ws, int B, int H, int W,
+                             void *stream);
 
 /* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC; with w_dgrad it is the data gradient.
  * addend (nullable, NHWC) is added to the result (residual-branch gradient). */

@@ -529,3 +529,37 @@ def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
             close(dw, ref, 2e-6, "wgrad affine-on-load %s %s" % (pa, pd))
     finally:
         query("cova_set_option", 2, 0)
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(1, 32, 64, 0), (2, 70, 150, 0), (2, 150, 330, 0), (2, 150, 330, 7)])
+def test_conv1_wgrad_with_pool_backward_folded_in(B, H, W, cap):
+    """cova_conv1_wgrad_poolbwd == cova_bn_relu_maxpool_bwd_apply followed by cova_conv1_wgrad
+    (same partial sums, same coefficients), incl. odd map sizes and windows across tile borders."""
+    g = torch.Generator().manual_seed(H * 3 + W)
+    x = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
+    H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
+    y = nhwc(torch.randn(B, 64, H1, W1, generator=g))
+    scale = (torch.rand(64, generator=g) - 0.3).to(DEV)
+    shift = (torch.randn(64, generator=g) * 0.2).to(DEV)
+    mean, invstd = (torch.randn(64, generator=g) * 0.1).to(DEV), (torch.rand(64, generator=g) + 0.5).to(DEV)
+    p1, idx = torch.empty(B, H2, W2, 64, device=DEV), torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
+    call("cova_bn_relu_maxpool_fwd", y, scale, shift, p1, idx, None, B, H1, W1)
+    dp = nhwc(torch.randn(B, 64, H2, W2, generator=g)) * (p1 > 0)            # ReLU mask already applied
+    npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
+    part = torch.empty(npart, 2, 64, device=DEV)
+    call("cova_bn_relu_maxpool_bwd_reduce", dp, idx, y, scale, shift, mean, invstd, part, B, H1, W1)
+    coef, abc = torch.empty(2, 64, device=DEV), torch.empty(3, 64, device=DEV)
+    call("cova_bn_finalize_bwd", part, npart, 64, float(B * H1 * W1), None, None, coef)
+    call("cova_bn_finalize_bwd_abc", part, npart, 64, float(B * H1 * W1), None, None, mean, invstd, scale, abc)
+    dy1 = torch.empty(B, H1, W1, 64, device=DEV)
+    call("cova_bn_relu_maxpool_bwd_apply", dp, idx, y, scale, shift, mean, invstd, coef, dy1, B, H1, W1)
+    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
+    ref, dw = torch.zeros(64, 3, 7, 7, device=DEV), torch.zeros(64, 3, 7, 7, device=DEV)
+    query("cova_set_option", 2, cap)
+    try:
+        call("cova_conv1_wgrad", x, dy1, ref, ws, B, H, W)
+        call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W)
+    finally:
+        query("cova_set_option", 2, 0)
+    close(dw, ref, 2e-5, "conv1 wgrad with folded pool backward")

@@ -972,9 +972,12 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
     using namespace c1;
     constexpr int NPOOL = POOL ? 3 : 0;           // (window, 4-channel group) items per thread: 5*17*16 = 1360
     constexpr int WIN_W = wg1::TW / 2 + 1, WIN_ITEMS = (wg1::TH / 2 + 1) * WIN_W * 16;
-    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS];
+    constexpr int NWIN = (wg1::TH / 2 + 1) * WIN_W;                  // 85 windows can reach a tile
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS + (POOL ? NWIN * 80 : 0)];
     float *s_in = lds;
     float *s_dy = lds + IN_FLOATS;
+    float *s_dpw = lds + IN_FLOATS + wg1::DY_FLOATS;                 // POOL: [window][64] pooled gradient
+    uint32_t *s_ixw = reinterpret_cast<uint32_t *>(s_dpw + NWIN * 64);   // POOL: [window][16] arg-max codes x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh2 = lane >> 5;
     const int cob = wave & 1, q = wave >> 1;
@@ -995,29 +998,34 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 
     float pre[NPRE];
     float4 pd[wg1::NPRE_D];
-    bool pd_in[wg1::NPRE_D];                      // POOL: pixel inside the map
+    uint32_t pd_in = 0;                           // POOL: bit it = pixel of slot it lies inside the map
     float4 pdp[POOL ? 3 : 1];
     uint32_t pix[POOL ? 3 : 1];
-    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA, cC = cA;      // this thread's 4 channels
-    if (POOL) {
-        const int c4 = tid & 15;
-        cA = *reinterpret_cast<const float4 *>(pool.abc + c4 * 4);
-        cB = *reinterpret_cast<const float4 *>(pool.abc + 64 + c4 * 4);
-        cC = *reinterpret_cast<const float4 *>(pool.abc + 128 + c4 * 4);
-    }
+    // this thread's 4 channels of A | B | C; fetched where used (kept out of the MFMA loop's registers)
+    auto coef = [&](int which) {
+        int o = which * 64 + (tid & 15) * 4;
+        asm volatile("" : "+v"(o));
+        return *reinterpret_cast<const float4 *>(pool.abc + o);
+    };
     // slot s < NPRE: image patch element; then NPRE_D float4 of the dy (POOL: y1) tile; then NPOOL
     // (window, channel group) items of the pooled gradient
     auto issue_slot = [&](int s, const float *img_b, const float *dy_b, int y0, int x0, int b) {
         if (s >= NPRE + wg1::NPRE_D) {
             if (POOL) {
                 const int k = s - NPRE - wg1::NPRE_D;
-                const int item = tid + k * THREADS;
+                int t_ = tid;
+                asm volatile("" : "+v"(t_));      // index math stays here (hoisted, it costs more registers than it saves)
+                const int item = t_ + k * THREADS;
                 const int wr = item / (WIN_W * 16), wc = (item >> 4) % WIN_W;
                 const int ph = (y0 >> 1) + wr, pw = (x0 >> 1) + wc;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint32_t code = 0;
+#if defined(POOL_ABL) && (POOL_ABL & 2)
+                if (false) {
+#else
                 if (item < WIN_ITEMS && ph < pool.H2 && pw < pool.W2) {
-                    const size_t o = (((size_t)b * pool.H2 + ph) * pool.W2 + pw) * 64 + (tid & 15) * 4;
+#endif
+                    const size_t o = (((size_t)b * pool.H2 + ph) * pool.W2 + pw) * 64 + (t_ & 15) * 4;
                     v = *reinterpret_cast<const float4 *>(pool.dp + o);
                     code = *reinterpret_cast<const uint32_t *>(pool.idx + o);
                 }
@@ -1044,7 +1052,7 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             const bool in = gy < H1 && gx < W1;
             if (in) v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
             pd[it] = v;
-            pd_in[it] = in;
+            pd_in = (pd_in & ~(1u << it)) | ((in ? 1u : 0u) << it);
         }
     };
     auto issue_loads = [&](int t) {
@@ -1067,34 +1075,88 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
                 s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
             }
         }
+        float4 cB = make_float4(0.f, 0.f, 0.f, 0.f), cC = cB;
+        if (POOL) {
+            cB = coef(1);
+            cC = coef(2);
+        }
 #pragma unroll
         for (int it = 0; it < wg1::NPRE_D; ++it) {
             float4 v = pd[it];
             if (POOL) {                                                   // B*y1 + C, 0 outside the map
-                v.x = pd_in[it] ? fmaf(cB.x, v.x, cC.x) : 0.f;
-                v.y = pd_in[it] ? fmaf(cB.y, v.y, cC.y) : 0.f;
-                v.z = pd_in[it] ? fmaf(cB.z, v.z, cC.z) : 0.f;
-                v.w = pd_in[it] ? fmaf(cB.w, v.w, cC.w) : 0.f;
+                const bool in = (pd_in >> it) & 1u;
+                v.x = in ? fmaf(cB.x, v.x, cC.x) : 0.f;
+                v.y = in ? fmaf(cB.y, v.y, cC.y) : 0.f;
+                v.z = in ? fmaf(cB.z, v.z, cC.z) : 0.f;
+                v.w = in ? fmaf(cB.w, v.w, cC.w) : 0.f;
             }
             *reinterpret_cast<float4 *>(s_dy + (tid + it * THREADS) * 4) = v;
         }
-    };
-    // POOL: route A*dp of this thread's windows to their arg-max pixels inside the staged tile
-    auto scatter_pool = [&]() {
-        const float av[4] = {cA.x, cA.y, cA.z, cA.w};
 #pragma unroll
         for (int k = 0; k < NPOOL; ++k) {
-            const int item = tid + k * THREADS;
-            const int wr = item / (WIN_W * 16), wc = (item >> 4) % WIN_W;
-            const float g[4] = {pdp[k].x, pdp[k].y, pdp[k].z, pdp[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int code = (pix[k] >> (8 * j)) & 255;
-                const int ky = (code * 11) >> 5, kx = code - 3 * ky;      // code / 3, code % 3 for code < 9
-                const int r = 2 * wr - 1 + ky, c = 2 * wc - 1 + kx;       // tile-relative (tile origin is even)
-                if (g[j] != 0.f && r >= 0 && r < wg1::TH && c >= 0 && c < wg1::TW)
-                    atomicAdd(s_dy + (r * wg1::TW + c) * 64 + (tid & 15) * 4 + j, av[j] * g[j]);
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int item = t_ + k * THREADS;                             // = window * 16 + channel group
+            if (item < WIN_ITEMS) {
+                *reinterpret_cast<float4 *>(s_dpw + item * 4) = pdp[k];
+                s_ixw[item] = pix[k];
             }
+        }
+    };
+    // POOL: finish dy1 in place.  Thread -> pixel (row it, column cc), channels 4*c4..+3; the column
+    // permutation gives every wave four columns of one parity, so the set of pooling windows that
+    // can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform and rows are
+    // compile-time.  No atomics: each thread gathers into its own pixels.
+    auto scatter_pool = [&]() {
+#if defined(POOL_ABL) && (POOL_ABL & 1)
+        return;
+#endif
+        const int qx = tid >> 4, c4 = tid & 15;
+        const float4 cA = coef(0);
+        const int cc = (((qx & 3) << 1) | ((qx >> 2) & 1)) + 8 * (qx >> 3);
+        const bool codd = (wave & 1) != 0;                                  // == cc & 1
+        const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
+        const int kx0 = codd ? 2 : 1;                                      // its kx; the second (odd only): wc0+1, kx 0
+        // four batches of two rows (2b, 2b+1); all LDS reads of a batch are issued before the first use
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            uint32_t word[3][2];
+            float4 dval[3][2], cur[2];
+            // candidates of rows 2b, 2b+1: (row, window row - b, ky)
+            constexpr int crow[3] = {0, 1, 1}, cwr[3] = {0, 0, 1}, cky[3] = {1, 2, 0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int win = (bq + cwr[k]) * WIN_W + wc0 + (codd ? e : 0);
+                    word[k][e] = s_ixw[win * 16 + c4];
+                    dval[k][e] = *reinterpret_cast<const float4 *>(s_dpw + win * 64 + c4 * 4);
+                }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+                cur[rr] = *reinterpret_cast<const float4 *>(s_dy + ((2 * bq + rr) * wg1::TW + cc) * 64 + c4 * 4);
+            float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    // even columns have one candidate: the second slot re-reads it with an impossible code
+                    const uint32_t code = e == 0 ? (uint32_t)(cky[k] * 3 + kx0) : (codd ? (uint32_t)(cky[k] * 3) : 255u);
+                    const float dv[4] = {dval[k][e].x, dval[k][e].y, dval[k][e].z, dval[k][e].w};
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        g[crow[k]][jx] += (((word[k][e] >> (8 * jx)) & 255u) == code) ? dv[jx] : 0.f;
+                }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float4 v = cur[rr];
+                v.x = fmaf(cA.x, g[rr][0], v.x);
+                v.y = fmaf(cA.y, g[rr][1], v.y);
+                v.z = fmaf(cA.z, g[rr][2], v.z);
+                v.w = fmaf(cA.w, g[rr][3], v.w);
+                *reinterpret_cast<float4 *>(s_dy + ((2 * bq + rr) * wg1::TW + cc) * 64 + c4 * 4) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // one batch in flight at a time (registers)
         }
     };
 

@@ -144,6 +144,22 @@ def main():
         dt = float(t.item())
     loss_val = float(loss.item())
 
+    # forward only (eval mode, running statistics): the second number SURVEY.md section 8d asks for.
+    # Not the metric; reported as an extra object.
+    for _ in range(2):
+        trainer.predict(batch)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.predict(batch)
+    barrier()
+    dt_fwd = time.perf_counter() - t1
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt_fwd], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_fwd = float(t.item())
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = world * args.pages * args.steps / dt
@@ -180,6 +196,9 @@ def main():
                          "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
                          "flop_per_launch": flops},
         }
+        out["forward_only"] = {"value": round(world * args.pages * args.steps / dt_fwd, 2), "unit": "webpages/s",
+                               "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),
+                               "mode": "eval forward (running statistics) + per-box argmax, same batch"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

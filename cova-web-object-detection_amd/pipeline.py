@@ -16,9 +16,10 @@ from ._lib import call
 
 
 class DeviceCollate:
-    def __init__(self, context_size, device, n_additional_feat=0):
+    def __init__(self, context_size, device, n_additional_feat=0, pin=False):
         assert context_size >= 0
         self.cs, self.device, self.A = int(context_size), torch.device(device), int(n_additional_feat)
+        self.pin = bool(pin)            # stage host arrays in pinned memory: H2D copies become asynchronous
 
     def __call__(self, u8_pages, rows_per_page, additional_feats=None):
         """u8_pages: uint8 [B,H,W,3] (numpy or torch, host or device); rows_per_page: list of
@@ -34,9 +35,10 @@ class DeviceCollate:
             if N else np.zeros((0, 5), np.float32)
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         dev = self.device
-        u8 = u8.to(dev, non_blocking=True).contiguous()
-        rows_d = torch.from_numpy(rows).to(dev, non_blocking=True)
-        offs_d = torch.from_numpy(offs).to(dev, non_blocking=True)
+        host = (lambda t: t.pin_memory()) if self.pin else (lambda t: t)
+        u8 = (host(u8) if u8.device.type == "cpu" else u8).to(dev, non_blocking=True).contiguous()
+        rows_d = host(torch.from_numpy(rows)).to(dev, non_blocking=True)
+        offs_d = host(torch.from_numpy(offs)).to(dev, non_blocking=True)
         images = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         call("cova_images_u8_to_f32", u8, images, B, H, W)
         bboxes = torch.empty((N, 5), dtype=torch.float32, device=dev)
@@ -50,6 +52,48 @@ class DeviceCollate:
             addl = torch.as_tensor(additional_feats, dtype=torch.float32).to(dev).contiguous()
         return dict(images=images, bboxes=bboxes, additional_feats=addl, context_indices=ctx,
                     labels=labels, page_start=offs_d.to(torch.int64))
+
+
+class Prefetcher:
+    """Iterates device batches while the NEXT one is uploaded and collated on a side stream.
+
+    ``source`` yields ``(u8_pages, rows_per_page)`` (or with a third ``additional_feats`` item).  The
+    uint8 upload (19.7 MB per 1280x1280 page fp32 -> 4.9 MB) and the two collate kernels of batch i+1
+    run on their own HIP stream under the train step of batch i; ``__next__`` makes the consumer's
+    stream wait on the upload's event -- the PCIe time never shows in the step time."""
+
+    def __init__(self, collate, source):
+        self.collate, self.it = collate, iter(source)
+        self.stream = torch.cuda.Stream(device=collate.device)
+        self._pending = None
+        self._preload()
+
+    def _preload(self):
+        try:
+            item = next(self.it)
+        except StopIteration:
+            self._pending = None
+            return
+        with torch.cuda.stream(self.stream):
+            batch = self.collate(*item)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._pending = (batch, ev)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._pending is None:
+            raise StopIteration
+        batch, ev = self._pending
+        cur = torch.cuda.current_stream(self.collate.device)
+        cur.wait_event(ev)
+        for v in batch.values():
+            if torch.is_tensor(v):
+                v.record_stream(cur)         # allocated on the side stream, consumed on this one
+        self._preload()
+        return batch
 
 
 @torch.no_grad()

@@ -397,3 +397,32 @@ def test_attention_export_rows_match_reference_dump():
     K = batch["context_indices"].shape[1]
     assert torch.equal(rows[:, :5 + 4 * K], ref[:, :5 + 4 * K])
     np.testing.assert_allclose(rows[:, 5 + 4 * K:].numpy(), ref[:, 5 + 4 * K:].numpy(), atol=2e-5)
+
+
+def test_prefetcher_overlapped_upload_matches_direct_collate():
+    """pipeline.Prefetcher (pinned staging, side-stream upload + collate kernels) yields exactly the
+    batches of the synchronous DeviceCollate, in order, and a train step consumes them."""
+    from cova_web_object_detection_amd.pipeline import DeviceCollate, Prefetcher
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    rs = np.random.RandomState(5)
+    items = []
+    for counts in ([12, 30], [25, 9], [40, 18]):
+        u8 = rs.randint(0, 256, (2, 64, 64, 3)).astype(np.uint8)
+        rows = []
+        for n in counts:
+            xy, wh = rs.uniform(0, 30, (n, 2)), rs.uniform(8, 30, (n, 2))
+            lab = np.zeros((n, 1)); lab[:3, 0] = [1, 2, 3]
+            rows.append(np.concatenate([xy, wh, lab], 1).astype(np.float32))
+        items.append((u8, rows))
+    direct = [DeviceCollate(4, DEV)(*it) for it in items]
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=32, bbox_hidden_dim=8,
+               n_additional_feat=0, drop_prob=0.0)
+    tr = HotPathTrainer(cfg, weights.seeded_state_dict(3, **{k: v for k, v in cfg.items() if k != "drop_prob"}), DEV)
+    n = 0
+    for got, ref in zip(Prefetcher(DeviceCollate(4, DEV, pin=True), items), direct):
+        for k in ("images", "bboxes", "labels", "context_indices", "page_start"):
+            assert torch.equal(got[k], ref[k]), k
+        loss, _ = tr.train_step(got)
+        assert torch.isfinite(loss).all()
+        n += 1
+    assert n == len(items)

@@ -189,9 +189,11 @@ def main():
                          "executed_frac": round(achieved / 2.25 / PEAK_F32_MFMA_TFLOPS, 4),
                          # HBM bytes per forward launch from PMC (separate --pmc FETCH_SIZE /
                          # WRITE_SIZE passes, FETCH doubled per the gfx950 correction):
-                         # 2*232.7 MiB + 408.3 MiB, profiles/r01_pmc_conv_kernels_isolated.txt;
-                         # algorithmic = 2 * 419.4 MB (one read + one write of [16,320,320,64] f32)
-                         "traffic": 916e6 * args.pages / 16, "traffic_unit": "B/launch",
+                         # plain forward launch: FETCH_SIZE 2*236.6 MiB (gfx950 half-count correction) +
+                         # WRITE_SIZE 408.6 MiB, profiles/r01_pmc_hbm_traffic_final.txt; algorithmic =
+                         # 2 * 419.4 MB (one read + one write of [16,320,320,64] f32).  The fused
+                         # variants read 1-3 more maps (BatchNorm operands) -- see DESIGN.md 4.6.
+                         "traffic": 924.6e6 * args.pages / 16, "traffic_unit": "B/launch",
                          "algorithmic_bytes": 2 * 4 * 64 * args.pages * (IMG // 4) * (IMG // 4),
                          "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
                          "flop_per_launch": flops},

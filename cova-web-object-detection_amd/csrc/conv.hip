@@ -1117,9 +1117,9 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         const bool codd = (wave & 1) != 0;                                  // == cc & 1
         const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
         const int kx0 = codd ? 2 : 1;                                      // its kx; the second (odd only): wc0+1, kx 0
-        // four batches of two rows (2b, 2b+1); all LDS reads of a batch are issued before the first use
-#pragma unroll
-        for (int bq = 0; bq < 4; ++bq) {
+        // four batches of two rows (2b, 2b+1); all LDS reads of a batch are issued before the first use.
+        // Odd columns have two candidate window columns, even ones a single one (wave-uniform branch).
+        auto batch = [&](const int bq, const int ne) {
             uint32_t word[3][2];
             float4 dval[3][2], cur[2];
             // candidates of rows 2b, 2b+1: (row, window row - b, ky)
@@ -1128,7 +1128,8 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int win = (bq + cwr[k]) * WIN_W + wc0 + (codd ? e : 0);
+                    if (e >= ne) continue;
+                    const int win = (bq + cwr[k]) * WIN_W + wc0 + e;
                     word[k][e] = s_ixw[win * 16 + c4];
                     dval[k][e] = *reinterpret_cast<const float4 *>(s_dpw + win * 64 + c4 * 4);
                 }
@@ -1140,8 +1141,8 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    // even columns have one candidate: the second slot re-reads it with an impossible code
-                    const uint32_t code = e == 0 ? (uint32_t)(cky[k] * 3 + kx0) : (codd ? (uint32_t)(cky[k] * 3) : 255u);
+                    if (e >= ne) continue;
+                    const uint32_t code = (uint32_t)(cky[k] * 3 + (e == 0 ? kx0 : 0));
                     const float dv[4] = {dval[k][e].x, dval[k][e].y, dval[k][e].z, dval[k][e].w};
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx)
@@ -1157,6 +1158,13 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
                 *reinterpret_cast<float4 *>(s_dy + ((2 * bq + rr) * wg1::TW + cc) * 64 + c4 * 4) = v;
             }
             __builtin_amdgcn_sched_barrier(0);       // one batch in flight at a time (registers)
+        };
+        if (codd) {
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) batch(bq, 2);
+        } else {
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) batch(bq, 1);
         }
     };
 

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + j;
         float v = 0.f;
         if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = img_b[((size_t)c * H + gy) * W + gx];
+            v = img_b[(unsigned)((c * H + gy) * W + gx)];          // 32-bit in-image offset (checked at launch)
         pre[it] = v;
     };
     auto issue_loads = [&](int t) {
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
             float v = 0.f;
             if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = img_b[((size_t)c * H + gy) * W + gx];
+                v = img_b[(unsigned)((c * H + gy) * W + gx)];          // 32-bit in-image offset (checked at launch)
             pre[s] = v;
         } else {
             const int it = s - NPRE;
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
             const int gy = y0 + r, gx = x0 + c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool in = gy < H1 && gx < W1;
-            if (in) v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
+            if (in) v = *reinterpret_cast<const float4 *>(dy_b + (unsigned)(((gy * W1 + gx) << 6) + c4 * 4));
             pd[it] = v;
             pd_in = (pd_in & ~(1u << it)) | ((in ? 1u : 0u) << it);
         }
@@ -1189,27 +1189,24 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         // this wave: tile rows 2q, 2q+1; k-pair t -> pixels p = 2t + kh2 (row 2q + (p>>5), col p&31)
         const float *a_ptr = s_dy + (2 * q * wg1::TW + kh2) * 64 + cob * 32 + li;
         const float *b_ptr = s_in + (4 * q) * RSTR + kh2;
-        float a_cur = a_ptr[0];
-        float b_cur[5];
+        float a_op[2], b_op[2][5];                 // operands of k-pair t in slot t & 1 (no copies)
+        a_op[0] = a_ptr[0];
 #pragma unroll
-        for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_ptr[toff[tb]];
+        for (int tb = 0; tb < 5; ++tb) b_op[0][tb] = b_ptr[toff[tb]];
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
             if (t < NPRE + wg1::NPRE_D + NPOOL && has_next)
                 issue_slot(t, nimg, ndy, nty * wg1::TH, ntx * wg1::TW, nb);
-            const int tn = t < 31 ? t + 1 : t;
-            const int pn = 2 * tn;
-            const int rown = pn >> 5, coln = pn & 31;
-            const float a_nxt = a_ptr[(rown * wg1::TW + coln) * 64];
-            const float *bn = b_ptr + (2 * rown) * RSTR + coln;
-            float b_nxt[5];
+            if (t < 31) {
+                const int pn = 2 * (t + 1);
+                const int rown = pn >> 5, coln = pn & 31;
+                a_op[(t + 1) & 1] = a_ptr[(rown * wg1::TW + coln) * 64];
+                const float *bn = b_ptr + (2 * rown) * RSTR + coln;
 #pragma unroll
-            for (int tb = 0; tb < 5; ++tb) b_nxt[tb] = bn[toff[tb]];
+                for (int tb = 0; tb < 5; ++tb) b_op[(t + 1) & 1][tb] = bn[toff[tb]];
+            }
 #pragma unroll
-            for (int tb = 0; tb < 5; ++tb) acc[tb] = mfma32(a_cur, b_cur[tb], acc[tb]);
-            a_cur = a_nxt;
-#pragma unroll
-            for (int tb = 0; tb < 5; ++tb) b_cur[tb] = b_nxt[tb];
+            for (int tb = 0; tb < 5; ++tb) acc[tb] = mfma32(a_op[t & 1], b_op[t & 1][tb], acc[tb]);
         }
         __syncthreads();
         if (has_next) write_lds();
@@ -1460,6 +1457,7 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
                                       int B, int H, int W, void *stream)
 {
     COVA_REQUIRE(img && y1 && dp && idx && abc && dw && ws && B > 0 && H > 0 && W > 0);
+    COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));            // 32-bit in-image offsets in the kernel
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
@@ -1479,6 +1477,7 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
                               int W, void *stream)
 {
     COVA_REQUIRE(img && dy && dw && ws && B > 0 && H > 0 && W > 0);
+    COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));            // 32-bit in-image offsets in the kernel
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);

@@ -1271,6 +1271,8 @@ int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many t
 
 // shared with conv_wino.hip (same shared object; hidden visibility)
 int cova_internal_persistent_grid(int ntiles) { return persistent_grid(ntiles); }
+int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu) { return persistent_grid(ntiles, blocks_per_cu); }
+extern "C" int cova_internal_set_wino_geometry(int v);
 int cova_internal_ablate() { return g_ablate; }
 
 // ====================================================================================
@@ -1284,6 +1286,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 3) { g_wgrad3_variant = value; return COVA_OK; }
     if (key == 4) { g_conv1_variant = value; return COVA_OK; }
     if (key == 5) { g_ablate = value; return COVA_OK; }
+    if (key == 6) return cova_internal_set_wino_geometry(value);
     return COVA_ERR_BAD_ARG;
 }
 

@@ -41,21 +41,61 @@ struct ProIn {
     int relu;
 };
 
-namespace wn {
-constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
-constexpr int NPIX = PH * PW;                 // 340
-constexpr int PIXS = 341;                     // odd channel-plane stride
-constexpr int IN_FLOATS = 64 * PIXS;          // 21,824 floats = 87.3 KB
-constexpr int UROW = 20;                      // one (ci, co) row = 16 positions + 4 pad floats
-constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
-constexpr int UCH_G = 16 * 4 * 64;            // 4,096 floats per chunk in global memory
-constexpr int THREADS = 512;
-// L2 prefetch of the epilogue operands during the chunk loop: measured 4% slower (the extra
-// in-order loads delay the weight-chunk waits), kept for experiments only
-constexpr bool PREFETCH_EPI = false;
-constexpr int RED_FLOATS = 8 * 64;
-constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.3 KB
-}  // namespace wn
+// Two geometries of the forward / data-gradient kernel:
+//  GeoA: 8x32-pixel tiles, 512 threads, one block per CU.  Wave w = (tile row w&3, co half w>>2);
+//        weights in LDS as [ci 4][co 64] rows of 16 positions padded to 20 floats.
+//  GeoB: 8x16-pixel tiles, 256 threads, TWO blocks per CU (each wave alone on its SIMD within its
+//        block, paired with a wave of the other block that is in a different phase: barrier waits,
+//        LDS latencies and the epilogue's memory round trips of one block hide under the MFMAs of
+//        the other).  Wave w = (tile-row pair w&1, co half w>>1); weight rows unpadded (the two
+//        blocks must fit 2 x 80 KB) with the four 16-byte slots of a row XOR-swizzled by
+//        (row >> 2) & 3, which makes the b128 operand reads of 16 consecutive rows conflict free.
+struct GeoA {
+    static constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
+    static constexpr int NPIX = PH * PW;                 // 340
+    static constexpr int PIXS = 341;                     // odd channel-plane stride
+    static constexpr int IN_FLOATS = 64 * PIXS;          // 21,824 floats = 87.3 KB
+    static constexpr int UROW = 20;                      // one (ci, co) row = 16 positions + 4 pad floats
+    static constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
+    static constexpr int THREADS = 512, NWAVES = 8, BLOCKS_PER_CU = 1;
+    static constexpr int NUL = 2;                        // float4 of a weight chunk per thread
+    static constexpr int RED_FLOATS = NWAVES * 64;
+    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.3 KB
+    __device__ static int cbp(int wave) { return wave >> 2; }
+    __device__ static int trow(int wave, int ti) { return wave & 3; }     // Winograd tile row / column of lane ti
+    __device__ static int tcol(int ti) { return ti; }
+    __device__ static constexpr int nrowgroups() { return 4; }             // waves sharing a co half
+    __device__ static int wave_of(int half, int g) { return half * 4 + g; }
+    // float4 index f (global chunk layout [k 4][co 64][pos 16]) -> LDS float offset inside a chunk
+    __device__ static int u_lds_off(int f) { return ((f * 4) >> 4) * UROW + ((f * 4) & 15); }
+    // LDS float offset of the operands of position group p4 in row `row`
+    __device__ static int u_op_off(int row, int p4) { return row * UROW + p4 * 4; }
+};
+struct GeoB {
+    static constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;
+    static constexpr int NPIX = PH * PW;                 // 180
+    static constexpr int PIXS = 181;
+    static constexpr int IN_FLOATS = 64 * PIXS;          // 11,584 floats = 46.3 KB
+    static constexpr int UROW = 16;
+    static constexpr int UCH = 4 * 64 * UROW;            // 4,096 floats = 16 KB per chunk
+    static constexpr int THREADS = 256, NWAVES = 4, BLOCKS_PER_CU = 2;
+    static constexpr int NUL = 4;
+    static constexpr int RED_FLOATS = NWAVES * 64;
+    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 79.4 KB
+    __device__ static int cbp(int wave) { return wave >> 1; }
+    __device__ static int trow(int wave, int ti) { return 2 * (wave & 1) + (ti >> 3); }
+    __device__ static int tcol(int ti) { return ti & 7; }
+    __device__ static constexpr int nrowgroups() { return 2; }
+    __device__ static int wave_of(int half, int g) { return half * 2 + g; }
+    __device__ static int u_lds_off(int f)
+    {
+        const int row = f >> 2, p4 = f & 3;
+        return row * UROW + ((p4 ^ ((row >> 2) & 3)) << 2);
+    }
+    __device__ static int u_op_off(int row, int p4) { return row * UROW + ((p4 ^ ((row >> 2) & 3)) << 2); }
+};
+constexpr int UCH_G = 16 * 4 * 64;             // 4,096 floats per weight chunk in global memory
+// L2 prefetch of the epilogue operands during the chunk loop was measured 4% slower and removed.
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
 {
@@ -65,9 +105,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
 }
 
 // Input transform of one 4x4 patch: V = B^T d B (32 adds), d read from LDS with immediate offsets.
+template <int PW>
 __device__ __forceinline__ void wino_input_transform(const float *__restrict__ a, float (&V)[16])
 {
-    using namespace wn;
     float d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -92,8 +132,8 @@ __device__ __forceinline__ void wino_input_transform(const float *__restrict__ a
 
 // BN: 0 = plain epilogue, 1 = ReLU mask from z (fma(msc, z, msh) > 0) + BatchNorm-backward sums,
 //     2 = ReLU mask from the materialised activation + BatchNorm-backward sums
-template <bool STATS, bool PRO, bool ADD, int BN>
-__global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
+template <class G, bool STATS, bool PRO, bool ADD, int BN>
+__global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino_kernel(
     const float *__restrict__ in, const float *__restrict__ ug, const float *__restrict__ addend,
     float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y,
     int ntiles, const BnBwdEpiW bn, const ProIn pro, int abl_arg)
@@ -103,15 +143,18 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     // 4 no refill loads, 8 no weight restaging, 16 no per-chunk barrier, 32 no input transform,
     // 64 no statistics reduction, 128 no epilogue operand loads, 256 no output stores,
     // 512 no L2 prefetch of the epilogue operands, 1024 no MFMA/VALU/LDS interleave hints
-    using namespace wn;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 192];
+    constexpr int TH = G::TH, TW = G::TW, PW = G::PW, NPIX = G::NPIX, PIXS = G::PIXS;
+    constexpr int IN_FLOATS = G::IN_FLOATS, UROW = G::UROW, UCH = G::UCH, THREADS = G::THREADS;
+    constexpr int LDS_FLOATS = G::LDS_FLOATS, NUL = G::NUL;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + (PRO ? 192 : 0)];
     float *s_in = lds;
     float *s_u = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + 2 * UCH;
     float *s_pro = lds + LDS_FLOATS;               // A | B | C per channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tb = wave & 3, cbp = wave >> 2;
+    const int cbp = G::cbp(wave);
     const int ti = lane & 15, kq = lane >> 4;
+    const int trow = G::trow(wave, ti), tcol = G::tcol(ti);      // this lane's Winograd tile in the block tile
     const bool pro2 = PRO && pro.in2 != nullptr;
     if (PRO) {
         if (tid < 192) s_pro[tid] = pro.abc[tid];
@@ -137,12 +180,10 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
     if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
 
-    // transformed-weight chunk s: 1024 float4 in global memory, 2 per thread
-    auto u_lds_off = [&](int f) {            // float4 index -> LDS float offset inside a chunk
-        const int flat = f * 4;                 // global chunk layout [k 4][co 64][pos 16]
-        return (flat >> 4) * UROW + (flat & 15);
-    };
-    const int uo0 = u_lds_off(tid), uo1 = u_lds_off(tid + THREADS);
+    // transformed-weight chunk s: 1024 float4 in global memory, NUL per thread
+    // (named scalars, not arrays: LLVM otherwise promotes the small arrays to LDS / scratch)
+    const int uo0 = G::u_lds_off(tid), uo1 = G::u_lds_off(tid + THREADS);
+    const int uo2 = NUL > 2 ? G::u_lds_off(tid + 2 * THREADS) : 0, uo3 = NUL > 2 ? G::u_lds_off(tid + 3 * THREADS) : 0;
 
     // ---- first tile: whole halo'd input tile, channel-major in LDS
     {
@@ -167,10 +208,13 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             s_in[(c + 2) * PIXS + px] = v.z;
             s_in[(c + 3) * PIXS + px] = v.w;
         }
-        const float4 u0 = reinterpret_cast<const float4 *>(ug)[tid];
-        const float4 u1 = reinterpret_cast<const float4 *>(ug)[tid + THREADS];
-        *reinterpret_cast<float4 *>(s_u + uo0) = u0;
-        *reinterpret_cast<float4 *>(s_u + uo1) = u1;
+        const float4 *ug4 = reinterpret_cast<const float4 *>(ug);
+        *reinterpret_cast<float4 *>(s_u + uo0) = ug4[tid];
+        *reinterpret_cast<float4 *>(s_u + uo1) = ug4[tid + THREADS];
+        if (NUL > 2) {
+            *reinterpret_cast<float4 *>(s_u + uo2) = ug4[tid + 2 * THREADS];
+            *reinterpret_cast<float4 *>(s_u + uo3) = ug4[tid + 3 * THREADS];
+        }
     }
     __syncthreads();
 
@@ -186,18 +230,20 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
         float4 v, w;        // planes 4s..4s+3 of the next tile's pixel (w: second input of PRO)
         int plane;          // first plane, or -1: nothing to write
         bool in;            // pixel lies inside the image
-        float pf;           // landing register of the epilogue-operand prefetch (value unused)
     };
     const int rpx = tid < NPIX ? tid : 0;
     const int rrow = rpx / PW, rcol = rpx - rrow * PW;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    Ring ringA{zero4, zero4, -1, false, 0.f}, ringB{zero4, zero4, -1, false, 0.f};
+    Ring ringA{zero4, zero4, -1, false}, ringB{zero4, zero4, -1, false};
 
-    int ubuf = 0;
-    const float *a_lane = s_in + kq * PIXS + (2 * tb) * PW + 2 * ti;      // this lane's patch origin
-    const float *b_lane = s_u + (kq * 64 + cbp * 32 + ti) * UROW;   // row (ci kq, co cbp*32 + ti)
+    const float *a_lane = s_in + kq * PIXS + (2 * trow) * PW + 2 * tcol;  // this lane's patch origin
+    // weight operands: rows (ci kq, co cbp*32 + ti) and +16; one LDS offset per position group
+    // (the +16 rows of the second co block only add the immediate 16 * UROW: (row >> 2) & 3 is unchanged)
+    const int urow = kq * 64 + cbp * 32 + ti;
+    const int uq0 = G::u_op_off(urow, 0), uq1 = G::u_op_off(urow, 1), uq2 = G::u_op_off(urow, 2),
+              uq3 = G::u_op_off(urow, 3);
     float V[16], V1[16];            // transformed input of the even / odd chunk (double buffer)
-    wino_input_transform(a_lane, V);                                       // chunk 0 of the first tile
+    wino_input_transform<PW>(a_lane, V);                                   // chunk 0 of the first tile
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x;
         const int ty = (tile / tiles_x) % tiles_y;
@@ -213,21 +259,6 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
         const float *nsrc = in + noff;
         const float *nsrc2 = pro2 ? pro.in2 + noff : in + noff;
         const size_t img = (size_t)b * H * W * 64;
-
-        // Epilogue operands (addend / z / activation): every chunk each wave touches one dword in
-        // 4 of the 64 128-byte lines of its output region (2 rows x 32 pixels x 32 channels) per
-        // tensor, so that the epilogue finds them in L2 instead of waiting for HBM.
-        constexpr int NPF = PREFETCH_EPI ? (ADD ? 1 : 0) + (BN != 0 ? 1 : 0) + (BN == 2 ? 1 : 0) : 0;
-        const float *pf_base = in;
-        if (NPF > 0) {
-            const float *t0 = ADD ? addend : bn.z;
-            const float *t1 = ADD ? (BN != 0 ? bn.z : addend) : (BN == 2 ? bn.act : bn.z);
-            const float *t2 = BN == 2 ? bn.act : t0;
-            const int g = lane >> 2;
-            pf_base = (g == 1 && NPF > 1) ? t1 : ((g == 2 && NPF > 2) ? t2 : t0);
-            pf_base += img + cbp * 32;
-        }
-        const int pf_li = (lane < 4 * NPF) ? (lane & 3) : 0;
 
         f32x4 acc[2][16];
 #pragma unroll
@@ -250,10 +281,15 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             //     vmcnt retires in order, so the wait for these (end of this chunk) must not have
             //     the long-latency HBM loads below in front of it.
             const int ns = (s + 1) & 15;
-            float4 un0 = zero4, un1 = zero4;
+            float4 un0 = zero4, un1 = zero4, un2 = zero4, un3 = zero4;
             if (!(abl & 8)) {
-                un0 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid];
-                un1 = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G)[tid + THREADS];
+                const float4 *ugn = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G);
+                un0 = ugn[tid];
+                un1 = ugn[tid + THREADS];
+                if (NUL > 2) {
+                    un2 = ugn[tid + 2 * THREADS];
+                    un3 = ugn[tid + 3 * THREADS];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) fetch this chunk's planes for the next tile; consumed two chunks from now
@@ -263,21 +299,16 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             }
             ring.plane = has_next ? 4 * s : -1;
             ring.in = nload;
-            if (NPF > 0 && !(abl & 512)) {
-                const int line = s * 4 + pf_li;
-                const int prow = min(y0 + 2 * tb + (line >> 5), H - 1), pcol = min(x0 + (line & 31), W - 1);
-                asm volatile("" ::"v"(ring.pf));          // the load of two chunks ago has long landed
-                ring.pf = pf_base[(size_t)(unsigned)((prow * W + pcol) * 64)];
-            }
             __builtin_amdgcn_sched_barrier(0);
 
             // (4) 32 MFMAs of this chunk
             // the 16 positions of a (ci, co) pair are contiguous: 4 ds_read_b128 per channel block
-            const float *bp = b_lane + ubuf * UCH;
+            const float *bp = s_u + (s & 1) * UCH;            // chunk s sits in ring slot s & 1
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) {
-                const float4 u0 = *reinterpret_cast<const float4 *>(bp + p4 * 4);
-                const float4 u1 = *reinterpret_cast<const float4 *>(bp + 16 * UROW + p4 * 4);
+                const int uq = p4 == 0 ? uq0 : p4 == 1 ? uq1 : p4 == 2 ? uq2 : uq3;
+                const float4 u0 = *reinterpret_cast<const float4 *>(bp + uq);
+                const float4 u1 = *reinterpret_cast<const float4 *>(bp + uq + 16 * UROW);
                 // D[co][tile] += U[co][ci] * V[ci][tile]
                 acc[0][p4 * 4 + 0] = mfma16(u0.x, V[p4 * 4 + 0], acc[0][p4 * 4 + 0]);
                 acc[1][p4 * 4 + 0] = mfma16(u1.x, V[p4 * 4 + 0], acc[1][p4 * 4 + 0]);
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             //     its first use, where both waves of a SIMD run it with the matrix pipe idle) and the
             //     group barriers weave its 8 LDS reads and 32 adds between the MFMAs.
             if (!(abl & 32)) {
-                wino_input_transform(a_lane + (4 * ns) * PIXS, Vn);
+                wino_input_transform<PW>(a_lane + (4 * ns) * PIXS, Vn);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(Vn[k]));
             }
@@ -309,10 +340,13 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             }
             // (6) publish the next weight chunk
             if (!(abl & 8)) {
-                float *ud = s_u + (ubuf ^ 1) * UCH;
+                float *ud = s_u + ((s & 1) ^ 1) * UCH;
                 *reinterpret_cast<float4 *>(ud + uo0) = un0;
                 *reinterpret_cast<float4 *>(ud + uo1) = un1;
-                ubuf ^= 1;
+                if (NUL > 2) {
+                    *reinterpret_cast<float4 *>(ud + uo2) = un2;
+                    *reinterpret_cast<float4 *>(ud + uo3) = un3;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // nothing of this chunk sinks below its barrier
             if (!(abl & 16)) __syncthreads();
@@ -325,7 +359,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.
         // D layout (rows = co, cols = tiles): this lane holds, for c2 = 0..1 and q = 0..3, channel
-        // cbp*32 + c2*16 + kq*4 + q of Winograd tile (tb, ti) -- four consecutive channels per
+        // cbp*32 + c2*16 + kq*4 + q of Winograd tile (trow, tcol) -- four consecutive channels per
         // pixel, so every epilogue access is a float4.
         float ssum[2][4], ssq[2][4];
         if (abl & 16) __syncthreads();
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
             unsigned off[4], offc[4];
 #pragma unroll
             for (int pq = 0; pq < 4; ++pq) {
-                const int oy = y0 + 2 * tb + (pq >> 1), ox = x0 + 2 * ti + (pq & 1);
+                const int oy = y0 + 2 * trow + (pq >> 1), ox = x0 + 2 * tcol + (pq & 1);
                 ok[pq] = oy < H && ox < W;
                 off[pq] = (unsigned)((oy * W + ox) * 64 + co0);
                 offc[pq] = (unsigned)((min(oy, H - 1) * W + min(ox, W - 1)) * 64 + co0);
@@ -485,7 +519,8 @@ __global__ __launch_bounds__(wn::THREADS) void conv3x3_c64_wino_kernel(
                 const int half = ch >> 5, idx = ch & 31;
                 float tsum = 0.f;
 #pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) tsum += s_red[(half * 4 + w4) * 64 + which * 32 + idx];
+                for (int g = 0; g < G::nrowgroups(); ++g)
+                    tsum += s_red[G::wave_of(half, g) * 64 + which * 32 + idx];
                 stat_part[(size_t)tile * 128 + tid] = tsum;
             }
         }
@@ -520,6 +555,7 @@ __global__ void prep_wino_kernel(const float *__restrict__ w, float *__restrict_
 }  // namespace
 
 extern int cova_internal_persistent_grid(int ntiles);
+extern int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 extern int cova_internal_ablate();
 
 // u_fwd / u_dgrad: [16 chunks][4 ci][64 co][16 positions] floats each (65,536)
@@ -547,45 +583,72 @@ struct WinoArgs {
     hipStream_t st;
 };
 
-template <bool STATS, bool PRO, bool ADD, int BN>
+template <class G, bool STATS, bool PRO, bool ADD, int BN>
 static void launch_wino_variant(const WinoArgs &a)
 {
-    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<STATS, PRO, ADD, BN>), a.grid, dim3(wn::THREADS), 0, a.st,
+    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<G, STATS, PRO, ADD, BN>), a.grid, dim3(G::THREADS), 0, a.st,
                        a.in, a.u, a.addend, a.out, a.stat_part, a.H, a.W, a.tiles_x, a.tiles_y, a.ntiles,
                        a.bn, a.pro, a.abl);
 }
 
-template <bool STATS, int BN>
+template <class G, bool STATS, int BN>
 static void launch_wino_epi(const WinoArgs &a)
 {
     const bool p = a.pro.abc != nullptr, ad = a.addend != nullptr;
-    if (p && ad) launch_wino_variant<STATS, true, true, BN>(a);
-    else if (p) launch_wino_variant<STATS, true, false, BN>(a);
-    else if (ad) launch_wino_variant<STATS, false, true, BN>(a);
-    else launch_wino_variant<STATS, false, false, BN>(a);
+    if (p && ad) launch_wino_variant<G, STATS, true, true, BN>(a);
+    else if (p) launch_wino_variant<G, STATS, true, false, BN>(a);
+    else if (ad) launch_wino_variant<G, STATS, false, true, BN>(a);
+    else launch_wino_variant<G, STATS, false, false, BN>(a);
+}
+
+// cova_set_option(6, 1 | 2): GeoA (8x32, 1 block/CU; default) | GeoB (8x16, 2 blocks/CU).  Measured:
+// B is 3-6 % faster on the epilogue-heavy variants and equal on the plain ones -- the kernel is bound
+// by instruction issue (MFMA + VALU + LDS share the SIMD's issue slots), not by latencies a second
+// block could hide -- and 0.5-1 % slower over the whole step (twice the statistics partials, more halo).
+static int g_wino_geometry = 1;
+extern "C" int cova_internal_set_wino_geometry(int v)
+{
+    if (v != 1 && v != 2) return COVA_ERR_BAD_ARG;
+    g_wino_geometry = v;
+    return COVA_OK;
+}
+
+template <class G>
+static int launch_wino_geo(const float *in, const float *u, const float *addend, const BnBwdEpiW bn,
+                           const ProIn pro, float *out, float *stat_part, int B, int H, int W, void *stream)
+{
+    WinoArgs a;
+    a.in = in; a.u = u; a.addend = addend; a.out = out; a.stat_part = stat_part;
+    a.H = H; a.W = W;
+    a.tiles_x = cdiv(W, G::TW); a.tiles_y = cdiv(H, G::TH);
+    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.bn = bn; a.pro = pro;
+    a.abl = cova_internal_ablate();
+    a.grid = dim3(cova_internal_persistent_grid2(a.ntiles, G::BLOCKS_PER_CU));
+    a.st = (hipStream_t)stream;
+    const int mode = bn.z == nullptr ? 0 : (bn.act == nullptr ? 1 : 2);    // BN epilogues need stat_part
+    if (mode == 1) launch_wino_epi<G, true, 1>(a);
+    else if (mode == 2) launch_wino_epi<G, true, 2>(a);
+    else if (stat_part) launch_wino_epi<G, true, 0>(a);
+    else launch_wino_epi<G, false, 0>(a);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }
 
 static int launch_wino(const float *in, const float *u, const float *addend, const BnBwdEpiW bn,
                        const ProIn pro, float *out, float *stat_part, int B, int H, int W, void *stream)
 {
-    WinoArgs a;
-    a.in = in; a.u = u; a.addend = addend; a.out = out; a.stat_part = stat_part;
-    a.H = H; a.W = W;
-    a.tiles_x = cdiv(W, wn::TW); a.tiles_y = cdiv(H, wn::TH);
-    a.ntiles = B * a.tiles_x * a.tiles_y;
-    a.bn = bn; a.pro = pro;
-    a.abl = cova_internal_ablate();
-    a.grid = dim3(cova_internal_persistent_grid(a.ntiles));
-    a.st = (hipStream_t)stream;
     // 32-bit in-image offsets in the epilogue
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));
-    const int mode = bn.z == nullptr ? 0 : (bn.act == nullptr ? 1 : 2);    // BN epilogues need stat_part
-    if (mode == 1) launch_wino_epi<true, 1>(a);
-    else if (mode == 2) launch_wino_epi<true, 2>(a);
-    else if (stat_part) launch_wino_epi<true, 0>(a);
-    else launch_wino_epi<false, 0>(a);
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    if (g_wino_geometry == 1) return launch_wino_geo<GeoA>(in, u, addend, bn, pro, out, stat_part, B, H, W, stream);
+    return launch_wino_geo<GeoB>(in, u, addend, bn, pro, out, stat_part, B, H, W, stream);
+}
+
+// rows of the statistics partials written by cova_conv3x3_wino(_pro): one per tile of the active geometry
+COVA_API int cova_conv3x3_wino_num_tiles(int B, int H, int W)
+{
+    if (g_wino_geometry == 1) return B * cdiv(W, GeoA::TW) * cdiv(H, GeoA::TH);
+    return B * cdiv(W, GeoB::TW) * cdiv(H, GeoB::TH);
 }
 
 // Same contract as cova_conv3x3_fwd / cova_conv3x3_dgrad_bnbwd (stat_part is indexed by the

@@ -114,6 +114,15 @@ USE_WINOGRAD = True
 FUSE_AFFINE = os.environ.get("COVA_FUSE_AFFINE", "1") != "0"
 
 
+if os.environ.get("COVA_WINO_GEO"):         # A/B switch: 1 (default) = 8x32 tiles, one block per CU; 2 = 8x16, two per CU
+    query("cova_set_option", 6, int(os.environ["COVA_WINO_GEO"]))
+
+
+def conv3_num_tiles(B, H, W):
+    """rows of the statistics partials of the active 3x3 conv kernels"""
+    return query("cova_conv3x3_wino_num_tiles" if USE_WINOGRAD else "cova_conv3x3_num_tiles", B, H, W)
+
+
 def conv3x3(x, wts, addend, out, part, B, H, W, bn=None):
     """wts = (direct layout, winograd layout) of either the forward or the dgrad weights.
     bn = (act, z, mean, invstd): fused ReLU mask + BatchNorm-backward sums in the epilogue."""
@@ -166,7 +175,7 @@ def convstack_fwd(images, params, buffers, training, save=True):
     sv.update(y1=y1, bn1=bn1, idx=idx, ymax=ymax)
     # layer1: two BasicBlocks
     R = B * H2 * W2
-    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    nt = conv3_num_tiles(B, H2, W2)
     x = p1
     blocks = []
     for blk in (0, 1):
@@ -236,7 +245,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
-    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    nt = conv3_num_tiles(B, H2, W2)
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
     # the last bn2 were taken by cova_roipool_bwd_bn
     dA, pend, npend = dfeat, None, nt
@@ -297,7 +306,7 @@ def _layer1_bwd_unfused(sv, dfeat, gout, grads):
     R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
     WGRAD3 = "cova_conv3x3_wgrad_wino" if USE_WINOGRAD else "cova_conv3x3_wgrad"
-    nt = query("cova_conv3x3_num_tiles", B, H2, W2)
+    nt = conv3_num_tiles(B, H2, W2)
     dA, pend = dfeat, None          # pend: partials of the fused reduction for dA (already masked)
     for blk in (1, 0):
         s = sv["blocks"][blk]
@@ -358,7 +367,7 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None):
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
     if fused and sv.get("pool_part") is not None:
-        part, npart = sv["pool_part"], query("cova_conv3x3_num_tiles", B, H2, W2)
+        part, npart = sv["pool_part"], conv3_num_tiles(B, H2, W2)
     else:
         npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
         part = _empty((npart, 2, C64), dfeat)

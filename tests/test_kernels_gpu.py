@@ -402,8 +402,9 @@ def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     close(part.sum(0), part_ref.sum(0), 1e-5, "fused bn-bwd sums")
 
 
+@pytest.mark.parametrize("geo", [1, 2])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
-def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap):
+def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap, geo):
     """Winograd F(2x2,3x3) kernel: forward (+statistics), data gradient (+addend) and the fused
     ReLU-mask / BN-backward epilogue against torch-CPU and the direct kernel."""
     g = torch.Generator().manual_seed(H * W + B)
@@ -414,9 +415,11 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap):
     uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
     query("cova_set_option", 2, cap)
+    query("cova_set_option", 6, geo)          # 8x32 tiles / 1 block per CU | 8x16 tiles / 2 blocks per CU
     try:
         nt = query("cova_conv3x3_num_tiles", B, H, W)
-        out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+        ntw = query("cova_conv3x3_wino_num_tiles", B, H, W)
+        out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(ntw, 2, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(x), uf, None, None, None, None, None, out, part, B, H, W)
         ref = F.conv2d(x, w, padding=1)
         close(nchw(out), ref, 1e-4, "winograd fwd")
@@ -435,12 +438,13 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap):
         call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
         dy_d, part_d = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
         call("cova_conv3x3_dgrad_bnbwd", nhwc(dz), wd, nhwc(add), act, z, mean, invstd, dy_d, part_d, B, H, W)
-        dy_w, part_w = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
+        dy_w, part_w = torch.empty(B, H, W, 64, device=DEV), torch.empty(ntw, 2, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(dz), ud, nhwc(add), act, z, mean, invstd, dy_w, part_w, B, H, W)
         close(dy_w, dy_d, 1e-5, "winograd fused dy")
         close(part_w.sum(0), part_d.sum(0), 1e-4, "winograd fused sums")
     finally:
         query("cova_set_option", 2, 0)
+        query("cova_set_option", 6, 1)
 
 
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
@@ -460,8 +464,9 @@ def test_conv3x3_winograd_wgrad(B, H, W, cap):
         query("cova_set_option", 2, 0)
 
 
+@pytest.mark.parametrize("geo", [1, 2])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
-def test_conv3x3_winograd_affine_on_load(B, H, W, cap):
+def test_conv3x3_winograd_affine_on_load(B, H, W, cap, geo):
     """cova_conv3x3_wino_pro == cova_conv3x3_wino on a pre-transformed input (bit-exact: the
     prologue evaluates the same fma as cova_bn_act_fwd), for BatchNorm+ReLU on load, the
     BatchNorm-backward apply on load, and the z-derived ReLU mask in the epilogue."""
@@ -473,7 +478,8 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap):
     abc = rnd(3, 64).to(DEV)
     uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
-    nt = query("cova_conv3x3_num_tiles", B, H, W)
+    query("cova_set_option", 6, geo)
+    nt = query("cova_conv3x3_wino_num_tiles", B, H, W)
     R = B * H * W
     query("cova_set_option", 2, cap)
     try:
@@ -506,6 +512,7 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap):
         assert torch.equal(out, ref)
     finally:
         query("cova_set_option", 2, 0)
+        query("cova_set_option", 6, 1)
 
 
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])

@@ -34,7 +34,7 @@ w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 wf, wd = torch.empty(9, 64, 64, device=dev), torch.empty(9, 64, 64, device=dev)
 call("cova_conv3x3_prep_weights", w, wf, wd)
 out = torch.empty_like(x)
-part = torch.empty(query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)
+part = torch.empty(2 * query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)   # enough for both Winograd geometries
 flop3 = 2 * 64 * 64 * 9 * B * H * W
 for variant in (1, 2):
     query("cova_set_option", 1, variant)

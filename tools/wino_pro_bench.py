@@ -28,7 +28,7 @@ w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 uf, ud = torch.empty(16, 16, 4, 64, device=dev), torch.empty(16, 16, 4, 64, device=dev)
 call("cova_conv3x3_prep_weights_wino", w, uf, ud)
 out = torch.empty_like(x)
-part = torch.empty(query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)
+part = torch.empty(2 * query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)   # enough for both Winograd geometries
 abc = torch.randn(3, 64, device=dev)
 mean, invstd = torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5
 N = None
@@ -68,3 +68,17 @@ if os.environ.get("COVA_ABLATE"):
             query("cova_set_option", 5, abl)
             print("%-20s abl %3d %-22s %.3f ms" % (nm, abl, what, timeit(fn)))
     query("cova_set_option", 5, 0)
+print("--- geometry A (8x32 tiles, 1 block/CU) vs B (8x16 tiles, 2 blocks/CU)")
+for geo in (1, 2):
+    query("cova_set_option", 6, geo)
+    cases = [
+        ("fwd plain", lambda: call("cova_conv3x3_wino", x, uf, N, N, N, N, N, out, N, B, H, W)),
+        ("fwd plain +stats", lambda: call("cova_conv3x3_wino", x, uf, N, N, N, N, N, out, part, B, H, W)),
+        ("fwd relu(A x + C) on load +stats", lambda: call("cova_conv3x3_wino_pro", x, N, abc, 1, uf, N, N, N, N, N, N, N, out, part, B, H, W)),
+        ("dgrad plain +addend +act mask", lambda: call("cova_conv3x3_wino", x, ud, add, x2, z, mean, invstd, out, part, B, H, W)),
+        ("dgrad pro +addend +act mask", lambda: call("cova_conv3x3_wino_pro", x, x2, abc, 0, ud, add, x2, N, N, z, mean, invstd, out, part, B, H, W)),
+        ("dgrad pro, z mask", lambda: call("cova_conv3x3_wino_pro", x, x2, abc, 0, ud, N, N, abc[0], abc[2], z, mean, invstd, out, part, B, H, W)),
+    ]
+    for name, fn in cases:
+        print("geo %d  %-36s %.3f ms" % (geo, name, timeit(fn)))
+query("cova_set_option", 6, 1)

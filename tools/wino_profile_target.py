@@ -13,7 +13,7 @@ w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 uf, ud = torch.empty(16, 16, 4, 64, device=dev), torch.empty(16, 16, 4, 64, device=dev)
 call("cova_conv3x3_prep_weights_wino", w, uf, ud)
 out = torch.empty_like(x)
-part = torch.empty(query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)
+part = torch.empty(2 * query("cova_conv3x3_num_tiles", B, H, W), 2, 64, device=dev)   # enough for both Winograd geometries
 abc = torch.randn(3, 64, device=dev)
 mean, invstd = torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5
 N = None

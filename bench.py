@@ -83,8 +83,8 @@ def cpu_baseline(steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

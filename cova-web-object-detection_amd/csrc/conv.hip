@@ -488,19 +488,28 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     float *s_w = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + W_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // wave-uniform copy: scalar index math
     const int li = lane & 31, kh2 = lane >> 5;
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
 
     float pre[NPRE];
     auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
-        const int idx = tid + it * THREADS;
-        const int c = idx / (PR * 69);
-        const int rem = idx - c * (PR * 69);
-        const int r = rem / 69, j = rem - r * 69;
+        // slots 0..7 take columns 0..63 (= lane) of row segment wave + 8*it (63 segments = 3 channels x
+        // 21 rows: channel, row and the image row address are wave-uniform, i.e. scalar work);
+        // slot 8 takes the remaining columns 64..68 (threads 0..314)
+        int seg, j;
+        if (it < 8) {
+            seg = wave_u + 8 * it;
+            j = lane;
+        } else {
+            seg = tid / 5;
+            j = 64 + tid - 5 * seg;
+        }
+        const int c = seg / PR, r = seg - c * PR;
         const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + j;
         float v = 0.f;
-        if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        if (seg < 3 * PR && gy >= 0 && gy < H && gx >= 0 && gx < W)
             v = img_b[(unsigned)((c * H + gy) * W + gx)];          // 32-bit in-image offset (checked at launch)
         pre[it] = v;
     };
@@ -514,11 +523,16 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     auto write_lds = [&]() {
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) {
-            const int idx = tid + it * THREADS;
-            if (idx < PATCH) {
-                const int c = idx / (PR * 69);
-                const int rem = idx - c * (PR * 69);
-                const int r = rem / 69, j = rem - r * 69;
+            int seg, j;
+            if (it < 8) {
+                seg = wave_u + 8 * it;
+                j = lane;
+            } else {
+                seg = tid / 5;
+                j = 64 + tid - 5 * seg;
+            }
+            if (seg < 3 * PR) {
+                const int c = seg / PR, r = seg - c * PR;
                 s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
             }
         }
@@ -979,6 +993,7 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
     float *s_dpw = lds + IN_FLOATS + wg1::DY_FLOATS;                 // POOL: [window][64] pooled gradient
     uint32_t *s_ixw = reinterpret_cast<uint32_t *>(s_dpw + NWIN * 64);   // POOL: [window][16] arg-max codes x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // wave-uniform copy: scalar index math
     const int li = lane & 31, kh2 = lane >> 5;
     const int cob = wave & 1, q = wave >> 1;
 
@@ -1033,13 +1048,18 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
                 pix[k] = code;
             }
         } else if (s < NPRE) {
-            const int idx = tid + s * THREADS;
-            const int c = idx / (PR * 69);
-            const int rem = idx - c * (PR * 69);
-            const int r = rem / 69, j = rem - r * 69;
+            int seg, j;                           // same slot -> patch element mapping as conv1_7x7_v2_kernel
+            if (s < 8) {
+                seg = wave_u + 8 * s;
+                j = lane;
+            } else {
+                seg = tid / 5;
+                j = 64 + tid - 5 * seg;
+            }
+            const int c = seg / PR, r = seg - c * PR;
             const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
             float v = 0.f;
-            if (idx < PATCH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            if (seg < 3 * PR && gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = img_b[(unsigned)((c * H + gy) * W + gx)];          // 32-bit in-image offset (checked at launch)
             pre[s] = v;
         } else {
@@ -1067,11 +1087,16 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
     auto write_lds = [&]() {
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) {
-            const int idx = tid + it * THREADS;
-            if (idx < PATCH) {
-                const int c = idx / (PR * 69);
-                const int rem = idx - c * (PR * 69);
-                const int r = rem / 69, j = rem - r * 69;
+            int seg, j;
+            if (it < 8) {
+                seg = wave_u + 8 * it;
+                j = lane;
+            } else {
+                seg = tid / 5;
+                j = 64 + tid - 5 * seg;
+            }
+            if (seg < 3 * PR) {
+                const int c = seg / PR, r = seg - c * PR;
                 s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
             }
         }

@@ -59,8 +59,8 @@ struct GeoA {
     static constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
     static constexpr int THREADS = 512, NWAVES = 8, BLOCKS_PER_CU = 1;
     static constexpr int NUL = 2;                        // float4 of a weight chunk per thread
-    static constexpr int RED_FLOATS = NWAVES * 64;
-    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.3 KB
+    static constexpr int RED_FLOATS = NWAVES * 64 + 128;  // per-wave partial sums + the block's running totals
+    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.8 KB
     __device__ static int cbp(int wave) { return wave >> 2; }
     __device__ static int trow(int wave, int ti) { return wave & 3; }     // Winograd tile row / column of lane ti
     __device__ static int tcol(int ti) { return ti; }
@@ -80,8 +80,8 @@ struct GeoB {
     static constexpr int UCH = 4 * 64 * UROW;            // 4,096 floats = 16 KB per chunk
     static constexpr int THREADS = 256, NWAVES = 4, BLOCKS_PER_CU = 2;
     static constexpr int NUL = 4;
-    static constexpr int RED_FLOATS = NWAVES * 64;
-    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 79.4 KB
+    static constexpr int RED_FLOATS = NWAVES * 64 + 128;
+    static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 79.9 KB
     __device__ static int cbp(int wave) { return wave >> 1; }
     __device__ static int trow(int wave, int ti) { return 2 * (wave & 1) + (ti >> 3); }
     __device__ static int tcol(int ti) { return ti & 7; }
@@ -150,8 +150,10 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
     float *s_in = lds;
     float *s_u = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + 2 * UCH;
+    float *s_acc = s_red + G::NWAVES * 64;         // STATS: sums of all tiles of this block (one partial row per block)
     float *s_pro = lds + LDS_FLOATS;               // A | B | C per channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (STATS && tid < 128) s_acc[tid] = 0.f;      // (ordered before its first use by the barriers below)
     const int cbp = G::cbp(wave);
     const int ti = lane & 15, kq = lane >> 4;
     const int trow = G::trow(wave, ti), tcol = G::tcol(ti);      // this lane's Winograd tile in the block tile
@@ -521,11 +523,13 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
 #pragma unroll
                 for (int g = 0; g < G::nrowgroups(); ++g)
                     tsum += s_red[G::wave_of(half, g) * 64 + which * 32 + idx];
-                stat_part[(size_t)tile * 128 + tid] = tsum;
+                s_acc[tid] += tsum;                // same thread every tile: no race
             }
         }
         __syncthreads();
     }
+    // one row [sum 64 | second moment 64] per block: cova_conv3x3_wino_num_partials rows, no fold pass
+    if (STATS && tid < 128) stat_part[(size_t)blockIdx.x * 128 + tid] = s_acc[tid];
 }
 
 // U[s][k][co][pos = a*4+b] = (G g G^T)[a][b] for input channel 4s+k.
@@ -644,11 +648,13 @@ static int launch_wino(const float *in, const float *u, const float *addend, con
     return launch_wino_geo<GeoB>(in, u, addend, bn, pro, out, stat_part, B, H, W, stream);
 }
 
-// rows of the statistics partials written by cova_conv3x3_wino(_pro): one per tile of the active geometry
+// rows of the statistics partials written by cova_conv3x3_wino(_pro): one per (persistent) block of
+// the active geometry
 COVA_API int cova_conv3x3_wino_num_tiles(int B, int H, int W)
 {
-    if (g_wino_geometry == 1) return B * cdiv(W, GeoA::TW) * cdiv(H, GeoA::TH);
-    return B * cdiv(W, GeoB::TW) * cdiv(H, GeoB::TH);
+    if (g_wino_geometry == 1)
+        return cova_internal_persistent_grid2(B * cdiv(W, GeoA::TW) * cdiv(H, GeoA::TH), GeoA::BLOCKS_PER_CU);
+    return cova_internal_persistent_grid2(B * cdiv(W, GeoB::TW) * cdiv(H, GeoB::TH), GeoB::BLOCKS_PER_CU);
 }
 
 // Same contract as cova_conv3x3_fwd / cova_conv3x3_dgrad_bnbwd (stat_part is indexed by the

@@ -76,7 +76,8 @@ int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float 
 /* Winograd F(2x2,3x3) form of the same convolution (2.25x fewer MFMAs, same fp32 error): weights
  * are transformed once per step into u_fwd / u_dgrad [16,16,4,64]; cova_conv3x3_wino has the
  * semantics of cova_conv3x3_fwd (act = z = mean = invstd = NULL) or cova_conv3x3_dgrad_bnbwd. */
-/* rows of the statistics partials of cova_conv3x3_wino(_pro) (one per tile of the active geometry) */
+/* rows of the statistics partials of cova_conv3x3_wino(_pro): one per persistent block (depends on the
+ * device's CU count and on cova_set_option 2 / 6: query it right before allocating) */
 int cova_conv3x3_wino_num_tiles(int B, int H, int W);
 int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
 int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,

@@ -479,9 +479,9 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap, geo):
     uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
     query("cova_set_option", 6, geo)
-    nt = query("cova_conv3x3_wino_num_tiles", B, H, W)
-    R = B * H * W
     query("cova_set_option", 2, cap)
+    nt = query("cova_conv3x3_wino_num_tiles", B, H, W)        # rows = persistent blocks: after the options
+    R = B * H * W
     try:
         # (a) relu(A*x + C) on load, with statistics
         a1 = torch.empty_like(x)

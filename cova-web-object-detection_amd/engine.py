@@ -163,7 +163,7 @@ def convstack_fwd(images, params, buffers, training, save=True):
     sv["wd"] = wd
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
-    nt1 = query("cova_conv1_num_tiles", B, H, W)
+    nt1 = query("cova_conv1_num_partials", B, H, W)
     part = _empty((nt1, 2, C64), images) if training else None
     call("cova_conv1_fwd", images, w1k, y1, part, B, H, W)
     bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1)

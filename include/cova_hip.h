@@ -50,6 +50,8 @@ int cova_conv3x3_prep_weights(const float *w_oihw /*[64,64,3,3]*/, float *w_fwd 
  * stat_part (nullable) [cova_conv1_num_tiles][2][64]: per-tile channel sum / sum of squares of
  * the output (feeds cova_bn_finalize_fwd: train-mode BatchNorm2d statistics). */
 int cova_conv1_num_tiles(int B, int H, int W);
+/* rows of the statistics partials written by cova_conv1_fwd (per tile, or per persistent block) */
+int cova_conv1_num_partials(int B, int H, int W);
 int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part, int B, int H,
                    int W, void *stream);
 /* gradient of conv1's weight (the image needs no gradient): dw OIHW [64,3,7,7] */

@@ -82,7 +82,7 @@ def test_conv1_full_size_crops_and_adjoint():
     wk, vk = torch.empty(154, 64, device=DEV), torch.empty(154, 64, device=DEV)
     call("cova_conv1_prep_weights", w, wk)
     call("cova_conv1_prep_weights", v, vk)
-    nt = query("cova_conv1_num_tiles", B, H, W)
+    nt = query("cova_conv1_num_partials", B, H, W)
     y, part = torch.empty(B, 640, 640, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
     call("cova_conv1_fwd", img, wk, y, part, B, H, W)
     wc = w.cpu()

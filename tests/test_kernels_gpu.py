@@ -92,7 +92,7 @@ def test_conv1_fwd_wgrad(B, H, W):
     wk = torch.empty(154, 64, device=DEV)
     call("cova_conv1_prep_weights", w.to(DEV), wk)
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
-    nt = query("cova_conv1_num_tiles", B, H, W)
+    nt = query("cova_conv1_num_partials", B, H, W)
     out, part = torch.empty(B, H1, W1, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
     call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
     wr = w.clone().requires_grad_(True)
@@ -359,11 +359,12 @@ def test_conv1_variants_multi_tile():
     (ref * dy).sum().backward()
     wk = torch.empty(154, 64, device=DEV)
     call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
-    nt = query("cova_conv1_num_tiles", B, H, W)
+    nt = query("cova_conv1_num_partials", B, H, W)
     ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
     for variant, cap in ((2, 0), (2, 7), (1, 0), (1, 7)):
         query("cova_set_option", 4, variant)
         query("cova_set_option", 2, cap)
+        nt = query("cova_conv1_num_partials", B, H, W)        # depends on the kernel variant / grid cap
         out, part = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
         call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
         close(nchw(out), ref, 1e-4, "conv1 fwd v%d cap %d" % (variant, cap))

@@ -650,7 +650,7 @@ static int launch_wino(const float *in, const float *u, const float *addend, con
 
 // rows of the statistics partials written by cova_conv3x3_wino(_pro): one per (persistent) block of
 // the active geometry
-COVA_API int cova_conv3x3_wino_num_tiles(int B, int H, int W)
+COVA_API int cova_conv3x3_wino_num_partials(int B, int H, int W)
 {
     if (g_wino_geometry == 1)
         return cova_internal_persistent_grid2(B * cdiv(W, GeoA::TW) * cdiv(H, GeoA::TH), GeoA::BLOCKS_PER_CU);

@@ -120,7 +120,7 @@ if os.environ.get("COVA_WINO_GEO"):         # A/B switch: 1 (default) = 8x32 til
 
 def conv3_num_tiles(B, H, W):
     """rows of the statistics partials of the active 3x3 conv kernels"""
-    return query("cova_conv3x3_wino_num_tiles" if USE_WINOGRAD else "cova_conv3x3_num_tiles", B, H, W)
+    return query("cova_conv3x3_wino_num_partials" if USE_WINOGRAD else "cova_conv3x3_num_tiles", B, H, W)
 
 
 def conv3x3(x, wts, addend, out, part, B, H, W, bn=None):

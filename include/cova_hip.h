@@ -80,7 +80,7 @@ int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float 
  * semantics of cova_conv3x3_fwd (act = z = mean = invstd = NULL) or cova_conv3x3_dgrad_bnbwd. */
 /* rows of the statistics partials of cova_conv3x3_wino(_pro): one per persistent block (depends on the
  * device's CU count and on cova_set_option 2 / 6: query it right before allocating) */
-int cova_conv3x3_wino_num_tiles(int B, int H, int W);
+int cova_conv3x3_wino_num_partials(int B, int H, int W);
 int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
 int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,
                       const float *z, const float *mean, const float *invstd, float *out,

@@ -419,7 +419,7 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap, geo):
     query("cova_set_option", 6, geo)          # 8x32 tiles / 1 block per CU | 8x16 tiles / 2 blocks per CU
     try:
         nt = query("cova_conv3x3_num_tiles", B, H, W)
-        ntw = query("cova_conv3x3_wino_num_tiles", B, H, W)
+        ntw = query("cova_conv3x3_wino_num_partials", B, H, W)
         out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(ntw, 2, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(x), uf, None, None, None, None, None, out, part, B, H, W)
         ref = F.conv2d(x, w, padding=1)
@@ -481,7 +481,7 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap, geo):
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
     query("cova_set_option", 6, geo)
     query("cova_set_option", 2, cap)
-    nt = query("cova_conv3x3_wino_num_tiles", B, H, W)        # rows = persistent blocks: after the options
+    nt = query("cova_conv3x3_wino_num_partials", B, H, W)        # rows = persistent blocks: after the options
     R = B * H * W
     try:
         # (a) relu(A*x + C) on load, with statistics

@@ -596,9 +596,11 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     return logits, (sv if save else None)
 
 
-def model_bwd(sv, dlogits, params, gout=None):
+def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     """-> {state_dict key: gradient} for every trainable parameter.  ``gout`` (optional) maps
-    keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket."""
+    keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket.
+    ``after_head`` (optional callable) runs once every gradient outside the conv stack is final
+    (the trainer starts their all-reduce there, under the conv-stack backward)."""
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
     dcomb, grads = decoder_bwd(sv["dec"], dlogits, params, gout)
     if D > 0:
@@ -611,6 +613,8 @@ def model_bwd(sv, dlogits, params, gout=None):
         grads["bn_additional_feat.weight"], grads["bn_additional_feat.bias"] = dg, db
     if Hd > 0:
         grads.update(bbox_bwd(sv["bbox"], dcomb[:, n_vis:], T, gout))
+    if after_head is not None:
+        after_head()
     conv = sv["conv"]
     if USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None and N > 0:
         dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["blocks"][1])

@@ -49,7 +49,15 @@ def _worker(rank, world, port, out_dir):
     bucket = FlatBucket({k: tuple(v.shape) for k, v in sd.items() if is_param_key(k)}, "cpu")
     for k, g in grads.items():
         bucket.views[k].copy_(g)
+    # the trainer's two-phase exchange (head asynchronously first, conv stack at the end) on a copy
+    two = FlatBucket({k: tuple(v.shape) for k, v in sd.items() if is_param_key(k)}, "cpu")
+    two.flat.copy_(bucket.flat)
+    lo = two.split_at("bbox_feat_encoder.0.weight")
+    work = two.all_reduce_range(lo, two.flat.numel(), async_op=True)
+    two.all_reduce_range(0, lo)
+    work.wait()
     bucket.all_reduce_sum()
+    assert torch.equal(two.flat, bucket.flat), "two-phase all-reduce differs from the single collective"
     torch.save({k: v.clone() for k, v in bucket.views.items()}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.destroy_process_group()
 

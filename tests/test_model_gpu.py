@@ -426,3 +426,43 @@ def test_prefetcher_overlapped_upload_matches_direct_collate():
         assert torch.isfinite(loss).all()
         n += 1
     assert n == len(items)
+
+
+def test_overlapped_gradient_exchange_path_on_rccl():
+    """The two-phase gradient exchange (head all-reduced asynchronously under the conv-stack backward,
+    conv stack at the end) through a real RCCL process group.  One GPU only allows a 1-rank group, so
+    the sums are identities: the steps must track the single-process trainer (within Adam's +-lr
+    noise), i.e. the asynchronous collective, its wait and Adam run in a consistent order."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=64, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.2)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(17, **wcfg)
+    batch = synthetic.make_batch(3, img_h=128, boxes_per_page=[20, 33, 9], context_size=6, seed=17)
+    dbatch = {k: v.to(DEV) for k, v in batch.items() if torch.is_tensor(v)}
+    ref = HotPathTrainer(cfg, sd, DEV, dropout_seed=5)
+    for _ in range(3):
+        loss_ref, _ = ref.train_step(dbatch)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        tr = HotPathTrainer(cfg, sd, DEV, world_size=2, dropout_seed=5)     # world_size > 1: exchange path on
+        for _ in range(3):
+            loss, _ = tr.train_step(dbatch)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    # (not bit-exact: RoIPool's atomic scatter order varies between runs and Adam amplifies it)
+    assert abs(float(loss) - float(loss_ref)) <= 2e-3 * abs(float(loss_ref))
+    a, b = tr.state_dict(), ref.state_dict()
+    for k in a:
+        if a[k].is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            assert float((a[k] - b[k]).abs().max()) <= 2 * 3 * 5e-4 + 1e-3 * float(b[k].abs().max()), k

@@ -17,10 +17,17 @@ namespace {
 
 // ------------------------------------------------------------------------------------ RoIPool
 // one wave per (roi, bin); lane = channel (C multiple of 64 handled by a loop)
+// LAZY: the feature map is not read but formed on the fly as relu(fma(scale, z, shift) + x) -- the last
+// BasicBlock's bn2 + residual + ReLU (same expression as cova_bn_act_fwd), never written to HBM.
+struct LazyFeat {
+    const float *x, *scale, *shift;       // feat points at z
+};
+
+template <bool LAZY>
 __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int C, int H, int W,
     int PH, int PW, float spatial_scale, float *__restrict__ out, int ld_out,
-    int32_t *__restrict__ argmax)
+    int32_t *__restrict__ argmax, const LazyFeat lz)
 {
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -47,23 +54,34 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     wend = min(max(wend + rs_w, 0), W);
     const bool empty = (hend <= hstart) || (wend <= wstart);
     const float *fb = feat + (size_t)b * H * W * C;
+    const float *xb = LAZY ? lz.x + (size_t)b * H * W * C : nullptr;
     for (int c = lane; c < C; c += 64) {
         float maxv = empty ? 0.f : -FLT_MAX;
         int maxi = -1;
         const int nw = wend - wstart;
+        const float sc = LAZY ? lz.scale[c] : 0.f, sh = LAZY ? lz.shift[c] : 0.f;
         for (int h = hstart; h < hend; ++h) {
-            const float *row = fb + ((size_t)h * W + wstart) * C + c;
+            const size_t ro = ((size_t)h * W + wstart) * C + c;
+            const float *zrow = fb + ro;
+            const float *xrow = LAZY ? xb + ro : nullptr;
+            // element w of the row: the feature value (LAZY: bn2 + residual + ReLU on the fly)
+            auto at = [&](int w) {
+                const float z = zrow[(size_t)w * C];
+                if (!LAZY) return z;
+                const float y = fmaf(sc, z, sh) + xrow[(size_t)w * C];
+                return y > 0.f ? y : 0.f;
+            };
             int w = 0;
             for (; w + 3 < nw; w += 4) {       // 4 loads in flight; compares in scan order
-                const float v0 = row[(size_t)w * C], v1 = row[(size_t)(w + 1) * C];
-                const float v2 = row[(size_t)(w + 2) * C], v3 = row[(size_t)(w + 3) * C];
+                const float v0 = at(w), v1 = at(w + 1);
+                const float v2 = at(w + 2), v3 = at(w + 3);
                 if (v0 > maxv) { maxv = v0; maxi = h * W + wstart + w; }
                 if (v1 > maxv) { maxv = v1; maxi = h * W + wstart + w + 1; }
                 if (v2 > maxv) { maxv = v2; maxi = h * W + wstart + w + 2; }
                 if (v3 > maxv) { maxv = v3; maxi = h * W + wstart + w + 3; }
             }
             for (; w < nw; ++w) {
-                const float v = row[(size_t)w * C];
+                const float v = at(w);
                 if (v > maxv) { maxv = v; maxi = h * W + wstart + w; }
             }
         }
@@ -99,7 +117,8 @@ __global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
     const int32_t *__restrict__ argmax, int n_rois, int C, int H, int W, int PH, int PW,
     const float *__restrict__ act, const float *__restrict__ z, const float *__restrict__ mean,
-    const float *__restrict__ invstd, float *__restrict__ gfeat, float *__restrict__ partial)
+    const float *__restrict__ invstd, float *__restrict__ gfeat, float *__restrict__ partial,
+    const LazyFeat lz)
 {
     constexpr int MAXCB = 4;                      // C <= 256
     __shared__ float s_red[4][2][64 * MAXCB];
@@ -123,10 +142,13 @@ __global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
             if (mi < 0) continue;
             const size_t pos = boff + (size_t)mi * C + c;
             float g = gout[(size_t)n * ld_g + c * (PH * PW) + bin];
-            if (!(act[pos] > 0.f)) g = 0.f;
+            const float zv = z[pos];
+            // mask of out = relu(bn(z) + x): the materialised map, or the same expression recomputed
+            const float a = act != nullptr ? act[pos] : fmaf(lz.scale[c], zv, lz.shift[c]) + lz.x[pos];
+            if (!(a > 0.f)) g = 0.f;
             atomicAdd(gfeat + pos, g);
             su[k] += g;
-            sq[k] += g * ((z[pos] - mu[k]) * is[k]);
+            sq[k] += g * ((zv - mu[k]) * is[k]);
         }
     }
 #pragma unroll
@@ -348,9 +370,25 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
 {
     COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && C > 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
-    hipLaunchKernelGGL(roipool_fwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
+    hipLaunchKernelGGL(roipool_fwd_kernel<false>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, feat, rois, n_rois, C, H, W, PH, PW, spatial_scale, out,
-                       ld_out, argmax);
+                       ld_out, argmax, LazyFeat{nullptr, nullptr, nullptr});
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// RoIPool over feat = relu(scale * z + shift + x) formed on the fly (z, x NHWC [B,H,W,C]; scale, shift
+// [C]): the last BasicBlock's bn2 + residual + ReLU without the pass that would materialise it.
+COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale,
+                                 const float *shift, const float *rois, int n_rois, int C, int H,
+                                 int W, int PH, int PW, float spatial_scale, float *out, int ld_out,
+                                 int32_t *argmax, void *stream)
+{
+    COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && C > 0 && PH > 0 && PW > 0);
+    if (n_rois == 0) return COVA_OK;
+    hipLaunchKernelGGL(roipool_fwd_kernel<true>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
+                       (hipStream_t)stream, z, rois, n_rois, C, H, W, PH, PW, spatial_scale, out, ld_out,
+                       argmax, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -377,21 +415,25 @@ COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW)
     return g < 1 ? 1 : g;
 }
 
-// cova_roipool_bwd whose scattered gradient is masked by act > 0 and which also emits the
+// cova_roipool_bwd whose scattered gradient is masked by act > 0 (act == NULL: by
+// scale*z + shift + x > 0, the un-materialised map of cova_roipool_fwd_bn) and which also emits the
 // BatchNorm-backward partial sums [num_partials][2][C] of (g', g' * (z - mean) * invstd); C % 64 == 0,
 // C <= 256.  gfeat (zero-filled here) then holds the ReLU-masked gradient.
 COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                                  int n_rois, int B, int C, int H, int W, int PH, int PW,
-                                 const float *act, const float *z, const float *mean,
+                                 const float *act, const float *x, const float *scale,
+                                 const float *shift, const float *z, const float *mean,
                                  const float *invstd, float *gfeat, float *partial, void *stream)
 {
-    COVA_REQUIRE(gout && rois && argmax && act && z && mean && invstd && gfeat && partial && B > 0);
+    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && B > 0);
+    COVA_REQUIRE(act || (x && scale && shift));   // mask: act > 0, or relu argument scale*z + shift + x > 0
     COVA_REQUIRE(C % 64 == 0 && C <= 256);
     hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * H * W * C, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     const int grid = cova_roipool_bwd_bn_num_partials(n_rois, PH, PW);
     hipLaunchKernelGGL(roipool_bwd_bn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gout, ld_g,
-                       rois, argmax, n_rois, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial);
+                       rois, argmax, n_rois, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial,
+                       LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

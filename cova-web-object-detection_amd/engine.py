@@ -139,8 +139,18 @@ CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "co
 BN3_KEYS = ["convnet.4.0.bn1.", "convnet.4.0.bn2.", "convnet.4.1.bn1.", "convnet.4.1.bn2."]
 
 
-def convstack_fwd(images, params, buffers, training, save=True):
-    """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,64]  (models.py:49-51,125)."""
+class LazyFeature:
+    """The last BasicBlock's output relu(bn2(z2) + x) left un-materialised: RoIPool (forward and
+    backward mask) forms it on the fly (cova_roipool_fwd_bn / cova_roipool_bwd_bn)."""
+    __slots__ = ("z", "x", "scale", "shift", "shape")
+
+    def __init__(self, z, x, scale, shift):
+        self.z, self.x, self.scale, self.shift, self.shape = z, x, scale, shift, tuple(z.shape)
+
+
+def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
+    """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,64]  (models.py:49-51,125);
+    with ``lazy_out`` (Winograd path) a LazyFeature instead of the tensor."""
     _check(images)
     B, _, H, W = images.shape
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
@@ -193,12 +203,17 @@ def convstack_fwd(images, params, buffers, training, save=True):
             call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
             conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
         bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R)
-        out = _empty((B, H2, W2, C64), images)
-        call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
+        if blk == 1 and lazy_out and USE_WINOGRAD and FUSE_AFFINE:
+            out = None
+            feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
+        else:
+            out = _empty((B, H2, W2, C64), images)
+            call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
+            feat = out
         blocks.append(dict(x=x, z1=z1, a1=a1, z2=z2, out=out, bna=bna, bnb=bnb))
         x = out
     sv["blocks"] = blocks
-    return x, (sv if save else None)
+    return feat, (sv if save else None)
 
 
 def block_a1(blk):
@@ -210,6 +225,16 @@ def block_a1(blk):
     a1 = torch.empty_like(z1)
     call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, z1.numel() // C64, C64, 1)
     return a1
+
+
+def block_out(blk):
+    """out = relu(bn2(z2) + x) of a BasicBlock; materialised on demand when the forward left it lazy."""
+    if blk["out"] is not None:
+        return blk["out"]
+    z2, bnb = blk["z2"], blk["bnb"]
+    out = torch.empty_like(z2)
+    call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, blk["x"], C64, out, C64, z2.numel() // C64, C64, 1)
+    return out
 
 
 def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
@@ -259,7 +284,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         # ---- out = relu(bn2(z2) + x): dz2 = abc_b . (dres, z2); dres = masked incoming gradient
         if pend is None:
             dres, dz2 = torch.empty_like(dA), torch.empty_like(dA)
-            dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, bnb, R, dz2, C64, dres, C64,
+            dg, db = bn_backward(dA, C64, block_out(s), C64, s["z2"], C64, bnb, R, dz2, C64, dres, C64,
                                  gout, pb)
             g_in, g_in2, g_abc = dz2, None, None
         else:
@@ -316,7 +341,7 @@ def _layer1_bwd_unfused(sv, dfeat, gout, grads):
         dz2 = torch.empty_like(dA)
         if pend is None:
             dres = torch.empty_like(dA)
-            dg, db = bn_backward(dA, C64, s["out"], C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres,
+            dg, db = bn_backward(dA, C64, block_out(s), C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres,
                                  C64, gout, pb)
         else:
             dres = dA                                 # masked dy doubles as the residual gradient
@@ -399,13 +424,18 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None):
 
 # ------------------------------------------------------------------------------- RoIPool
 def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
+    """feat: NHWC tensor or a LazyFeature (then bn2 + residual + ReLU are formed inside the kernel)."""
     _check(bboxes)
     B, Hf, Wf, C = feat.shape
     N = bboxes.shape[0]
     PH, PW = roi_size
-    argmax = _empty((N, C * PH * PW), feat, torch.int32)
-    call("cova_roipool_fwd", feat, bboxes, N, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
-         argmax)
+    argmax = _empty((N, C * PH * PW), bboxes, torch.int32)
+    if isinstance(feat, LazyFeature):
+        call("cova_roipool_fwd_bn", feat.z, feat.x, feat.scale, feat.shift, bboxes, N, C, Hf, Wf, PH, PW,
+             float(spatial_scale), out, ld_out, argmax)
+    else:
+        call("cova_roipool_fwd", feat, bboxes, N, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
+             argmax)
     return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW))
 
 
@@ -428,8 +458,10 @@ def roipool_bwd_bn(sv, gout, ld_g, last_block):
     npart = query("cova_roipool_bwd_bn_num_partials", n, PH, PW)
     part = _empty((npart, 2, C), gout)
     bnb = last_block["bnb"]
+    lazy = last_block["out"] is None              # mask recomputed from (z2, x) like the forward did
     call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
-         last_block["out"], last_block["z2"], bnb.mean, bnb.invstd, gfeat, part)
+         last_block["out"], last_block["x"] if lazy else None, bnb.scale if lazy else None,
+         bnb.shift if lazy else None, last_block["z2"], bnb.mean, bnb.invstd, gfeat, part)
     return gfeat, (part, npart)
 
 
@@ -577,7 +609,7 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     F = n_vis + Hd + A
     D = cfg["hidden_dim"] if cfg["use_context"] else 0
     T = F + D
-    feat, sv_conv = convstack_fwd(images, params, buffers, training, save)
+    feat, sv_conv = convstack_fwd(images, params, buffers, training, save, lazy_out=True)
     comb = _empty((N, T), images)
     scale = cfg.get("spatial_scale") or feat.shape[1] / images.shape[2]   # models.py:56
     sv = dict(cfg=cfg, N=N, F=F, D=D, T=T, n_vis=n_vis, Hd=Hd, A=A, conv=sv_conv, comb=comb)

@@ -170,9 +170,15 @@ int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32
  * produced the map: gfeat = masked gradient, partial [cova_roipool_bwd_bn_num_partials][2][C] */
 int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW);
 int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                        int n_rois, int B, int C, int H, int W, int PH, int PW, const float *act,
-                        const float *z, const float *mean, const float *invstd, float *gfeat,
-                        float *partial, void *stream);
+                        int n_rois, int B, int C, int H, int W, int PH, int PW,
+                        const float *act /*nullable: then x, scale, shift give the mask*/,
+                        const float *x /*nullable*/, const float *scale /*nullable*/,
+                        const float *shift /*nullable*/, const float *z, const float *mean,
+                        const float *invstd, float *gfeat, float *partial, void *stream);
+/* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
+int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
+                        const float *rois, int n_rois, int C, int H, int W, int PH, int PW,
+                        float spatial_scale, float *out, int ld_out, int32_t *argmax, void *stream);
 
 /* ------------------------------------------------------------------ positional encoder
  * replaces: CoVA._get_bbox_features up to nn.Linear(5, Hd) (models.py:134-144):

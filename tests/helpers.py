@@ -79,7 +79,7 @@ def routing_from_saved(sv):
     r["gate_bn1"] = nchw(conv["y1"] * bn1.scale + bn1.shift > 0)
     for i, blk in enumerate(conv["blocks"]):
         r["gate_a1_%d" % i] = nchw(E.block_a1(blk) > 0)
-        r["gate_out_%d" % i] = nchw(blk["out"] > 0)
+        r["gate_out_%d" % i] = nchw(E.block_out(blk) > 0)
     n_vis, hd = sv["n_vis"], sv["Hd"]
     if hd > 0:
         r["gate_bbox"] = (sv["comb"][:, n_vis:n_vis + hd] > 0).cpu()

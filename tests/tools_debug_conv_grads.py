@@ -27,7 +27,7 @@ dcomb, grads = engine.decoder_bwd(sv["dec"], dl, params)
 grads.update(engine.gat_bwd(sv["gat"], dcomb[:, sv["F"]:], sv["T"], params, dcomb, sv["T"], True))
 def rel(a, b, name):
     print("%-20s rel err %.3e  (max ref %.3e)" % (name, (a - b).abs().max().item() / b.abs().max().item(), b.abs().max().item()))
-feat = sv["conv"]["blocks"][1]["out"].cpu().permute(0, 3, 1, 2)
+feat = engine.block_out(sv["conv"]["blocks"][1]).cpu().permute(0, 3, 1, 2)
 rel(feat, inter["feat"].detach(), "feat fwd")
 rel(sv["comb"][:, :576].cpu(), inter["visual"].detach(), "visual fwd")
 rel(dcomb[:, :576].cpu(), inter["visual"].grad, "d visual")

@@ -24,6 +24,10 @@
 
 namespace {
 
+// 256 zero bytes in global memory: refill loads of halo pixels outside the image (and of idle
+// threads) read from here, so the value needs no select afterwards (plain kernels)
+__device__ __attribute__((aligned(256))) float g_wino_zero_page[64];
+
 // ReLU mask + BatchNorm-backward sums in the epilogue.  The mask is act > 0, or, when the
 // activation was never materialised (act == nullptr), fma(msc, z, msh) > 0 -- the same expression
 // the affine-on-load prologue evaluates, so both sides take identical decisions.
@@ -258,8 +262,10 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
         const bool nload = has_next && tid < NPIX && ngy >= 0 && ngy < H && ngx >= 0 && ngx < W;
         const size_t noff = (size_t)(next / (tiles_x * tiles_y)) * H * W * 64 +
                             ((size_t)min(max(ngy, 0), H - 1) * W + min(max(ngx, 0), W - 1)) * 64;
-        const float *nsrc = in + noff;
-        const float *nsrc2 = pro2 ? pro.in2 + noff : in + noff;
+        // plain kernels: out-of-image pixels load zeros from the zero page (no select later); the
+        // prologue variants load a clamped address and select after the affine transform
+        const float *nsrc = (PRO || nload) ? in + noff : g_wino_zero_page;
+        const float *nsrc2 = pro2 ? pro.in2 + noff : nsrc;
         const size_t img = (size_t)b * H * W * 64;
 
         f32x4 acc[2][16];
@@ -268,11 +274,18 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
 #pragma unroll
             for (int p = 0; p < 16; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        auto chunk = [&](const int s, Ring &ring, const float (&V)[16], float (&Vn)[16]) {
+        // np / np2: refill source of the chunk PAIR (advanced once per loop iteration); the chunk's own
+        // 16 bytes are an immediate offset
+        auto chunk = [&](const int s, const int e, const float *np, const float *np2, Ring &ring,
+                         const float (&V)[16], float (&Vn)[16]) {
             // (1) refill: planes consumed two chunks ago <- data of the tile after theirs
             if (ring.plane >= 0 && tid < NPIX && !(abl & 2)) {
                 float4 v = zero4;
-                if (ring.in) v = PRO ? pro_apply(ring.v, ring.w, ring.plane) : ring.v;
+                if (PRO) {
+                    if (ring.in) v = pro_apply(ring.v, ring.w, ring.plane);
+                } else {
+                    v = ring.v;                       // already zero outside the image (zero page)
+                }
                 float *dst = s_in + (size_t)ring.plane * PIXS + rpx;
                 dst[0] = v.x;
                 dst[PIXS] = v.y;
@@ -285,19 +298,21 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
             const int ns = (s + 1) & 15;
             float4 un0 = zero4, un1 = zero4, un2 = zero4, un3 = zero4;
             if (!(abl & 8)) {
-                const float4 *ugn = reinterpret_cast<const float4 *>(ug + (size_t)ns * UCH_G);
-                un0 = ugn[tid];
-                un1 = ugn[tid + THREADS];
+                // wave-uniform chunk base + this thread's fixed 32-bit byte offset (scalar-base addressing)
+                const char *ugn = reinterpret_cast<const char *>(ug + (size_t)ns * UCH_G);
+                const unsigned toff = (unsigned)tid * 16u;
+                un0 = *reinterpret_cast<const float4 *>(ugn + toff);
+                un1 = *reinterpret_cast<const float4 *>(ugn + toff + THREADS * 16u);
                 if (NUL > 2) {
-                    un2 = ugn[tid + 2 * THREADS];
-                    un3 = ugn[tid + 3 * THREADS];
+                    un2 = *reinterpret_cast<const float4 *>(ugn + toff + 2u * THREADS * 16u);
+                    un3 = *reinterpret_cast<const float4 *>(ugn + toff + 3u * THREADS * 16u);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) fetch this chunk's planes for the next tile; consumed two chunks from now
             if (!(abl & 4)) {
-                ring.v = *reinterpret_cast<const float4 *>(nsrc + 4 * s);
-                if (pro2) ring.w = *reinterpret_cast<const float4 *>(nsrc2 + 4 * s);
+                ring.v = *reinterpret_cast<const float4 *>(np + 4 * e);
+                if (pro2) ring.w = *reinterpret_cast<const float4 *>(np2 + 4 * e);
             }
             ring.plane = has_next ? 4 * s : -1;
             ring.in = nload;
@@ -355,8 +370,9 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
         };
 #pragma unroll 1
         for (int s2 = 0; s2 < 8; ++s2) {
-            chunk(2 * s2, ringA, V, V1);
-            chunk(2 * s2 + 1, ringB, V1, V);
+            const float *np = nsrc + 8 * s2, *np2 = nsrc2 + 8 * s2;
+            chunk(2 * s2, 0, np, np2, ringA, V, V1);
+            chunk(2 * s2 + 1, 1, np, np2, ringB, V1, V);
         }
 
         // ---- output transform Y = A^T M A in registers, straight to HBM.

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must be imported first so that libamdhip64 is tor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(PKG_DIR, "..", "include", "cova_hip.h")
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libcova_hip.so")
+LIB_PATH = os.environ.get("COVA_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libcova_hip.so")   # env: A/B builds
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,

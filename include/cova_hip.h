@@ -77,7 +77,8 @@ int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float 
                              float *dy, float *stat_part, int B, int H, int W, void *stream);
 /* Winograd F(2x2,3x3) form of the same convolution (2.25x fewer MFMAs, same fp32 error): weights
  * are transformed once per step into u_fwd / u_dgrad [16,16,4,64]; cova_conv3x3_wino has the
- * semantics of cova_conv3x3_fwd (act = z = mean = invstd = NULL) or cova_conv3x3_dgrad_bnbwd. */
+ * semantics of cova_conv3x3_fwd (act = z = mean = invstd = NULL) or cova_conv3x3_dgrad_bnbwd,
+ * except that stat_part has one row per persistent block: [cova_conv3x3_wino_num_partials][2][64]. */
 /* rows of the statistics partials of cova_conv3x3_wino(_pro): one per persistent block (depends on the
  * device's CU count and on cova_set_option 2 / 6: query it right before allocating) */
 int cova_conv3x3_wino_num_partials(int B, int H, int W);

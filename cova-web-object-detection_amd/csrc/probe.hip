@@ -227,3 +227,55 @@ COVA_API int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *st
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+// Lane-pattern probe: copies an NHWC-64 tensor (npix pixels) in runs of 32 pixels per wave with the
+// lane -> (pixel, channel) mapping of  mode 0: the Winograd epilogue (16 lanes = 16 pixels 512 B apart,
+// lane>>4 = 16-byte slice),  mode 1: fully contiguous (16 lanes = one pixel),  mode 2: 4 consecutive
+// lanes = one 64-byte segment.  8 float4 loads in flight per lane, then 8 stores.  lds_bytes of dynamic
+// LDS limit the blocks per CU (the conv kernels run 2 waves per SIMD).
+__global__ __launch_bounds__(512) void lane_pattern_probe_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                 long long nruns, int mode, int loads_only)
+{
+    extern __shared__ float dyn_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long run = (long long)blockIdx.x * 8 + wave; run < nruns; run += (long long)gridDim.x * 8) {
+        const float *src = in + run * 32 * 64;
+        float *dst = out + run * 32 * 64;
+        int off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (mode == 0) off[j] = (2 * (lane & 15) + (j & 1)) * 64 + (j >> 1) * 16 + (lane >> 4) * 4;
+            else if (mode == 1) off[j] = ((lane >> 4) + 4 * j) * 64 + (lane & 15) * 4;
+            else off[j] = ((lane >> 2) + 16 * (j & 1)) * 64 + (lane & 3) * 4 + 16 * (j >> 1);
+        }
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(src + off[j]);
+        if (loads_only) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4 *>(dst + off[j]) = v[j];
+        }
+    }
+    if (loads_only && acc.x == 12345.678f) *reinterpret_cast<float4 *>(out + threadIdx.x * 4) = acc;
+    if (dyn_lds[0] == 12345.678f && threadIdx.x == 9999) out[0] = 0.f;
+}
+
+COVA_API int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
+                                     int blocks, int lds_bytes, void *stream)
+{
+    COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 2 && blocks > 0 && lds_bytes >= 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(lane_pattern_probe_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lane_pattern_probe_kernel, dim3(blocks), dim3(512), (size_t)lds_bytes, (hipStream_t)stream,
+                       in, out, npix / 32, mode, loads_only);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -255,6 +255,10 @@ int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blo
 /* mixed probe: mfma_blocks MFMA blocks + stream_blocks blocks streaming buf (n4 float4, `passes` times) */
 int cova_probe_mix(float *scratch, const float *buf, long long n4, int mfma_blocks, int stream_blocks,
                    int iters, int passes, void *stream);
+/* lane-pattern probe: NHWC-64 copy (or load-only) with the Winograd epilogue's lane mapping (mode 0),
+ * fully contiguous lanes (1) or 64-byte segments per 4 lanes (2); lds_bytes limits blocks per CU */
+int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
+                            int blocks, int lds_bytes, void *stream);
 
 #ifdef __cplusplus
 }

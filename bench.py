@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm statistics over the whole data-parallel batch (default: per rank, as DDP)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +107,8 @@ def main():
 
     wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
     sd = weights.seeded_state_dict(123, **wcfg)
-    trainer = HotPathTrainer(CFG, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank)
+    trainer = HotPathTrainer(CFG, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank,
+                             sync_bn=args.sync_bn)
     batch = make_device_batch(123 + rank, device, args.pages)
     n_boxes = batch["bboxes"].shape[0]
 
@@ -176,7 +179,8 @@ def main():
                                    "train step = fwd+CE+bwd+allreduce+Adam, dropout 0.2"
                                    % (args.pages, BOXES, 2 * CS),
                        "pages_per_gpu": args.pages, "global_pages": world * args.pages,
-                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world, "loss": round(loss_val, 3)},
+                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else ""),
+                       "loss": round(loss_val, 3)},
             # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md section 8d; the
             # kernel is Winograd F(2x2,3x3) and executes 2.25x fewer MFMA FLOPs, so the algorithmic rate
             # can exceed the MFMA peak; `executed_*` is the matrix-pipe view of the same launches.

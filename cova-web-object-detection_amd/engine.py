@@ -59,8 +59,56 @@ def fold_partials(partial, nparts, width):
     return partial, nparts
 
 
+# Optional SyncBN (SURVEY.md section 8e "exact large-batch mode"): while STAT_SYNC is set (by the
+# trainer, for the duration of one training step) every BatchNorm statistic row -- (sum x, sum x^2)
+# forward, (sum dy, sum dy*xhat) backward -- is summed over the data-parallel group before it is
+# finalized, with the element count scaled to the whole batch.  Messages are 2*C floats.
+class StatSync:
+    def __init__(self, group, ratio_pages, ratio_boxes):
+        self.group = group
+        self.ratio = {"pages": float(ratio_pages), "boxes": float(ratio_boxes)}   # global / local count
+
+    def all_reduce(self, row):
+        import torch.distributed as dist
+        dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group)
+
+
+STAT_SYNC = None
+
+
+def _global_stats(partial, nparts, width, count, unit):
+    """Local partial rows -> ONE row summed over all ranks, and the count of the whole batch."""
+    row = _empty((1, width), partial)
+    call("cova_partials_fold", partial, nparts, width, max(int(nparts), 1), row)
+    STAT_SYNC.all_reduce(row)
+    return row, 1, count * STAT_SYNC.ratio[unit]
+
+
+def bn_finalize_bwd(part, nparts, C, count, dgamma, dbeta, unit, abc_from=None):
+    """cova_bn_finalize_bwd (-> coef [2,C]) or, with ``abc_from`` = the layer's BNState,
+    cova_bn_finalize_bwd_abc (-> A|B|C [3,C]).  Under SyncBN the parameter gradients come from the
+    LOCAL sums (the gradient exchange adds the ranks up) and the dz coefficients from the sums and
+    the count of the whole batch (torch.nn.SyncBatchNorm's backward does the same)."""
+    part, nparts = fold_partials(part, nparts, 2 * C)
+    out = _empty((3 if abc_from is not None else 2, C), part)
+
+    def fin(p, n, cnt, dg, db):
+        if abc_from is not None:
+            call("cova_bn_finalize_bwd_abc", p, n, C, float(cnt), dg, db, abc_from.mean, abc_from.invstd,
+                 abc_from.scale, out)
+        else:
+            call("cova_bn_finalize_bwd", p, n, C, float(cnt), dg, db, out)
+
+    fin(part, nparts, count, dgamma, dbeta)
+    if STAT_SYNC is not None:
+        gp, gn, gc = _global_stats(part, nparts, 2 * C, count, unit)
+        scratch = _empty((2, C), part)
+        fin(gp, gn, gc, scratch[0], scratch[1])
+    return out
+
+
 def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
-              update_running=True):
+              update_running=True, unit="boxes"):
     st = BNState()
     st.C, st.count = C, float(count)
     st.abc = _empty((3, C), like)               # scale | (unused) | shift: the prologue's A | B | C
@@ -71,6 +119,9 @@ def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0
     if training:
         upd = update_running
         partial, nparts = fold_partials(partial, nparts, 2 * C)
+        if STAT_SYNC is not None:
+            partial, nparts, count = _global_stats(partial, nparts, 2 * C, count, unit)
+            st.count = float(count)
         call("cova_bn_finalize_fwd", partial, nparts, C, float(count), g, b, rm if upd else None,
              rv if upd else None, BN_MOMENTUM, BN_EPS, st.scale, st.shift, st.mean, st.invstd)
         if upd:
@@ -88,7 +139,7 @@ def colstats(x, ld, R, C):
 
 
 def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=0, gout=None,
-                prefix=None):
+                prefix=None, unit="boxes"):
     """Returns (dgamma, dbeta); writes dz (and dres = relu-masked dout)."""
     C = st.C
     n = query("cova_colreduce_num_chunks", R, C)
@@ -96,9 +147,7 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
     call("cova_bn_bwd_reduce", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, R, C, part)
     dgamma = _gbuf(gout, (prefix or "") + "weight", (C,), z)
     dbeta = _gbuf(gout, (prefix or "") + "bias", (C,), z)
-    coef = _empty((2, C), z)
-    part, n = fold_partials(part, n, 2 * C)
-    call("cova_bn_finalize_bwd", part, n, C, float(R), dgamma, dbeta, coef)
+    coef = bn_finalize_bwd(part, n, C, R, dgamma, dbeta, unit)
     call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
          lddz, dres, lddres, R, C)
     return dgamma, dbeta
@@ -176,7 +225,7 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     nt1 = query("cova_conv1_num_partials", B, H, W)
     part = _empty((nt1, 2, C64), images) if training else None
     call("cova_conv1_fwd", images, w1k, y1, part, B, H, W)
-    bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1)
+    bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1, unit="pages")
     p1 = _empty((B, H2, W2, C64), images)
     idx = _empty((B, H2, W2, C64), images, torch.uint8)
     # ymax = y1 at each window's arg-max: lets the last data-gradient conv take bn1's backward sums
@@ -192,7 +241,7 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
         conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
-        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R)
+        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
         z2 = _empty((B, H2, W2, C64), images)
         if USE_WINOGRAD and FUSE_AFFINE:            # a1 = relu(bn1(z1)) formed on load
             a1 = None
@@ -202,7 +251,7 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
             a1 = _empty((B, H2, W2, C64), images)
             call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
             conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
-        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R)
+        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R, unit="pages")
         if blk == 1 and lazy_out and USE_WINOGRAD and FUSE_AFFINE:
             out = None
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
@@ -243,9 +292,7 @@ def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
     C = st.C
     dgamma = _gbuf(gout, prefix + "weight", (C,), z)
     dbeta = _gbuf(gout, prefix + "bias", (C,), z)
-    coef = _empty((2, C), z)
-    part, nparts = fold_partials(part, nparts, 2 * C)
-    call("cova_bn_finalize_bwd", part, nparts, C, float(R), dgamma, dbeta, coef)
+    coef = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages")
     call("cova_bn_bwd_apply", dy, C, None, 0, z, C, st.mean, st.invstd, st.scale, coef, dz, C, None, 0,
          R, C)
     return dgamma, dbeta
@@ -256,10 +303,7 @@ def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
     C = st.C
     dgamma = _gbuf(gout, prefix + "weight", (C,), like)
     dbeta = _gbuf(gout, prefix + "bias", (C,), like)
-    abc = _empty((3, C), like)
-    part, nparts = fold_partials(part, nparts, 2 * C)
-    call("cova_bn_finalize_bwd_abc", part, nparts, C, float(R), dgamma, dbeta, st.mean, st.invstd,
-         st.scale, abc)
+    abc = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages", abc_from=st)
     return dgamma, dbeta, abc
 
 
@@ -285,7 +329,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         if pend is None:
             dres, dz2 = torch.empty_like(dA), torch.empty_like(dA)
             dg, db = bn_backward(dA, C64, block_out(s), C64, s["z2"], C64, bnb, R, dz2, C64, dres, C64,
-                                 gout, pb)
+                                 gout, pb, unit="pages")
             g_in, g_in2, g_abc = dz2, None, None
         else:
             dres = dA
@@ -342,7 +386,7 @@ def _layer1_bwd_unfused(sv, dfeat, gout, grads):
         if pend is None:
             dres = torch.empty_like(dA)
             dg, db = bn_backward(dA, C64, block_out(s), C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres,
-                                 C64, gout, pb)
+                                 C64, gout, pb, unit="pages")
         else:
             dres = dA                                 # masked dy doubles as the residual gradient
             dg, db = bn_bwd_from_partials(pend, nt, dA, s["z2"], s["bnb"], R, dz2, gout, pb)
@@ -400,19 +444,15 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None):
              bn1.invstd, part, B, H1, W1)
     dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
     db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
-    part, npart = fold_partials(part, npart, 2 * C64)
     ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
     dw1 = _gbuf(gout, "convnet.0.weight", (64, 3, 7, 7), dfeat)
     if fused and sv.get("pool_part") is not None:
         # dA is already ReLU-masked (epilogue of the last data-gradient conv): the pooling/BN backward
         # apply is folded into conv1's weight-gradient kernel, dy1 is never written
-        abc = _empty((3, C64), dfeat)
-        call("cova_bn_finalize_bwd_abc", part, npart, C64, float(B * H1 * W1), dg, db, bn1.mean,
-             bn1.invstd, bn1.scale, abc)
+        abc = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", abc_from=bn1)
         call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
     else:
-        coef = _empty((2, C64), dfeat)
-        call("cova_bn_finalize_bwd", part, npart, C64, float(B * H1 * W1), dg, db, coef)
+        coef = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages")
         dy1 = torch.empty_like(sv["y1"])
         call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
              bn1.invstd, coef, dy1, B, H1, W1)

@@ -7,7 +7,10 @@ pages; the model (1.6 M parameters) is replicated.  Every parameter lives in ONE
 and every gradient in ONE flat bucket, so a step needs exactly one all-reduce (6.47 MB, latency
 bound on xGMI) and one Adam launch.  The loss is a SUM over boxes (main.py:139), so SUM-reduced
 gradients equal the single-device large-batch gradient except for BatchNorm, whose batch
-statistics stay per-rank (standard DDP behaviour; the reference has no SyncBN).
+statistics stay per-rank (standard DDP behaviour; the reference has no SyncBN).  ``sync_bn=True``
+switches on the exact large-batch mode: every BatchNorm statistic row is summed over the ranks
+(engine.StatSync, 2*C floats per message), after which a data-parallel step equals the
+single-device step on the concatenated batch.
 """
 from collections import OrderedDict
 
@@ -82,7 +85,7 @@ class HotPathTrainer:
     """Owns flat parameters / gradients / Adam moments on one GPU and runs training steps."""
 
     def __init__(self, cfg, state_dict, device, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, world_size=1, process_group=None, dropout_seed=123):
+                 eps=1e-8, world_size=1, process_group=None, dropout_seed=123, sync_bn=False):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         spec = state_dict_spec(**{k: cfg[k] for k in ("roi_output_size", "n_classes", "use_context",
@@ -104,6 +107,7 @@ class HotPathTrainer:
         self.hp = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
         self.world_size, self.group = world_size, process_group
         self.step_count, self.dropout_seed = 0, int(dropout_seed)
+        self.sync_bn = bool(sync_bn) and world_size > 1
 
     def state_dict(self):
         sd = OrderedDict()
@@ -115,14 +119,31 @@ class HotPathTrainer:
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
         self.step_count += 1
         base = (self.dropout_seed * 0x9E3779B1 + 2 * self.step_count) & 0xFFFFFFFFFFFF
-        logits, sv = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],
-                                      batch["bboxes"], batch["additional_feats"],
-                                      batch["context_indices"], True, (base, base + 1), masks)
-        loss, dl, pred = engine.ce_sum(logits, batch["labels"])
-        self._head_work = None
-        overlap = self.world_size > 1 and os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
-        engine.model_bwd(sv, dl, self.params, self.grads, after_head=self._reduce_head if overlap else None)
+        if self.sync_bn:
+            engine.STAT_SYNC = self._stat_sync(batch)
+        try:
+            logits, sv = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],
+                                          batch["bboxes"], batch["additional_feats"],
+                                          batch["context_indices"], True, (base, base + 1), masks)
+            loss, dl, pred = engine.ce_sum(logits, batch["labels"])
+            self._head_work = None
+            overlap = self.world_size > 1 and os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
+            engine.model_bwd(sv, dl, self.params, self.grads,
+                             after_head=self._reduce_head if overlap else None)
+        finally:
+            engine.STAT_SYNC = None
         return loss, pred
+
+    def _stat_sync(self, batch):
+        """SyncBN bookkeeping of one step: whole-batch / local element-count ratios for the page-shaped
+        (conv stack) and box-shaped (BatchNorm1d) statistics; one tiny all-reduce + host read."""
+        import torch.distributed as dist
+        local = torch.tensor([batch["images"].shape[0], batch["bboxes"].shape[0]], dtype=torch.float64,
+                             device=self.device)
+        total = local.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        r = (total / local.clamp_min(1.0)).tolist()
+        return engine.StatSync(self.group, r[0], r[1])
 
     # Gradient exchange: the head (positional encoder, GAT, decoder = 96 % of the 6.5 MB bucket, the
     # tail of the flat buffer) is complete before the conv-stack backward starts, so its all-reduce is

@@ -270,7 +270,7 @@ COVA_API int cova_probe_lane_pattern(const float *in, float *out, long long npix
     COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 2 && blocks > 0 && lds_bytes >= 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(lane_pattern_probe_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lane_pattern_probe_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }

@@ -97,13 +97,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # Diagnostic only (code-path check of the N > 1 launch on a 1-GPU box): COVA_BENCH_BACKEND=gloo lets
+    # all ranks share cuda:0; the throughput of such a run means nothing and is labelled in `config`.
+    backend = os.environ.get("COVA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
     sd = weights.seeded_state_dict(123, **wcfg)
@@ -179,7 +187,8 @@ def main():
                                    "train step = fwd+CE+bwd+allreduce+Adam, dropout 0.2"
                                    % (args.pages, BOXES, 2 * CS),
                        "pages_per_gpu": args.pages, "global_pages": world * args.pages,
-                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else ""),
+                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") +
+                       ("" if backend == "nccl" else " (DIAGNOSTIC: %s backend, shared GPU)" % backend),
                        "loss": round(loss_val, 3)},
             # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md section 8d; the
             # kernel is Winograd F(2x2,3x3) and executes 2.25x fewer MFMA FLOPs, so the algorithmic rate

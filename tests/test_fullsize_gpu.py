@@ -6,6 +6,8 @@ structure of convolution / pooling), adjoint identities tying the gradient kerne
 kernel (<dW, V> = <dz, conv(x; V)>, <dgrad(dz), x> = <dz, conv(x)>), exactness of the fused
 statistics, BatchNorm output moments, and one full single-page train step against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -178,3 +180,19 @@ def test_single_page_train_step_full_resolution_matches_oracle():
     for k in buffers:
         if not k.endswith("num_batches_tracked"):
             assert rel(buffers[k], after[k]) < 1e-4, k
+
+
+def test_activations_beyond_2_31_elements_index_correctly():
+    """96 pages of 1280x1280 (conv1 output 2.5 G elements, 10 GB): six copies of a 16-page batch share
+    its BatchNorm statistics, so every copy's logits equal the 16-page logits and the gradient is six
+    times the 16-page gradient (tools/large_batch_check.py; 176 pages = 4.6 G elements checked there)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "large_batch_check.py")],
+                         env=dict(os.environ, REPS="6"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"pages\s+96 .*logits err ([0-9.e+-]+)\s+loss ratio ([0-9.]+)\s+grad err ([0-9.e+-]+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    assert float(m.group(1)) < 1e-4 and abs(float(m.group(2)) - 1.0) < 1e-5 and float(m.group(3)) < 1e-3

@@ -33,6 +33,7 @@ __device__ __attribute__((aligned(256))) float g_wino_zero_page[64];
 // the affine-on-load prologue evaluates, so both sides take identical decisions.
 struct BnBwdEpiW {
     const float *act, *z, *mean, *invstd, *msc, *msh;
+    int epi_relu;          // BN == 3 (inference epilogue  out = f(msc*y + msh + addend)): f = ReLU
 };
 
 // Affine-on-load prologue: the conv input is  f(A[c]*in + B[c]*in2 + C[c])  (f = ReLU or identity),
@@ -135,7 +136,9 @@ __device__ __forceinline__ void wino_input_transform(const float *__restrict__ a
 }
 
 // BN: 0 = plain epilogue, 1 = ReLU mask from z (fma(msc, z, msh) > 0) + BatchNorm-backward sums,
-//     2 = ReLU mask from the materialised activation + BatchNorm-backward sums
+//     2 = ReLU mask from the materialised activation + BatchNorm-backward sums,
+//     3 = inference: out = f(msc*y + msh + addend), the BatchNorm (running statistics) + residual +
+//         ReLU that follows the conv, in cova_bn_act_fwd's operation order (bit-identical to it)
 template <class G, bool STATS, bool PRO, bool ADD, int BN>
 __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino_kernel(
     const float *__restrict__ in, const float *__restrict__ ug, const float *__restrict__ addend,
@@ -436,20 +439,20 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
             };
             auto load_ops = [&](const int c2, Ops &o) {
                 o.mu4 = o.is4 = o.sc4 = o.sh4 = zero4;
-                if (BN != 0) {
+                if (BN == 1 || BN == 2) {
                     o.mu4 = *reinterpret_cast<const float4 *>(bn.mean + co0 + c2 * 16);
                     o.is4 = *reinterpret_cast<const float4 *>(bn.invstd + co0 + c2 * 16);
-                    if (BN == 1) {
-                        o.sc4 = *reinterpret_cast<const float4 *>(bn.msc + co0 + c2 * 16);
-                        o.sh4 = *reinterpret_cast<const float4 *>(bn.msh + co0 + c2 * 16);
-                    }
+                }
+                if (BN == 1 || BN == 3) {
+                    o.sc4 = *reinterpret_cast<const float4 *>(bn.msc + co0 + c2 * 16);
+                    o.sh4 = *reinterpret_cast<const float4 *>(bn.msh + co0 + c2 * 16);
                 }
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
                     o.ad[pq] = o.a4[pq] = o.z4[pq] = zero4;
                     const size_t e = (size_t)(offc[pq] + c2 * 16);
                     if (ADD && !(abl & 128)) o.ad[pq] = *reinterpret_cast<const float4 *>(add_b + e);
-                    if (BN != 0 && !(abl & 128)) o.z4[pq] = *reinterpret_cast<const float4 *>(z_b + e);
+                    if ((BN == 1 || BN == 2) && !(abl & 128)) o.z4[pq] = *reinterpret_cast<const float4 *>(z_b + e);
                     if (BN == 2 && !(abl & 128)) o.a4[pq] = *reinterpret_cast<const float4 *>(act_b + e);
                 }
             };
@@ -467,7 +470,11 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v = y[c2][pq][q] + adv[q];
-                        if (BN != 0) {
+                        if (BN == 3) {
+                            v = fmaf(msc[q], y[c2][pq][q], msh[q]);
+                            if (ADD) v += adv[q];
+                            if (bn.epi_relu) v = v > 0.f ? v : 0.f;
+                        } else if (BN != 0) {
                             const float av = BN == 2 ? aa[q] : fmaf(msc[q], zv[q], msh[q]);
                             if (!(av > 0.f) || !ok[pq]) v = 0.f;
                             ssum[c2][q] += v;
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
                     }
                 }
             };
-            constexpr int NT = (ADD ? 1 : 0) + (BN != 0 ? 1 : 0) + (BN == 2 ? 1 : 0);
+            constexpr int NT = (ADD ? 1 : 0) + (BN == 1 || BN == 2 ? 1 : 0) + (BN == 2 ? 1 : 0);
             if (NT <= 1) {              // everything in flight at once: one round trip
                 Ops o0, o1;
                 load_ops(0, o0);
@@ -646,8 +653,10 @@ static int launch_wino_geo(const float *in, const float *u, const float *addend,
     a.abl = cova_internal_ablate();
     a.grid = dim3(cova_internal_persistent_grid2(a.ntiles, G::BLOCKS_PER_CU));
     a.st = (hipStream_t)stream;
-    const int mode = bn.z == nullptr ? 0 : (bn.act == nullptr ? 1 : 2);    // BN epilogues need stat_part
-    if (mode == 1) launch_wino_epi<G, true, 1>(a);
+    const int mode = bn.z == nullptr ? (bn.msc != nullptr ? 3 : 0)
+                                     : (bn.act == nullptr ? 1 : 2);       // BN epilogues 1, 2 need stat_part
+    if (mode == 3) launch_wino_epi<G, false, 3>(a);
+    else if (mode == 1) launch_wino_epi<G, true, 1>(a);
     else if (mode == 2) launch_wino_epi<G, true, 2>(a);
     else if (stat_part) launch_wino_epi<G, true, 0>(a);
     else launch_wino_epi<G, false, 0>(a);
@@ -683,8 +692,21 @@ COVA_API int cova_conv3x3_wino(const float *in, const float *u, const float *add
 {
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((z == nullptr) || (act && mean && invstd && stat_part));
-    return launch_wino(in, u, addend, BnBwdEpiW{act, z, mean, invstd, nullptr, nullptr},
+    return launch_wino(in, u, addend, BnBwdEpiW{act, z, mean, invstd, nullptr, nullptr, 0},
                        ProIn{nullptr, nullptr, 0}, out, stat_part, B, H, W, stream);
+}
+
+// Inference form: out = f(scale[c]*conv(in) + shift[c] + addend), f = ReLU if relu -- the
+// BatchNorm (running statistics), residual add and ReLU that follow the conv in a BasicBlock
+// (torchvision resnet.py BasicBlock.forward; models.py:49-51), in the epilogue instead of a
+// cova_bn_act_fwd pass; same operation order, bit-identical result.
+COVA_API int cova_conv3x3_wino_bnact(const float *in, const float *u, const float *addend,
+                                     const float *scale, const float *shift, int relu, float *out,
+                                     int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(in && u && scale && shift && out && B > 0 && H > 0 && W > 0);
+    return launch_wino(in, u, addend, BnBwdEpiW{nullptr, nullptr, nullptr, nullptr, scale, shift, relu},
+                       ProIn{nullptr, nullptr, 0}, out, nullptr, B, H, W, stream);
 }
 
 // cova_conv3x3_wino whose input is  f(A[c]*in + B[c]*in2 + C[c])  applied on load (f = ReLU if
@@ -701,7 +723,8 @@ COVA_API int cova_conv3x3_wino_pro(const float *in, const float *in2, const floa
 {
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((z == nullptr) || ((act || (mask_scale && mask_shift)) && mean && invstd && stat_part));
-    return launch_wino(in, u, addend, BnBwdEpiW{act, z, mean, invstd, mask_scale, mask_shift},
+    return launch_wino(in, u, addend,
+                       BnBwdEpiW{act, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr, 0},
                        ProIn{pro_abc, pro_abc ? in2 : nullptr, pro_relu}, out, stat_part, B, H, W, stream);
 }
 

@@ -238,6 +238,17 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     x = p1
     blocks = []
     for blk in (0, 1):
+        if not training and not save and USE_WINOGRAD and FUSE_AFFINE:
+            # inference: running statistics are known up front, so BatchNorm (+ residual) + ReLU sit in
+            # the conv epilogues -- two launches per BasicBlock, nothing else touches the maps
+            bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, False)
+            bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, False)
+            a1, out = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
+            call("cova_conv3x3_wino_bnact", x, wf[2 * blk][1], None, bna.scale, bna.shift, 1, a1, B, H2, W2)
+            call("cova_conv3x3_wino_bnact", a1, wf[2 * blk + 1][1], x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
+            blocks.append(dict(x=x, z1=None, a1=a1, z2=None, out=out, bna=bna, bnb=bnb))
+            x = feat = out
+            continue
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
         conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)

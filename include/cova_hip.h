@@ -86,6 +86,12 @@ int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_d
 int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,
                       const float *z, const float *mean, const float *invstd, float *out,
                       float *stat_part, int B, int H, int W, void *stream);
+/* Inference form of cova_conv3x3_wino: out = f(scale[c]*conv(in) + shift[c] + addend), f = ReLU if relu --
+ * the BatchNorm (running statistics, cova_bn_eval_params), residual add (addend, nullable) and ReLU that
+ * follow each conv of a BasicBlock (models.py:49-51 -> torchvision BasicBlock.forward), evaluated in the
+ * epilogue in cova_bn_act_fwd's operation order (bit-identical to conv + cova_bn_act_fwd). */
+int cova_conv3x3_wino_bnact(const float *in, const float *u, const float *addend, const float *scale,
+                            const float *shift, int relu, float *out, int B, int H, int W, void *stream);
 /* input transformed on load: f(A[c]*in + B[c]*in2 + C[c]), f = ReLU if pro_relu; pro_abc [3,64]
  * (nullable = plain input); in2 nullable (B ignored).  Folds BatchNorm+ReLU (models.py:49-51 via
  * torchvision BasicBlock bn1/relu), or the BatchNorm-backward apply, into the consuming conv.

@@ -536,6 +536,38 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap, geo):
         query("cova_set_option", 6, 1)
 
 
+@pytest.mark.parametrize("geo", [1, 2])
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 5)])
+def test_conv3x3_winograd_inference_epilogue(B, H, W, cap, geo):
+    """cova_conv3x3_wino_bnact == cova_conv3x3_wino followed by cova_bn_act_fwd (BatchNorm with given
+    scale/shift, optional residual, optional ReLU), bit-exact, and against torch-CPU."""
+    g = torch.Generator().manual_seed(11 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    xc, rc = rnd(B, 64, H, W), rnd(B, 64, H, W)
+    x, res = nhwc(xc), nhwc(rc)
+    w = rnd(64, 64, 3, 3) * 0.05
+    sc, sh = rnd(64) * 0.5 + 1.0, rnd(64) * 0.3
+    uf, ud = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
+    call("cova_conv3x3_prep_weights_wino", w.to(DEV), uf, ud)
+    query("cova_set_option", 6, geo)
+    query("cova_set_option", 2, cap)
+    R = B * H * W
+    try:
+        conv = torch.empty_like(x)
+        call("cova_conv3x3_wino", x, uf, None, None, None, None, None, conv, None, B, H, W)
+        for addend, relu in ((None, 1), (res, 1), (None, 0), (res, 0)):
+            ref, out = torch.empty_like(x), torch.empty_like(x)
+            call("cova_bn_act_fwd", conv, 64, sc.to(DEV), sh.to(DEV), addend, 64 if addend is not None else 0,
+                 ref, 64, R, 64, relu)
+            call("cova_conv3x3_wino_bnact", x, uf, addend, sc.to(DEV), sh.to(DEV), relu, out, B, H, W)
+            assert torch.equal(out, ref), (addend is not None, relu)
+        t = F.conv2d(xc, w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + rc
+        close(out.permute(0, 3, 1, 2), t, 2e-5, "inference epilogue vs torch")     # last case: +res, no relu
+    finally:
+        query("cova_set_option", 2, 0)
+        query("cova_set_option", 6, 1)
+
+
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
 def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
     g = torch.Generator().manual_seed(3 * H + W + B)

@@ -49,6 +49,18 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r..16r+15); every lane ends up with the row's total.
+// Four v_add_f32 with DPP operands (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror) instead of four ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v)
 {
 #pragma unroll

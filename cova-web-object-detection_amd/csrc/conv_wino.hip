@@ -64,7 +64,7 @@ struct GeoA {
     static constexpr int UCH = 4 * 64 * UROW;            // 5,120 floats = 20 KB per chunk in LDS
     static constexpr int THREADS = 512, NWAVES = 8, BLOCKS_PER_CU = 1;
     static constexpr int NUL = 2;                        // float4 of a weight chunk per thread
-    static constexpr int RED_FLOATS = NWAVES * 64 + 128;  // per-wave partial sums + the block's running totals
+    static constexpr int RED_FLOATS = NWAVES * 64;       // per-wave running statistics (32 channels x 2 kinds)
     static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 130.8 KB
     __device__ static int cbp(int wave) { return wave >> 2; }
     __device__ static int trow(int wave, int ti) { return wave & 3; }     // Winograd tile row / column of lane ti
@@ -85,7 +85,7 @@ struct GeoB {
     static constexpr int UCH = 4 * 64 * UROW;            // 4,096 floats = 16 KB per chunk
     static constexpr int THREADS = 256, NWAVES = 4, BLOCKS_PER_CU = 2;
     static constexpr int NUL = 4;
-    static constexpr int RED_FLOATS = NWAVES * 64 + 128;
+    static constexpr int RED_FLOATS = NWAVES * 64;
     static constexpr int LDS_FLOATS = IN_FLOATS + 2 * UCH + RED_FLOATS;   // 79.9 KB
     __device__ static int cbp(int wave) { return wave >> 1; }
     __device__ static int trow(int wave, int ti) { return 2 * (wave & 1) + (ti >> 3); }
@@ -157,10 +157,12 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
     float *s_in = lds;
     float *s_u = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + 2 * UCH;
-    float *s_acc = s_red + G::NWAVES * 64;         // STATS: sums of all tiles of this block (one partial row per block)
     float *s_pro = lds + LDS_FLOATS;               // A | B | C per channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (STATS && tid < 128) s_acc[tid] = 0.f;      // (ordered before its first use by the barriers below)
+    // STATS: s_red[wave][0..31 sums | 32..63 second moments] are running totals over all tiles of this
+    // block, updated by the same four lanes of each wave every tile (no barrier); the waves' rows are
+    // added up once, after the tile loop (one partial row per block)
+    if (STATS && tid < G::NWAVES * 64) s_red[tid] = 0.f;       // (ordered before its first use by the barriers below)
     const int cbp = G::cbp(wave);
     const int ti = lane & 15, kq = lane >> 4;
     const int trow = G::trow(wave, ti), tcol = G::tcol(ti);      // this lane's Winograd tile in the block tile
@@ -523,36 +525,37 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        ssum[c2][q] += __shfl_xor(ssum[c2][q], o, 64);
-                        ssq[c2][q] += __shfl_xor(ssq[c2][q], o, 64);
-                    }
+                    ssum[c2][q] = row16_sum(ssum[c2][q]);        // over the 16 tiles of this lane row
+                    ssq[c2][q] = row16_sum(ssq[c2][q]);
                 }
-            if (ti == 0) {         // s_red[wave][0..31] sums, [32..63] sums of squares (32 channels)
+            if (ti == 0) {         // 32 channels of this wave: two float4 read-modify-writes per kind
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s_red[wave * 64 + c2 * 16 + kq * 4 + q] = ssum[c2][q];
-                        s_red[wave * 64 + 32 + c2 * 16 + kq * 4 + q] = ssq[c2][q];
-                    }
-            }
-            __syncthreads();
-            if (tid < 128) {
-                const int which = tid >> 6, ch = tid & 63;        // 0 = sum, 1 = sumsq
-                const int half = ch >> 5, idx = ch & 31;
-                float tsum = 0.f;
-#pragma unroll
-                for (int g = 0; g < G::nrowgroups(); ++g)
-                    tsum += s_red[G::wave_of(half, g) * 64 + which * 32 + idx];
-                s_acc[tid] += tsum;                // same thread every tile: no race
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float4 *ps = reinterpret_cast<float4 *>(s_red + wave * 64 + c2 * 16 + kq * 4);
+                    float4 *pq = reinterpret_cast<float4 *>(s_red + wave * 64 + 32 + c2 * 16 + kq * 4);
+                    float4 a = *ps, b = *pq;
+                    a.x += ssum[c2][0]; a.y += ssum[c2][1]; a.z += ssum[c2][2]; a.w += ssum[c2][3];
+                    b.x += ssq[c2][0]; b.y += ssq[c2][1]; b.z += ssq[c2][2]; b.w += ssq[c2][3];
+                    *ps = a;
+                    *pq = b;
+                }
             }
         }
-        __syncthreads();
+        // (no barrier here: the next tile's first LDS writes that could clash -- the refill of planes
+        //  read two chunks ago, the weight ring -- are ordered by the chunk barriers, as inside a tile)
     }
-    // one row [sum 64 | second moment 64] per block: cova_conv3x3_wino_num_partials rows, no fold pass
-    if (STATS && tid < 128) stat_part[(size_t)blockIdx.x * 128 + tid] = s_acc[tid];
+    if (STATS) {
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, ch = tid & 63;        // 0 = sum, 1 = second moment
+            const int half = ch >> 5, idx = ch & 31;
+            float tsum = 0.f;
+#pragma unroll
+            for (int g = 0; g < G::nrowgroups(); ++g) tsum += s_red[G::wave_of(half, g) * 64 + which * 32 + idx];
+            stat_part[(size_t)blockIdx.x * 128 + tid] = tsum;
+        }
+    }
+    // (one row [sum 64 | second moment 64] per block: cova_conv3x3_wino_num_partials rows, no fold pass)
 }
 
 // U[s][k][co][pos = a*4+b] = (G g G^T)[a][b] for input channel 4s+k.

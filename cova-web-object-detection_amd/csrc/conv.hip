@@ -483,13 +483,14 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
 {
     const int abl = COVA_ABL(abl_arg);
     using namespace c1;
-    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS + 8 * 128 + 128];
+    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS + 8 * 128];
     float *s_in = lds;
     float *s_w = lds + IN_FLOATS;
     float *s_red = lds + IN_FLOATS + W_FLOATS;
-    float *s_acc = s_red + 8 * 128;               // statistics of all tiles of this block: one partial row
+    // STATS: s_red[wave][128] are per-wave running totals over all tiles of this block (same lanes every
+    // tile, no barrier); the eight rows are added up once after the tile loop: one partial row per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (STATS && tid < 128) s_acc[tid] = 0.f;
+    if (STATS) { s_red[tid] = 0.f; s_red[tid + 512] = 0.f; }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // wave-uniform copy: scalar index math
     const int li = lane & 31, kh2 = lane >> 5;
     int tile = blockIdx.x;
@@ -593,23 +594,19 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
                                  oy < H1, lane, s0, s1, q0, q1);
         __syncthreads();                 // every wave is done reading the patch
         if (has_next && !(abl & 2)) write_lds();
-        if (STATS) {                      // block_stats_reduce, accumulated over the block's tiles
-            if (lane < 32) {
-                s_red[wave * 128 + lane] = s0;
-                s_red[wave * 128 + 32 + lane] = s1;
-                s_red[wave * 128 + 64 + lane] = q0;
-                s_red[wave * 128 + 96 + lane] = q1;
-            }
-            __syncthreads();
-            if (tid < 128) {
-                float t = 0.f;
-                for (int w = 0; w < 8; ++w) t += s_red[w * 128 + tid];
-                s_acc[tid] += t;
-            }
+        if (STATS && lane < 32) {
+            s_red[wave * 128 + lane] += s0;
+            s_red[wave * 128 + 32 + lane] += s1;
+            s_red[wave * 128 + 64 + lane] += q0;
+            s_red[wave * 128 + 96 + lane] += q1;
         }
         __syncthreads();
     }
-    if (STATS && tid < 128) stat_part[(size_t)blockIdx.x * 128 + tid] = s_acc[tid];
+    if (STATS && tid < 128) {            // (the loop's last barrier orders the waves' final updates)
+        float t = 0.f;
+        for (int w = 0; w < 8; ++w) t += s_red[w * 128 + tid];
+        stat_part[(size_t)blockIdx.x * 128 + tid] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
                     const float aa[4] = {o.a4[pq].x, o.a4[pq].y, o.a4[pq].z, o.a4[pq].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v = y[c2][pq][q] + adv[q];
+                        float v = ADD ? y[c2][pq][q] + adv[q] : y[c2][pq][q];     // (y + 0.f is not folded)
                         if (BN == 3) {
                             v = fmaf(msc[q], y[c2][pq][q], msh[q]);
                             if (ADD) v += adv[q];
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(G::THREADS, G::BLOCKS_PER_CU) void conv3x3_c64_wino
                             if (!(av > 0.f) || !ok[pq]) v = 0.f;
                             ssum[c2][q] += v;
                             ssq[c2][q] += v * ((zv[q] - mu[q]) * is[q]);
-                        } else {
+                        } else if (STATS) {
                             if (!ok[pq]) v = 0.f;
                             ssum[c2][q] += v;
                             ssq[c2][q] += v * v;

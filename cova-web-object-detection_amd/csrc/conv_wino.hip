@@ -772,6 +772,16 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
         if (PROD && tid >= 192 && tid < 384) s_pd[tid - 192] = prod.abc[tid - 192];
         __syncthreads();
     }
+    auto affine_regs = [&](const float4 A, const float4 Bc, const float4 Cc, float4 v, float4 w, int relu,
+                           bool useb) {
+        float4 r;      // same expression as the forward prologue (identical ReLU decisions)
+        r.x = fmaf(A.x, v.x, useb ? fmaf(Bc.x, w.x, Cc.x) : Cc.x);
+        r.y = fmaf(A.y, v.y, useb ? fmaf(Bc.y, w.y, Cc.y) : Cc.y);
+        r.z = fmaf(A.z, v.z, useb ? fmaf(Bc.z, w.z, Cc.z) : Cc.z);
+        r.w = fmaf(A.w, v.w, useb ? fmaf(Bc.w, w.w, Cc.w) : Cc.w);
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        return r;
+    };
     auto affine = [&](const float *tab, float4 v, float4 w, int c, int relu, bool useb) {
         const float4 A = *reinterpret_cast<const float4 *>(tab + c);
         const float4 Bc = *reinterpret_cast<const float4 *>(tab + 64 + c);
@@ -984,16 +994,35 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
             }
             __syncthreads();          // everyone is done with this band
             if (has_next) {
+                // every slot of this thread is the same channel quad (THREADS % 16 == 0): the affine
+                // tables are read once per band, all values are formed, then stored
+                if (PROA || PROD) {
+                    const int c = (tid & 15) * 4;
+                    if (PROA) {
+                        const float4 A = *reinterpret_cast<const float4 *>(s_pa + c);
+                        const float4 Cc = *reinterpret_cast<const float4 *>(s_pa + 128 + c);
+#pragma unroll
+                        for (int k = 0; k < kMaxD; ++k)
+                            if (tid + k * THREADS < nd_rows * PW * 16 && okd[k])
+                                rd[k] = affine_regs(A, zero4, Cc, rd[k], zero4, proa.relu, false);
+                    }
+                    if (PROD) {
+                        const bool useb = prod.in2 != nullptr;
+                        const float4 A = *reinterpret_cast<const float4 *>(s_pd + c);
+                        const float4 Bc = *reinterpret_cast<const float4 *>(s_pd + 64 + c);
+                        const float4 Cc = *reinterpret_cast<const float4 *>(s_pd + 128 + c);
+#pragma unroll
+                        for (int k = 0; k < kDy; ++k)
+                            if (okdy[k]) rdy[k] = affine_regs(A, Bc, Cc, rdy[k], rdy2[k], prod.relu, useb);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < kMaxD; ++k) {
                     const int idx = tid + k * THREADS;
-                    if (idx < nd_rows * PW * 16)
-                        stage4(s_d + (2 * tr) * PW * 64, idx, fin_d(rd[k], okd[k], idx));
+                    if (idx < nd_rows * PW * 16) stage4(s_d + (2 * tr) * PW * 64, idx, rd[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < kDy; ++k)
-                    stage4(s_dy + (2 * tr) * TW * 64, tid + k * THREADS,
-                           fin_dy(rdy[k], rdy2[k], okdy[k], tid + k * THREADS));
+                for (int k = 0; k < kDy; ++k) stage4(s_dy + (2 * tr) * TW * 64, tid + k * THREADS, rdy[k]);
             }
         }
         __syncthreads();              // the refilled tile is complete before the next tile starts

@@ -133,7 +133,9 @@ def main():
         trainer.train_step(batch)
     barrier()
     _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": [], "cova_conv3x3_wino": [],
-                    "cova_conv3x3_wino_pro": []}
+                    "cova_conv3x3_wino_pro": [], "cova_conv1_fwd": [], "cova_conv1_wgrad_poolbwd": [],
+                    "cova_conv1_wgrad": [], "cova_conv3x3_wgrad_wino_pro": [], "cova_conv3x3_wgrad_wino": [],
+                    "cova_bn_relu_maxpool_fwd": []}
     if os.environ.get("COVA_PROFILE_ALL"):          # per-entry-point HIP-event timing (diagnostic)
         _lib.PROFILE = {name: [] for name in _lib.lib().protos}
     t0 = time.perf_counter()
@@ -143,6 +145,30 @@ def main():
     dt = time.perf_counter() - t0
     prof = (_lib.PROFILE["cova_conv3x3_fwd"] + _lib.PROFILE["cova_conv3x3_dgrad_bnbwd"] +
             _lib.PROFILE["cova_conv3x3_wino"] + _lib.PROFILE["cova_conv3x3_wino_pro"])
+    def mean_ms(*names):
+        ev = [p for n in names for p in _lib.PROFILE.get(n, [])]
+        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (0.0, 0)
+
+    others = {}
+    hw = (IMG // 4) * (IMG // 4)
+    f_conv1 = 2 * 64 * 147 * args.pages * (IMG // 2) * (IMG // 2)
+    for key, names, flop, nbytes in (
+            ("conv1_7x7_fwd", ("cova_conv1_fwd",), f_conv1, 0),
+            ("conv1_7x7_wgrad_with_pool_backward", ("cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"), f_conv1, 0),
+            ("conv3x3_wgrad_winograd", ("cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino"),
+             CONV3_FLOP_PER_PIXEL * args.pages * hw, 0),
+            # reads conv1's output, writes the pooled map, its arg-max pre-activation and uint8 indices
+            ("bn_relu_maxpool_fwd", ("cova_bn_relu_maxpool_fwd",), 0,
+             args.pages * 64 * (4 * (IMG // 2) * (IMG // 2) + (4 + 4 + 1) * hw))):
+        ms, n = mean_ms(*names)
+        if n:
+            o = {"avg_launch_ms": round(ms, 4), "launches_timed": n}
+            if flop:
+                o.update(algorithmic_tflops=round(flop / ms / 1e9, 1),
+                         frac_of_f32_mfma_peak=round(flop / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 3))
+            if nbytes:
+                o.update(algorithmic_tb_per_s=round(nbytes / ms / 1e9, 2), frac_of_hbm_peak=round(nbytes / ms / 1e9 / 8.0, 3))
+            others[key] = o
     if os.environ.get("COVA_PROFILE_ALL") and rank == 0:
         rows = [(sum(a.elapsed_time(b) for a, b in v) / args.steps, len(v) // args.steps, k)
                 for k, v in _lib.PROFILE.items() if v]
@@ -212,6 +238,8 @@ def main():
                          "algorithmic_bytes": 2 * 4 * 64 * args.pages * (IMG // 4) * (IMG // 4),
                          "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
                          "flop_per_launch": flops},
+            # the other large kernels of the step, same live HIP-event timing (algorithmic FLOPs / bytes)
+            "other_kernels": others,
         }
         out["forward_only"] = {"value": round(world * args.pages * args.steps / dt_fwd, 2), "unit": "webpages/s",
                                "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),

@@ -81,9 +81,36 @@ def _arg(a):
 PROFILE = None
 
 
+def _device_of(name, args):
+    """The one ROCm device all tensor arguments live on (mixed devices are an error)."""
+    dev = None
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda:
+                raise CovaHipError("%s: got a %s tensor; the hot path runs on the ROCm device only "
+                                   "(no CPU fallback)" % (name, a.device))
+            if dev is None:
+                dev = a.device
+            elif a.device != dev:
+                raise CovaHipError("%s: tensor arguments on different devices (%s, %s)" % (name, dev, a.device))
+    return dev
+
+
 def call(name, *args, stream=None):
-    """Call a stream-taking entry point with tensors/None/scalars; raises on a non-zero status."""
+    """Call a stream-taking entry point with tensors/None/scalars; raises on a non-zero status.
+
+    The launch goes to the device the tensors live on, on THAT device's current stream: the
+    reference picks ``cuda:<-d>`` (main.py:17, evaluate.py:92) and never calls set_device, so the
+    process' current device may well be another GPU."""
     L = lib()
+    dev = _device_of(name, args)
+    if dev is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return _launch(L, name, args, stream)
+    return _launch(L, name, args, stream)
+
+
+def _launch(L, name, args, stream):
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
     prof = PROFILE.get(name) if PROFILE is not None else None

@@ -288,6 +288,35 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
     }
 }
 
+// out = act((z*scale + shift) + (z2*scale2 + shift2)): the join of a Bottleneck whose identity branch has
+// its own conv + BatchNorm (torchvision Bottleneck.forward with `downsample`); contiguous [R, C], C % 4 == 0
+__global__ __launch_bounds__(256) void bn_act2_fwd_kernel(
+    const float *__restrict__ z, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ z2, const float *__restrict__ scale2, const float *__restrict__ shift2,
+    float *__restrict__ out, long long R, int C, int relu)
+{
+    const int CV = C / 4;
+    const long long total = R * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(z + i * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(z2 + i * 4);
+        const float4 sa = *reinterpret_cast<const float4 *>(scale + c), ha = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 sb = *reinterpret_cast<const float4 *>(scale2 + c), hb = *reinterpret_cast<const float4 *>(shift2 + c);
+        float4 y;
+        y.x = fmaf(sa.x, a.x, ha.x) + fmaf(sb.x, b.x, hb.x);
+        y.y = fmaf(sa.y, a.y, ha.y) + fmaf(sb.y, b.y, hb.y);
+        y.z = fmaf(sa.z, a.z, ha.z) + fmaf(sb.z, b.z, hb.z);
+        y.w = fmaf(sa.w, a.w, ha.w) + fmaf(sb.w, b.w, hb.w);
+        if (relu) {
+            y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
+            y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = y;
+    }
+}
+
 // dz = scale * (dy - c1 - xhat*c2), dy = dout * (act > 0) if act; optional dres = dy
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
@@ -710,6 +739,20 @@ COVA_API int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const 
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_grid(R * C)), dim3(256), 0,
                            (hipStream_t)stream, z, ldz, scale, shift, res, ldres, out, ldo, R, C, relu);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// out = act(bn(z) + bn2(z2)), contiguous [R, C]
+COVA_API int cova_bn_act2_fwd(const float *z, const float *scale, const float *shift, const float *z2,
+                              const float *scale2, const float *shift2, float *out, long long R, int C,
+                              int relu, void *stream)
+{
+    COVA_REQUIRE(z && scale && shift && z2 && scale2 && shift2 && out && R > 0 && C > 0 && C % 4 == 0);
+    COVA_REQUIRE(vec4_ok(z, C) && vec4_ok(z2, C) && vec4_ok(out, C) && vec4_ok(scale, 0) && vec4_ok(shift, 0) &&
+                 vec4_ok(scale2, 0) && vec4_ok(shift2, 0));
+    hipLaunchKernelGGL(bn_act2_fwd_kernel, dim3(ew_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream, z,
+                       scale, shift, z2, scale2, shift2, out, R, C, relu);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

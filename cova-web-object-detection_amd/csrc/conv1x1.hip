@@ -1,0 +1,503 @@
+// 1x1 convolutions of the ResNet-50-stem extension (BASELINE.json configs[2] / configs[4]: the
+// representation network is torchvision resnet50 `children()[:-5]`, i.e. conv1, bn1, relu, maxpool
+// and layer1 = 3 Bottleneck blocks: 1x1 Cin->64, 3x3 64->64, 1x1 64->256, + a 1x1 64->256
+// downsample branch in block 0).  The reference itself only wires resnet18 (models.py:49); this
+// file is the build-defined extension of that call site, with the same NHWC layout and the same
+// prologue / epilogue conventions as the Winograd 3x3 kernels (conv_wino.hip):
+//
+//   out[r, co] = sum_ci f(A[ci]*in[r,ci] + B[ci]*in2[r,ci] + C[ci]) * w[co, ci]      r = pixel row
+//
+// * prologue  : BatchNorm(+ReLU) of the producer, or the BatchNorm-backward apply
+//               dz = A*dy + B*z + C, evaluated on load (the normalised map / dz is never written);
+// * epilogue  : per-channel statistics partials (sum y, sum y^2) for the train-mode BatchNorm that
+//               follows, or -- data gradient -- (+ residual-branch gradient) * ReLU mask and the
+//               BatchNorm-backward sums (sum dy, sum dy*xhat) of the layer in front.
+//
+// Implicit GEMM M = pixels, N = Cout, K = Cin on v_mfma_f32_32x32x2_f32 (exact f32).  A wave owns
+// 32 pixel rows: lane (p = lane&31, h = lane>>5) supplies row p's channels of K-half h, so its
+// operand is 128 contiguous bytes per 32-channel chunk -- loaded straight from HBM into registers
+// (8 float4), no LDS staging of activations.  K is permuted (step s of half h = channel h*Cin/2+s)
+// identically for both operands, which leaves every dot product an exact f32 FMA chain.  The
+// weight [Cout][Cin+4] stays resident in LDS for the whole persistent launch; a lane's four
+// consecutive k are one ds_read_b128 (row stride Cin+4 floats: the 16 lanes of a b128 group hit
+// 16 distinct 16-byte slots).  Output: lane owns channel n*32+p of 16 rows per accumulator, so
+// channel statistics are plain per-lane sums kept in registers across all tiles of the launch.
+//
+// Roofline bookkeeping: 2*Cin*Cout FLOP and 4*(Cin+Cout) compulsory bytes per pixel --
+// 64->256 / 256->64: 32,768 FLOP vs 1,280 B (25.6 FLOP/B: at the f32-MFMA / HBM ridge),
+// 64->64: 8,192 FLOP vs 512 B (HBM bound).
+#include "common.h"
+
+int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
+
+namespace {
+
+struct C11Args {
+    const float *in, *in2, *pro;          // pro [3][Cin] = A | B | C (nullable)
+    const float *w;                       // [Cout][Cin], or [Cin][Cout] when w_trans
+    const float *addend;                  // nullable [R][Cout]
+    const float *act;                     // mask source (act > 0), or null: fma(msc, z, msh) > 0
+    const float *msc, *msh;
+    const float *z, *mean, *invstd;       // xhat source of the BatchNorm-backward sums
+    const float *z2, *mean2, *invstd2;    // optional second xhat source (block 0's downsample BN)
+    float *out, *part, *part2;
+    long long R;
+    int pro_relu, w_trans;
+};
+
+template <int CIN, int COUT>
+struct C11Geo {
+    static constexpr int WSTR = CIN + 4;
+    static constexpr int KH = CIN / 2;                 // channels per half-wave
+    static constexpr int CHUNKS = KH / 32;             // 32-channel register chunks per half
+    static constexpr int NT = COUT / 32;               // 32-column accumulators per row tile
+    static constexpr int NTP = NT > 4 ? 4 : NT;        // accumulators per pass (register budget)
+    static constexpr int PASSES = NT / NTP;
+    static constexpr int W_FLOATS = COUT * WSTR;
+    static constexpr int RED_FLOATS = 4 * 3 * COUT;    // aliased onto the weights after the tile loop
+    static constexpr int LDS_FLOATS = W_FLOATS + 3 * CIN;
+};
+
+// PRO: 0 plain input | 1 f(A*in + C) | 2 f(A*in + B*in2 + C).  EPI: 0 store | 1 store + (sum y, sum y^2)
+// | 2 (acc + addend) * mask, (sum dy, sum dy*xhat[, sum dy*xhat2]).
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool HAS_X2>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const C11Args a)
+{
+    using G = C11Geo<CIN, COUT>;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    float *Ws = lds, *s_pro = lds + G::W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+
+    // ---- stage the weight [co][WSTR] (+ the prologue table) once per block
+    if (!a.w_trans) {
+        for (int i = tid; i < COUT * (CIN / 4); i += 256) {
+            const int co = i / (CIN / 4), c4 = i - co * (CIN / 4);
+            *reinterpret_cast<float4 *>(Ws + co * G::WSTR + 4 * c4) =
+                *reinterpret_cast<const float4 *>(a.w + (size_t)co * CIN + 4 * c4);
+        }
+    } else {
+        for (int i = tid; i < CIN * COUT; i += 256) {
+            const int ci = i / COUT, co = i - ci * COUT;
+            Ws[co * G::WSTR + ci] = a.w[i];
+        }
+    }
+    if (PRO != 0)
+        for (int i = tid; i < 3 * CIN; i += 256) s_pro[i] = a.pro[i];
+    __syncthreads();
+
+    const long long ntiles = (a.R + 31) / 32;
+    const long long stride = (long long)gridDim.x * 4;
+    float su[G::NT], sq[G::NT], sq2[G::NT];
+#pragma unroll
+    for (int n = 0; n < G::NT; ++n) su[n] = sq[n] = sq2[n] = 0.f;
+
+    // operand chunk of (tile, chunk c): 8 float4 = channels h*KH + 32c .. +31 of row tile*32 + p
+    auto issue = [&](long long tile, int c, float4 (&v)[8], float4 (&v2)[8]) {
+        long long row = tile * 32 + p;
+        if (row >= a.R) row = a.R - 1;                       // clamped: loads stay unconditional
+        const size_t o = (size_t)row * CIN + h * G::KH + c * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(a.in + o + 4 * j);
+        if (PRO == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v2[j] = *reinterpret_cast<const float4 *>(a.in2 + o + 4 * j);
+        }
+    };
+    auto prologue = [&](int c, float4 (&v)[8], const float4 (&v2)[8], float (&x)[32]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            if (PRO != 0) {
+                int ch = h * G::KH + c * 32 + 4 * j;
+                asm volatile("" : "+v"(ch));           // keep the table reads here: hoisted, they cost 96 registers
+                const float4 A = *reinterpret_cast<const float4 *>(s_pro + ch);
+                const float4 C = *reinterpret_cast<const float4 *>(s_pro + 2 * CIN + ch);
+                const float Aa[4] = {A.x, A.y, A.z, A.w}, Ca[4] = {C.x, C.y, C.z, C.w};
+                if (PRO == 2) {
+                    const float4 B = *reinterpret_cast<const float4 *>(s_pro + CIN + ch);
+                    const float Ba[4] = {B.x, B.y, B.z, B.w};
+                    const float e2[4] = {v2[j].x, v2[j].y, v2[j].z, v2[j].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = fmaf(Aa[k], e[k], fmaf(Ba[k], e2[k], Ca[k]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = fmaf(Aa[k], e[k], Ca[k]);
+                }
+                if (a.pro_relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = e[k] > 0.f ? e[k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[4 * j + k] = e[k];
+        }
+    };
+
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    float4 nv[8], nv2[8];
+    if (tile < ntiles) issue(tile, 0, nv, nv2);
+    for (; tile < ntiles; tile += stride) {
+        // With CHUNKS == 1 the operand of a tile is 32 registers and is reused by every pass; with
+        // CHUNKS == 4 (Cin = 256) there is a single pass (Cout = 64) and chunks stream through.
+        f32x16 acc[G::NT];
+#pragma unroll
+        for (int n = 0; n < G::NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < G::CHUNKS; ++c) {
+            float x[32];
+            prologue(c, nv, nv2, x);
+            // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
+            if (c + 1 < G::CHUNKS) issue(tile, c + 1, nv, nv2);
+            else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float4 b[G::NTP];
+#pragma unroll
+                    for (int n = 0; n < G::NTP; ++n)
+                        b[n] = *reinterpret_cast<const float4 *>(
+                            Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + h * G::KH + c * 32 + 4 * q);
+#pragma unroll
+                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 0], b[n].x, acc[ps * G::NTP + n]);
+#pragma unroll
+                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 1], b[n].y, acc[ps * G::NTP + n]);
+#pragma unroll
+                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 2], b[n].z, acc[ps * G::NTP + n]);
+#pragma unroll
+                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 3], b[n].w, acc[ps * G::NTP + n]);
+                }
+            }
+        }
+        // ---- epilogue: lane owns channel n*32 + p of rows mfma32_row(r, lane); 8 rows at a time so
+        // that the operands in flight (up to 4 per row) stay within the register budget
+        const long long r0 = tile * 32;
+#pragma unroll
+        for (int n = 0; n < G::NT; ++n) {
+            const int cn = n * 32 + p;
+            float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f;
+            if (EPI == 2) {
+                mu = a.mean[cn]; is = a.invstd[cn];
+                if (!MASK_ACT) { msc = a.msc[cn]; msh = a.msh[cn]; }
+                if (HAS_X2) { mu2 = a.mean2[cn]; is2 = a.invstd2[cn]; }
+            }
+#pragma unroll
+            for (int rh = 0; rh < 16; rh += 8) {
+                float ad[8], mk[8], zz[8], z2v[8];
+                if (EPI == 2) {                            // request every operand first, store last
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        long long row = r0 + mfma32_row(rh + r, lane);
+                        if (row >= a.R) row = a.R - 1;
+                        const size_t o = (size_t)row * COUT + cn;
+                        if (HAS_ADD) ad[r] = a.addend[o];
+                        if (MASK_ACT) mk[r] = a.act[o];
+                        zz[r] = a.z[o];
+                        if (HAS_X2) z2v[r] = a.z2[o];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const long long row = r0 + mfma32_row(rh + r, lane);
+                    if (row < a.R) {
+                        float v = acc[n][rh + r];
+                        if (EPI == 2) {
+                            if (HAS_ADD) v += ad[r];
+                            const float m = MASK_ACT ? mk[r] : fmaf(msc, zz[r], msh);
+                            if (!(m > 0.f)) v = 0.f;
+                            su[n] += v;
+                            sq[n] += v * ((zz[r] - mu) * is);
+                            if (HAS_X2) sq2[n] += v * ((z2v[r] - mu2) * is2);
+                        } else if (EPI == 1) {
+                            su[n] += v;
+                            sq[n] += v * v;
+                        }
+                        a.out[(size_t)row * COUT + cn] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (EPI != 0) {
+        __syncthreads();                                   // every wave is done with the weights
+        float *s_red = lds;                                // [4][3][COUT]
+#pragma unroll
+        for (int n = 0; n < G::NT; ++n) {
+            const float s0 = su[n] + __shfl_xor(su[n], 32, 64);
+            const float s1 = sq[n] + __shfl_xor(sq[n], 32, 64);
+            const float s2 = HAS_X2 ? sq2[n] + __shfl_xor(sq2[n], 32, 64) : 0.f;
+            if (h == 0) {
+                s_red[(wave * 3 + 0) * COUT + n * 32 + p] = s0;
+                s_red[(wave * 3 + 1) * COUT + n * 32 + p] = s1;
+                s_red[(wave * 3 + 2) * COUT + n * 32 + p] = s2;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * COUT; i += 256) {
+            const int which = i / COUT, c = i - which * COUT;
+            float t = 0.f;
+            for (int w = 0; w < 4; ++w) t += s_red[(w * 3 + which) * COUT + c];
+            a.part[(size_t)blockIdx.x * 2 * COUT + i] = t;
+        }
+        if (HAS_X2)
+            for (int i = tid; i < 2 * COUT; i += 256) {
+                const int which = i / COUT, c = i - which * COUT;
+                float t = 0.f;
+                for (int w = 0; w < 4; ++w) t += s_red[(w * 3 + (which ? 2 : 0)) * COUT + c];
+                a.part2[(size_t)blockIdx.x * 2 * COUT + i] = t;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient
+// dw[co][ci] = sum_r fz(dz[r,co]) * fa(act[r,ci]):  GEMM M = co, N = ci, K = pixels.  One MFMA k-step is a
+// pixel pair (half-wave h takes pixel 2s+h); lane p supplies channels {2p, 2p+1} of its 64-channel block as
+// one float2, so accumulator (i, j) holds co = 64u + 2*row + i, ci = 64v + 2*col + j.  A wave owns one
+// 64x64 unit of dw: with 4 units (256x64 / 64x256) the four waves share the pixel range, with one unit
+// (64x64) they split it and are summed through LDS.  Every block writes one fp32 partial [CO][CI]; the
+// reduce kernel folds them in fp64 (fixed order: deterministic).
+struct W11Args {
+    const float *dz, *dz2, *dz_abc;       // dz_abc [3][CO] nullable
+    const float *act, *act_abc;           // act_abc [3][CI] nullable (A | unused | C)
+    float *ws;
+    long long R;
+    int act_relu;
+};
+
+template <int CO, int CI, bool PRO_DZ, bool PRO_ACT>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const W11Args a)
+{
+    constexpr int UNITS = (CO / 64) * (CI / 64);
+    static_assert(UNITS == 1 || UNITS == 4, "64x64, 256x64 or 64x256");
+    __shared__ float s_sum[UNITS == 1 ? 4 * 4096 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int u = UNITS == 4 ? wave : 0;
+    const int cob = (CO == 256 ? u : 0) * 64, cib = (CI == 256 ? u : 0) * 64;
+
+    float zA[2] = {1.f, 1.f}, zB[2] = {0.f, 0.f}, zC[2] = {0.f, 0.f}, aA[2] = {1.f, 1.f}, aC[2] = {0.f, 0.f};
+    if (PRO_DZ) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            zA[k] = a.dz_abc[cob + 2 * p + k];
+            zB[k] = a.dz_abc[CO + cob + 2 * p + k];
+            zC[k] = a.dz_abc[2 * CO + cob + 2 * p + k];
+        }
+    }
+    if (PRO_ACT) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            aA[k] = a.act_abc[cib + 2 * p + k];
+            aC[k] = a.act_abc[2 * CI + cib + 2 * p + k];
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // pixel pairs of this block: a contiguous range; with one unit the waves interleave inside it
+    const long long npairs = (a.R + 1) / 2;
+    const long long per = (npairs + gridDim.x - 1) / gridDim.x;
+    const long long s_lo = (long long)blockIdx.x * per;
+    long long s_hi = s_lo + per;
+    if (s_hi > npairs) s_hi = npairs;
+    constexpr int U = 8;                                    // pairs in flight per wave
+    const int wstep = UNITS == 1 ? 4 : 1, woff = UNITS == 1 ? wave : 0;
+    for (long long s0 = s_lo + (long long)woff * U; s0 < s_hi; s0 += (long long)wstep * U) {
+        float2 g[U], g2[U], x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            long long row = 2 * (s0 + k) + h;
+            if (row >= a.R) row = a.R - 1;
+            g[k] = *reinterpret_cast<const float2 *>(a.dz + (size_t)row * CO + cob + 2 * p);
+            if (PRO_DZ) g2[k] = *reinterpret_cast<const float2 *>(a.dz2 + (size_t)row * CO + cob + 2 * p);
+            x[k] = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + cib + 2 * p);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const bool valid = (s0 + k) < s_hi && (2 * (s0 + k) + h) < a.R;
+            float d0 = g[k].x, d1 = g[k].y, x0 = x[k].x, x1 = x[k].y;
+            if (PRO_DZ) {
+                d0 = fmaf(zA[0], d0, fmaf(zB[0], g2[k].x, zC[0]));
+                d1 = fmaf(zA[1], d1, fmaf(zB[1], g2[k].y, zC[1]));
+            }
+            if (PRO_ACT) {
+                x0 = fmaf(aA[0], x0, aC[0]);
+                x1 = fmaf(aA[1], x1, aC[1]);
+                if (a.act_relu) { x0 = x0 > 0.f ? x0 : 0.f; x1 = x1 > 0.f ? x1 : 0.f; }
+            }
+            if (!valid) d0 = d1 = 0.f;
+            acc[0][0] = mfma32(d0, x0, acc[0][0]);
+            acc[0][1] = mfma32(d0, x1, acc[0][1]);
+            acc[1][0] = mfma32(d1, x0, acc[1][0]);
+            acc[1][1] = mfma32(d1, x1, acc[1][1]);
+        }
+    }
+    float *dst = a.ws + (size_t)blockIdx.x * CO * CI;
+    if (UNITS == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s_sum[wave * 4096 + (2 * mfma32_row(r, lane) + i) * 64 + 2 * p + j] = acc[i][j][r];
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256)
+            dst[i] = (s_sum[i] + s_sum[4096 + i]) + (s_sum[2 * 4096 + i] + s_sum[3 * 4096 + i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(size_t)(cob + 2 * mfma32_row(r, lane) + i) * CI + cib + 2 * p + j] = acc[i][j][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float *__restrict__ ws, int nparts,
+                                                                   int n, float *__restrict__ dw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nparts; ++q) s += (double)ws[(size_t)q * n + i];
+    dw[i] = (float)s;
+}
+
+template <int CIN, int COUT>
+int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_x2, int pro, int grid,
+               hipStream_t st)
+{
+#define C11_LAUNCH(PRO, EPI, ADD, MA, X2)                                                            \
+    do {                                                                                             \
+        hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, PRO, EPI, ADD, MA, X2>), dim3(grid), dim3(256), \
+                           0, st, a);                                                                \
+        return COVA_OK;                                                                              \
+    } while (0)
+    if (epi == 0) {
+        if (pro == 0) C11_LAUNCH(0, 0, false, false, false);
+        if (pro == 1) C11_LAUNCH(1, 0, false, false, false);
+        C11_LAUNCH(2, 0, false, false, false);
+    }
+    if (epi == 1) {
+        if (pro == 0) C11_LAUNCH(0, 1, false, false, false);
+        if (pro == 1) C11_LAUNCH(1, 1, false, false, false);
+        C11_LAUNCH(2, 1, false, false, false);
+    }
+    // data-gradient epilogue: always with the two-input prologue (dz = A*dy + B*z + C)
+    if (pro != 2) return COVA_ERR_BAD_ARG;
+    if (has_add) {
+        if (mask_act) {
+            if (has_x2) C11_LAUNCH(2, 2, true, true, true);
+            C11_LAUNCH(2, 2, true, true, false);
+        }
+        if (has_x2) return COVA_ERR_BAD_ARG;
+        C11_LAUNCH(2, 2, true, false, false);
+    }
+    if (has_x2) return COVA_ERR_BAD_ARG;
+    if (mask_act) C11_LAUNCH(2, 2, false, true, false);
+    C11_LAUNCH(2, 2, false, false, false);
+#undef C11_LAUNCH
+}
+
+inline int c11_grid(long long R)
+{
+    const long long ntiles = (R + 31) / 32, nb = (ntiles + 3) / 4;
+    return cova_internal_persistent_grid2(nb > (1 << 30) ? (1 << 30) : (int)nb, 2);
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+COVA_API int cova_conv1x1_num_partials(long long R, int Cin, int Cout)
+{
+    (void)Cin; (void)Cout;
+    return c11_grid(R);
+}
+
+// nn.Conv2d(Cin, Cout, 1, bias=False) on NHWC rows (torchvision Bottleneck conv1 / conv3 / downsample[0]
+// behind models.py:49-51 for the resnet50 extension), forward or -- with w_trans -- data gradient.
+// (Cin, Cout) in {(64,64), (64,256), (256,64)}.  Arguments as cova_conv3x3_wino_pro; stat_part rows =
+// cova_conv1x1_num_partials, [2][Cout] each: (sum y, sum y^2) when z == NULL, else (sum dy, sum dy*xhat);
+// stat_part2 (with z2/mean2/invstd2): (sum dy, sum dy*xhat2) of a second BatchNorm fed by the same dy.
+COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_abc, int pro_relu,
+                          const float *w, int w_trans, const float *addend, const float *act,
+                          const float *mask_scale, const float *mask_shift, const float *z,
+                          const float *mean, const float *invstd, const float *z2, const float *mean2,
+                          const float *invstd2, float *out, float *stat_part, float *stat_part2,
+                          long long R, int Cin, int Cout, void *stream)
+{
+    COVA_REQUIRE(in && w && out && R > 0);
+    COVA_REQUIRE(!in2 || pro_abc);
+    const int pro = !pro_abc ? 0 : (in2 ? 2 : 1);
+    int epi = 0;
+    if (z) {
+        COVA_REQUIRE(mean && invstd && stat_part && (act || (mask_scale && mask_shift)));
+        COVA_REQUIRE(!z2 || (mean2 && invstd2 && stat_part2));
+        epi = 2;
+    } else {
+        COVA_REQUIRE(!addend && !act && !z2);
+        epi = stat_part ? 1 : 0;
+    }
+    const C11Args a{in, in2, pro_abc, w, addend, act, mask_scale, mask_shift, z, mean, invstd, z2, mean2,
+                    invstd2, out, stat_part, stat_part2, R, pro_relu, w_trans};
+    const int grid = c11_grid(R);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = COVA_ERR_BAD_ARG;
+    if (Cin == 64 && Cout == 64) rc = launch_c11<64, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
+    else if (Cin == 64 && Cout == 256) rc = launch_c11<64, 256>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
+    else if (Cin == 256 && Cout == 64) rc = launch_c11<256, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
+    if (rc != COVA_OK) return rc;
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+COVA_API int cova_conv1x1_wgrad_workspace_floats(long long R, int Co, int Ci)
+{
+    (void)R;
+    return cova_internal_persistent_grid2(1 << 30, 2) * Co * Ci;
+}
+
+// Weight gradient of the same convolution: dw [Co][Ci] (= OIHW [Co,Ci,1,1]) = sum_r fz(dz)[r,co] * fa(act)[r,ci]
+// with fz = dz_abc[0]*dz + dz_abc[1]*dz2 + dz_abc[2] (dz_abc nullable: plain dz) and
+// fa = relu?(act_abc[0]*act + act_abc[2]) (act_abc nullable).  (Co, Ci) in {(64,64), (256,64), (64,256)}.
+COVA_API int cova_conv1x1_wgrad(const float *dz, const float *dz2, const float *dz_abc, const float *act,
+                                const float *act_abc, int act_relu, float *dw, float *ws, long long R,
+                                int Co, int Ci, void *stream)
+{
+    COVA_REQUIRE(dz && act && dw && ws && R > 0);
+    COVA_REQUIRE(!dz_abc || dz2);
+    const W11Args a{dz, dz2, dz_abc, act, act_abc, ws, R, act_relu};
+    const long long npairs = (R + 1) / 2, want = (npairs + 63) / 64;       // >= 64 pairs per block
+    int grid = cova_internal_persistent_grid2(want > (1 << 30) ? (1 << 30) : (int)want, 2);
+    hipStream_t st = (hipStream_t)stream;
+    const bool pz = dz_abc != nullptr, pa = act_abc != nullptr;
+#define W11_LAUNCH(CO, CI)                                                                                  \
+    do {                                                                                                    \
+        if (pz && pa) hipLaunchKernelGGL((conv1x1_wgrad_kernel<CO, CI, true, true>), dim3(grid), dim3(256), 0, st, a);   \
+        else if (pz) hipLaunchKernelGGL((conv1x1_wgrad_kernel<CO, CI, true, false>), dim3(grid), dim3(256), 0, st, a);   \
+        else if (pa) hipLaunchKernelGGL((conv1x1_wgrad_kernel<CO, CI, false, true>), dim3(grid), dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((conv1x1_wgrad_kernel<CO, CI, false, false>), dim3(grid), dim3(256), 0, st, a);          \
+    } while (0)
+    if (Co == 64 && Ci == 64) W11_LAUNCH(64, 64);
+    else if (Co == 256 && Ci == 64) W11_LAUNCH(256, 64);
+    else if (Co == 64 && Ci == 256) W11_LAUNCH(64, 256);
+    else return COVA_ERR_BAD_ARG;
+#undef W11_LAUNCH
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(Co * Ci, 256)), dim3(256), 0, st, ws, grid,
+                       Co * Ci, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}

@@ -25,8 +25,8 @@ struct LazyFeat {
 
 template <bool LAZY>
 __global__ __launch_bounds__(256) void roipool_fwd_kernel(
-    const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int C, int H, int W,
-    int PH, int PW, float spatial_scale, float *__restrict__ out, int ld_out,
+    const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int B, int C, int H,
+    int W, int PH, int PW, float spatial_scale, float *__restrict__ out, int ld_out,
     int32_t *__restrict__ argmax, const LazyFeat lz)
 {
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     hend = min(max(hend + rs_h, 0), H);
     wstart = min(max(wstart + rs_w, 0), W);
     wend = min(max(wend + rs_w, 0), W);
+    // a page index outside the batch (torchvision asserts / faults) reads nothing: bin = 0, argmax = -1
+    const bool bad_page = b < 0 || b >= B;
+    if (bad_page) hend = hstart;
     const bool empty = (hend <= hstart) || (wend <= wstart);
-    const float *fb = feat + (size_t)b * H * W * C;
-    const float *xb = LAZY ? lz.x + (size_t)b * H * W * C : nullptr;
+    const float *fb = feat + (size_t)(bad_page ? 0 : b) * H * W * C;
+    const float *xb = LAZY ? lz.x + (size_t)(bad_page ? 0 : b) * H * W * C : nullptr;
     for (int c = lane; c < C; c += 64) {
         float maxv = empty ? 0.f : -FLT_MAX;
         int maxi = -1;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
 
 __global__ __launch_bounds__(256) void roipool_bwd_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
-    const int32_t *__restrict__ argmax, int n_rois, int C, int H, int W, int PH, int PW,
+    const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
     float *__restrict__ gfeat)
 {
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_kernel(
     if (task >= n_rois * PH * PW) return;
     const int n = task / (PH * PW), bin = task - n * (PH * PW);
     const int b = (int)rois[5 * n];
+    if (b < 0 || b >= B) return;                 // forward wrote argmax = -1 for such boxes anyway
     float *gb = gfeat + (size_t)b * H * W * C;
     for (int c = lane; c < C; c += 64) {
         const int mi = argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_kernel(
 // Tasks (box, bin) are assigned to waves by a fixed grid-stride rule: the partial sums are deterministic.
 __global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
-    const int32_t *__restrict__ argmax, int n_rois, int C, int H, int W, int PH, int PW,
+    const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
     const float *__restrict__ act, const float *__restrict__ z, const float *__restrict__ mean,
     const float *__restrict__ invstd, float *__restrict__ gfeat, float *__restrict__ partial,
     const LazyFeat lz)
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
     }
     for (int task = blockIdx.x * 4 + wave; task < ntask; task += gridDim.x * 4) {
         const int n = task / (PH * PW), bin = task - n * (PH * PW);
-        const size_t boff = (size_t)(int)rois[5 * n] * H * W * C;
+        const int b = (int)rois[5 * n];
+        if (b < 0 || b >= B) continue;
+        const size_t boff = (size_t)b * H * W * C;
 #pragma unroll
         for (int k = 0; k < MAXCB; ++k) {
             if (k >= ncb) break;
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
     float e = -INFINITY;
     if (lane < K) {
         j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;                                 // out-of-range id: memory-safe, acts as a pad
         const float u = s[n] + (j >= 0 ? t[j] : 0.f);
         const float lr = u > 0.f ? u : slope * u;
         e = j >= 0 ? lr : -9e15f;                          // models.py:202-203
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel(
     float alpha = 0.f;
     if (lane < K) {
         j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;
         alpha = attn[(size_t)n * K + lane];
     }
     const int jj = (int)j;
@@ -364,14 +372,14 @@ __global__ __launch_bounds__(1024) void gat_bwd_att_kernel(const float *__restri
 // ====================================================================================
 // feat NHWC [B,H,W,C]; rois [N,5]; out row n at out + n*ld_out, C*PH*PW entries in the
 // reference's channel-major order; argmax [N, C*PH*PW] int32 (h*W + w, or -1)
-COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int C, int H, int W,
-                              int PH, int PW, float spatial_scale, float *out, int ld_out,
+COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, int C, int H,
+                              int W, int PH, int PW, float spatial_scale, float *out, int ld_out,
                               int32_t *argmax, void *stream)
 {
-    COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && C > 0 && PH > 0 && PW > 0);
+    COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<false>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
-                       (hipStream_t)stream, feat, rois, n_rois, C, H, W, PH, PW, spatial_scale, out,
+                       (hipStream_t)stream, feat, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out,
                        ld_out, argmax, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -380,14 +388,14 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
 // RoIPool over feat = relu(scale * z + shift + x) formed on the fly (z, x NHWC [B,H,W,C]; scale, shift
 // [C]): the last BasicBlock's bn2 + residual + ReLU without the pass that would materialise it.
 COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale,
-                                 const float *shift, const float *rois, int n_rois, int C, int H,
-                                 int W, int PH, int PW, float spatial_scale, float *out, int ld_out,
-                                 int32_t *argmax, void *stream)
+                                 const float *shift, const float *rois, int n_rois, int B, int C,
+                                 int H, int W, int PH, int PW, float spatial_scale, float *out,
+                                 int ld_out, int32_t *argmax, void *stream)
 {
-    COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && C > 0 && PH > 0 && PW > 0);
+    COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<true>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
-                       (hipStream_t)stream, z, rois, n_rois, C, H, W, PH, PW, spatial_scale, out, ld_out,
+                       (hipStream_t)stream, z, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out, ld_out,
                        argmax, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -403,7 +411,7 @@ COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, co
     if (e != hipSuccess) return (int)e;
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_bwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, C, H, W, PH, PW, gfeat);
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, gfeat);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -432,7 +440,7 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois,
     if (e != hipSuccess) return (int)e;
     const int grid = cova_roipool_bwd_bn_num_partials(n_rois, PH, PW);
     hipLaunchKernelGGL(roipool_bwd_bn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gout, ld_g,
-                       rois, argmax, n_rois, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial,
+                       rois, argmax, n_rois, B, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial,
                        LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;

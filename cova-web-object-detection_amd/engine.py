@@ -43,7 +43,7 @@ def feature_map_size(n):
 # ------------------------------------------------------------------------------- BatchNorm
 class BNState:
     """scale/shift/mean/invstd of one BatchNorm application (+ what backward needs)."""
-    __slots__ = ("scale", "shift", "mean", "invstd", "count", "C", "abc")
+    __slots__ = ("scale", "shift", "mean", "invstd", "count", "C", "abc", "frozen")
 
 
 FOLD_ABOVE, FOLD_GROUP = 256, 64
@@ -84,11 +84,14 @@ def _global_stats(partial, nparts, width, count, unit):
     return row, 1, count * STAT_SYNC.ratio[unit]
 
 
-def bn_finalize_bwd(part, nparts, C, count, dgamma, dbeta, unit, abc_from=None):
+def bn_finalize_bwd(part, nparts, C, count, dgamma, dbeta, unit, abc_from=None, frozen=False):
     """cova_bn_finalize_bwd (-> coef [2,C]) or, with ``abc_from`` = the layer's BNState,
     cova_bn_finalize_bwd_abc (-> A|B|C [3,C]).  Under SyncBN the parameter gradients come from the
     LOCAL sums (the gradient exchange adds the ranks up) and the dz coefficients from the sums and
-    the count of the whole batch (torch.nn.SyncBatchNorm's backward does the same)."""
+    the count of the whole batch (torch.nn.SyncBatchNorm's backward does the same).
+    ``frozen`` (eval-mode BatchNorm, running statistics): the layer is a fixed per-channel affine, so
+    dz = scale*dy -- the batch-coupling terms are dropped (A = scale, B = C = 0 / coef = 0) while
+    dgamma = sum dy*xhat and dbeta = sum dy keep their meaning (torch's eval-mode batch_norm backward)."""
     part, nparts = fold_partials(part, nparts, 2 * C)
     out = _empty((3 if abc_from is not None else 2, C), part)
 
@@ -104,13 +107,17 @@ def bn_finalize_bwd(part, nparts, C, count, dgamma, dbeta, unit, abc_from=None):
         gp, gn, gc = _global_stats(part, nparts, 2 * C, count, unit)
         scratch = _empty((2, C), part)
         fin(gp, gn, gc, scratch[0], scratch[1])
+    if frozen:
+        out.zero_()
+        if abc_from is not None:
+            out[0].copy_(abc_from.scale)
     return out
 
 
 def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
               update_running=True, unit="boxes"):
     st = BNState()
-    st.C, st.count = C, float(count)
+    st.C, st.count, st.frozen = C, float(count), not training
     st.abc = _empty((3, C), like)               # scale | (unused) | shift: the prologue's A | B | C
     st.scale, st.shift = st.abc[0], st.abc[2]
     st.mean, st.invstd = _empty((C,), like), _empty((C,), like)
@@ -147,7 +154,7 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
     call("cova_bn_bwd_reduce", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, R, C, part)
     dgamma = _gbuf(gout, (prefix or "") + "weight", (C,), z)
     dbeta = _gbuf(gout, (prefix or "") + "bias", (C,), z)
-    coef = bn_finalize_bwd(part, n, C, R, dgamma, dbeta, unit)
+    coef = bn_finalize_bwd(part, n, C, R, dgamma, dbeta, unit, frozen=st.frozen)
     call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
          lddz, dres, lddres, R, C)
     return dgamma, dbeta
@@ -197,29 +204,31 @@ class LazyFeature:
         self.z, self.x, self.scale, self.shift, self.shape = z, x, scale, shift, tuple(z.shape)
 
 
+def is_bottleneck(params):
+    """ResNet-50-stem extension (layer1 = 3 Bottlenecks, 256 channels) vs the reference's ResNet-18."""
+    return "convnet.4.0.conv3.weight" in params
+
+
+def prep_wino(w, like):
+    """conv3x3 OIHW weight -> Winograd-domain forward / data-gradient operands"""
+    a, b = _empty((16, 16, 4, 64), like), _empty((16, 16, 4, 64), like)
+    call("cova_conv3x3_prep_weights_wino", w, a, b)
+    return a, b
+
+
 def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
-    """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,64]  (models.py:49-51,125);
+    """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,C]  (models.py:49-51,125);
     with ``lazy_out`` (Winograd path) a LazyFeature instead of the tensor."""
     _check(images)
     B, _, H, W = images.shape
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
-    sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2)}
+    bottleneck = is_bottleneck(params)
+    if bottleneck and not (USE_WINOGRAD and FUSE_AFFINE):
+        raise RuntimeError("the resnet50 extension is built on the fused Winograd path only")
+    sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
     w1k = _empty((154, 64), images)
     call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
-    wf, wd = [], []
-    for k in CONV3_KEYS:
-        if USE_WINOGRAD:
-            a, b = _empty((16, 16, 4, 64), images), _empty((16, 16, 4, 64), images)
-            call("cova_conv3x3_prep_weights_wino", params[k + ".weight"], a, b)
-            wf.append((None, a))
-            wd.append((None, b))
-        else:
-            a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
-            call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
-            wf.append((a, None))
-            wd.append((b, None))
-    sv["wd"] = wd
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
     nt1 = query("cova_conv1_num_partials", B, H, W)
@@ -229,10 +238,33 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     p1 = _empty((B, H2, W2, C64), images)
     idx = _empty((B, H2, W2, C64), images, torch.uint8)
     # ymax = y1 at each window's arg-max: lets the last data-gradient conv take bn1's backward sums
-    ymax = _empty((B, H2, W2, C64), images) if (training and save and USE_WINOGRAD and FUSE_AFFINE) else None
+    want_ymax = save and USE_WINOGRAD and FUSE_AFFINE and (training or bottleneck)
+    ymax = _empty((B, H2, W2, C64), images) if want_ymax else None
     call("cova_bn_relu_maxpool_fwd", y1, bn1.scale, bn1.shift, p1, idx, ymax, B, H1, W1)
     sv.update(y1=y1, bn1=bn1, idx=idx, ymax=ymax)
-    # layer1: two BasicBlocks
+    if bottleneck:
+        feat = _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv)
+    else:
+        feat = _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv)
+    return feat, (sv if save else None)
+
+
+def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
+    """layer1 of ResNet-18: two BasicBlocks (the reference's backbone, models.py:49-51)"""
+    images = p1
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    wf, wd = [], []
+    for k in CONV3_KEYS:
+        if USE_WINOGRAD:
+            a, b = prep_wino(params[k + ".weight"], images)
+            wf.append((None, a))
+            wd.append((None, b))
+        else:
+            a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
+            call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
+            wf.append((a, None))
+            wd.append((b, None))
+    sv["wd"] = wd
     R = B * H2 * W2
     nt = conv3_num_tiles(B, H2, W2)
     x = p1
@@ -273,7 +305,163 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
         blocks.append(dict(x=x, z1=z1, a1=a1, z2=z2, out=out, bna=bna, bnb=bnb))
         x = out
     sv["blocks"] = blocks
-    return feat, (sv if save else None)
+    # what RoIPool's backward needs of the block that produced the feature map
+    last = blocks[1]
+    sv["last"] = dict(out=last["out"], x=last["x"], z=last["z2"], bn=last["bnb"])
+    return feat
+
+
+# ---- ResNet-50-stem extension: layer1 = 3 torchvision Bottlenecks (conv1x1 Cin->64, bn, relu, conv3x3
+# 64->64, bn, relu, conv1x1 64->256, bn, (+ downsample conv1x1 64->256 + bn in block 0), add, relu).
+# Same structure as the BasicBlock path: every BatchNorm(+ReLU) between convs is applied on load by the
+# consumer, statistics come from the producers' epilogues, the last block's output stays un-materialised.
+C256 = 4 * C64
+
+
+def conv1x1(inp, in2, abc, relu, w, w_trans, out, part, R, cin, cout, addend=None, act=None, msc=None,
+            msh=None, z=None, mean=None, invstd=None, z2=None, mean2=None, invstd2=None, part2=None):
+    call("cova_conv1x1", inp, in2, abc, 1 if relu else 0, w, 1 if w_trans else 0, addend, act, msc, msh,
+         z, mean, invstd, z2, mean2, invstd2, out, part, part2, R, cin, cout)
+
+
+def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    R = B * H2 * W2
+    nt = conv3_num_tiles(B, H2, W2)
+
+    def stats(cin, cout):
+        n = query("cova_conv1x1_num_partials", R, cin, cout)
+        return (_empty((n, 2, cout), p1) if training else None), n
+
+    def bn(prefix, C, part, n):
+        return bn_params(prefix, params, buffers, C, p1, training, part, n, R, unit="pages")
+
+    x, cin, blocks, feat = p1, C64, [], None
+    for blk in (0, 1, 2):
+        pre = "convnet.4.%d." % blk
+        s = dict(x=x, cin=cin, pre=pre)
+        part, n = stats(cin, C64)
+        s["z1"] = _empty((B, H2, W2, C64), p1)
+        conv1x1(x, None, None, 0, params[pre + "conv1.weight"], 0, s["z1"], part, R, cin, C64)
+        s["bn1"] = bn(pre + "bn1.", C64, part, n)
+        uf, s["ud"] = prep_wino(params[pre + "conv2.weight"], p1)
+        part = _empty((nt, 2, C64), p1) if training else None
+        s["z2"] = _empty((B, H2, W2, C64), p1)
+        call("cova_conv3x3_wino_pro", s["z1"], None, s["bn1"].abc, 1, uf, None, None, None, None, None, None,
+             None, s["z2"], part, B, H2, W2)
+        s["bn2"] = bn(pre + "bn2.", C64, part, nt)
+        part, n = stats(C64, C256)
+        s["z3"] = _empty((B, H2, W2, C256), p1)
+        conv1x1(s["z2"], None, s["bn2"].abc, 1, params[pre + "conv3.weight"], 0, s["z3"], part, R, C64, C256)
+        s["bn3"] = bn(pre + "bn3.", C256, part, n)
+        bn3 = s["bn3"]
+        if blk == 0:
+            part, n = stats(C64, C256)
+            s["zd"] = _empty((B, H2, W2, C256), p1)
+            conv1x1(x, None, None, 0, params[pre + "downsample.0.weight"], 0, s["zd"], part, R, C64, C256)
+            s["bnd"] = bn(pre + "downsample.1.", C256, part, n)
+            s["out"] = _empty((B, H2, W2, C256), p1)
+            call("cova_bn_act2_fwd", s["z3"], bn3.scale, bn3.shift, s["zd"], s["bnd"].scale, s["bnd"].shift,
+                 s["out"], R, C256, 1)
+            feat = s["out"]
+        elif blk == 2 and lazy_out:
+            s["out"] = None
+            feat = LazyFeature(s["z3"], x, bn3.scale, bn3.shift)
+        else:
+            s["out"] = _empty((B, H2, W2, C256), p1)
+            call("cova_bn_act_fwd", s["z3"], C256, bn3.scale, bn3.shift, x, C256, s["out"], C256, R, C256, 1)
+            feat = s["out"]
+        blocks.append(s)
+        x, cin = s["out"], C256
+    sv["blocks"] = blocks
+    last = blocks[2]
+    sv["last"] = dict(out=last["out"], x=last["x"], z=last["z3"], bn=last["bn3"])
+    return feat
+
+
+def bn_act(z, st, res=None, relu=True):
+    """relu?(bn(z) (+ res)) materialised with the same fma the fused prologues evaluate (tests, tools)."""
+    C = st.C
+    out = torch.empty_like(z)
+    call("cova_bn_act_fwd", z, C, st.scale, st.shift, res, C if res is not None else 0, out, C,
+         z.numel() // C, C, 1 if relu else 0)
+    return out
+
+
+def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
+    """Backward of the three Bottlenecks.  ``g`` = gradient w.r.t. the last block's output, already
+    ReLU-masked, ``head_part`` = (partials, rows) of its (sum g, sum g*xhat(z3)) from RoIPool's backward.
+    Returns the ReLU-masked gradient w.r.t. the max-pool output (sv['pool_part'] holds the stem's sums)."""
+    B, H, W, H1, W1, H2, W2 = sv["dims"]
+    R = B * H2 * W2
+    nt = conv3_num_tiles(B, H2, W2)
+    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
+    ws1 = _empty((query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),), g)
+    pend, pend_d = head_part, None
+    stem = sv["bn1"]
+    for blk in (2, 1, 0):
+        s = sv["blocks"][blk]
+        pre, cin, bn1, bn2, bn3 = s["pre"], s["cin"], s["bn1"], s["bn2"], s["bn3"]
+        w1, w3 = params[pre + "conv1.weight"], params[pre + "conv3.weight"]
+        dg, db, abc3 = _bn_abc_from_partials(pend[0], pend[1], bn3, R, gout, pre + "bn3.", g)
+        grads[pre + "bn3.weight"], grads[pre + "bn3.bias"] = dg, db
+        # conv3 (64->256): dz3 = abc3 . (g, z3) on load; its input a2 = relu(bn2(z2)) on load
+        dw = _gbuf(gout, pre + "conv3.weight", (C256, C64, 1, 1), g)
+        call("cova_conv1x1_wgrad", g, s["z3"], abc3, s["z2"], bn2.abc, 1, dw, ws1, R, C256, C64)
+        grads[pre + "conv3.weight"] = dw
+        n2 = query("cova_conv1x1_num_partials", R, C256, C64)
+        part = _empty((n2, 2, C64), g)
+        dy2 = _empty((B, H2, W2, C64), g)
+        conv1x1(g, s["z3"], abc3, 0, w3, 1, dy2, part, R, C256, C64, msc=bn2.scale, msh=bn2.shift,
+                z=s["z2"], mean=bn2.mean, invstd=bn2.invstd)
+        dg, db, abc2 = _bn_abc_from_partials(part, n2, bn2, R, gout, pre + "bn2.", g)
+        grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
+        # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
+        dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
+        call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
+        grads[pre + "conv2.weight"] = dw
+        dy1 = _empty((B, H2, W2, C64), g)
+        part = _empty((nt, 2, C64), g)
+        call("cova_conv3x3_wino_pro", dy2, s["z2"], abc2, 0, s["ud"], None, None, bn1.scale, bn1.shift,
+             s["z1"], bn1.mean, bn1.invstd, dy1, part, B, H2, W2)
+        dg, db, abc1 = _bn_abc_from_partials(part, nt, bn1, R, gout, pre + "bn1.", g)
+        grads[pre + "bn1.weight"], grads[pre + "bn1.bias"] = dg, db
+        # conv1 (Cin->64): dz1 = abc1 . (dy1, z1) on load
+        dw = _gbuf(gout, pre + "conv1.weight", (C64, cin, 1, 1), g)
+        call("cova_conv1x1_wgrad", dy1, s["z1"], abc1, s["x"], None, 0, dw, ws1, R, C64, cin)
+        grads[pre + "conv1.weight"] = dw
+        if blk > 0:
+            # gradient w.r.t. the previous block's output = conv1's data gradient + the identity branch,
+            # masked by that output's ReLU; (sum, sum*xhat) for its bn3 (and block 0's downsample BN)
+            prev = sv["blocks"][blk - 1]
+            n1 = query("cova_conv1x1_num_partials", R, C64, C256)
+            pnew = _empty((n1, 2, C256), g)
+            pnew_d = _empty((n1, 2, C256), g) if blk == 1 else None
+            bnd = prev.get("bnd")
+            dx = _empty((B, H2, W2, C256), g)
+            conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, pnew, R, C64, C256, addend=g, act=s["x"],
+                    z=prev["z3"], mean=prev["bn3"].mean, invstd=prev["bn3"].invstd,
+                    z2=prev["zd"] if blk == 1 else None, mean2=bnd.mean if blk == 1 else None,
+                    invstd2=bnd.invstd if blk == 1 else None, part2=pnew_d)
+            g, pend, pend_d = dx, (pnew, n1), (pnew_d, n1)
+        else:
+            bnd, wdn = s["bnd"], params[pre + "downsample.0.weight"]
+            dg, db, abcd = _bn_abc_from_partials(pend_d[0], pend_d[1], bnd, R, gout, pre + "downsample.1.", g)
+            grads[pre + "downsample.1.weight"], grads[pre + "downsample.1.bias"] = dg, db
+            dw = _gbuf(gout, pre + "downsample.0.weight", (C256, C64, 1, 1), g)
+            call("cova_conv1x1_wgrad", g, s["zd"], abcd, s["x"], None, 0, dw, ws1, R, C256, C64)
+            grads[pre + "downsample.0.weight"] = dw
+            # dp1 = conv1's + the downsample conv's data gradients, then the stem's ReLU mask (from the
+            # pooled arg-max pre-activation) and BatchNorm sums
+            t = _empty((B, H2, W2, C64), g)
+            conv1x1(dy1, s["z1"], abc1, 0, w1, 1, t, None, R, C64, C64)
+            n0 = query("cova_conv1x1_num_partials", R, C256, C64)
+            sv["pool_part"], sv["pool_npart"] = _empty((n0, 2, C64), g), n0
+            dp = _empty((B, H2, W2, C64), g)
+            conv1x1(g, s["zd"], abcd, 0, wdn, 1, dp, sv["pool_part"], R, C256, C64, addend=t,
+                    msc=stem.scale, msh=stem.shift, z=sv["ymax"], mean=stem.mean, invstd=stem.invstd)
+            g = dp
+    return g
 
 
 def block_a1(blk):
@@ -303,7 +491,7 @@ def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
     C = st.C
     dgamma = _gbuf(gout, prefix + "weight", (C,), z)
     dbeta = _gbuf(gout, prefix + "bias", (C,), z)
-    coef = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages")
+    coef = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages", frozen=st.frozen)
     call("cova_bn_bwd_apply", dy, C, None, 0, z, C, st.mean, st.invstd, st.scale, coef, dz, C, None, 0,
          R, C)
     return dgamma, dbeta
@@ -314,7 +502,7 @@ def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
     C = st.C
     dgamma = _gbuf(gout, prefix + "weight", (C,), like)
     dbeta = _gbuf(gout, prefix + "bias", (C,), like)
-    abc = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages", abc_from=st)
+    abc = bn_finalize_bwd(part, nparts, C, R, dgamma, dbeta, "pages", abc_from=st, frozen=st.frozen)
     return dgamma, dbeta, abc
 
 
@@ -371,7 +559,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         elif sv.get("ymax") is not None:
             # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
             bn1 = sv["bn1"]
-            sv["pool_part"] = _empty((nt, 2, C64), dfeat)
+            sv["pool_part"], sv["pool_npart"] = _empty((nt, 2, C64), dfeat), nt
             call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
                  bn1.scale, bn1.shift, sv["ymax"], bn1.mean, bn1.invstd, dx, sv["pool_part"], B, H2, W2)
         else:
@@ -429,25 +617,49 @@ def _layer1_bwd_unfused(sv, dfeat, gout, grads):
     return dA
 
 
-def convstack_bwd(sv, dfeat, gout=None, head_part=None):
-    """dfeat NHWC [B,Hf,Wf,64] -> {state_dict key: grad} for the 5 convs and 5 BatchNorms.
+def masked_grad_and_sums(dout, last, R):
+    """Stand-alone form of what cova_roipool_bwd_bn fuses: g = dout * (out > 0) and the partial rows of
+    (sum g, sum g*xhat(z)) for the BatchNorm in front of the feature map."""
+    st, z = last["bn"], last["z"]
+    C = st.C
+    out = last["out"] if last["out"] is not None else bn_act(z, st, last["x"])
+    n = query("cova_colreduce_num_chunks", R, C)
+    part = _empty((n, 2, C), z)
+    call("cova_bn_bwd_reduce", dout, C, out, C, z, C, st.mean, st.invstd, R, C, part)
+    g = torch.empty_like(dout)
+    zero = torch.zeros((2, C), device=z.device)
+    # coef = 0 and scale = 1 turn the apply kernel into the plain ReLU mask: dres = dout * (out > 0)
+    call("cova_bn_bwd_apply", dout, C, out, C, z, C, st.mean, st.invstd, torch.ones_like(st.scale), zero,
+         torch.empty_like(dout), C, g, C, R, C)
+    return g, (part, n)
+
+
+def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
+    """dfeat NHWC [B,Hf,Wf,C] -> {state_dict key: grad} for the convs and BatchNorms of the stack.
 
     The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
     in front of them in their epilogue (cova_conv3x3_dgrad_bnbwd), so only the last block's bn2
-    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass."""
+    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass.
+    ``params`` is needed by the resnet50 extension only (its 1x1 convs read the weights directly)."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     grads = {}
-    fused = USE_WINOGRAD and FUSE_AFFINE and sv["blocks"][0]["a1"] is None
-    if fused:
-        dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
+    if sv["kind"] == "bottleneck":
+        fused = True
+        if head_part is None:          # piecewise API (_get_visual_features): mask + sums stand-alone
+            dfeat, head_part = masked_grad_and_sums(dfeat, sv["last"], R)
+        dA = _layer1_bottleneck_bwd(sv, dfeat, params, gout, grads, head_part)
     else:
-        assert head_part is None
-        dA = _layer1_bwd_unfused(sv, dfeat, gout, grads)
+        fused = USE_WINOGRAD and FUSE_AFFINE and sv["blocks"][0]["a1"] is None
+        if fused:
+            dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
+        else:
+            assert head_part is None
+            dA = _layer1_bwd_unfused(sv, dfeat, gout, grads)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
     if fused and sv.get("pool_part") is not None:
-        part, npart = sv["pool_part"], conv3_num_tiles(B, H2, W2)
+        part, npart = sv["pool_part"], sv["pool_npart"]
     else:
         npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
         part = _empty((npart, 2, C64), dfeat)
@@ -460,10 +672,10 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None):
     if fused and sv.get("pool_part") is not None:
         # dA is already ReLU-masked (epilogue of the last data-gradient conv): the pooling/BN backward
         # apply is folded into conv1's weight-gradient kernel, dy1 is never written
-        abc = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", abc_from=bn1)
+        abc = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", abc_from=bn1, frozen=bn1.frozen)
         call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
     else:
-        coef = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages")
+        coef = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", frozen=bn1.frozen)
         dy1 = torch.empty_like(sv["y1"])
         call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
              bn1.invstd, coef, dy1, B, H1, W1)
@@ -482,10 +694,10 @@ def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
     PH, PW = roi_size
     argmax = _empty((N, C * PH * PW), bboxes, torch.int32)
     if isinstance(feat, LazyFeature):
-        call("cova_roipool_fwd_bn", feat.z, feat.x, feat.scale, feat.shift, bboxes, N, C, Hf, Wf, PH, PW,
+        call("cova_roipool_fwd_bn", feat.z, feat.x, feat.scale, feat.shift, bboxes, N, B, C, Hf, Wf, PH, PW,
              float(spatial_scale), out, ld_out, argmax)
     else:
-        call("cova_roipool_fwd", feat, bboxes, N, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
+        call("cova_roipool_fwd", feat, bboxes, N, B, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
              argmax)
     return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW))
 
@@ -499,20 +711,21 @@ def roipool_bwd(sv, gout, ld_g):
     return gfeat
 
 
-def roipool_bwd_bn(sv, gout, ld_g, last_block):
+def roipool_bwd_bn(sv, gout, ld_g, last):
     """RoIPool backward that also applies the ReLU mask of the feature map's producer
-    (out = relu(bn2(z2) + x)) and takes bn2's backward sums -> (masked gradient, (partials, count))."""
+    (out = relu(bn(z) + x)) and takes that BatchNorm's backward sums -> (masked gradient, (partials,
+    count)).  ``last`` = dict(out, x, z, bn) of the block that produced the map (out None = lazy)."""
     B, Hf, Wf, C = sv["shape"]
     PH, PW = sv["roi"]
     n = sv["bboxes"].shape[0]
     gfeat = _empty((B, Hf, Wf, C), gout)
     npart = query("cova_roipool_bwd_bn_num_partials", n, PH, PW)
     part = _empty((npart, 2, C), gout)
-    bnb = last_block["bnb"]
-    lazy = last_block["out"] is None              # mask recomputed from (z2, x) like the forward did
+    bn = last["bn"]
+    lazy = last["out"] is None                    # mask recomputed from (z, x) like the forward did
     call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
-         last_block["out"], last_block["x"] if lazy else None, bnb.scale if lazy else None,
-         bnb.shift if lazy else None, last_block["z2"], bnb.mean, bnb.invstd, gfeat, part)
+         last["out"], last["x"] if lazy else None, bn.scale if lazy else None,
+         bn.shift if lazy else None, last["z"], bn.mean, bn.invstd, gfeat, part)
     return gfeat, (part, npart)
 
 
@@ -582,6 +795,41 @@ def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None):
     call("cova_sgemm", 0, 0, N, F, D, dWh[:, D:], 2 * D, Wj, F, dh, lddh, None, 1)
     return {prefix + "W_i.weight": dWi, prefix + "W_j.weight": dWj,
             prefix + "attention_layer.weight": daw, prefix + "attention_layer.bias": dab}
+
+
+def gat_stack_fwd(comb, T, N, F, D, ctx, params, n_heads=1, n_gat_layers=1):
+    """The reference's single GraphAttentionLayer (models.py:114) or the multi-head / stacked extension:
+    every layer concatenates its heads (hidden_dim/n_heads channels each, written side by side), layers
+    are chained; the last one writes the context columns comb[:, F:]."""
+    from .weights import gat_prefixes
+    prefixes = gat_prefixes(n_heads, n_gat_layers)
+    dh = D // n_heads
+    layers, h, ldh, fin = [], comb, T, F
+    for l, heads in enumerate(prefixes):
+        last = l == len(prefixes) - 1
+        out, ldo = (comb[:, F:], T) if last else (_empty((N, D), comb), D)
+        svs = [gat_fwd(h, ldh, N, fin, ctx, params, out[:, i * dh:], ldo, prefix=p)
+               for i, p in enumerate(heads)]
+        layers.append(dict(heads=svs, out=out))
+        h, ldh, fin = out, ldo, D
+    return layers
+
+
+def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
+    """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F]."""
+    grads = {}
+    g, ldg = dcomb[:, F:], T
+    for l in reversed(range(len(layers))):
+        heads = layers[l]["heads"]
+        dh = D // len(heads)
+        if l == 0:
+            dst, ldd, acc0 = dcomb, T, True
+        else:
+            dst, ldd, acc0 = _empty((N, D), dcomb), D, False
+        for i, sv in enumerate(heads):
+            grads.update(gat_bwd(sv, g[:, i * dh:], ldg, params, dst, ldd, acc0 or i > 0, gout))
+        g, ldg = dst, ldd
+    return grads
 
 
 # ------------------------------------------------------------------------------- decoder
@@ -655,7 +903,7 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     """CoVA.forward (models.py:94-122) -> (logits [N,n_classes], saved-for-backward or None)."""
     N = bboxes.shape[0]
     PH, PW = cfg["roi_output_size"]
-    n_vis = C64 * PH * PW
+    n_vis = (C256 if is_bottleneck(params) else C64) * PH * PW
     Hd, A = cfg["bbox_hidden_dim"], cfg["n_additional_feat"]
     F = n_vis + Hd + A
     D = cfg["hidden_dim"] if cfg["use_context"] else 0
@@ -673,7 +921,8 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
         sv["addl"] = bn1d_fwd(additional_feats, A, N, A, "bn_additional_feat.", params, buffers,
                               training, comb[:, n_vis + Hd:], T, False)
     if D > 0:
-        sv["gat"] = gat_fwd(comb, T, N, F, context_indices, params, comb[:, F:], T)
+        sv["gat"] = gat_stack_fwd(comb, T, N, F, D, context_indices, params, cfg.get("n_heads", 1),
+                                  cfg.get("n_gat_layers", 1))
     logits, sv["dec"] = decoder_fwd(comb, N, T, params, buffers, training, cfg["drop_prob"], seeds,
                                     masks)
     return logits, (sv if save else None)
@@ -687,7 +936,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
     dcomb, grads = decoder_bwd(sv["dec"], dlogits, params, gout)
     if D > 0:
-        grads.update(gat_bwd(sv["gat"], dcomb[:, F:], T, params, dcomb, T, True, gout))
+        grads.update(gat_stack_bwd(sv["gat"], dcomb, T, N, F, D, params, gout))
     if A > 0:
         st = sv["addl"]
         dz = _empty((N, A), dcomb)
@@ -699,12 +948,13 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     if after_head is not None:
         after_head()
     conv = sv["conv"]
-    if USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None and N > 0:
-        dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["blocks"][1])
-        grads.update(convstack_bwd(conv, dfeat, gout, head_part))
+    fused = conv["kind"] == "bottleneck" or (USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None)
+    if fused and N > 0:
+        dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"])
+        grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
     else:
         dfeat = roipool_bwd(sv["roi"], dcomb, T)
-        grads.update(convstack_bwd(conv, dfeat, gout))
+        grads.update(convstack_bwd(conv, dfeat, gout, None, params))
     return grads
 
 

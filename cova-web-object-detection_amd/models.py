@@ -13,11 +13,15 @@ Everything on the device is executed by the hand-written HIP kernels behind
 parameter containers only (they give the reference's parameter names and shapes) and their own
 ``forward`` is never used.  Inputs must live on a ROCm device; there is no CPU fallback.
 """
+import os
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import engine
+from .weights import backbone_channels
 
 _FIELDS = ("roi_output_size", "n_classes", "use_context", "hidden_dim", "bbox_hidden_dim",
            "n_additional_feat", "drop_prob")
@@ -33,6 +37,27 @@ class _ParamBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        raise RuntimeError("parameter container only; the conv stack runs in libcova_hip.so")
+
+
+class _ParamBottleneck(nn.Module):
+    """torchvision Bottleneck-shaped parameter holder (resnet50 layer1; extension): conv1 1x1, bn1,
+    conv2 3x3, bn2, conv3 1x1, bn3, relu, optional downsample = Sequential(conv 1x1, bn)."""
+
+    def __init__(self, cin, planes, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, 4 * planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(4 * planes)
+        self.relu = nn.ReLU(inplace=True)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, 4 * planes, 1, bias=False),
+                                            nn.BatchNorm2d(4 * planes))
 
     def forward(self, x):
         raise RuntimeError("parameter container only; the conv stack runs in libcova_hip.so")
@@ -100,13 +125,13 @@ class _VisualFn(torch.autograd.Function):
         out = torch.empty((bboxes.shape[0], model.n_visual_feat), device=images.device)
         rsv = engine.roipool_fwd(feat, bboxes, model.roi_pool.output_size,
                                  model.roi_pool.spatial_scale, out, model.n_visual_feat)
-        ctx.sv, ctx.rsv, ctx.keys, ctx.nv = sv, rsv, keys, model.n_visual_feat
+        ctx.sv, ctx.rsv, ctx.keys, ctx.nv, ctx.params = sv, rsv, keys, model.n_visual_feat, params
         return out
 
     @staticmethod
     def backward(ctx, gout):
         gfeat = engine.roipool_bwd(ctx.rsv, gout.contiguous(), ctx.nv)
-        grads = engine.convstack_bwd(ctx.sv, gfeat)
+        grads = engine.convstack_bwd(ctx.sv, gfeat, params=ctx.params)
         return (None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
 
@@ -210,10 +235,47 @@ class GraphAttentionLayer(nn.Module):
         return h_prime
 
 
+class _GATHeads(nn.Module):
+    def __init__(self, in_features, hidden_dim, n_heads):
+        super().__init__()
+        self.heads = nn.ModuleList([GraphAttentionLayer(in_features, hidden_dim // n_heads)
+                                    for _ in range(n_heads)])
+
+
+class MultiHeadGraphAttention(nn.Module):
+    """Extension (BASELINE.json configs[2], [4]; the reference has one single-head layer,
+    models.py:78-79): ``n_layers`` stacked layers, each the concatenation of ``n_heads``
+    GraphAttentionLayers of hidden_dim/n_heads channels over the same neighbour table.  Same call
+    contract as GraphAttentionLayer; the attention weights returned are the last layer's, per head
+    [N, n_heads, n_context]."""
+
+    def __init__(self, in_features, hidden_dim, n_heads, n_layers):
+        super().__init__()
+        if hidden_dim % n_heads:
+            raise ValueError("hidden_dim must be divisible by n_heads")
+        self.layers = nn.ModuleList([_GATHeads(in_features if l == 0 else hidden_dim, hidden_dim, n_heads)
+                                     for l in range(n_layers)])
+
+    def forward(self, h_i, context_indices, return_attn_wts=False):
+        h, attn = h_i, None
+        for layer in self.layers:
+            outs = [head(h, context_indices, True) for head in layer.heads]
+            h = torch.cat([o for o, _ in outs], dim=1)
+            attn = torch.stack([a for _, a in outs], dim=1)
+        return (h, attn) if return_attn_wts else h
+
+
 class CoVA(nn.Module):
     def __init__(self, roi_output_size, img_H, n_classes, use_context=True, hidden_dim=384,
-                 bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.2, class_names=None):
-        """Arguments exactly as the reference's CoVA (models.py:10-34)."""
+                 bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.2, class_names=None,
+                 backbone="resnet18", n_heads=1, n_gat_layers=1, backbone_state_dict=None):
+        """The first nine arguments exactly as the reference's CoVA (models.py:10-34; called positionally
+        at main.py:122-132).  Keyword-only-in-practice extensions, whose defaults are the reference's
+        model: ``backbone`` 'resnet18' | 'resnet50' (torchvision ``children()[:-5]`` of either),
+        ``n_heads`` / ``n_gat_layers`` (MultiHeadGraphAttention), ``backbone_state_dict`` = a torchvision
+        ResNet state_dict (or a path to one) whose conv1 / bn1 / layer1 entries initialise the stack --
+        the offline stand-in for the reference's ``pretrained=True`` download (models.py:49).
+        ``img_H`` is only used for the RoIPool scale (models.py:53-56): pages may be any H x W."""
         super(CoVA, self).__init__()
         self.n_classes = n_classes
         self.use_context = use_context
@@ -225,16 +287,25 @@ class CoVA(nn.Module):
         roi_output_size = (int(roi_output_size[0]), int(roi_output_size[1]))
 
         # ---- representation network.  ImageNet weights (models.py:49 pretrained=True) cannot be
-        # fetched offline: convs get torchvision's kaiming-normal(fan_out) init; load a reference
-        # checkpoint with load_state_dict to get trained weights.
+        # fetched offline: convs get torchvision's kaiming-normal(fan_out) init unless a torchvision
+        # state_dict is supplied (backbone_state_dict / $COVA_BACKBONE_WEIGHTS) or a reference
+        # checkpoint is loaded afterwards with load_state_dict.
         c = engine.C64
+        c_out = backbone_channels(backbone)
         conv1 = nn.Conv2d(3, c, 7, 2, 3, bias=False)
-        layer1 = nn.Sequential(_ParamBlock(c), _ParamBlock(c))
+        if backbone == "resnet18":
+            layer1 = nn.Sequential(_ParamBlock(c), _ParamBlock(c))
+        else:
+            layer1 = nn.Sequential(_ParamBottleneck(c, c, True), _ParamBottleneck(c_out, c, False),
+                                   _ParamBottleneck(c_out, c, False))
+        self.backbone = backbone
         self.convnet = nn.Sequential(conv1, nn.BatchNorm2d(c), nn.ReLU(inplace=True),
                                      nn.MaxPool2d(3, 2, 1), layer1)
         for m in self.convnet.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._init_backbone(backbone_state_dict or os.environ.get("COVA_BACKBONE_WEIGHTS"))
+        c = c_out
         # models.py:53-56 reads the output size off a dummy forward; it is a closed form
         feat_h = engine.feature_map_size(img_H)
         self.roi_pool = _RoIPoolSpec(roi_output_size, feat_h / img_H)
@@ -250,7 +321,10 @@ class CoVA(nn.Module):
             self.bn_additional_feat = lambda x: x
 
         if self.use_context:
-            self.gat = GraphAttentionLayer(self.n_feat, self.hidden_dim)
+            if n_heads == 1 and n_gat_layers == 1:
+                self.gat = GraphAttentionLayer(self.n_feat, self.hidden_dim)
+            else:
+                self.gat = MultiHeadGraphAttention(self.n_feat, self.hidden_dim, n_heads, n_gat_layers)
         self.n_total_feat = self.n_feat + (self.hidden_dim if self.use_context else 0)
         self.decoder = nn.Sequential(nn.Dropout(drop_prob),
                                      nn.Linear(self.n_total_feat, self.n_total_feat),
@@ -261,13 +335,32 @@ class CoVA(nn.Module):
         self._cfg = dict(roi_output_size=roi_output_size, n_classes=n_classes, use_context=use_context,
                          hidden_dim=hidden_dim, bbox_hidden_dim=bbox_hidden_dim,
                          n_additional_feat=n_additional_feat, drop_prob=float(drop_prob),
-                         spatial_scale=self.roi_pool.spatial_scale)
+                         spatial_scale=self.roi_pool.spatial_scale, backbone=backbone,
+                         n_heads=n_heads, n_gat_layers=n_gat_layers)
         self._param_keys = [k for k, _ in self.named_parameters()]
         self._conv_keys = [k for k in self._param_keys if k.startswith("convnet.")]
         self._bbox_keys = [k for k in self._param_keys if k.startswith("bbox_feat_encoder.")]
         self._dropout_seed, self._dropout_calls = 0x5EED, 0
         self._forced_masks = None      # parity tests inject keep-masks here
         print("Model Parameters:", sum(p.numel() for p in self.parameters() if p.requires_grad))
+
+    def _init_backbone(self, source):
+        """conv1 / bn1 / layer1 of a torchvision ResNet state_dict -> convnet.0 / .1 / .4 (keys map 1:1).
+        Without one the stack keeps its random init, which the reference never does: say so."""
+        if source is None:
+            warnings.warn("CoVA: no ImageNet weights for the %s stack (the reference downloads them, "
+                          "models.py:49); it starts from a random init.  Pass backbone_state_dict= / set "
+                          "COVA_BACKBONE_WEIGHTS to a torchvision state_dict, or load a checkpoint."
+                          % self.backbone, stacklevel=3)
+            return
+        sd = torch.load(source, map_location="cpu") if isinstance(source, (str, bytes, os.PathLike)) else source
+        mapped = {}
+        for k, v in sd.items():
+            for src, dst in (("conv1.", "0."), ("bn1.", "1."), ("layer1.", "4.")):
+                if k.startswith(src):
+                    mapped[dst + k[len(src):]] = v
+        missing = self.convnet.load_state_dict(mapped, strict=True)
+        assert not missing.missing_keys
 
     # ---------------------------------------------------------------- dropout randomness
     def seed_dropout(self, seed):

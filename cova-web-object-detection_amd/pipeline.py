@@ -102,7 +102,7 @@ def attention_rows(trainer, batch):
     _, sv = engine.model_fwd(trainer.cfg, trainer.params, trainer.buffers, batch["images"],
                              batch["bboxes"], batch["additional_feats"], batch["context_indices"],
                              False, save=True)
-    attn, ctx = sv["gat"]["attn"], batch["context_indices"]
+    attn, ctx = sv["gat"][-1]["heads"][0]["attn"], batch["context_indices"]
     N, K = ctx.shape
     out = torch.empty((N, 5 + 5 * K), dtype=torch.float32, device=attn.device)
     call("cova_attn_export_rows", batch["bboxes"], ctx, attn, batch["labels"], N, K, out)

@@ -191,11 +191,20 @@ class HotPathTrainer:
         n_pages, nc = page_start.numel() - 1, logits.shape[1]
         topk = torch.empty((n_pages, nc, k), dtype=torch.int64, device=logits.device)
         engine.call("cova_page_class_topk", logits, page_start.contiguous(), n_pages, nc, k, topk)
-        labels, correct = batch["labels"], []
-        for c in range(1, nc):          # one labelled box per class and page (README.md:17)
-            pos = torch.nonzero(labels == c).view(-1)
-            true_local = pos - page_start[:-1]
-            correct.append((topk[:, c, :] == true_local.view(-1, 1)).any(dim=1))
+        # train.py:146: the labelled box of class c is the FIRST box of that class within the page;
+        # a page without one scores False (the reference would raise an IndexError there)
+        labels = batch["labels"]
+        n_boxes = labels.numel()
+        page_of = torch.searchsorted(page_start[1:].contiguous(), torch.arange(n_boxes, device=labels.device),
+                                     right=True)
+        local = torch.arange(n_boxes, device=labels.device) - page_start[page_of]
+        correct = []
+        for c in range(1, nc):
+            first = torch.full((n_pages,), n_boxes, dtype=torch.int64, device=labels.device)
+            sel = labels == c
+            first.scatter_reduce_(0, page_of[sel], local[sel], reduce="amin")
+            has = first < n_boxes
+            correct.append(has & (topk[:, c, :] == first.view(-1, 1)).any(dim=1))
         return topk, torch.stack(correct, dim=1)
 
     @torch.no_grad()

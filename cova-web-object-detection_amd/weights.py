@@ -26,19 +26,59 @@ def _bn_entries(prefix, c):
     ]
 
 
+def backbone_channels(backbone="resnet18"):
+    """Channels of the truncated ResNet's output: layer1 of ResNet-18 keeps 64, of ResNet-50 expands to 256."""
+    if backbone == "resnet18":
+        return BACKBONE_CHANNELS
+    if backbone == "resnet50":
+        return 4 * BACKBONE_CHANNELS
+    raise ValueError("backbone must be 'resnet18' (the reference, models.py:49) or 'resnet50' (extension)")
+
+
+def gat_prefixes(n_heads=1, n_gat_layers=1):
+    """state_dict prefixes of the attention heads, [layer][head].  One single-head layer keeps the
+    reference's keys (``gat.W_i.weight`` ..., models.py:78-79,161-165); the multi-head / stacked
+    extension nests them as ``gat.layers.<l>.heads.<h>.``."""
+    if n_heads == 1 and n_gat_layers == 1:
+        return [["gat."]]
+    return [["gat.layers.%d.heads.%d." % (l, h) for h in range(n_heads)] for l in range(n_gat_layers)]
+
+
 def state_dict_spec(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
-                    bbox_hidden_dim=32, n_additional_feat=0):
-    """Ordered (key, shape) list, identical to ``reference CoVA(...).state_dict()``."""
+                    bbox_hidden_dim=32, n_additional_feat=0, backbone="resnet18", n_heads=1,
+                    n_gat_layers=1):
+    """Ordered (key, shape) list, identical to ``reference CoVA(...).state_dict()`` for the defaults.
+
+    Extensions (BASELINE.json configs[2], configs[4]; absent from the reference, defaults keep its
+    behaviour): ``backbone="resnet50"`` = torchvision resnet50 ``children()[:-5]`` (3 Bottleneck
+    blocks, 256 output channels, torchvision's key names); ``n_heads`` / ``n_gat_layers`` = several
+    GraphAttentionLayer heads of hidden_dim/n_heads channels each, concatenated, stacked n_gat_layers
+    times (layer 0 reads the n_feat own features, later layers the previous layer's hidden_dim)."""
     c = BACKBONE_CHANNELS
     spec = [("convnet.0.weight", (c, 3, 7, 7))]
     spec += _bn_entries("convnet.1.", c)
-    for blk in (0, 1):
-        p = "convnet.4.%d." % blk
-        spec.append((p + "conv1.weight", (c, c, 3, 3)))
-        spec += _bn_entries(p + "bn1.", c)
-        spec.append((p + "conv2.weight", (c, c, 3, 3)))
-        spec += _bn_entries(p + "bn2.", c)
-    n_visual = c * roi_output_size[0] * roi_output_size[1]
+    if backbone == "resnet18":
+        for blk in (0, 1):
+            p = "convnet.4.%d." % blk
+            spec.append((p + "conv1.weight", (c, c, 3, 3)))
+            spec += _bn_entries(p + "bn1.", c)
+            spec.append((p + "conv2.weight", (c, c, 3, 3)))
+            spec += _bn_entries(p + "bn2.", c)
+    else:
+        cout = backbone_channels(backbone)
+        for blk in (0, 1, 2):
+            p = "convnet.4.%d." % blk
+            cin = c if blk == 0 else cout
+            spec.append((p + "conv1.weight", (c, cin, 1, 1)))
+            spec += _bn_entries(p + "bn1.", c)
+            spec.append((p + "conv2.weight", (c, c, 3, 3)))
+            spec += _bn_entries(p + "bn2.", c)
+            spec.append((p + "conv3.weight", (cout, c, 1, 1)))
+            spec += _bn_entries(p + "bn3.", cout)
+            if blk == 0:
+                spec.append((p + "downsample.0.weight", (cout, c, 1, 1)))
+                spec += _bn_entries(p + "downsample.1.", cout)
+    n_visual = backbone_channels(backbone) * roi_output_size[0] * roi_output_size[1]
     n_feat = n_visual + bbox_hidden_dim + n_additional_feat
     if bbox_hidden_dim > 0:
         spec += [("bbox_feat_encoder.0.weight", (bbox_hidden_dim, 5)),
@@ -48,10 +88,16 @@ def state_dict_spec(roi_output_size=(3, 3), n_classes=4, use_context=True, hidde
         spec += _bn_entries("bn_additional_feat.", n_additional_feat)
     n_total = n_feat
     if use_context:
-        spec += [("gat.W_i.weight", (hidden_dim, n_feat)),
-                 ("gat.W_j.weight", (hidden_dim, n_feat)),
-                 ("gat.attention_layer.weight", (1, 2 * hidden_dim)),
-                 ("gat.attention_layer.bias", (1,))]
+        if hidden_dim % n_heads:
+            raise ValueError("hidden_dim must be divisible by n_heads")
+        dh = hidden_dim // n_heads
+        for l, heads in enumerate(gat_prefixes(n_heads, n_gat_layers)):
+            fin = n_feat if l == 0 else hidden_dim
+            for p in heads:
+                spec += [(p + "W_i.weight", (dh, fin)),
+                         (p + "W_j.weight", (dh, fin)),
+                         (p + "attention_layer.weight", (1, 2 * dh)),
+                         (p + "attention_layer.bias", (1,))]
         n_total += hidden_dim
     spec += [("decoder.1.weight", (n_total, n_total)), ("decoder.1.bias", (n_total,))]
     spec += _bn_entries("decoder.2.", n_total)

@@ -113,6 +113,29 @@ int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);
 
+/* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
+ * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.
+ * out[r,co] = sum_ci f(A[ci]*in[r,ci] + B[ci]*in2[r,ci] + C[ci]) * w[co,ci], (Cin,Cout) in {(64,64),(64,256),
+ * (256,64)}; w [Cout,Cin] row-major (= OIHW), or with w_trans [Cin,Cout] (data gradient of the conv whose
+ * weight it is).  Prologue / epilogue arguments as cova_conv3x3_wino_pro; stat_part
+ * [cova_conv1x1_num_partials][2][Cout] = (sum y, sum y^2) when z == NULL, else (sum dy, sum dy*xhat);
+ * z2/mean2/invstd2 + stat_part2: a second BatchNorm (the downsample branch) fed by the same dy. */
+int cova_conv1x1_num_partials(long long R, int Cin, int Cout);
+int cova_conv1x1(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable [3,Cin]*/,
+                 int pro_relu, const float *w, int w_trans, const float *addend /*nullable*/,
+                 const float *act /*nullable*/, const float *mask_scale /*nullable*/,
+                 const float *mask_shift /*nullable*/, const float *z /*nullable*/,
+                 const float *mean /*nullable*/, const float *invstd /*nullable*/,
+                 const float *z2 /*nullable*/, const float *mean2 /*nullable*/,
+                 const float *invstd2 /*nullable*/, float *out, float *stat_part /*nullable*/,
+                 float *stat_part2 /*nullable*/, long long R, int Cin, int Cout, void *stream);
+/* dw [Co,Ci] = sum_r (dz_abc[0]*dz + dz_abc[1]*dz2 + dz_abc[2])[r,co] * relu?(act_abc[0]*act + act_abc[2])[r,ci];
+ * (Co,Ci) in {(64,64),(256,64),(64,256)}; ws >= cova_conv1x1_wgrad_workspace_floats */
+int cova_conv1x1_wgrad_workspace_floats(long long R, int Co, int Ci);
+int cova_conv1x1_wgrad(const float *dz, const float *dz2 /*nullable*/, const float *dz_abc /*nullable [3,Co]*/,
+                       const float *act, const float *act_abc /*nullable [3,Ci]*/, int act_relu, float *dw,
+                       float *ws, long long R, int Co, int Ci, void *stream);
+
 /* ------------------------------------------------------------------ BatchNorm / ReLU / MaxPool
  * replaces: nn.BatchNorm2d / nn.BatchNorm1d (train: batch statistics + running-stat update with
  * momentum, unbiased running_var; eval: running statistics), nn.ReLU, the BasicBlock residual
@@ -134,6 +157,10 @@ int cova_bn_eval_params(const float *gamma, const float *beta, const float *runn
 int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const float *shift,
                     const float *res /*nullable*/, int ldres, float *out, int ldo, long long R, int C,
                     int relu, void *stream);
+/* out = act(bn(z) + bn2(z2)): join of a Bottleneck whose identity branch is conv + BatchNorm */
+int cova_bn_act2_fwd(const float *z, const float *scale, const float *shift, const float *z2,
+                     const float *scale2, const float *shift2, float *out, long long R, int C, int relu,
+                     void *stream);
 int cova_bn_bwd_reduce(const float *dout, int ldd, const float *act /*nullable: relu mask source*/,
                        int lda, const float *z, int ldz, const float *mean, const float *invstd,
                        long long R, int C, float *partial /*[chunks,2,C]*/, void *stream);
@@ -166,9 +193,10 @@ int cova_bn_relu_maxpool_bwd_apply(const float *dp, const uint8_t *idx, const fl
  * replaces: torchvision.ops.RoIPool(output_size, spatial_scale)(feat, rois) and its backward.
  * feat NHWC [B,H,W,C]; rois [N,5] = [batch_idx,x1,y1,x2,y2]; row n of the output (C*PH*PW
  * values, index c*PH*PW + ph*PW + pw exactly like `.view(N, n_visual_feat)` at models.py:125-127)
- * is written at out + n*ld_out so it can land directly in the concatenated feature matrix. */
-int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int C, int H, int W, int PH,
-                     int PW, float spatial_scale, float *out, int ld_out, int32_t *argmax,
+ * is written at out + n*ld_out so it can land directly in the concatenated feature matrix.
+ * Memory safety: a box whose page index is outside [0,B) pools nothing (all bins 0, argmax -1). */
+int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, int C, int H, int W,
+                     int PH, int PW, float spatial_scale, float *out, int ld_out, int32_t *argmax,
                      void *stream);
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                      int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
@@ -184,7 +212,7 @@ int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const in
                         const float *invstd, float *gfeat, float *partial, void *stream);
 /* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
 int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
-                        const float *rois, int n_rois, int C, int H, int W, int PH, int PW,
+                        const float *rois, int n_rois, int B, int C, int H, int W, int PH, int PW,
                         float spatial_scale, float *out, int ld_out, int32_t *argmax, void *stream);
 
 /* ------------------------------------------------------------------ positional encoder
@@ -203,7 +231,8 @@ int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int 
 
 /* ------------------------------------------------------------------ graph attention (models.py:171-212)
  * replaces: GraphAttentionLayer.forward after the projections: gather, score, LeakyReLU, mask,
- * softmax, weighted sum.  Wh [N,2D] = h [W_i;W_j]^T.  K <= 64. */
+ * softmax, weighted sum.  Wh [N,2D] = h [W_i;W_j]^T.  K <= 64.  Neighbour ids >= N are treated like the
+ * -1 pad (the reference's h_i_padded[context_indices] raises an index error for them). */
 int cova_gat_fwd(const float *Wh, int ldw, const float *att_w /*[2D]*/, const float *att_b /*[1]*/,
                  const int64_t *ctx /*[N,K]*/, int N, int K, int D, float slope, float *s /*[N]*/,
                  float *t /*[N]*/, float *attn /*[N,K]*/, float *hprime, int ldh, void *stream);

@@ -19,6 +19,14 @@ What is restated, and from where (all citations into /root/reference):
 * ``predictions``        train.py:53 and train.py:131-154
 * ``adam``               main.py:133-135  torch.optim.Adam(lr, weight_decay) (L2-in-grad)
 
+EXTENSIONS (BASELINE.json configs[2] and configs[4] name a ResNet-50 representation network and
+multi-head / stacked GAT layers that the reference does not contain -- it wires resnet18 and one
+single-head layer only, models.py:49,78-79): ``convnet`` also restates torchvision's resnet50
+``children()[:-5]`` (3 Bottleneck blocks) and ``gat_stack`` the build-defined multi-head /
+multi-layer composition of the reference's GraphAttentionLayer.  These are a SELF-ORACLE:
+"parity unpinned" by construction (no reference code, tests or vectors exist for them); what is
+pinned is that with the default arguments they reduce to the reference formulation above.
+
 PARITY STATUS: everything that lives in the reference's own files (bbox features, concat
 order, GAT, decoder, loss, decision rules) is pinned by tests/golden/*.npz, which were
 produced by importing the reference's models.py/train.py in the dev container
@@ -186,12 +194,27 @@ def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
 
 
 def convnet(images, sd, training, routing=None):
-    """conv1 -> bn1 -> relu -> maxpool -> layer1 (models.py:49-51); [B,3,H,W] -> [B,64,H/4,W/4].
-    ``routing`` (tests only): forced max-pool indices / ReLU gates for the backward pass."""
+    """conv1 -> bn1 -> relu -> maxpool -> layer1 (models.py:49-51); [B,3,H,W] -> [B,C,H/4,W/4].
+    ``routing`` (tests only): forced max-pool indices / ReLU gates for the backward pass.
+    ResNet-18 layer1 (the reference): 2 BasicBlocks, C = 64.  ResNet-50 layer1 (extension, selected
+    by the presence of ``convnet.4.0.conv3.weight``): 3 Bottlenecks, C = 256."""
     routing = routing or {}
     x = F.conv2d(images, sd["convnet.0.weight"], None, stride=2, padding=3)
     x = _relu(_bn(x, sd, "convnet.1.", training), routing, "gate_bn1")
     x = _MaxPool3x3s2Fn.apply(x, routing.get("pool_idx"))
+    if "convnet.4.0.conv3.weight" in sd:
+        for blk in (0, 1, 2):
+            p = "convnet.4.%d." % blk
+            idt = x
+            y = F.conv2d(x, sd[p + "conv1.weight"])
+            y = _relu(_bn(y, sd, p + "bn1.", training), routing, "gate_a1_%d" % blk)
+            y = F.conv2d(y, sd[p + "conv2.weight"], None, stride=1, padding=1)
+            y = _relu(_bn(y, sd, p + "bn2.", training), routing, "gate_a2_%d" % blk)
+            y = _bn(F.conv2d(y, sd[p + "conv3.weight"]), sd, p + "bn3.", training)
+            if p + "downsample.0.weight" in sd:
+                idt = _bn(F.conv2d(x, sd[p + "downsample.0.weight"]), sd, p + "downsample.1.", training)
+            x = _relu(y + idt, routing, "gate_out_%d" % blk)
+        return x
     for blk in (0, 1):
         p = "convnet.4.%d." % blk
         idt = x
@@ -216,18 +239,49 @@ def bbox_features_raw(bboxes):
     return torch.cat((f, asp), dim=1)
 
 
-def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False):
+def gat_prefixes(sd):
+    """[layer][head] state_dict prefixes: the reference's single ``gat.`` layer, or the extension's
+    ``gat.layers.<l>.heads.<h>.`` nesting (same rule as the product's weights.gat_prefixes)."""
+    if "gat.W_i.weight" in sd:
+        return [["gat."]]
+    layers = []
+    while "gat.layers.%d.heads.0.W_i.weight" % len(layers) in sd:
+        l, heads = len(layers), []
+        while "gat.layers.%d.heads.%d.W_i.weight" % (l, len(heads)) in sd:
+            heads.append("gat.layers.%d.heads.%d." % (l, len(heads)))
+        layers.append(heads)
+    return layers
+
+
+def gat_stack(h_i, context_indices, sd, alpha=0.2):
+    """Extension: every layer concatenates its heads' outputs (each head = the reference's
+    GraphAttentionLayer on the same neighbour table), layers are chained without a nonlinearity in
+    between (the reference layer has none after the aggregation either, models.py:206-208).
+    Returns (h' [N, hidden_dim], attention of the LAST layer's first head)."""
+    h, attn0 = h_i, None
+    for heads in gat_prefixes(sd):
+        outs = []
+        for p in heads:
+            o, a = gat(h, context_indices, sd, alpha, True, prefix=p)
+            outs.append(o)
+            if p == heads[0]:
+                attn0 = a
+        h = torch.cat(outs, dim=1)
+    return h, attn0
+
+
+def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False, prefix="gat."):
     """models.py:171-212, same operation order as the reference."""
     N, K = context_indices.shape
-    W_i, W_j = sd["gat.W_i.weight"], sd["gat.W_j.weight"]
+    W_i, W_j = sd[prefix + "W_i.weight"], sd[prefix + "W_j.weight"]
     D = W_i.shape[0]
     h_pad = torch.cat((h_i, torch.zeros((1, h_i.shape[1]), dtype=h_i.dtype)), dim=0)
     h_j = h_pad[context_indices.view(-1)].view(N, K, h_i.shape[1])
     Wh_i = F.linear(h_i, W_i)
     Wh_i_rep = Wh_i.repeat_interleave(K, dim=0).view(N, K, D)
     Wh_j = F.linear(h_j, W_j)
-    e = F.linear(torch.cat((Wh_i_rep, Wh_j), dim=2), sd["gat.attention_layer.weight"],
-                 sd["gat.attention_layer.bias"]).squeeze(2)
+    e = F.linear(torch.cat((Wh_i_rep, Wh_j), dim=2), sd[prefix + "attention_layer.weight"],
+                 sd[prefix + "attention_layer.bias"]).squeeze(2)
     e = F.leaky_relu(e, alpha)
     e = torch.where(context_indices >= 0, e, -9e15 * torch.ones_like(e))
     attn = torch.softmax(e, dim=1)
@@ -269,7 +323,7 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     own = torch.cat(parts, dim=1)                           # models.py:110
     inter = {"feat": feat, "visual": visual, "own": own}
     if cfg.get("use_context", True):
-        ctx_repr, attn = gat(own, context_indices, sd, return_attn_wts=True)
+        ctx_repr, attn = gat_stack(own, context_indices, sd)
         inter["attn"] = attn
         inter["context"] = ctx_repr
     else:
@@ -298,15 +352,16 @@ def param_keys(sd):
 
 
 def loss_and_grads(sd, images, bboxes, additional_feats, context_indices, labels, cfg,
-                   drop_masks=None, routing=None):
+                   drop_masks=None, routing=None, training=True):
     """One train-mode forward + CE(sum) + backward (train.py:47-59).  Returns
-    (loss, logits, grads{key: tensor}, sd_after) with BN running stats advanced in sd_after."""
+    (loss, logits, grads{key: tensor}, sd_after) with BN running stats advanced in sd_after.
+    ``training=False``: the same through eval-mode BatchNorm (running statistics; frozen-BN fine-tuning)."""
     work = clone_state_dict(sd)
     leaves = {}
     for k in param_keys(work):
         work[k] = work[k].clone().requires_grad_(True)
         leaves[k] = work[k]
-    logits, inter = forward(work, images, bboxes, additional_feats, context_indices, cfg, True,
+    logits, inter = forward(work, images, bboxes, additional_feats, context_indices, cfg, training,
                             drop_masks, return_intermediates=True, routing=routing)
     loss = F.cross_entropy(logits, labels, reduction="sum")
     loss.backward()

@@ -78,8 +78,14 @@ def routing_from_saved(sv):
     bn1 = conv["bn1"]
     r["gate_bn1"] = nchw(conv["y1"] * bn1.scale + bn1.shift > 0)
     for i, blk in enumerate(conv["blocks"]):
-        r["gate_a1_%d" % i] = nchw(E.block_a1(blk) > 0)
-        r["gate_out_%d" % i] = nchw(E.block_out(blk) > 0)
+        if conv["kind"] == "bottleneck":
+            r["gate_a1_%d" % i] = nchw(E.bn_act(blk["z1"], blk["bn1"]) > 0)
+            r["gate_a2_%d" % i] = nchw(E.bn_act(blk["z2"], blk["bn2"]) > 0)
+            out = blk["out"] if blk["out"] is not None else E.bn_act(blk["z3"], blk["bn3"], blk["x"])
+            r["gate_out_%d" % i] = nchw(out > 0)
+        else:
+            r["gate_a1_%d" % i] = nchw(E.block_a1(blk) > 0)
+            r["gate_out_%d" % i] = nchw(E.block_out(blk) > 0)
     n_vis, hd = sv["n_vis"], sv["Hd"]
     if hd > 0:
         r["gate_bbox"] = (sv["comb"][:, n_vis:n_vis + hd] > 0).cpu()

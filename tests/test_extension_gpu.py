@@ -1,0 +1,259 @@
+"""GPU parity tests of the extensions BASELINE.json's configs name but the reference does not contain
+(it wires resnet18 and one single-head GAT layer, models.py:49,78-79): the ResNet-50-stem representation
+network (3 Bottlenecks: 1x1 / 3x3 / 1x1 convolutions, 256 channels), multi-head / stacked graph attention,
+non-square pages (configs[4]: 1280 x 4096) and N = 300 boxes / K = 48 neighbours per page.
+
+The oracle for the new pieces is the build's own torch-CPU restatement (oracle/cova_oracle.py: SELF-ORACLE,
+parity unpinned by the reference); geometry cases on the reference's own model use the reference-pinned oracle.
+Tolerances as in test_model_gpu.py: forward 1e-4 of the tensor scale, loss 2e-4, gradients 2e-4 of each
+tensor's scale under forced routing.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cova_web_object_detection_amd import engine, synthetic, weights  # noqa: E402
+from cova_web_object_detection_amd._lib import call, query  # noqa: E402
+from cova_web_object_detection_amd.models import CoVA  # noqa: E402
+from helpers import compare_grads, margins_ok, routing_from_saved  # noqa: E402
+from oracle import cova_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def close(got, ref, tol, what):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-6))
+    assert err < tol, "%s: %.3e" % (what, err)
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 256), (256, 64)])
+@pytest.mark.parametrize("R", [1, 37, 2048, 40000 + 13])
+def test_conv1x1_forward_variants(cin, cout, R):
+    rs = np.random.RandomState(cin + cout + R)
+    x, x2 = rnd(rs, R, cin), rnd(rs, R, cin)
+    w = rnd(rs, cout, cin, scale=0.1)
+    abc = torch.stack([torch.from_numpy(rs.uniform(0.5, 1.5, cin).astype(np.float32)),
+                       rnd(rs, cin, scale=0.5), rnd(rs, cin, scale=0.3)])
+    xd, x2d, wd, abcd = x.to(DEV), x2.to(DEV), w.to(DEV), abc.to(DEV)
+    n = query("cova_conv1x1_num_partials", R, cin, cout)
+    for pro, relu, stats in ((0, 0, 1), (1, 1, 1), (1, 0, 0), (2, 0, 1), (0, 0, 0)):
+        if pro == 0:
+            a = x
+        elif pro == 1:
+            a = abc[0] * x + abc[2]
+        else:
+            a = abc[0] * x + abc[1] * x2 + abc[2]
+        if relu:
+            a = a.clamp_min(0)
+        ref = a.double() @ w.double().t()
+        out = torch.full((R, cout), 7.0, device=DEV)
+        part = torch.full((n, 2, cout), 3.0, device=DEV) if stats else None
+        engine.conv1x1(xd, x2d if pro == 2 else None, abcd if pro else None, relu, wd, 0, out, part, R, cin, cout)
+        close(out, ref, 2e-5, "conv1x1 %d->%d pro %d" % (cin, cout, pro))
+        if stats:
+            close(part[:, 0].double().sum(0), ref.sum(0), 1e-4 * max(1.0, np.sqrt(R) / 10), "sum y")
+            close(part[:, 1].double().sum(0), (ref * ref).sum(0), 1e-4, "sum y^2")
+        # transposed weight argument (the data-gradient form) gives the same product
+        out_t = torch.empty((R, cout), device=DEV)
+        engine.conv1x1(xd, x2d if pro == 2 else None, abcd if pro else None, relu, w.t().contiguous().to(DEV), 1,
+                       out_t, None, R, cin, cout)
+        assert torch.equal(out_t, out)
+
+
+@pytest.mark.parametrize("cin,cout,add,mask_act,x2", [(256, 64, False, False, False), (256, 64, True, False, False),
+                                                      (64, 256, True, True, False), (64, 256, True, True, True),
+                                                      (64, 64, False, True, False)])
+def test_conv1x1_data_gradient_epilogue(cin, cout, add, mask_act, x2):
+    rs = np.random.RandomState(11 + cin + 2 * cout + add + 3 * mask_act + 5 * x2)
+    R = 5000 + 29
+    dy, zin = rnd(rs, R, cin), rnd(rs, R, cin)
+    w = rnd(rs, cin, cout, scale=0.1)                      # forward weight of the adjoint conv: [Cin_of_this, Cout]^T
+    abc = torch.stack([rnd(rs, cin), rnd(rs, cin, scale=0.5), rnd(rs, cin, scale=0.3)])
+    addend, act, z, zb = rnd(rs, R, cout), rnd(rs, R, cout), rnd(rs, R, cout), rnd(rs, R, cout)
+    msc = torch.from_numpy(rs.uniform(-1, 1.5, cout).astype(np.float32))
+    msh = rnd(rs, cout, scale=0.3)
+    mean, invstd = rnd(rs, cout, scale=0.2), torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    mean2, invstd2 = rnd(rs, cout, scale=0.2), torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    dz = abc[0] * dy + abc[1] * zin + abc[2]
+    ref = dz.double() @ w.double()                          # w given as [Cin, Cout] + w_trans
+    if add:
+        ref = ref + addend.double()
+    m = (act > 0) if mask_act else (torch.addcmul(msh, msc, z) > 0)
+    # decisions of the fma form the kernel evaluates (addcmul on CPU is not fused): exclude the ulp-close ones
+    sure = torch.ones_like(m) if mask_act else ((msc * z + msh).abs() > 1e-5)
+    ref = ref * m
+    n = query("cova_conv1x1_num_partials", R, cin, cout)
+    out = torch.empty((R, cout), device=DEV)
+    part, part2 = torch.empty((n, 2, cout), device=DEV), (torch.empty((n, 2, cout), device=DEV) if x2 else None)
+    d = lambda t: t.to(DEV)
+    engine.conv1x1(d(dy), d(zin), d(abc), 0, d(w), 1, out, part, R, cin, cout, addend=d(addend) if add else None,
+                   act=d(act) if mask_act else None, msc=None if mask_act else d(msc), msh=None if mask_act else d(msh),
+                   z=d(z), mean=d(mean), invstd=d(invstd), z2=d(zb) if x2 else None, mean2=d(mean2) if x2 else None,
+                   invstd2=d(invstd2) if x2 else None, part2=part2)
+    got = out.cpu().double()
+    assert float(((got - ref).abs() * sure).max()) < 2e-5 * float(ref.abs().max())
+    xh = ((z - mean) * invstd).double()
+    close(part[:, 0].double().sum(0), (got).sum(0), 1e-4, "sum dy")
+    close(part[:, 1].double().sum(0), (got * xh).sum(0), 1e-4, "sum dy*xhat")
+    if x2:
+        xh2 = ((zb - mean2) * invstd2).double()
+        close(part2[:, 0].double().sum(0), got.sum(0), 1e-4, "sum dy (2)")
+        close(part2[:, 1].double().sum(0), (got * xh2).sum(0), 1e-4, "sum dy*xhat2")
+
+
+@pytest.mark.parametrize("co,ci", [(64, 64), (256, 64), (64, 256)])
+@pytest.mark.parametrize("R", [1, 2, 777, 100001])
+def test_conv1x1_weight_gradient(co, ci, R):
+    rs = np.random.RandomState(co + 3 * ci + R)
+    dy, z, act = rnd(rs, R, co), rnd(rs, R, co), rnd(rs, R, ci)
+    zabc = torch.stack([rnd(rs, co), rnd(rs, co, scale=0.5), rnd(rs, co, scale=0.3)])
+    aabc = torch.stack([torch.from_numpy(rs.uniform(0.5, 1.5, ci).astype(np.float32)), rnd(rs, ci), rnd(rs, ci, scale=0.3)])
+    ws = torch.empty(query("cova_conv1x1_wgrad_workspace_floats", R, co, ci), device=DEV)
+    d = lambda t: t.to(DEV)
+    for pz, pa, relu in ((True, True, 1), (True, False, 0), (False, True, 0), (False, False, 0)):
+        dz = (zabc[0] * dy + zabc[1] * z + zabc[2]) if pz else dy
+        a = (aabc[0] * act + aabc[2]) if pa else act
+        if relu:
+            a = a.clamp_min(0)
+        ref = dz.double().t() @ a.double()
+        dw = torch.empty((co, ci), device=DEV)
+        call("cova_conv1x1_wgrad", d(dy), d(z) if pz else None, d(zabc) if pz else None, d(act),
+             d(aabc) if pa else None, relu, dw, ws, R, co, ci)
+        close(dw, ref, 1e-4, "wgrad %dx%d" % (co, ci))
+        dw2 = torch.empty((co, ci), device=DEV)
+        call("cova_conv1x1_wgrad", d(dy), d(z) if pz else None, d(zabc) if pz else None, d(act),
+             d(aabc) if pa else None, relu, dw2, ws, R, co, ci)
+        assert torch.equal(dw, dw2)                          # fixed reduction order: bit-identical reruns
+
+
+def test_bn_act2():
+    rs = np.random.RandomState(5)
+    R, C = 1000, 256
+    z, z2 = rnd(rs, R, C), rnd(rs, R, C)
+    s, h, s2, h2 = rnd(rs, C), rnd(rs, C), rnd(rs, C), rnd(rs, C)
+    out = torch.empty((R, C), device=DEV)
+    call("cova_bn_act2_fwd", z.to(DEV), s.to(DEV), h.to(DEV), z2.to(DEV), s2.to(DEV), h2.to(DEV), out, R, C, 1)
+    close(out, ((s * z + h) + (s2 * z2 + h2)).clamp_min(0), 1e-6, "bn_act2")
+
+
+# ------------------------------------------------------------------------------------ whole model
+def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4):
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=hidden, bbox_hidden_dim=32,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(seed, logit_gain=4.0, **{k: v for k, v in cfg.items() if k != "drop_prob"},
+                                   **cfg_kw)
+    batch = synthetic.make_batch(len(boxes), img_h=img_h, img_w=img_w, boxes_per_page=boxes, context_size=cs,
+                                 seed=seed)
+    m = CoVA((3, 3), img_h, 4, True, hidden, 32, 0, 0.0, None, **cfg_kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
+    ocfg = dict(cfg)
+    # ---- eval
+    m.eval()
+    with torch.no_grad():
+        logits = m(*args)
+    ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"], batch["additional_feats"],
+                    batch["context_indices"], ocfg, False)
+    err = float((logits.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    ok = margins_ok(ref, 10 * max(err, 1e-6) * float(ref.abs().max()))
+    assert torch.equal(logits.argmax(1).cpu()[ok], ref.argmax(1)[ok])
+    # ---- train: loss, gradients under forced routing, running statistics
+    m.train()
+    logits = m(*args)
+    routing = routing_from_saved(logits.grad_fn.sv)
+    loss = F.cross_entropy(logits, batch["labels"].to(DEV), reduction="sum")
+    loss.backward()
+    loss_ref, logits_ref, grads_ref, after, _ = O.loss_and_grads(
+        sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
+        batch["labels"], ocfg, None, routing)
+    assert float((logits.detach().cpu() - logits_ref).abs().max() / logits_ref.abs().max()) < 2e-4
+    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert set(grads) == set(grads_ref)
+    compare_grads(grads, grads_ref, rtol=tight, outlier_frac=0.0)
+    for k, buf in m.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(buf) == 1
+        else:
+            close(buf, after[k], 1e-4, k)
+    return m, batch
+
+
+def test_resnet50_two_head_gat_matches_self_oracle():                # BASELINE.json configs[2] architecture
+    run_case(dict(backbone="resnet50", n_heads=2), 64, 64, [23, 31], 6, 31)
+
+
+def test_resnet50_two_head_two_layer_nonsquare():                    # configs[4] architecture, 1:3.2 page
+    run_case(dict(backbone="resnet50", n_heads=2, n_gat_layers=2), 160, 96, [40, 9], 24, 32)
+
+
+def test_multi_head_gat_on_reference_backbone():
+    run_case(dict(n_heads=4, n_gat_layers=2), 64, 64, [17, 30], 12, 33)
+
+
+def test_reference_model_on_config5_geometry():
+    """configs[4]'s geometry on the reference's own architecture (reference-pinned oracle): a long,
+    non-square page (H:W = 3.2), 300 boxes on it, K = 48 neighbours (-cs 24)."""
+    run_case(dict(), 256, 80, [300], 24, 34, hidden=384)
+
+
+def test_eval_mode_backward_uses_frozen_batchnorm():
+    """model.eval() + backward (frozen-BN fine-tuning, saliency): BatchNorm is a fixed affine map, so
+    dz = scale*dy (torch's eval-mode batch_norm backward), not the train-mode formula."""
+    for kw in (dict(), dict(backbone="resnet50", n_heads=2)):
+        cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=96, bbox_hidden_dim=32,
+                   n_additional_feat=0, drop_prob=0.0)
+        sd = weights.seeded_state_dict(41, logit_gain=4.0, **{k: v for k, v in cfg.items() if k != "drop_prob"}, **kw)
+        batch = synthetic.make_batch(2, img_h=64, boxes_per_page=[19, 26], context_size=6, seed=41)
+        m = CoVA((3, 3), 64, 4, True, 96, 32, 0, 0.0, None, **kw)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
+        logits = m(*args)
+        routing = routing_from_saved(logits.grad_fn.sv)
+        F.cross_entropy(logits, batch["labels"].to(DEV), reduction="sum").backward()
+        _, _, grads_ref, after, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
+                                                     batch["context_indices"], batch["labels"], cfg, None, routing,
+                                                     training=False)
+        compare_grads({k: p.grad for k, p in m.named_parameters()}, grads_ref, rtol=2e-4, outlier_frac=0.0)
+        for k, buf in m.named_buffers():                     # eval mode leaves the running statistics alone
+            assert torch.equal(buf.cpu(), sd[k])
+
+
+def test_full_size_long_page_train_step_properties():
+    """One train step of the reference architecture on a full-size configs[4] page (4096 x 1280, 300 boxes,
+    K = 48): finite, BatchNorm output moments, and the crop property of the conv stack against torch-CPU."""
+    H, W = 4096, 1280
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384, bbox_hidden_dim=32,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(7, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    boxes = synthetic.make_boxes_only(1, H, W, 300, 24, 7)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    images = torch.rand((1, 3, H, W), generator=g, device=DEV)
+    params = {k: sd[k].to(DEV) for k in O.param_keys(sd)}
+    buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+    logits, sv = engine.model_fwd(cfg, params, buffers, images, boxes["bboxes"].to(DEV),
+                                  boxes["additional_feats"].to(DEV), boxes["context_indices"].to(DEV), True)
+    loss, dl, pred = engine.ce_sum(logits, boxes["labels"].to(DEV))
+    grads = engine.model_bwd(sv, dl, params)
+    assert logits.shape == (300, 4) and torch.isfinite(logits).all() and torch.isfinite(loss).all()
+    for k, gk in grads.items():
+        assert torch.isfinite(gk).all(), k
+    # crop property: the top-left 64x64 corner of the feature map depends on the top-left ~300x300 pixels only
+    # when BatchNorm uses fixed (eval) statistics
+    feat, _ = engine.convstack_fwd(images, params, buffers, False, save=False)
+    crop = images[:, :, :384, :384].cpu()
+    ref = O.convnet(crop, O.clone_state_dict(sd), False)[:, :, :64, :64]
+    close(feat[0, :64, :64].permute(2, 0, 1).unsqueeze(0), ref, 1e-4, "long-page crop")
+    assert feat.shape == (1, 1024, 320, 64)

@@ -197,7 +197,7 @@ def test_roipool_matches_oracle_bit_exact():
     ref, ref_arg = O.roi_pool_argmax(feat, rois, (3, 3), 0.25)
     out = torch.full((n, 600), -5.0, device=DEV)
     arg = torch.empty((n, 576), device=DEV, dtype=torch.int32)
-    call("cova_roipool_fwd", nhwc(feat), rois.to(DEV), n, C, H, W, 3, 3, 0.25, out, 600, arg)
+    call("cova_roipool_fwd", nhwc(feat), rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out, 600, arg)
     assert torch.equal(out[:, :576].cpu(), ref.reshape(n, 576))
     assert torch.equal(arg.cpu(), ref_arg.reshape(n, 576))
     assert (out[:, 576:] == -5.0).all()
@@ -230,8 +230,8 @@ def test_roipool_matches_oracle_bit_exact():
     call("cova_bn_act_fwd", z, C, scale, shift, xres, C, fmat, C, B * H * W, C, 1)
     out_m, arg_m = torch.empty(n, 576, device=DEV), torch.empty((n, 576), device=DEV, dtype=torch.int32)
     out_l, arg_l = torch.empty(n, 576, device=DEV), torch.empty((n, 576), device=DEV, dtype=torch.int32)
-    call("cova_roipool_fwd", fmat, rois.to(DEV), n, C, H, W, 3, 3, 0.25, out_m, 576, arg_m)
-    call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, C, H, W, 3, 3, 0.25, out_l, 576, arg_l)
+    call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_m, 576, arg_m)
+    call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_l, 576, arg_l)
     assert torch.equal(out_l, out_m) and torch.equal(arg_l, arg_m)
     g_m, g_l = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
     p_m, p_l = torch.empty(npart, 2, C, device=DEV), torch.empty(npart, 2, C, device=DEV)
@@ -242,6 +242,18 @@ def test_roipool_matches_oracle_bit_exact():
     assert torch.equal(g_l == 0, g_m == 0)
     close(g_l, g_m, 1e-6, "lazy roipool bwd")
     close(p_l.sum(0), p_m.sum(0), 1e-5, "lazy roipool bwd sums")
+    # memory safety: page indices outside [0, B) pool nothing and scatter nothing
+    bad = rois.clone()
+    bad[::7, 0] = float(B + 3)
+    bad[3::11, 0] = -2.0
+    isbad = ((bad[:, 0] < 0) | (bad[:, 0] >= B))
+    out_b, arg_b = torch.empty(n, 576, device=DEV), torch.empty((n, 576), device=DEV, dtype=torch.int32)
+    call("cova_roipool_fwd", nhwc(feat), bad.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_b, 576, arg_b)
+    assert (out_b.cpu()[isbad] == 0).all() and (arg_b.cpu()[isbad] == -1).all()
+    assert torch.equal(out_b.cpu()[~isbad], ref.reshape(n, 576)[~isbad])
+    g_b = torch.empty(B, H, W, C, device=DEV)
+    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, g_b)
+    assert torch.isfinite(g_b).all()
 
 
 def test_bbox_linear():

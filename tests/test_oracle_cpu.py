@@ -135,3 +135,131 @@ def test_attention_rows_restatement_matches_reference_dump():
     K = batch["context_indices"].shape[1]
     assert np.array_equal(rows[:, :5 + 4 * K].numpy(), ref[:, :5 + 4 * K])
     np.testing.assert_allclose(rows[:, 5 + 4 * K:].numpy(), ref[:, 5 + 4 * K:], atol=1e-6)
+
+
+def _roipool_numpy(feat, rois, ph_n, pw_n, scale):
+    """Independent second formulation of torchvision 0.7.0's RoIPool: explicit window
+    loops in numpy with float32 arithmetic at every step the C code has it, written without looking at
+    oracle/roipool_ref.c's structure (bins are materialised as numpy slices, the arg-max comes from
+    np.argmax over the flattened window, which also returns the FIRST maximum in row-major order)."""
+    f32 = np.float32
+    B, C, H, W = feat.shape
+    out = np.zeros((len(rois), C, ph_n, pw_n), f32)
+    arg = np.full((len(rois), C, ph_n, pw_n), -1, np.int32)
+
+    def rnd(v):                       # C round(): half away from zero, on the float32 product
+        v = f32(v)
+        return int(np.floor(v + f32(0.5))) if v >= 0 else -int(np.floor(-v + f32(0.5)))
+
+    for n, (b, x1, y1, x2, y2) in enumerate(rois):
+        b = int(b)
+        sw, sh = rnd(f32(x1) * f32(scale)), rnd(f32(y1) * f32(scale))
+        ew, eh = rnd(f32(x2) * f32(scale)), rnd(f32(y2) * f32(scale))
+        rw, rh = max(ew - sw + 1, 1), max(eh - sh + 1, 1)
+        bh, bw = f32(rh) / f32(ph_n), f32(rw) / f32(pw_n)
+        for ph in range(ph_n):
+            hs = min(max(int(np.floor(f32(ph) * bh)) + sh, 0), H)
+            he = min(max(int(np.ceil(f32(ph + 1) * bh)) + sh, 0), H)
+            for pw in range(pw_n):
+                ws = min(max(int(np.floor(f32(pw) * bw)) + sw, 0), W)
+                we = min(max(int(np.ceil(f32(pw + 1) * bw)) + sw, 0), W)
+                if he <= hs or we <= ws:
+                    continue
+                win = feat[b, :, hs:he, ws:we].reshape(C, -1)
+                k = win.argmax(axis=1)
+                out[n, :, ph, pw] = win[np.arange(C), k]
+                arg[n, :, ph, pw] = (hs + k // (we - ws)) * W + ws + k % (we - ws)
+    return out, arg
+
+
+def test_roipool_against_independent_numpy_formulation_edge_cases():
+    """Border-crossing, negative, zero-area, inverted, sub-pixel and x.5-rounding boxes, plus tied maxima:
+    oracle/roipool_ref.c and the numpy window-loop formulation must agree bit for bit (values and argmax)."""
+    rs = np.random.RandomState(12)
+    B, C, H, W = 2, 6, 13, 17
+    feat = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    feat[0, :, 4:8, 4:8] = 1.5                       # plateau: ties -> first maximum wins
+    feat[1, 2] = np.round(feat[1, 2])                # many exact ties
+    s = 0.25
+    rois = [[0, -30, -20, 10, 14], [1, -8, -8, -2, -2], [0, 60, 40, 200, 200], [1, 66, 50, 70, 54],
+            [0, 10, 10, 10, 10], [1, 10, 10, 10.4, 10.2], [0, 30, 30, 10, 10], [1, 40, 8, 8, 40],
+            [0, 2, 2, 6, 6], [1, 6, 6, 10, 10], [0, 10, 14, 30, 18], [1, 0, 0, 67.9, 51.9],
+            [0, 0, 0, 4 * W + 40, 4 * H + 40], [1, 17.9, 13.9, 18.1, 14.1], [0, 1.99, 2.0, 2.01, 49.99],
+            [0, 16, 16, 31, 31], [0, 15.9, 15.9, 28, 28]]
+    for _ in range(200):
+        x1, y1 = rs.uniform(-20, 4 * W + 10), rs.uniform(-20, 4 * H + 10)
+        rois.append([rs.randint(0, B), x1, y1, x1 + rs.uniform(-5, 60), y1 + rs.uniform(-5, 60)])
+    for _ in range(60):                              # coordinates on the .5 rounding boundary after scaling
+        x1, y1 = 4 * rs.randint(-2, W) + 2, 4 * rs.randint(-2, H) + 2
+        rois.append([rs.randint(0, B), x1, y1, x1 + 4 * rs.randint(0, 8) + 2, y1 + 4 * rs.randint(0, 8)])
+    rois = np.asarray(rois, np.float32)
+    for size in ((3, 3), (1, 1), (2, 5)):
+        ref, ref_arg = _roipool_numpy(feat, rois, size[0], size[1], s)
+        out, arg = O.roi_pool_argmax(torch.from_numpy(feat), torch.from_numpy(rois), size, s)
+        assert np.array_equal(out.numpy(), ref)
+        assert np.array_equal(arg.numpy(), ref_arg)
+    assert (ref_arg == -1).any() and (ref_arg >= 0).any()
+
+
+def test_extension_oracle_reduces_to_reference_formulation():
+    """The multi-head / stacked GAT self-oracle with one head and one layer IS the reference's layer, and
+    the extension state_dict layout only adds keys (defaults keep the reference's 50)."""
+    from cova_web_object_detection_amd import weights
+    fx = np.load(GOLDEN + "/gat_layer.npz")
+    sd = {"gat." + k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w/")}
+    h, ctx = torch.from_numpy(fx["h"]), torch.from_numpy(fx["ctx"])
+    hp, attn = O.gat_stack(h, ctx, sd)
+    assert torch.equal(hp, O.gat(h, ctx, sd)) and np.allclose(attn.numpy(), fx["attn"], atol=1e-7, rtol=1e-5)
+    # two heads = two independent reference layers side by side; two layers = composition
+    D = sd["gat.W_i.weight"].shape[0]
+    sd2 = {}
+    for hd in (0, 1):
+        for k, v in sd.items():
+            sd2[k.replace("gat.", "gat.layers.0.heads.%d." % hd)] = v * (1.0 + hd)
+    rs = np.random.RandomState(0)
+    for k, v in sd.items():
+        shape = (D, 2 * D) if k.endswith(("W_i.weight", "W_j.weight")) else tuple(v.shape)
+        sd2[k.replace("gat.", "gat.layers.1.heads.0.")] = torch.from_numpy(rs.standard_normal(shape).astype(np.float32)) * 0.1
+    assert O.gat_prefixes(sd2) == [["gat.layers.0.heads.0.", "gat.layers.0.heads.1."], ["gat.layers.1.heads.0."]]
+    assert O.gat_prefixes(sd2)[0] == weights.gat_prefixes(2, 2)[0]
+    l0 = torch.cat([O.gat(h, ctx, sd2, prefix=p) for p in O.gat_prefixes(sd2)[0]], dim=1)
+    assert torch.equal(l0[:, :D], hp)
+    out, _ = O.gat_stack(h, ctx, sd2)
+    assert torch.equal(out, O.gat(l0, ctx, sd2, prefix="gat.layers.1.heads.0."))
+    assert len(weights.state_dict_spec()) == 50
+    r50 = dict(weights.state_dict_spec(backbone="resnet50", n_heads=2))
+    assert r50["convnet.4.0.downsample.0.weight"] == (256, 64, 1, 1) and r50["convnet.4.2.conv1.weight"] == (64, 256, 1, 1)
+    assert r50["gat.layers.0.heads.1.W_j.weight"] == (192, 2336) and r50["decoder.1.weight"] == (2720, 2720)
+
+
+def test_resnet50_oracle_wiring_is_torchvision_bottleneck():
+    """The bottleneck path of oracle.convnet against an independently assembled nn.Module graph with
+    torchvision's Bottleneck wiring (conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, (+downsample), add, relu)."""
+    import torch.nn as nn
+    from cova_web_object_detection_amd import weights
+    sd = weights.seeded_state_dict(9, backbone="resnet50")
+
+    class Bott(nn.Module):
+        def __init__(self, cin, down):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(cin, 64, 1, bias=False), nn.BatchNorm2d(64)
+            self.conv2, self.bn2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64)
+            self.conv3, self.bn3 = nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, 256, 1, bias=False), nn.BatchNorm2d(256)) if down else None
+
+        def forward(self, x):
+            o = torch.relu(self.bn1(self.conv1(x)))
+            o = torch.relu(self.bn2(self.conv2(o)))
+            o = self.bn3(self.conv3(o))
+            return torch.relu(o + (x if self.downsample is None else self.downsample(x)))
+
+    net = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1),
+                        nn.Sequential(Bott(64, True), Bott(256, False), Bott(256, False)))
+    net.load_state_dict({k[len("convnet."):]: v for k, v in sd.items() if k.startswith("convnet.")}, strict=True)
+    x = torch.rand(2, 3, 48, 80, generator=torch.Generator().manual_seed(1))
+    for training in (False, True):
+        net.train(training)
+        got = O.convnet(x, O.clone_state_dict(sd), training)
+        with torch.no_grad():
+            ref = net(x)
+        assert got.shape == (2, 256, 12, 20) and torch.allclose(got, ref, atol=1e-6, rtol=1e-5)

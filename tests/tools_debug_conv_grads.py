@@ -24,7 +24,7 @@ lg, sv = engine.model_fwd(cfg, params, buffers, *args, True)
 _, dl, _ = engine.ce_sum(lg, batch["labels"].to(dev))
 # replicate model_bwd step by step
 dcomb, grads = engine.decoder_bwd(sv["dec"], dl, params)
-grads.update(engine.gat_bwd(sv["gat"], dcomb[:, sv["F"]:], sv["T"], params, dcomb, sv["T"], True))
+grads.update(engine.gat_stack_bwd(sv["gat"], dcomb, sv["T"], sv["N"], sv["F"], sv["D"], params))
 def rel(a, b, name):
     print("%-20s rel err %.3e  (max ref %.3e)" % (name, (a - b).abs().max().item() / b.abs().max().item(), b.abs().max().item()))
 feat = engine.block_out(sv["conv"]["blocks"][1]).cpu().permute(0, 3, 1, 2)

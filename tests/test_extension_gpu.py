@@ -252,7 +252,8 @@ def test_full_size_long_page_train_step_properties():
         assert torch.isfinite(gk).all(), k
     # crop property: the top-left 64x64 corner of the feature map depends on the top-left ~300x300 pixels only
     # when BatchNorm uses fixed (eval) statistics
-    feat, _ = engine.convstack_fwd(images, params, buffers, False, save=False)
+    fresh = {k: v.to(DEV) for k, v in sd.items() if k not in params}      # the train step advanced `buffers`
+    feat, _ = engine.convstack_fwd(images, params, fresh, False, save=False)
     crop = images[:, :, :384, :384].cpu()
     ref = O.convnet(crop, O.clone_state_dict(sd), False)[:, :, :64, :64]
     close(feat[0, :64, :64].permute(2, 0, 1).unsqueeze(0), ref, 1e-4, "long-page crop")

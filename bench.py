@@ -2,84 +2,211 @@
 """Benchmark of the CoVA hot path on MI355X: webpages/s of one full training step
 (forward + CrossEntropy(sum) + backward + gradient all-reduce + Adam; train.py:42-60).
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic
-1280x1280 screenshots, 16 pages per GPU, 90 boxes per page, K = 24 DOM-window neighbours,
-ResNet-18 stem+layer1 representation network + 1-head GAT, Dropout p = 0.2, fp32.
-Inputs are device resident before the timed region.  N > 1: one process per GPU (launched by
-torch.distributed.run), every rank trains on its own 16 pages (weak scaling) and the flat
-6.5 MB gradient bucket is all-reduced over RCCL once per step.
+Workloads = BASELINE.json's configs (`--config`, numbered as the list reads, 1-based):
+  2  configs[1]  1280x1280, 16 pages/GPU, 90 boxes, K=24, ResNet-18 RN + 1-head GAT        (default; the
+                 configuration the metric is quoted on)
+  3  configs[2]  same pages, 32 pages/GPU, ResNet-50 RN + 2-head GAT                        (extension)
+  4  configs[3]  configs[1]'s model, global batch 256 = 32 pages/GPU x 8 GPUs, RCCL all-reduce
+  5  configs[4]  1280x4096 pages, 300 boxes, K=48, ResNet-50 RN + 2-head x 2-layer GAT      (extension)
+Inputs are synthetic and device resident before the timed region.  N > 1: one process per GPU; `python
+bench.py --gpus N` launches itself through torch.distributed.run when it is not already inside one.
+`--scaling weak` (default) keeps the pages per GPU fixed, `--scaling strong` fixes the GLOBAL batch
+(256 pages unless --global-pages) and splits it over the ranks.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- the dominant kernel (conv3x3 64->64 implicit GEMM on f32 MFMA): algorithmic
-                  FLOPs per launch / mean launch time measured with HIP events on the launching
-                  stream inside the timed steps, against the 157.3 TFLOP/s f32-MFMA peak.
-  cpu_baseline -- the CPU oracle (oracle/cova_oracle.py, a restatement of the reference's
-                  torch-CPU path) timed on this host on a bounded sample (2 pages per step).
+  roofline     -- the dominant kernel family (Winograd conv3x3 64->64 on exact-f32 MFMA), timed live with HIP
+                  events on the launching stream inside the timed steps.  `frac` = EXECUTED MFMA FLOP/s over
+                  the 157.3 TFLOP/s f32-MFMA peak (<= 1 by construction); the algorithmic (direct-convolution,
+                  SURVEY.md 8d) rate of the same launches is reported beside it -- Winograd F(2x2,3x3)
+                  executes 2.25x fewer multiplies, so that rate may exceed the direct-form peak.
+  step         -- whole-step FLOP accounting: algorithmic TFLOP/s, fraction of the direct-convolution MFMA
+                  ceiling, fraction of the executed-MFMA floor.
+  cpu_baseline -- the CPU oracle (oracle/cova_oracle.py, a restatement of the reference's torch-CPU path)
+                  timed on this host: 2-page and 16-page batches, forward and forward+backward+Adam, medians.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL: before the HIP runtime starts
 
-import torch  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import cova_amd  # noqa: E402,F401
-from cova_web_object_detection_amd import _lib, synthetic, weights  # noqa: E402
-from cova_web_object_detection_amd.trainer import HotPathTrainer  # noqa: E402
 
-CFG = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
-           bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.2)
-IMG, PAGES_PER_GPU, BOXES, CS = 1280, 16, 90, 12
 PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-input MFMA
-CONV3_FLOP_PER_PIXEL = 2 * 64 * 64 * 9             # SURVEY.md section 8d
+PEAK_HBM_TBS = 8.0
+WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3)
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+
+WORKLOADS = {
+    2: dict(name="configs[1]", H=1280, W=1280, pages=16, boxes=90, cs=12, backbone="resnet18", n_heads=1,
+            n_gat_layers=1, desc="ResNet-18 stem+layer1 RN + 1-head GAT"),
+    3: dict(name="configs[2]", H=1280, W=1280, pages=32, boxes=90, cs=12, backbone="resnet50", n_heads=2,
+            n_gat_layers=1, desc="ResNet-50 stem+layer1 RN + 2-head GAT (extension: not in the reference)"),
+    4: dict(name="configs[3]", H=1280, W=1280, pages=32, boxes=90, cs=12, backbone="resnet18", n_heads=1,
+            n_gat_layers=1, desc="ResNet-18 RN + 1-head GAT, global batch 256 = 32 pages/GPU at 8 GPUs"),
+    5: dict(name="configs[4]", H=4096, W=1280, pages=8, boxes=300, cs=24, backbone="resnet50", n_heads=2,
+            n_gat_layers=2, desc="long pages, ResNet-50 RN + 2-head x 2-layer GAT (extension)"),
+}
 
 
-def make_device_batch(seed, device, pages=PAGES_PER_GPU, img=IMG):
-    """Boxes / neighbour tables from the numpy generator; pixels drawn on the device (uniform
-    [0,1) like datasets.py:41-45's ToTensor output) to keep start-up short."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    images = torch.rand((pages, 3, img, img), generator=g, device=device, dtype=torch.float32)
-    boxes = synthetic.make_boxes_only(pages, img, img, BOXES, CS, seed)
-    out = {k: v.to(device) for k, v in boxes.items() if torch.is_tensor(v)}
-    out["images"] = images
+def model_cfg(wl):
+    return dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384, bbox_hidden_dim=32,
+                n_additional_feat=0, drop_prob=0.2, backbone=wl["backbone"], n_heads=wl["n_heads"],
+                n_gat_layers=wl["n_gat_layers"])
+
+
+def weight_cfg(cfg):
+    return {k: v for k, v in cfg.items() if k != "drop_prob"}
+
+
+# ------------------------------------------------------------------------------------ FLOP accounting
+def flop_model(wl):
+    """Algorithmic FLOPs per page (SURVEY.md 8d conventions: 2*MACs, W_j once per node, backward = data +
+    weight gradient except conv1 (weight only), head x3) and the part of them executed as Winograd."""
+    H1, W1 = wl["H"] // 2, wl["W"] // 2
+    px = (H1 // 2) * (W1 // 2)
+    conv1 = 2 * 64 * 147 * H1 * W1
+    c3 = 2 * 64 * 64 * 9 * px
+    if wl["backbone"] == "resnet18":
+        n3, c1x1, cfeat = 4, 0, 64
+    else:
+        n3 = 3
+        c1x1 = 2 * px * (64 * 64 + 2 * 64 * 256 + 2 * (256 * 64 + 64 * 256))
+        cfeat = 256
+    n, K, D = wl["boxes"], 2 * wl["cs"], 384
+    F = cfeat * 9 + 32
+    T = F + D
+    gat = 0
+    for l in range(wl["n_gat_layers"]):
+        fin = F if l == 0 else D
+        gat += n * (2 * fin * 2 * D + 2 * K * D)
+    head = gat + n * (2 * T * T + 2 * T * 4)
+    fwd = conv1 + n3 * c3 + c1x1 + head
+    bwd = conv1 + 2 * n3 * c3 + 2 * c1x1 + 2 * head
+    wino = 3 * n3 * c3                                  # fwd + dgrad + wgrad all run as Winograd
+    return dict(total=fwd + bwd, fwd=fwd, wino=wino, conv3_launch_per_page=c3)
+
+
+def read_traffic(kernel_key, pages):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/hbm_traffic.py writes the file)."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        e = d["kernels"][kernel_key]
+        return e["traffic_bytes_per_launch"] * pages / d["pages"], TRAFFIC_FILE
+    except Exception:
+        return None, None
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_info():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count() or 1)
+
+
+def cpu_baseline(wl, full=False):
+    """The oracle's train step (reference formulation: torch-CPU conv / batch_norm / linear, own RoIPool,
+    the [N,K,F] gather GAT) on the host cores, same synthetic generator: batches of 2 and 16
+    pages, forward-only and forward+backward+Adam, median of the timed steps."""
+    import torch
+    from oracle import cova_oracle as O
+    from cova_web_object_detection_amd import synthetic, weights
+    cfg = model_cfg(wl)
+    model, phys = cpu_info()
+    torch.set_num_threads(phys)
+    out = {"unit": "webpages/s", "cores": torch.get_num_threads(), "physical_cores": phys, "cpu_model": model,
+           "kind": "port", "statistic": "median"}
+    legs = []
+    for pages, warm, timed in ((2, 3, 5), (16, 3 if full else 1, 5 if full else 3)):
+        sd = weights.seeded_state_dict(123, **weight_cfg(cfg))
+        b = synthetic.make_boxes_only(pages, wl["H"], wl["W"], wl["boxes"], wl["cs"], 123)
+        images = torch.rand((pages, 3, wl["H"], wl["W"]), generator=torch.Generator().manual_seed(123))
+        n, T = b["bboxes"].shape[0], None
+        keys = O.param_keys(sd)
+        state = [None]
+        box = [sd]
+
+        def masks():
+            nonlocal T
+            if T is None:
+                T = box[0]["decoder.1.weight"].shape[0]
+            return [(torch.rand(n, T) > cfg["drop_prob"]).float() for _ in range(2)]
+
+        def train():
+            sd_ = box[0]
+            _, _, grads, after, _ = O.loss_and_grads(sd_, images, b["bboxes"], b["additional_feats"],
+                                                     b["context_indices"], b["labels"], cfg, masks())
+            new_p, state[0] = O.adam_reference([sd_[k] for k in keys], [grads[k] for k in keys], state[0])
+            for k, p in zip(keys, new_p):
+                after[k] = p
+            box[0] = after
+
+        def fwd():
+            with torch.no_grad():
+                O.forward(O.clone_state_dict(box[0]), images, b["bboxes"], b["additional_feats"],
+                          b["context_indices"], cfg, False)
+
+        res = {}
+        for name, fn in (("fwd_bwd_adam", train), ("fwd", fwd)):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(timed):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            res[name] = {"pages_per_s": round(pages / statistics.median(ts), 4),
+                         "s_per_step": round(statistics.median(ts), 3), "warmup": warm, "timed": timed}
+        legs.append((pages, res))
+        out["batch_%d" % pages] = res
+    out["value"] = legs[-1][1]["fwd_bwd_adam"]["pages_per_s"]
+    out["sample"] = ("%s workload (%dx%d, %d boxes, K=%d, dropout masks drawn per step), torch-CPU fp32 oracle; value = "
+                     "16-page batches, forward+backward+Adam, median of %d steps after %d warm-up; 2-page batches: "
+                     "%d after %d" % (wl["name"], wl["H"], wl["W"], wl["boxes"], 2 * wl["cs"],
+                                      legs[-1][1]["fwd"]["timed"], legs[-1][1]["fwd"]["warmup"], 5, 3))
     return out
 
 
-def cpu_baseline(steps=2):
-    """Oracle train step (forward, CE-sum, backward, Adam) on the host cores, 2 pages per step."""
-    from oracle import cova_oracle as O
-    pages = 2
-    cfg = dict(CFG, drop_prob=0.0)      # oracle takes explicit masks; p=0 costs the same FLOPs
-    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
-    sd = weights.seeded_state_dict(123, **wcfg)
-    boxes = synthetic.make_boxes_only(pages, IMG, IMG, BOXES, CS, 123)
-    images = torch.rand((pages, 3, IMG, IMG), generator=torch.Generator().manual_seed(123))
-    keys = O.param_keys(sd)
-    state = None
+# ------------------------------------------------------------------------------------ launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    def one():
-        nonlocal sd, state
-        _, _, grads, after, _ = O.loss_and_grads(sd, images, boxes["bboxes"], boxes["additional_feats"],
-                                                 boxes["context_indices"], boxes["labels"], cfg, None)
-        new_p, state = O.adam_reference([sd[k] for k in keys], [grads[k] for k in keys], state)
-        for k, p in zip(keys, new_p):
-            after[k] = p
-        sd = after
 
-    one()                                # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(pages / dt, 4), "unit": "webpages/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d steps x %d pages of the same workload (1280x1280, 90 boxes, K=24), "
-                      "torch-CPU fp32 oracle incl. Adam, %.2f s/step" % (steps, pages, dt)}
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        # code-path check on a box with fewer GPUs: ranks share devices, collectives through gloo
+        env.setdefault("COVA_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -87,20 +214,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS),
+                    help="BASELINE.json config, 1-based (default 2 = configs[1], the quoted one)")
+    ap.add_argument("--pages", type=int, default=0, help="pages per GPU (default: the config's)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-pages", type=int, default=256, help="--scaling strong: global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="3 warm-up + 5 timed steps for the 16-page leg too")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm statistics over the whole data-parallel batch (default: per rank, as DDP)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import torch
+    import cova_amd  # noqa: F401
+    from cova_web_object_detection_amd import _lib, synthetic, weights
+    from cova_web_object_detection_amd.trainer import HotPathTrainer, shard_pages
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    # Diagnostic only (code-path check of the N > 1 launch on a 1-GPU box): COVA_BENCH_BACKEND=gloo lets
-    # all ranks share cuda:0; the throughput of such a run means nothing and is labelled in `config`.
     backend = os.environ.get("COVA_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
@@ -109,17 +246,27 @@ def main():
     group = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
-    sd = weights.seeded_state_dict(123, **wcfg)
-    trainer = HotPathTrainer(CFG, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank,
+    wl = dict(WORKLOADS[args.config])
+    if args.scaling == "strong":
+        lo, hi = shard_pages(args.global_pages, rank, world)
+        pages, global_pages = hi - lo, args.global_pages
+    else:
+        pages = args.pages or wl["pages"]
+        global_pages = pages * world
+    cfg = model_cfg(wl)
+    sd = weights.seeded_state_dict(123, **weight_cfg(cfg))
+    trainer = HotPathTrainer(cfg, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank,
                              sync_bn=args.sync_bn)
-    batch = make_device_batch(123 + rank, device, args.pages)
+    g = torch.Generator(device=device).manual_seed(123 + rank)
+    batch = {k: v.to(device) for k, v in synthetic.make_boxes_only(pages, wl["H"], wl["W"], wl["boxes"], wl["cs"],
+                                                                    123 + rank).items() if torch.is_tensor(v)}
+    # pixels drawn on the device: uniform [0,1) like datasets.py:41-45's ToTensor output
+    batch["images"] = torch.rand((pages, 3, wl["H"], wl["W"]), generator=g, device=device, dtype=torch.float32)
     n_boxes = batch["bboxes"].shape[0]
 
     def barrier():
@@ -129,62 +276,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([x], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    _lib.PROFILE = {"cova_conv3x3_fwd": [], "cova_conv3x3_dgrad_bnbwd": [], "cova_conv3x3_wino": [],
-                    "cova_conv3x3_wino_pro": [], "cova_conv1_fwd": [], "cova_conv1_wgrad_poolbwd": [],
-                    "cova_conv1_wgrad": [], "cova_conv3x3_wgrad_wino_pro": [], "cova_conv3x3_wgrad_wino": [],
-                    "cova_bn_relu_maxpool_fwd": []}
-    if os.environ.get("COVA_PROFILE_ALL"):          # per-entry-point HIP-event timing (diagnostic)
-        _lib.PROFILE = {name: [] for name in _lib.lib().protos}
+    timed = ["cova_conv3x3_wino", "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
+             "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad", "cova_bn_relu_maxpool_fwd",
+             "cova_conv1x1", "cova_conv1x1_wgrad", "cova_bn_act_fwd", "cova_bn_act2_fwd", "cova_roipool_fwd_bn",
+             "cova_roipool_bwd_bn", "cova_sgemm", "cova_gat_fwd", "cova_gat_bwd"]
+    _lib.PROFILE = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else timed)}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    prof = (_lib.PROFILE["cova_conv3x3_fwd"] + _lib.PROFILE["cova_conv3x3_dgrad_bnbwd"] +
-            _lib.PROFILE["cova_conv3x3_wino"] + _lib.PROFILE["cova_conv3x3_wino_pro"])
-    def mean_ms(*names):
-        ev = [p for n in names for p in _lib.PROFILE.get(n, [])]
-        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (0.0, 0)
-
-    others = {}
-    hw = (IMG // 4) * (IMG // 4)
-    f_conv1 = 2 * 64 * 147 * args.pages * (IMG // 2) * (IMG // 2)
-    for key, names, flop, nbytes in (
-            ("conv1_7x7_fwd", ("cova_conv1_fwd",), f_conv1, 0),
-            ("conv1_7x7_wgrad_with_pool_backward", ("cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"), f_conv1, 0),
-            ("conv3x3_wgrad_winograd", ("cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino"),
-             CONV3_FLOP_PER_PIXEL * args.pages * hw, 0),
-            # reads conv1's output, writes the pooled map, its arg-max pre-activation and uint8 indices
-            ("bn_relu_maxpool_fwd", ("cova_bn_relu_maxpool_fwd",), 0,
-             args.pages * 64 * (4 * (IMG // 2) * (IMG // 2) + (4 + 4 + 1) * hw))):
-        ms, n = mean_ms(*names)
-        if n:
-            o = {"avg_launch_ms": round(ms, 4), "launches_timed": n}
-            if flop:
-                o.update(algorithmic_tflops=round(flop / ms / 1e9, 1),
-                         frac_of_f32_mfma_peak=round(flop / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 3))
-            if nbytes:
-                o.update(algorithmic_tb_per_s=round(nbytes / ms / 1e9, 2), frac_of_hbm_peak=round(nbytes / ms / 1e9 / 8.0, 3))
-            others[key] = o
-    if os.environ.get("COVA_PROFILE_ALL") and rank == 0:
-        rows = [(sum(a.elapsed_time(b) for a, b in v) / args.steps, len(v) // args.steps, k)
-                for k, v in _lib.PROFILE.items() if v]
-        for ms, n, k in sorted(rows, reverse=True):
-            print("%-36s %3d calls/step %8.3f ms/step" % (k, n, ms), file=sys.stderr)
-        print("sum %.3f ms/step" % sum(r[0] for r in rows), file=sys.stderr)
-    _lib.PROFILE = None
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    prof, _lib.PROFILE = _lib.PROFILE, None
+    dt = max_over_ranks(dt)
     loss_val = float(loss.item())
 
-    # forward only (eval mode, running statistics): the second number SURVEY.md section 8d asks for.
-    # Not the metric; reported as an extra object.
+    def mean_ms(names, pred=None):
+        ev = [p for n in names for p in prof.get(n, []) if pred is None or pred(p[2])]
+        return (sum(p[0].elapsed_time(p[1]) for p in ev) / len(ev), len(ev)) if ev else (0.0, 0)
+
+    if os.environ.get("COVA_PROFILE_ALL") and rank == 0:
+        rows = [(sum(p[0].elapsed_time(p[1]) for p in v) / args.steps, len(v) / args.steps, k) for k, v in prof.items() if v]
+        for ms, n, k in sorted(rows, reverse=True):
+            print("%-36s %5.1f calls/step %8.3f ms/step" % (k, n, ms), file=sys.stderr)
+        print("sum %.3f ms/step" % sum(r[0] for r in rows), file=sys.stderr)
+
+    # forward only (eval mode, running statistics): the second number SURVEY.md section 8d asks for
     for _ in range(2):
         trainer.predict(batch)
     barrier()
@@ -192,63 +319,127 @@ def main():
     for _ in range(args.steps):
         trainer.predict(batch)
     barrier()
-    dt_fwd = time.perf_counter() - t1
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt_fwd], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_fwd = float(t.item())
+    dt_fwd = max_over_ranks(time.perf_counter() - t1)
+
+    # the drop-in nn.Module route with the reference's loop cadence (train.py:45-60: zero_grad, forward,
+    # argmax + .item(), CE-sum + .item(), backward, torch.optim.Adam.step) -- two host reads per step
+    dropin = None
+    if world == 1 and args.config in (2, 3):
+        import warnings
+        from cova_web_object_detection_amd.models import CoVA
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = CoVA((3, 3), wl["H"], 4, True, 384, 32, 0, 0.2, None, backbone=wl["backbone"],
+                     n_heads=wl["n_heads"], n_gat_layers=wl["n_gat_layers"])
+        m.load_state_dict(sd)
+        m = m.to(device).train()
+        opt = torch.optim.Adam(m.parameters(), lr=5e-4, weight_decay=1e-3)
+        crit = torch.nn.CrossEntropyLoss(reduction="sum")
+
+        def ref_step():
+            opt.zero_grad()
+            out = m(batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"])
+            n_ok = (out.argmax(dim=1) == batch["labels"]).sum().item()
+            ls = crit(out, batch["labels"])
+            lv = ls.item()
+            ls.backward()
+            opt.step()
+            return n_ok, lv
+
+        nd = max(3, min(args.steps, 10))
+        for _ in range(2):
+            ref_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(nd):
+            ref_step()
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t2
+        dropin = {"value": round(pages * nd / dtd, 2), "unit": "webpages/s", "ms_per_step": round(1e3 * dtd / nd, 3),
+                  "steps": nd, "mode": "models.CoVA drop-in module + torch.optim.Adam, train.py:45-60 cadence "
+                                       "(two .item() host reads per step)"}
+        del m, opt
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        value = world * args.pages * args.steps / dt
-        conv_ms = sum(a.elapsed_time(b) for a, b in prof) / max(len(prof), 1)
-        flops = CONV3_FLOP_PER_PIXEL * args.pages * (IMG // 4) * (IMG // 4)
-        achieved = flops / (conv_ms * 1e-3) / 1e12
+        value = global_pages * args.steps / dt
+        fm = flop_model(wl)
+        px_pages = pages
+        conv_ms, conv_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
+        alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
+        executed = alg / WINO_RATIO
+        roof = {"bound": "mfma", "kernel": "conv3x3_c64_wino_kernel (forward + data-gradient launches of the step)",
+                "algorithm": "winograd F(2x2,3x3), exact f32 MFMA (v_mfma_f32_16x16x4_f32)",
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches_timed": conv_n}
+        if conv_n:
+            ach = executed / conv_ms / 1e9
+            traffic, src = read_traffic("conv3x3_c64_wino_kernel", px_pages)
+            roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        achieved_is="EXECUTED MFMA FLOP/s (algorithmic / 2.25)", avg_launch_ms=round(conv_ms, 4),
+                        executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
+                        algorithmic_achieved=round(alg / conv_ms / 1e9, 2),
+                        algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                        traffic=traffic, traffic_unit="B/launch", traffic_source=src,
+                        algorithmic_bytes=2 * 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4))
+        step_alg = fm["total"] * pages                                   # per rank
+        step_exec = (fm["total"] - fm["wino"] + fm["wino"] / WINO_RATIO) * pages
+        step = {"algorithmic_gflop_per_page": round(fm["total"] / 1e9, 2),
+                "algorithmic_tflops": round(step_alg / (ms_per_step * 1e-3) / 1e12, 2),
+                "frac_of_direct_ceiling": round(step_alg / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "executed_gflop_per_page": round(step_exec / pages / 1e9, 2),
+                "frac_of_executed_floor": round(step_exec / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": "per GPU; executed = 3x3 convolutions counted at Winograd's 1/2.25 of the direct multiplies"}
+        others = {}
+        hw = (wl["H"] // 4) * (wl["W"] // 4)
+        f_conv1 = 2 * 64 * 147 * pages * (wl["H"] // 2) * (wl["W"] // 2)
+        specs = [("conv1_7x7_fwd", ["cova_conv1_fwd"], None, f_conv1, 0),
+                 ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0),
+                 ("conv3x3_wgrad_winograd", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino"], None,
+                  fm["conv3_launch_per_page"] * pages / WINO_RATIO, 0),
+                 ("bn_relu_maxpool_fwd", ["cova_bn_relu_maxpool_fwd"], None, 0,
+                  pages * 64 * (4 * 4 * hw + (4 + 4 + 1) * hw))]
+        if wl["backbone"] == "resnet50":
+            R = pages * hw
+            for cin, cout in ((64, 64), (64, 256), (256, 64)):
+                specs.append(("conv1x1_%d_to_%d_fwd_dgrad" % (cin, cout), ["cova_conv1x1"],
+                              (lambda a, ci=cin, co=cout: a[-2:] == (ci, co)), 2 * cin * cout * R, 4 * (cin + cout) * R))
+                specs.append(("conv1x1_wgrad_%dx%d" % (cout, cin), ["cova_conv1x1_wgrad"],
+                              (lambda a, ci=cin, co=cout: a[-2:] == (co, ci)), 2 * cin * cout * R, 4 * (cin + cout) * R))
+        for key, names, pred, flop, nbytes in specs:
+            ms, n = mean_ms(names, pred)
+            if n:
+                o = {"avg_launch_ms": round(ms, 4), "launches_timed": n}
+                if flop:
+                    o.update(executed_tflops=round(flop / ms / 1e9, 1), frac_of_f32_mfma_peak=round(flop / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 3))
+                if nbytes:
+                    o.update(compulsory_tb_per_s=round(nbytes / ms / 1e9, 2), frac_of_hbm_peak=round(nbytes / ms / 1e9 / PEAK_HBM_TBS, 3))
+                others[key] = o
+        diag = "" if backend == "nccl" else " (DIAGNOSTIC: %s backend, ranks share GPUs; throughput meaningless)" % backend
         out = {
             "metric": "webpages/sec fwd+bwd (90 bboxes, K=24)", "value": round(value, 3),
             "unit": "webpages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 1280x1280 screenshots, %d pages/GPU, "
-                                   "%d boxes/page, K=%d, ResNet-18 stem+layer1 RN + 1-head GAT, "
+            "config": {"workload": "%s: synthetic %dx%d (HxW) screenshots, %d pages/GPU, %d boxes/page, K=%d, %s, "
                                    "train step = fwd+CE+bwd+allreduce+Adam, dropout 0.2"
-                                   % (args.pages, BOXES, 2 * CS),
-                       "pages_per_gpu": args.pages, "global_pages": world * args.pages,
-                       "boxes_per_gpu": n_boxes, "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") +
-                       ("" if backend == "nccl" else " (DIAGNOSTIC: %s backend, shared GPU)" % backend),
+                                   % (wl["name"], wl["H"], wl["W"], pages, wl["boxes"], 2 * wl["cs"], wl["desc"]),
+                       "baseline_config": args.config, "pages_per_gpu": pages, "global_pages": global_pages,
+                       "boxes_per_gpu": n_boxes, "world_size": world, "collective_backend": "rccl" if backend == "nccl" else backend,
+                       "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") + diag,
                        "loss": round(loss_val, 3)},
-            # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md section 8d; the
-            # kernel is Winograd F(2x2,3x3) and executes 2.25x fewer MFMA FLOPs, so the algorithmic rate
-            # can exceed the MFMA peak; `executed_*` is the matrix-pipe view of the same launches.
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_wino_kernel (4 forward + 4 data-gradient launches per step)",
-                         "algorithm": "winograd F(2x2,3x3), exact f32 MFMA (v_mfma_f32_16x16x4_f32)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "executed_flop_per_launch": int(flops / 2.25),
-                         "executed_achieved": round(achieved / 2.25, 2),
-                         "executed_frac": round(achieved / 2.25 / PEAK_F32_MFMA_TFLOPS, 4),
-                         # HBM bytes per forward launch from PMC (separate --pmc FETCH_SIZE /
-                         # WRITE_SIZE passes, FETCH doubled per the gfx950 correction):
-                         # plain forward launch: FETCH_SIZE 2*236.6 MiB (gfx950 half-count correction) +
-                         # WRITE_SIZE 408.6 MiB, profiles/r01_pmc_hbm_traffic_final.txt; algorithmic =
-                         # 2 * 419.4 MB (one read + one write of [16,320,320,64] f32).  The fused
-                         # variants read 1-3 more maps (BatchNorm operands) -- see DESIGN.md 4.6.
-                         "traffic": 924.6e6 * args.pages / 16, "traffic_unit": "B/launch",
-                         "algorithmic_bytes": 2 * 4 * 64 * args.pages * (IMG // 4) * (IMG // 4),
-                         "launches_timed": len(prof), "avg_launch_ms": round(conv_ms, 4),
-                         "flop_per_launch": flops},
-            # the other large kernels of the step, same live HIP-event timing (algorithmic FLOPs / bytes)
-            "other_kernels": others,
+            "roofline": roof, "step": step, "other_kernels": others,
+            "forward_only": {"value": round(global_pages * args.steps / dt_fwd, 2), "unit": "webpages/s",
+                             "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),
+                             "mode": "eval forward (running statistics) + per-box argmax, same batch"},
         }
-        out["forward_only"] = {"value": round(world * args.pages * args.steps / dt_fwd, 2), "unit": "webpages/s",
-                               "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),
-                               "mode": "eval forward (running statistics) + per-box argmax, same batch"}
+        if dropin:
+            out["dropin_module_loop"] = dropin
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -77,7 +77,7 @@ def _arg(a):
 
 
 # Optional per-entry-point timing with HIP events on the launching stream (bench.py's roofline
-# leg): PROFILE = {entry point name: [(start_event, end_event), ...]}
+# leg): PROFILE = {entry point name: [(start_event, end_event, integer arguments of the call), ...]}
 PROFILE = None
 
 
@@ -120,7 +120,7 @@ def _launch(L, name, args, stream):
     rc = L.fn[name](*[_arg(a) for a in args], stream)
     if prof is not None:
         e1.record()
-        prof.append((e0, e1))
+        prof.append((e0, e1, tuple(a for a in args if isinstance(a, int))))
     if rc != 0:
         raise CovaHipError("%s failed with status %d" % (name, rc))
 

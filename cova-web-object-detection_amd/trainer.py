@@ -89,8 +89,8 @@ class HotPathTrainer:
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         spec = state_dict_spec(**{k: cfg[k] for k in ("roi_output_size", "n_classes", "use_context",
-                                                     "hidden_dim", "bbox_hidden_dim",
-                                                     "n_additional_feat")})
+                                                     "hidden_dim", "bbox_hidden_dim", "n_additional_feat",
+                                                     "backbone", "n_heads", "n_gat_layers") if k in cfg})
         pshapes = OrderedDict((k, s) for k, s in spec if is_param_key(k))
         self.pbucket = FlatBucket(pshapes, self.device)
         self.gbucket = FlatBucket(pshapes, self.device)

@@ -61,7 +61,7 @@ struct C11Geo {
 // PRO: 0 plain input | 1 f(A*in + C) | 2 f(A*in + B*in2 + C).  EPI: 0 store | 1 store + (sum y, sum y^2)
 // | 2 (acc + addend) * mask, (sum dy, sum dy*xhat[, sum dy*xhat2]).
 template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool HAS_X2>
-__global__ __launch_bounds__(256) void conv1x1_kernel(const C11Args a)
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
 {
     using G = C11Geo<CIN, COUT>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
@@ -134,26 +134,40 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C11Args a)
         }
     };
 
+    // Cross-tile operand prefetch, except in the 256-channel data-gradient variants: those move ~5x more
+    // bytes in their epilogue (addend / mask / xhat operands) than through the MFMA operand, are bound by
+    // loads in flight, and need the 64 registers for a second resident wave per SIMD instead.
+    constexpr bool PREFETCH = !(EPI == 2 && COUT == 256);
     long long tile = (long long)blockIdx.x * 4 + wave;
     float4 nv[8], nv2[8];
-    if (tile < ntiles) issue(tile, 0, nv, nv2);
+    if (PREFETCH && tile < ntiles) issue(tile, 0, nv, nv2);
     for (; tile < ntiles; tile += stride) {
-        // With CHUNKS == 1 the operand of a tile is 32 registers and is reused by every pass; with
-        // CHUNKS == 4 (Cin = 256) there is a single pass (Cout = 64) and chunks stream through.
-        f32x16 acc[G::NT];
+        const long long r0 = tile * 32;
+        if (!PREFETCH) issue(tile, 0, nv, nv2);
+        // Cin = 64: the tile's operand is 32 registers and is reused by both 128-channel passes of a
+        // 256-channel output (so only 4 accumulators are live at a time).  Cin = 256: four chunks stream
+        // through a single 64-channel pass.
+        float x[32];
+        if (G::CHUNKS == 1) {
+            prologue(0, nv, nv2, x);
+            if (PREFETCH && tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);      // next tile in flight
+        }
 #pragma unroll
-        for (int n = 0; n < G::NT; ++n)
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            f32x16 acc[G::NTP];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+            for (int n = 0; n < G::NTP; ++n)
 #pragma unroll
-        for (int c = 0; c < G::CHUNKS; ++c) {
-            float x[32];
-            prologue(c, nv, nv2, x);
-            // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
-            if (c + 1 < G::CHUNKS) issue(tile, c + 1, nv, nv2);
-            else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 #pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps) {
+            for (int c = 0; c < G::CHUNKS; ++c) {
+                if (G::CHUNKS > 1) {
+                    prologue(c, nv, nv2, x);
+                    // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
+                    if (c + 1 < G::CHUNKS) issue(tile, c + 1, nv, nv2);
+                    else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
+                    __builtin_amdgcn_sched_barrier(0);     // one chunk of loads in flight, not all four
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float4 b[G::NTP];
@@ -162,60 +176,61 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C11Args a)
                         b[n] = *reinterpret_cast<const float4 *>(
                             Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + h * G::KH + c * 32 + 4 * q);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 0], b[n].x, acc[ps * G::NTP + n]);
+                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 0], b[n].x, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 1], b[n].y, acc[ps * G::NTP + n]);
+                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 1], b[n].y, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 2], b[n].z, acc[ps * G::NTP + n]);
+                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 2], b[n].z, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[ps * G::NTP + n] = mfma32(x[4 * q + 3], b[n].w, acc[ps * G::NTP + n]);
+                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 3], b[n].w, acc[n]);
                 }
             }
-        }
-        // ---- epilogue: lane owns channel n*32 + p of rows mfma32_row(r, lane); 8 rows at a time so
-        // that the operands in flight (up to 4 per row) stay within the register budget
-        const long long r0 = tile * 32;
+            // ---- epilogue of this pass: lane owns channel n*32 + p of rows mfma32_row(r, lane); 8 rows at
+            // a time so that the operands in flight (up to 4 per row) stay within the register budget
 #pragma unroll
-        for (int n = 0; n < G::NT; ++n) {
-            const int cn = n * 32 + p;
-            float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f;
-            if (EPI == 2) {
-                mu = a.mean[cn]; is = a.invstd[cn];
-                if (!MASK_ACT) { msc = a.msc[cn]; msh = a.msh[cn]; }
-                if (HAS_X2) { mu2 = a.mean2[cn]; is2 = a.invstd2[cn]; }
-            }
-#pragma unroll
-            for (int rh = 0; rh < 16; rh += 8) {
-                float ad[8], mk[8], zz[8], z2v[8];
-                if (EPI == 2) {                            // request every operand first, store last
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        long long row = r0 + mfma32_row(rh + r, lane);
-                        if (row >= a.R) row = a.R - 1;
-                        const size_t o = (size_t)row * COUT + cn;
-                        if (HAS_ADD) ad[r] = a.addend[o];
-                        if (MASK_ACT) mk[r] = a.act[o];
-                        zz[r] = a.z[o];
-                        if (HAS_X2) z2v[r] = a.z2[o];
-                    }
+            for (int nn = 0; nn < G::NTP; ++nn) {
+                const int n = ps * G::NTP + nn;
+                const int cn = n * 32 + p;
+                float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f;
+                if (EPI == 2) {
+                    mu = a.mean[cn]; is = a.invstd[cn];
+                    if (!MASK_ACT) { msc = a.msc[cn]; msh = a.msh[cn]; }
+                    if (HAS_X2) { mu2 = a.mean2[cn]; is2 = a.invstd2[cn]; }
                 }
+                constexpr int RB = (HAS_X2 && COUT == 256) ? 4 : 8;    // rows per operand batch
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const long long row = r0 + mfma32_row(rh + r, lane);
-                    if (row < a.R) {
-                        float v = acc[n][rh + r];
-                        if (EPI == 2) {
-                            if (HAS_ADD) v += ad[r];
-                            const float m = MASK_ACT ? mk[r] : fmaf(msc, zz[r], msh);
-                            if (!(m > 0.f)) v = 0.f;
-                            su[n] += v;
-                            sq[n] += v * ((zz[r] - mu) * is);
-                            if (HAS_X2) sq2[n] += v * ((z2v[r] - mu2) * is2);
-                        } else if (EPI == 1) {
-                            su[n] += v;
-                            sq[n] += v * v;
+                for (int rh = 0; rh < 16; rh += RB) {
+                    float ad[RB], mk[RB], zz[RB], z2v[RB];
+                    if (EPI == 2) {                        // request every operand first, store last
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) {
+                            long long row = r0 + mfma32_row(rh + r, lane);
+                            if (row >= a.R) row = a.R - 1;
+                            const size_t o = (size_t)row * COUT + cn;
+                            if (HAS_ADD) ad[r] = a.addend[o];
+                            if (MASK_ACT) mk[r] = a.act[o];
+                            zz[r] = a.z[o];
+                            if (HAS_X2) z2v[r] = a.z2[o];
                         }
-                        a.out[(size_t)row * COUT + cn] = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const long long row = r0 + mfma32_row(rh + r, lane);
+                        if (row < a.R) {
+                            float v = acc[nn][rh + r];
+                            if (EPI == 2) {
+                                if (HAS_ADD) v += ad[r];
+                                const float m = MASK_ACT ? mk[r] : fmaf(msc, zz[r], msh);
+                                if (!(m > 0.f)) v = 0.f;
+                                su[n] += v;
+                                sq[n] += v * ((zz[r] - mu) * is);
+                                if (HAS_X2) sq2[n] += v * ((z2v[r] - mu2) * is2);
+                            } else if (EPI == 1) {
+                                su[n] += v;
+                                sq[n] += v * v;
+                            }
+                            a.out[(size_t)row * COUT + cn] = v;
+                        }
                     }
                 }
             }
@@ -308,36 +323,74 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const W11Args a)
     const long long s_lo = (long long)blockIdx.x * per;
     long long s_hi = s_lo + per;
     if (s_hi > npairs) s_hi = npairs;
-    constexpr int U = 8;                                    // pairs in flight per wave
-    const int wstep = UNITS == 1 ? 4 : 1, woff = UNITS == 1 ? wave : 0;
-    for (long long s0 = s_lo + (long long)woff * U; s0 < s_hi; s0 += (long long)wstep * U) {
-        float2 g[U], g2[U], x[U];
+    constexpr int U = 8;                                    // pixel pairs per batch; two batches in flight
+    const int wstep = UNITS == 1 ? 4 : 1;
+    const int woff = UNITS == 1 ? __builtin_amdgcn_readfirstlane(wave) : 0;
+    float2 g[2][U], g2[2][U], x[2][U];
+    // full batches: wave-uniform base + one 32-bit lane offset, so the 3*U loads of a batch share three
+    // address registers (scalar base, immediate / scalar strides) instead of 3*U 64-bit lane addresses
+    const int lz = h * CO + cob + 2 * p, lx = h * CI + cib + 2 * p;
+    auto issue = [&](long long s0, float2 (&gg)[U], float2 (&gg2)[U], float2 (&xx)[U]) {
+        const float *bz = a.dz + (size_t)(2 * s0) * CO, *bx = a.act + (size_t)(2 * s0) * CI;
+        const float *bz2 = PRO_DZ ? a.dz2 + (size_t)(2 * s0) * CO : nullptr;
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            long long row = 2 * (s0 + k) + h;
-            if (row >= a.R) row = a.R - 1;
-            g[k] = *reinterpret_cast<const float2 *>(a.dz + (size_t)row * CO + cob + 2 * p);
-            if (PRO_DZ) g2[k] = *reinterpret_cast<const float2 *>(a.dz2 + (size_t)row * CO + cob + 2 * p);
-            x[k] = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + cib + 2 * p);
+            gg[k] = *reinterpret_cast<const float2 *>(bz + lz + k * 2 * CO);
+            if (PRO_DZ) gg2[k] = *reinterpret_cast<const float2 *>(bz2 + lz + k * 2 * CO);
+            xx[k] = *reinterpret_cast<const float2 *>(bx + lx + k * 2 * CI);
         }
+    };
+    auto mac = [&](float d0, float d1, float g0, float g1, float x0, float x1, bool valid) {
+        if (PRO_DZ) {
+            d0 = fmaf(zA[0], d0, fmaf(zB[0], g0, zC[0]));
+            d1 = fmaf(zA[1], d1, fmaf(zB[1], g1, zC[1]));
+        }
+        if (PRO_ACT) {
+            x0 = fmaf(aA[0], x0, aC[0]);
+            x1 = fmaf(aA[1], x1, aC[1]);
+            if (a.act_relu) { x0 = x0 > 0.f ? x0 : 0.f; x1 = x1 > 0.f ? x1 : 0.f; }
+        }
+        if (!valid) d0 = d1 = 0.f;
+        acc[0][0] = mfma32(d0, x0, acc[0][0]);
+        acc[0][1] = mfma32(d0, x1, acc[0][1]);
+        acc[1][0] = mfma32(d1, x0, acc[1][0]);
+        acc[1][1] = mfma32(d1, x1, acc[1][1]);
+    };
+    auto consume = [&](const float2 (&gg)[U], const float2 (&gg2)[U], const float2 (&xx)[U]) {
 #pragma unroll
+        for (int k = 0; k < U; ++k)
+            mac(gg[k].x, gg[k].y, PRO_DZ ? gg2[k].x : 0.f, PRO_DZ ? gg2[k].y : 0.f, xx[k].x, xx[k].y, true);
+    };
+    const long long step = (long long)wstep * U;
+    // batches [s0, s0+U) that lie fully inside the block's range AND inside the map (2*(s0+U) <= R)
+    long long full_hi = s_hi;
+    if (2 * full_hi > a.R) full_hi = a.R / 2;
+    long long s0 = s_lo + (long long)woff * U;
+    if (s0 + U <= full_hi) issue(s0, g[0], g2[0], x[0]);
+    while (s0 + U <= full_hi) {                             // the next batch's loads fly under this one's MFMAs
+        const bool more = s0 + step + U <= full_hi;
+        if (more) issue(s0 + step, g[1], g2[1], x[1]);
+        consume(g[0], g2[0], x[0]);
+        s0 += step;
+        if (!more) break;
+        const bool more2 = s0 + step + U <= full_hi;
+        if (more2) issue(s0 + step, g[0], g2[0], x[0]);
+        consume(g[1], g2[1], x[1]);
+        s0 += step;
+        if (!more2) break;
+    }
+    // ragged tail of the range (at most one partial batch per wave): clamped, predicated loads
+    for (; s0 < s_hi; s0 += step) {
         for (int k = 0; k < U; ++k) {
-            const bool valid = (s0 + k) < s_hi && (2 * (s0 + k) + h) < a.R;
-            float d0 = g[k].x, d1 = g[k].y, x0 = x[k].x, x1 = x[k].y;
-            if (PRO_DZ) {
-                d0 = fmaf(zA[0], d0, fmaf(zB[0], g2[k].x, zC[0]));
-                d1 = fmaf(zA[1], d1, fmaf(zB[1], g2[k].y, zC[1]));
-            }
-            if (PRO_ACT) {
-                x0 = fmaf(aA[0], x0, aC[0]);
-                x1 = fmaf(aA[1], x1, aC[1]);
-                if (a.act_relu) { x0 = x0 > 0.f ? x0 : 0.f; x1 = x1 > 0.f ? x1 : 0.f; }
-            }
-            if (!valid) d0 = d1 = 0.f;
-            acc[0][0] = mfma32(d0, x0, acc[0][0]);
-            acc[0][1] = mfma32(d0, x1, acc[0][1]);
-            acc[1][0] = mfma32(d1, x0, acc[1][0]);
-            acc[1][1] = mfma32(d1, x1, acc[1][1]);
+            const long long sp = s0 + k;
+            long long row = 2 * sp + h;
+            const bool valid = sp < s_hi && row < a.R;
+            if (row >= a.R) row = a.R - 1;
+            const float2 d = *reinterpret_cast<const float2 *>(a.dz + (size_t)row * CO + cob + 2 * p);
+            float2 d2 = make_float2(0.f, 0.f);
+            if (PRO_DZ) d2 = *reinterpret_cast<const float2 *>(a.dz2 + (size_t)row * CO + cob + 2 * p);
+            const float2 xv = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + cib + 2 * p);
+            mac(d.x, d.y, d2.x, d2.y, xv.x, xv.y, valid);
         }
     }
     float *dst = a.ws + (size_t)blockIdx.x * CO * CI;

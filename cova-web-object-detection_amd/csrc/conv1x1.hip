@@ -416,14 +416,23 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const W11Args a)
     }
 }
 
-__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float *__restrict__ ws, int nparts,
-                                                                   int n, float *__restrict__ dw)
+// block = 64 entries x 16 slices of the partial list; fp64, fixed order
+__global__ __launch_bounds__(1024) void conv1x1_wgrad_reduce_kernel(const float *__restrict__ ws, int nparts,
+                                                                    int n, float *__restrict__ dw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double s_acc[16][64];
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int q = 0; q < nparts; ++q) s += (double)ws[(size_t)q * n + i];
-    dw[i] = (float)s;
+    if (i < n)
+        for (int q = slice; q < nparts; q += 16) s += (double)ws[(size_t)q * n + i];
+    s_acc[slice][tx] = s;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
+        dw[i] = (float)t;
+    }
 }
 
 template <int CIN, int COUT>
@@ -549,7 +558,7 @@ COVA_API int cova_conv1x1_wgrad(const float *dz, const float *dz2, const float *
     else return COVA_ERR_BAD_ARG;
 #undef W11_LAUNCH
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(Co * Ci, 256)), dim3(256), 0, st, ws, grid,
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(Co * Ci, 64)), dim3(1024), 0, st, ws, grid,
                        Co * Ci, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

@@ -13,6 +13,8 @@
 // reductions), the D hidden channels live in lanes for the gather (256-byte coalesced rows).
 #include "common.h"
 
+int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
+
 namespace {
 
 // ------------------------------------------------------------------------------------ RoIPool
@@ -94,79 +96,103 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void roipool_bwd_kernel(
-    const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
-    const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
-    float *__restrict__ gfeat)
-{
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (task >= n_rois * PH * PW) return;
-    const int n = task / (PH * PW), bin = task - n * (PH * PW);
-    const int b = (int)rois[5 * n];
-    if (b < 0 || b >= B) return;                 // forward wrote argmax = -1 for such boxes anyway
-    float *gb = gfeat + (size_t)b * H * W * C;
-    for (int c = lane; c < C; c += 64) {
-        const int mi = argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin];
-        if (mi >= 0) atomicAdd(gb + (size_t)mi * C + c, gout[(size_t)n * ld_g + c * (PH * PW) + bin]);
-    }
-}
+// RoIPool backward WITHOUT atomics (deterministic): the reference's scatter `grad_in[b,c,argmax] += grad_out`
+// collides all the time on web pages (DOM parents contain their children), and float atomics make two runs of
+// the same step differ in the last bits.  Here every (page, feature row, 64-channel block, x segment) has ONE
+// owner wave: it finds the boxes whose bins touch its row (lane-parallel geometry test + ballot, ascending box
+// order), adds their contributions into an LDS row accumulator in program order (lanes = channels, so lanes never
+// collide), and writes the finished row -- which also replaces the zero-fill of the gradient map.
+// BN: the row is masked by the ReLU of the map's producer and the BatchNorm-backward sums are taken on the way
+// out (only where the gradient is non-zero: ~1 % of the map).
+constexpr int ROI_XS = 320;                       // pixels per LDS row segment (80 KB)
 
-// RoIPool backward fused with the ReLU mask and the BatchNorm-backward sums of the layer that produced
-// the feature map (out = relu(bn(z) + residual)):  g' = g * (act[pos] > 0) is scattered, and
-// (sum g', sum g' * xhat(z[pos])) are accumulated per channel -- both are linear in the scattered
-// contributions, so they can be taken here instead of by a pass over the dense gradient map.
-// Tasks (box, bin) are assigned to waves by a fixed grid-stride rule: the partial sums are deterministic.
-__global__ __launch_bounds__(256) void roipool_bwd_bn_kernel(
+struct RoiGeo {
+    int b, rs_h, rs_w;
+    float bin_h, bin_w;
+};
+
+__device__ __forceinline__ RoiGeo roi_geo(const float *__restrict__ roi, float spatial_scale, int PH, int PW)
+{
+    RoiGeo g;
+    g.b = (int)roi[0];
+    g.rs_w = (int)roundf(roi[1] * spatial_scale);
+    g.rs_h = (int)roundf(roi[2] * spatial_scale);
+    const int re_w = (int)roundf(roi[3] * spatial_scale);
+    const int re_h = (int)roundf(roi[4] * spatial_scale);
+    g.bin_h = (float)max(re_h - g.rs_h + 1, 1) / (float)PH;
+    g.bin_w = (float)max(re_w - g.rs_w + 1, 1) / (float)PW;
+    return g;
+}
+__device__ __forceinline__ int bin_lo(int i, float bin, int rs, int lim) { return min(max((int)floorf((float)i * bin) + rs, 0), lim); }
+__device__ __forceinline__ int bin_hi(int i, float bin, int rs, int lim) { return min(max((int)ceilf((float)(i + 1) * bin) + rs, 0), lim); }
+
+template <bool BN>
+__global__ __launch_bounds__(64) void roipool_bwd_rows_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
     const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
-    const float *__restrict__ act, const float *__restrict__ z, const float *__restrict__ mean,
-    const float *__restrict__ invstd, float *__restrict__ gfeat, float *__restrict__ partial,
-    const LazyFeat lz)
+    float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gfeat,
+    float *__restrict__ partial, const LazyFeat lz)
 {
-    constexpr int MAXCB = 4;                      // C <= 256
-    __shared__ float s_red[4][2][64 * MAXCB];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ntask = n_rois * PH * PW, ncb = C / 64;
-    float su[MAXCB], sq[MAXCB], mu[MAXCB], is[MAXCB];
-#pragma unroll
-    for (int k = 0; k < MAXCB; ++k) {
-        su[k] = sq[k] = 0.f;
-        mu[k] = k < ncb ? mean[k * 64 + lane] : 0.f;
-        is[k] = k < ncb ? invstd[k * 64 + lane] : 0.f;
+    __shared__ __attribute__((aligned(16))) float acc[ROI_XS * 64];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.y * 64 + lane;
+    const int nx = (W + ROI_XS - 1) / ROI_XS;
+    const long long ntask = (long long)B * H * nx;
+    float su = 0.f, sq = 0.f, mu = 0.f, is = 0.f, lsc = 0.f, lsh = 0.f;
+    if (BN) {
+        mu = mean[c]; is = invstd[c];
+        if (act == nullptr) { lsc = lz.scale[c]; lsh = lz.shift[c]; }
     }
-    for (int task = blockIdx.x * 4 + wave; task < ntask; task += gridDim.x * 4) {
-        const int n = task / (PH * PW), bin = task - n * (PH * PW);
-        const int b = (int)rois[5 * n];
-        if (b < 0 || b >= B) continue;
-        const size_t boff = (size_t)b * H * W * C;
-#pragma unroll
-        for (int k = 0; k < MAXCB; ++k) {
-            if (k >= ncb) break;
-            const int c = k * 64 + lane;
-            const int mi = argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin];
-            if (mi < 0) continue;
-            const size_t pos = boff + (size_t)mi * C + c;
-            float g = gout[(size_t)n * ld_g + c * (PH * PW) + bin];
-            const float zv = z[pos];
-            // mask of out = relu(bn(z) + x): the materialised map, or the same expression recomputed
-            const float a = act != nullptr ? act[pos] : fmaf(lz.scale[c], zv, lz.shift[c]) + lz.x[pos];
-            if (!(a > 0.f)) g = 0.f;
-            atomicAdd(gfeat + pos, g);
-            su[k] += g;
-            sq[k] += g * ((zv - mu[k]) * is[k]);
+    for (long long task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int xs = (int)(task % nx);
+        const int y = (int)((task / nx) % H);
+        const int b = (int)(task / ((long long)nx * H));
+        const int x0 = xs * ROI_XS, x1 = min(x0 + ROI_XS, W);
+        for (int i = lane; i < ROI_XS * 16; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n0 = 0; n0 < n_rois; n0 += 64) {
+            const int n = n0 + lane;
+            bool hit = false;
+            if (n < n_rois) {
+                const RoiGeo g = roi_geo(rois + 5 * n, spatial_scale, PH, PW);
+                hit = g.b == b && y >= bin_lo(0, g.bin_h, g.rs_h, H) && y < bin_hi(PH - 1, g.bin_h, g.rs_h, H) &&
+                      bin_lo(0, g.bin_w, g.rs_w, W) < x1 && bin_hi(PW - 1, g.bin_w, g.rs_w, W) > x0;
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {                                     // boxes touching this row, ascending: fixed order
+                const int nb = n0 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
+                for (int ph = 0; ph < PH; ++ph) {
+                    if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
+                    for (int pw = 0; pw < PW; ++pw) {
+                        if (bin_hi(pw, g.bin_w, g.rs_w, W) <= x0 || bin_lo(pw, g.bin_w, g.rs_w, W) >= x1) continue;
+                        const size_t e = (size_t)c * (PH * PW) + ph * PW + pw;
+                        const int mi = argmax[(size_t)nb * C * PH * PW + e];
+                        const int x = mi - y * W;
+                        if (mi >= 0 && x >= x0 && x < x1 && mi / W == y)
+                            acc[(x - x0) * 64 + lane] += gout[(size_t)nb * ld_g + e];
+                    }
+                }
+            }
+        }
+        const size_t row = ((size_t)b * H + y) * W;
+        for (int x = x0; x < x1; ++x) {
+            float v = acc[(x - x0) * 64 + lane];
+            const size_t pos = (row + x) * C + c;
+            if (BN && v != 0.f) {
+                const float zv = z[pos];
+                const float a = act != nullptr ? act[pos] : fmaf(lsc, zv, lsh) + lz.x[pos];
+                if (!(a > 0.f)) v = 0.f;
+                su += v;
+                sq += v * ((zv - mu) * is);
+            }
+            gfeat[pos] = v;
         }
     }
-#pragma unroll
-    for (int k = 0; k < MAXCB; ++k) {
-        s_red[wave][0][k * 64 + lane] = su[k];
-        s_red[wave][1][k * 64 + lane] = sq[k];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
-        const int which = i / C, c = i - which * C;
-        partial[((size_t)blockIdx.x * 2 + which) * C + c] =
-            (s_red[0][which][c] + s_red[1][which][c]) + (s_red[2][which][c] + s_red[3][which][c]);
+    if (BN) {
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = su;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sq;
     }
 }
 
@@ -327,6 +353,139 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel(
     }
 }
 
+// ---- transposed neighbour index (CSR over destination nodes): lets the backward GATHER what the
+// reference's autograd scatters (index_select backward), with a fixed summation order -> no float atomics,
+// bit-identical reruns, for ARBITRARY context_indices (models.py:171-177 accepts any ids), not only the
+// +-context_size windows the dataset builds (datasets.py:121-128).
+//   deg[j] = #{(i,k): ctx[i,k] = j};  row_ptr = exclusive scan;  edges of row j = the flat slots e = i*K + k,
+//   ascending (the integer atomics below only decide a provisional slot; every row is then rank-sorted).
+__global__ void csr_count_kernel(const int64_t *__restrict__ ctx, int E, int N, int *__restrict__ deg)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long j = ctx[e];
+    if (j >= 0 && j < N) atomicAdd(deg + j, 1);
+}
+
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int *__restrict__ deg, int N, int *__restrict__ row_ptr)
+{
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (N + 1023) / 1024, lo = min(tid * per, N), hi = min(lo + per, N);
+    int t = 0;
+    for (int i = lo; i < hi; ++i) t += deg[i];
+    s_part[tid] = t;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = s_part[i]; s_part[i] = run; run += v; }
+        row_ptr[N] = run;
+    }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int i = lo; i < hi; ++i) { row_ptr[i] = run; run += deg[i]; }
+}
+
+__global__ void csr_fill_kernel(const int64_t *__restrict__ ctx, int E, int N, const int *__restrict__ row_ptr,
+                                int *__restrict__ cursor, int *__restrict__ tmp)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long j = ctx[e];
+    if (j >= 0 && j < N) tmp[row_ptr[j] + atomicAdd(cursor + j, 1)] = e;
+}
+
+// one wave per row: rank every entry among the row's entries (entries are distinct) and store it at its rank
+__global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int *__restrict__ row_ptr, const int *__restrict__ tmp,
+                                                            int N, int *__restrict__ edges)
+{
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const int lo = row_ptr[j], deg = row_ptr[j + 1] - lo;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+        const int mine = c0 + lane < deg ? tmp[lo + c0 + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int d0 = 0; d0 < deg; d0 += 64) {
+            const int other = d0 + lane < deg ? tmp[lo + d0 + lane] : 0x7fffffff;
+            const int cnt = min(64, deg - d0);
+            for (int t = 0; t < cnt; ++t) rank += __shfl(other, t, 64) < mine ? 1 : 0;
+        }
+        if (c0 + lane < deg) edges[lo + rank] = mine;
+    }
+}
+
+// backward, source side (one wave per node i): everything that stays with node i -- du [N,K] (0 on pads),
+// ds, dWh_i = ds * a_i.  The contributions to OTHER nodes (dt[ctx], dWh_j[ctx]) are gathered by
+// gat_bwd_dst_kernel from du / attn / g through the transposed index.
+__global__ __launch_bounds__(256) void gat_bwd_src_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ Wh, int ldw,
+    const float *__restrict__ s, const float *__restrict__ t, const float *__restrict__ attn,
+    const int64_t *__restrict__ ctx, const float *__restrict__ att_w, int N, int K, int D,
+    float slope, float *__restrict__ dWh, int lddw, float *__restrict__ ds, float *__restrict__ du_out)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float alpha = 0.f;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;
+        alpha = attn[(size_t)n * K + lane];
+    }
+    const int jj = (int)j;
+    float dalpha = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int jk = __shfl(jj, k, 64);
+        float part = 0.f;
+        if (jk >= 0)
+            for (int d = lane; d < D; d += 64)
+                part += g[(size_t)n * ldg + d] * Wh[(size_t)jk * ldw + D + d];
+        part = wave_sum(part);
+        if (lane == k) dalpha = part;
+    }
+    const float dot = wave_sum(alpha * dalpha);
+    float du = 0.f;
+    if (lane < K && jj >= 0) {
+        const float de = alpha * (dalpha - dot);
+        const float u = s[n] + t[jj];
+        du = de * (u > 0.f ? 1.f : slope);
+    }
+    if (lane < K) du_out[(size_t)n * K + lane] = du;
+    const float dsn = wave_sum(du);
+    if (lane == 0) ds[n] = dsn;
+    for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
+}
+
+// backward, destination side (one wave per node j): dt[j] = sum_e du[e];
+// dWh_j[j] = sum_e alpha[e] * g[i_e] + dt[j] * a_j, e over row j of the transposed index, ascending
+__global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ attn, const float *__restrict__ du,
+    const int *__restrict__ row_ptr, const int *__restrict__ edges, const float *__restrict__ att_w, int N,
+    int K, int D, float *__restrict__ dWh, int lddw, float *__restrict__ dt)
+{
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const int lo = row_ptr[j], deg = row_ptr[j + 1] - lo;
+    float dtj = 0.f;
+    for (int q = 0; q < deg; ++q) dtj += du[edges[lo + q]];       // wave-uniform, fixed order
+    if (lane == 0) dt[j] = dtj;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float accv = 0.f;
+        for (int c0 = 0; c0 < deg; c0 += 64) {
+            const int e = c0 + lane < deg ? edges[lo + c0 + lane] : 0;
+            const float al = c0 + lane < deg ? attn[e] : 0.f;
+            const int cnt = min(64, deg - c0);
+            for (int q = 0; q < cnt; ++q) {
+                const int i = __shfl(e, q, 64) / K;
+                const float aq = __shfl(al, q, 64);
+                if (d < D) accv += aq * g[(size_t)i * ldg + d];
+            }
+        }
+        if (d < D) dWh[(size_t)j * lddw + D + d] = accv + dtj * att_w[D + d];
+    }
+}
+
 // dWh_j[n] += dt[n]*a_j  (elementwise), and the attention-vector gradients
 //   d att_w[d] = sum_n ds[n]*Wh[n][d] (d < D), sum_n dt[n]*Wh[n][d] (d >= D); d att_b = sum ds
 __global__ void gat_bwd_addt_kernel(float *__restrict__ dWh, int lddw, const float *__restrict__ dt,
@@ -401,47 +560,43 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
     return COVA_OK;
 }
 
-// gfeat NHWC [B,H,W,C] is zero-filled here, then receives scatter-adds
-COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                              int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
-                              void *stream)
+static int roipool_bwd_grid(int B, int H, int W)
 {
-    COVA_REQUIRE(gout && rois && argmax && gfeat && B > 0);
-    hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * H * W * C, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    if (n_rois == 0) return COVA_OK;
-    hipLaunchKernelGGL(roipool_bwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, gfeat);
+    const long long ntask = (long long)B * H * ((W + ROI_XS - 1) / ROI_XS);
+    return cova_internal_persistent_grid2(ntask > (1 << 30) ? (1 << 30) : (int)ntask, 2);
+}
+
+// gfeat NHWC [B,H,W,C] = sum over (box, bin) of gout routed to the arg-max positions; fully written here
+// (no zero-fill, no atomics: every row of the map has one owner wave).  C % 64 == 0.
+COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
+                              int n_rois, int B, int C, int H, int W, int PH, int PW,
+                              float spatial_scale, float *gfeat, void *stream)
+{
+    COVA_REQUIRE(gout && rois && argmax && gfeat && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    hipLaunchKernelGGL(roipool_bwd_rows_kernel<false>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(64), 0,
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                       nullptr, nullptr, nullptr, nullptr, gfeat, nullptr, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
 
-COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW)
-{
-    int g = cdiv(n_rois * PH * PW, 4);
-    if (g > 1024) g = 1024;
-    return g < 1 ? 1 : g;
-}
+COVA_API int cova_roipool_bwd_bn_num_partials(int B, int H, int W) { return roipool_bwd_grid(B, H, W); }
 
-// cova_roipool_bwd whose scattered gradient is masked by act > 0 (act == NULL: by
-// scale*z + shift + x > 0, the un-materialised map of cova_roipool_fwd_bn) and which also emits the
-// BatchNorm-backward partial sums [num_partials][2][C] of (g', g' * (z - mean) * invstd); C % 64 == 0,
-// C <= 256.  gfeat (zero-filled here) then holds the ReLU-masked gradient.
+// cova_roipool_bwd whose gradient is masked by act > 0 (act == NULL: by scale*z + shift + x > 0, the
+// un-materialised map of cova_roipool_fwd_bn) and which also emits the BatchNorm-backward partial sums
+// [num_partials][2][C] of (g', g' * (z - mean) * invstd).  gfeat then holds the ReLU-masked gradient.
 COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                                  int n_rois, int B, int C, int H, int W, int PH, int PW,
-                                 const float *act, const float *x, const float *scale,
+                                 float spatial_scale, const float *act, const float *x, const float *scale,
                                  const float *shift, const float *z, const float *mean,
                                  const float *invstd, float *gfeat, float *partial, void *stream)
 {
-    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && B > 0);
+    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && B > 0 && n_rois >= 0);
     COVA_REQUIRE(act || (x && scale && shift));   // mask: act > 0, or relu argument scale*z + shift + x > 0
-    COVA_REQUIRE(C % 64 == 0 && C <= 256);
-    hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * H * W * C, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    const int grid = cova_roipool_bwd_bn_num_partials(n_rois, PH, PW);
-    hipLaunchKernelGGL(roipool_bwd_bn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gout, ld_g,
-                       rois, argmax, n_rois, B, C, H, W, PH, PW, act, z, mean, invstd, gfeat, partial,
-                       LazyFeat{x, scale, shift});
+    COVA_REQUIRE(C > 0 && C % 64 == 0);
+    hipLaunchKernelGGL(roipool_bwd_rows_kernel<true>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(64), 0,
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                       act, z, mean, invstd, gfeat, partial, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -484,25 +639,61 @@ COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const fl
     return COVA_OK;
 }
 
-// dWh [N, 2D] (ld = lddw) is fully written; ds, dt [N] scratch; d_att_w [2D], d_att_b [1]
+// Transposed neighbour index of ctx [N,K]: csr[0..N] = row_ptr, csr[N+1 .. N+1+N*K) = the flat slots i*K+k that
+// name node j, ascending; the rest of the workspace is scratch.  Build it once per batch: every head and
+// layer of the GAT stack (and every backward call) shares it.
+COVA_API int cova_gat_transpose_ints(int N, int K) { return (N + 1) + 2 * N * K + 2 * N + 16; }
+
+COVA_API int cova_gat_transpose(const int64_t *ctx, int N, int K, int *csr, void *stream)
+{
+    COVA_REQUIRE(ctx && csr && N > 0 && K > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int E = N * K;
+    int *row_ptr = csr, *edges = csr + N + 1, *tmp = edges + E, *deg = tmp + E, *cursor = deg + N;
+    hipError_t e = hipMemsetAsync(deg, 0, sizeof(int) * 2 * (size_t)N, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(csr_count_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, ctx, E, N, deg);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, deg, N, row_ptr);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, ctx, E, N, row_ptr, cursor, tmp);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, row_ptr, tmp, N, edges);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// dWh [N, 2D] (ld = lddw) is fully written; ds, dt [N] scratch; d_att_w [2D], d_att_b [1].
+// csr (from cova_gat_transpose) + du [N,K] scratch: gather form, no float atomics, bit-identical reruns.
+// csr == NULL: the scatter form with float atomics (kept for A/B measurements).
 COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, const float *s,
                           const float *t, const float *attn, const int64_t *ctx, const float *att_w,
                           int N, int K, int D, float slope, float *dWh, int lddw, float *ds, float *dt,
-                          float *d_att_w, float *d_att_b, void *stream)
+                          float *d_att_w, float *d_att_b, const int *csr, float *du, void *stream)
 {
     COVA_REQUIRE(g && Wh && s && t && attn && ctx && att_w && dWh && ds && dt && d_att_w && d_att_b);
     COVA_REQUIRE(K > 0 && K <= 64 && D > 0 && N > 0);
+    COVA_REQUIRE(!csr || du);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dt, 0, sizeof(float) * (size_t)N, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemset2DAsync(dWh + D, sizeof(float) * (size_t)lddw, 0, sizeof(float) * (size_t)D, (size_t)N, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gat_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
-                       ctx, att_w, N, K, D, slope, dWh, lddw, ds, dt);
-    COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gat_bwd_addt_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, st, dWh, lddw, dt,
-                       att_w, N, D);
-    COVA_LAUNCH_CHECK();
+    if (csr != nullptr) {
+        hipLaunchKernelGGL(gat_bwd_src_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
+                           ctx, att_w, N, K, D, slope, dWh, lddw, ds, du);
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gat_bwd_dst_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, attn, du, csr,
+                           csr + N + 1, att_w, N, K, D, dWh, lddw, dt);
+        COVA_LAUNCH_CHECK();
+    } else {
+        hipError_t e = hipMemsetAsync(dt, 0, sizeof(float) * (size_t)N, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset2DAsync(dWh + D, sizeof(float) * (size_t)lddw, 0, sizeof(float) * (size_t)D, (size_t)N, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(gat_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
+                           ctx, att_w, N, K, D, slope, dWh, lddw, ds, dt);
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gat_bwd_addt_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, st, dWh, lddw, dt,
+                           att_w, N, D);
+        COVA_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(gat_bwd_att_kernel, dim3(cdiv(2 * D + 1, 64)), dim3(1024), 0, st, Wh, ldw, ds,
                        dt, d_att_w, d_att_b, N, D);
     COVA_LAUNCH_CHECK();

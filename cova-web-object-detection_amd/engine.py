@@ -699,7 +699,7 @@ def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
     else:
         call("cova_roipool_fwd", feat, bboxes, N, B, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
              argmax)
-    return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW))
+    return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW), scale=float(spatial_scale))
 
 
 def roipool_bwd(sv, gout, ld_g):
@@ -707,7 +707,7 @@ def roipool_bwd(sv, gout, ld_g):
     PH, PW = sv["roi"]
     gfeat = _empty((B, Hf, Wf, C), gout)
     call("cova_roipool_bwd", gout, ld_g, sv["bboxes"], sv["argmax"], sv["bboxes"].shape[0], B, C, Hf,
-         Wf, PH, PW, gfeat)
+         Wf, PH, PW, float(sv["scale"]), gfeat)
     return gfeat
 
 
@@ -719,12 +719,12 @@ def roipool_bwd_bn(sv, gout, ld_g, last):
     PH, PW = sv["roi"]
     n = sv["bboxes"].shape[0]
     gfeat = _empty((B, Hf, Wf, C), gout)
-    npart = query("cova_roipool_bwd_bn_num_partials", n, PH, PW)
+    npart = query("cova_roipool_bwd_bn_num_partials", B, Hf, Wf)
     part = _empty((npart, 2, C), gout)
     bn = last["bn"]
     lazy = last["out"] is None                    # mask recomputed from (z, x) like the forward did
     call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
-         last["out"], last["x"] if lazy else None, bn.scale if lazy else None,
+         float(sv["scale"]), last["out"], last["x"] if lazy else None, bn.scale if lazy else None,
          bn.shift if lazy else None, last["z"], bn.mean, bn.invstd, gfeat, part)
     return gfeat, (part, npart)
 
@@ -776,9 +776,25 @@ def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
     return dict(h=h, ldh=ldh, N=N, F=F, D=D, K=K, ctx=ctx, Wh=Wh, s=s, t=t, attn=attn, prefix=prefix)
 
 
-def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None):
+# Backward of the neighbour gather: deterministic gather through the transposed index (default) or the
+# scatter with float atomics (COVA_GAT_ATOMICS=1, kept for A/B timing).
+GAT_ATOMICS = os.environ.get("COVA_GAT_ATOMICS", "0") == "1"
+
+
+def gat_transpose(ctx):
+    """Transposed neighbour index of one batch (shared by every head / layer / backward call of the step)."""
+    N, K = ctx.shape
+    csr = torch.empty((query("cova_gat_transpose_ints", N, K),), dtype=torch.int32, device=ctx.device)
+    call("cova_gat_transpose", ctx, N, K, csr)
+    return csr
+
+
+def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None, csr=None):
     """g = dL/dh' (rows at g + n*ldg).  Writes / accumulates dL/dh into dh; returns param grads."""
     N, F, D, K, prefix = sv["N"], sv["F"], sv["D"], sv["K"], sv["prefix"]
+    if csr is None and not GAT_ATOMICS:
+        csr = gat_transpose(sv["ctx"])
+    du = _empty((N, K), g) if csr is not None else None
     Wi, Wj = params[prefix + "W_i.weight"], params[prefix + "W_j.weight"]
     aw = params[prefix + "attention_layer.weight"]
     dWh = _empty((N, 2 * D), g)
@@ -786,7 +802,7 @@ def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None):
     daw = _gbuf(gout, prefix + "attention_layer.weight", (1, 2 * D), g)
     dab = _gbuf(gout, prefix + "attention_layer.bias", (1,), g)
     call("cova_gat_bwd", g, ldg, sv["Wh"], 2 * D, sv["s"], sv["t"], sv["attn"], sv["ctx"], aw, N, K, D,
-         LEAKY_SLOPE, dWh, 2 * D, ds, dt, daw, dab)
+         LEAKY_SLOPE, dWh, 2 * D, ds, dt, daw, dab, csr, du)
     dWi = _gbuf(gout, prefix + "W_i.weight", (D, F), g)
     dWj = _gbuf(gout, prefix + "W_j.weight", (D, F), g)
     call("cova_sgemm", 1, 0, D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
@@ -819,6 +835,7 @@ def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
     """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F]."""
     grads = {}
     g, ldg = dcomb[:, F:], T
+    csr = None if GAT_ATOMICS else gat_transpose(layers[0]["heads"][0]["ctx"])
     for l in reversed(range(len(layers))):
         heads = layers[l]["heads"]
         dh = D // len(heads)
@@ -827,7 +844,7 @@ def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
         else:
             dst, ldd, acc0 = _empty((N, D), dcomb), D, False
         for i, sv in enumerate(heads):
-            grads.update(gat_bwd(sv, g[:, i * dh:], ldg, params, dst, ldd, acc0 or i > 0, gout))
+            grads.update(gat_bwd(sv, g[:, i * dh:], ldg, params, dst, ldd, acc0 or i > 0, gout, csr))
         g, ldg = dst, ldd
     return grads
 

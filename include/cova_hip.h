@@ -198,14 +198,17 @@ int cova_bn_relu_maxpool_bwd_apply(const float *dp, const uint8_t *idx, const fl
 int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, int C, int H, int W,
                      int PH, int PW, float spatial_scale, float *out, int ld_out, int32_t *argmax,
                      void *stream);
+/* backward: gfeat NHWC [B,H,W,C] (fully written: no zero-fill needed) = gout routed to the arg-max positions.
+ * Deterministic -- no float atomics: every feature row has one owner wave that adds the boxes touching it in
+ * ascending box order (the reference's scatter collides constantly: DOM parents contain their children). */
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                     int n_rois, int B, int C, int H, int W, int PH, int PW, float *gfeat,
-                     void *stream);
+                     int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
+                     float *gfeat, void *stream);
 /* same, fused with the ReLU mask (act > 0) and the BatchNorm-backward partial sums of the layer that
  * produced the map: gfeat = masked gradient, partial [cova_roipool_bwd_bn_num_partials][2][C] */
-int cova_roipool_bwd_bn_num_partials(int n_rois, int PH, int PW);
+int cova_roipool_bwd_bn_num_partials(int B, int H, int W);
 int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                        int n_rois, int B, int C, int H, int W, int PH, int PW,
+                        int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
                         const float *act /*nullable: then x, scale, shift give the mask*/,
                         const float *x /*nullable*/, const float *scale /*nullable*/,
                         const float *shift /*nullable*/, const float *z, const float *mean,
@@ -236,10 +239,17 @@ int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int 
 int cova_gat_fwd(const float *Wh, int ldw, const float *att_w /*[2D]*/, const float *att_b /*[1]*/,
                  const int64_t *ctx /*[N,K]*/, int N, int K, int D, float slope, float *s /*[N]*/,
                  float *t /*[N]*/, float *attn /*[N,K]*/, float *hprime, int ldh, void *stream);
+/* transposed neighbour index (CSR over destination nodes) of ctx: csr[0..N] row offsets, then the flat slots
+ * i*K+k naming each node, ascending.  Lets the backward gather with a fixed summation order instead of
+ * scattering with float atomics (torch's index_select backward): bit-identical reruns for ANY index table. */
+int cova_gat_transpose_ints(int N, int K);
+int cova_gat_transpose(const int64_t *ctx, int N, int K, int *csr /*[cova_gat_transpose_ints]*/, void *stream);
+/* csr + du [N,K] scratch: deterministic gather form; csr == NULL: scatter form with float atomics */
 int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, const float *s, const float *t,
                  const float *attn, const int64_t *ctx, const float *att_w, int N, int K, int D,
                  float slope, float *dWh /*[N,2D]*/, int lddw, float *ds /*[N]*/, float *dt /*[N]*/,
-                 float *d_att_w /*[2D]*/, float *d_att_b /*[1]*/, void *stream);
+                 float *d_att_w /*[2D]*/, float *d_att_b /*[1]*/, const int *csr /*nullable*/,
+                 float *du /*nullable [N,K]*/, void *stream);
 
 /* ------------------------------------------------------------------ decoder tail, loss, optimizer
  * replaces: nn.Dropout (models.py:84,88), nn.Linear(T, n_classes) (models.py:89),

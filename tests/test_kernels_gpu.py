@@ -206,17 +206,17 @@ def test_roipool_matches_oracle_bit_exact():
     import ctypes
     O._lib().oracle_roipool_bwd(O._fp(gout), O._fp(rois), O._fp(ref_arg), n, B, C, H, W, 3, 3, O._fp(gref))
     gfeat = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, gfeat)
+    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat)
     close(nchw(gfeat), gref, 1e-5, "roipool bwd")
     # fused variant: ReLU mask of the map's producer + BatchNorm-backward sums
     act = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
     z = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
     mean = torch.from_numpy(rs.standard_normal(C).astype(np.float32)).to(DEV) * 0.2
     invstd = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).to(DEV)
-    npart = query("cova_roipool_bwd_bn_num_partials", n, 3, 3)
+    npart = query("cova_roipool_bwd_bn_num_partials", B, H, W)
     part = torch.empty(npart, 2, C, device=DEV)
     gmask = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, act, None, None,
+    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, act, None, None,
          None, z, mean, invstd, gmask, part)
     ref_masked = gfeat * (act > 0)
     close(gmask, ref_masked, 1e-5, "roipool bwd masked")
@@ -235,9 +235,9 @@ def test_roipool_matches_oracle_bit_exact():
     assert torch.equal(out_l, out_m) and torch.equal(arg_l, arg_m)
     g_m, g_l = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
     p_m, p_l = torch.empty(npart, 2, C, device=DEV), torch.empty(npart, 2, C, device=DEV)
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, fmat, None, None,
+    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, fmat, None, None,
          None, z, mean, invstd, g_m, p_m)
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, None, xres, scale,
+    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, None, xres, scale,
          shift, z, mean, invstd, g_l, p_l)
     assert torch.equal(g_l == 0, g_m == 0)
     close(g_l, g_m, 1e-6, "lazy roipool bwd")
@@ -252,7 +252,7 @@ def test_roipool_matches_oracle_bit_exact():
     assert (out_b.cpu()[isbad] == 0).all() and (arg_b.cpu()[isbad] == -1).all()
     assert torch.equal(out_b.cpu()[~isbad], ref.reshape(n, 576)[~isbad])
     g_b = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, g_b)
+    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, 0.25, g_b)
     assert torch.isfinite(g_b).all()
 
 
@@ -635,3 +635,87 @@ def test_conv1_wgrad_with_pool_backward_folded_in(B, H, W, cap):
     finally:
         query("cova_set_option", 2, 0)
     close(dw, ref, 2e-5, "conv1 wgrad with folded pool backward")
+
+
+# ------------------------------------------------------------------------------------ deterministic backward
+def _gat_case(N, K, Fd, D, ctx, seed):
+    rs = np.random.RandomState(seed)
+    h = torch.from_numpy(rs.standard_normal((N, Fd)).astype(np.float32))
+    sd = {"gat.W_i.weight": torch.from_numpy(rs.uniform(-0.2, 0.2, (D, Fd)).astype(np.float32)),
+          "gat.W_j.weight": torch.from_numpy(rs.uniform(-0.2, 0.2, (D, Fd)).astype(np.float32)),
+          "gat.attention_layer.weight": torch.from_numpy(rs.uniform(-0.5, 0.5, (1, 2 * D)).astype(np.float32)),
+          "gat.attention_layer.bias": torch.from_numpy(rs.uniform(-0.1, 0.1, 1).astype(np.float32))}
+    g = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32))
+    return h, sd, g
+
+
+@pytest.mark.parametrize("kind", ["window", "random", "hub"])
+def test_gat_backward_gather_is_deterministic_for_arbitrary_graphs(kind):
+    """The transposed-index (gather) backward against autograd of the reference formulation, for the dataset's
+    +-cs windows AND for index tables the reference's API equally accepts (models.py:171-177): random ids that
+    cross pages and repeat inside a row, and a hub node named by every other node (in-degree >> 64)."""
+    N, K, Fd, D = 157, 24, 40, 96
+    rs = np.random.RandomState(7)
+    if kind == "window":
+        ctx = torch.from_numpy(synthetic.collate_context([synthetic.context_window_indices(n, 12) for n in (90, 11, 56)]))
+    elif kind == "random":
+        c = rs.randint(-1, N, (N, K))
+        c[5] = -1
+        c[9, :] = 3                                          # the same neighbour in every slot
+        ctx = torch.from_numpy(c.astype(np.int64))
+    else:
+        c = rs.randint(0, N, (N, K))
+        c[:, 0] = 42                                         # in-degree 157 + ... for node 42
+        c[:, 5] = 42
+        ctx = torch.from_numpy(c.astype(np.int64))
+    h, sd, g = _gat_case(N, K, Fd, D, ctx, 3)
+    hr = h.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (O.gat(hr, ctx, sdr) * g).sum().backward()
+    params = {k: v.to(DEV) for k, v in sd.items()}
+    outs = []
+    for rep in range(2):
+        hp = torch.empty(N, D, device=DEV)
+        sv = engine.gat_fwd(h.to(DEV), Fd, N, Fd, ctx.to(DEV), params, hp, D)
+        dh = torch.empty(N, Fd, device=DEV)
+        grads = engine.gat_bwd(sv, g.to(DEV), D, params, dh, Fd, False)
+        outs.append((dh, grads))
+    close(outs[0][0], hr.grad, 1e-4, "gat dh (%s)" % kind)
+    for k in sd:
+        close(outs[0][1][k], sdr[k].grad.view_as(outs[0][1][k].cpu()), 1e-4, k)
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k        # bit-identical reruns
+    assert torch.equal(outs[0][0], outs[1][0])
+    # the transposed index itself: row j lists exactly the flat slots naming j, ascending
+    csr = engine.gat_transpose(ctx.to(DEV)).cpu().numpy()
+    flat = ctx.numpy().reshape(-1)
+    for j in (0, 3, 42, N - 1):
+        lo, hi = csr[j], csr[j + 1]
+        assert np.array_equal(csr[N + 1 + lo:N + 1 + hi], np.nonzero(flat == j)[0])
+    assert csr[N] == int((flat >= 0).sum())
+
+
+def test_roipool_backward_rows_are_deterministic_and_cover_the_map():
+    """Heavily nested boxes (every box inside the previous one: maximal arg-max collisions), C = 256, a map
+    wider than one LDS segment: equals the oracle's sequential scatter, no element left unwritten, reruns equal."""
+    rs = np.random.RandomState(21)
+    B, C, H, W = 2, 256, 9, 700
+    feat = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+    n = 40
+    rois = np.zeros((n, 5), np.float32)
+    for i in range(n):
+        rois[i] = [i % B, 4.0 * i, 0.5 * i, 4 * W - 6.0 * i, 4 * H - 0.4 * i]
+    rois = torch.from_numpy(rois)
+    ref, ref_arg = O.roi_pool_argmax(feat, rois, (3, 3), 0.25)
+    gout = torch.from_numpy(rs.standard_normal((n, C * 9)).astype(np.float32))
+    gref = torch.empty(B, C, H, W)
+    O._lib().oracle_roipool_bwd(O._fp(gout), O._fp(rois), O._fp(ref_arg), n, B, C, H, W, 3, 3, O._fp(gref))
+    arg = ref_arg.reshape(n, C * 9).to(DEV)
+    res = []
+    for rep in range(2):
+        gfeat = torch.full((B, H, W, C), float("nan"), device=DEV)
+        call("cova_roipool_bwd", gout.to(DEV), C * 9, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat)
+        res.append(gfeat)
+    assert torch.isfinite(res[0]).all()
+    close(nchw(res[0]), gref, 1e-5, "roipool bwd rows")
+    assert torch.equal(res[0], res[1])
+    assert int((gref != 0).sum()) < n * C * 9                     # collisions did happen

@@ -119,8 +119,8 @@ def test_two_rank_step_with_local_batchnorm_sums_the_shard_gradients(tmp_path):
     r0, r1 = _run(tmp_path, False)
     assert torch.equal(r0["grads"], r1["grads"])
     summed = r0["local"] + r1["local"]
-    # (RoIPool's atomic scatter order differs between two runs of the same step: 1e-5, not 0)
-    assert float((summed - r0["grads"]).abs().max()) <= 1e-5 * float(summed.abs().max())
+    # no float atomics anywhere in the step (RoIPool / GAT backward gather in a fixed order): exact
+    assert torch.equal(summed, r0["grads"])
     # each rank's local gradient against the oracle on its shard
     sd = weights.seeded_state_dict(23, **WCFG)
     tr = HotPathTrainer(CFG, sd, "cpu")            # (flat layout only; no device work)

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from cova_web_object_detection_amd import _lib, engine  # noqa: E402
+from cova_web_object_detection_amd import _lib, engine, synthetic  # noqa: E402
 from oracle import cova_oracle as O  # noqa: E402
 
 call, query = _lib.call, _lib.query

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
 // collide), and writes the finished row -- which also replaces the zero-fill of the gradient map.
 // BN: the row is masked by the ReLU of the map's producer and the BatchNorm-backward sums are taken on the way
 // out (only where the gradient is non-zero: ~1 % of the map).
-constexpr int ROI_XS = 320;                       // pixels per LDS row segment (80 KB)
+constexpr int ROI_XW = 80;                        // pixels per owner wave (20 KB of LDS)
 
 struct RoiGeo {
     int b, rs_h, rs_w;
@@ -126,30 +126,45 @@ __device__ __forceinline__ RoiGeo roi_geo(const float *__restrict__ roi, float s
 __device__ __forceinline__ int bin_lo(int i, float bin, int rs, int lim) { return min(max((int)floorf((float)i * bin) + rs, 0), lim); }
 __device__ __forceinline__ int bin_hi(int i, float bin, int rs, int lim) { return min(max((int)ceilf((float)(i + 1) * bin) + rs, 0), lim); }
 
+// Owner = one wave per (page, feature row, 80-pixel segment), 64 channels (blockIdx.y = channel block); the four
+// waves of a block are independent (own LDS slice, own task stream, no block barrier in the task loop).
+//   accumulate: lane = channel; boxes touching the row are found 64 at a time (geometry test + ballot), visited
+//               in ascending order, their arg-max hits added into the LDS row -- program order, so deterministic;
+//   write out : lane = (pixel t*4 + lane/16, channels 4*(lane%16)..+3): one float4 per lane, 1 KB per store.
 template <bool BN>
-__global__ __launch_bounds__(64) void roipool_bwd_rows_kernel(
+__global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
     const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
     float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gfeat,
     float *__restrict__ partial, const LazyFeat lz)
 {
-    __shared__ __attribute__((aligned(16))) float acc[ROI_XS * 64];
-    const int lane = threadIdx.x;
-    const int c = blockIdx.y * 64 + lane;
-    const int nx = (W + ROI_XS - 1) / ROI_XS;
+    __shared__ __attribute__((aligned(16))) float lds[4 * ROI_XW * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *acc = lds + wave * ROI_XW * 64;
+    const int cb = blockIdx.y * 64;
+    const int c = cb + lane;                          // accumulate phase
+    const int ps = lane >> 4, c4 = cb + 4 * (lane & 15);   // write-out phase
+    const int nx = (W + ROI_XW - 1) / ROI_XW;
     const long long ntask = (long long)B * H * nx;
-    float su = 0.f, sq = 0.f, mu = 0.f, is = 0.f, lsc = 0.f, lsh = 0.f;
+    float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, lsc = mu, lsh = mu;
     if (BN) {
-        mu = mean[c]; is = invstd[c];
-        if (act == nullptr) { lsc = lz.scale[c]; lsh = lz.shift[c]; }
+        mu = *reinterpret_cast<const float4 *>(mean + c4);
+        is = *reinterpret_cast<const float4 *>(invstd + c4);
+        if (act == nullptr) {
+            lsc = *reinterpret_cast<const float4 *>(lz.scale + c4);
+            lsh = *reinterpret_cast<const float4 *>(lz.shift + c4);
+        }
     }
-    for (long long task = blockIdx.x; task < ntask; task += gridDim.x) {
+    for (long long task = (long long)blockIdx.x * 4 + wave; task < ntask; task += (long long)gridDim.x * 4) {
         const int xs = (int)(task % nx);
         const int y = (int)((task / nx) % H);
         const int b = (int)(task / ((long long)nx * H));
-        const int x0 = xs * ROI_XS, x1 = min(x0 + ROI_XS, W);
-        for (int i = lane; i < ROI_XS * 16; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int x0 = xs * ROI_XW, x1 = min(x0 + ROI_XW, W);
+#pragma unroll
+        for (int i = 0; i < ROI_XW * 16 / 64; ++i)
+            reinterpret_cast<float4 *>(acc)[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int n0 = 0; n0 < n_rois; n0 += 64) {
             const int n = n0 + lane;
             bool hit = false;
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(64) void roipool_bwd_rows_kernel(
                       bin_lo(0, g.bin_w, g.rs_w, W) < x1 && bin_hi(PW - 1, g.bin_w, g.rs_w, W) > x0;
             }
             unsigned long long m = __ballot(hit);
-            while (m) {                                     // boxes touching this row, ascending: fixed order
+            while (m) {                                     // boxes touching this segment, ascending: fixed order
                 const int nb = n0 + __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
@@ -170,29 +185,61 @@ __global__ __launch_bounds__(64) void roipool_bwd_rows_kernel(
                         const size_t e = (size_t)c * (PH * PW) + ph * PW + pw;
                         const int mi = argmax[(size_t)nb * C * PH * PW + e];
                         const int x = mi - y * W;
-                        if (mi >= 0 && x >= x0 && x < x1 && mi / W == y)
+                        if (mi >= 0 && x >= x0 && x < x1)
                             acc[(x - x0) * 64 + lane] += gout[(size_t)nb * ld_g + e];
                     }
                 }
             }
         }
         const size_t row = ((size_t)b * H + y) * W;
-        for (int x = x0; x < x1; ++x) {
-            float v = acc[(x - x0) * 64 + lane];
-            const size_t pos = (row + x) * C + c;
-            if (BN && v != 0.f) {
-                const float zv = z[pos];
-                const float a = act != nullptr ? act[pos] : fmaf(lsc, zv, lsh) + lz.x[pos];
-                if (!(a > 0.f)) v = 0.f;
-                su += v;
-                sq += v * ((zv - mu) * is);
+#pragma unroll 4
+        for (int t = 0; t < ROI_XW / 4; ++t) {
+            const int x = x0 + t * 4 + ps;
+            if (x >= x1) continue;
+            float4 v = *reinterpret_cast<const float4 *>(acc + (t * 4 + ps) * 64 + 4 * (lane & 15));
+            const size_t pos = (row + x) * C + c4;
+            if (BN && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
+                const float4 zv = *reinterpret_cast<const float4 *>(z + pos);
+                float4 a;
+                if (act != nullptr) {
+                    a = *reinterpret_cast<const float4 *>(act + pos);
+                } else {
+                    const float4 xr = *reinterpret_cast<const float4 *>(lz.x + pos);
+                    a.x = fmaf(lsc.x, zv.x, lsh.x) + xr.x; a.y = fmaf(lsc.y, zv.y, lsh.y) + xr.y;
+                    a.z = fmaf(lsc.z, zv.z, lsh.z) + xr.z; a.w = fmaf(lsc.w, zv.w, lsh.w) + xr.w;
+                }
+                if (!(a.x > 0.f)) v.x = 0.f;
+                if (!(a.y > 0.f)) v.y = 0.f;
+                if (!(a.z > 0.f)) v.z = 0.f;
+                if (!(a.w > 0.f)) v.w = 0.f;
+                su[0] += v.x; sq[0] += v.x * ((zv.x - mu.x) * is.x);
+                su[1] += v.y; sq[1] += v.y * ((zv.y - mu.y) * is.y);
+                su[2] += v.z; sq[2] += v.z * ((zv.z - mu.z) * is.z);
+                su[3] += v.w; sq[3] += v.w * ((zv.w - mu.w) * is.w);
             }
-            gfeat[pos] = v;
+            *reinterpret_cast<float4 *>(gfeat + pos) = v;
         }
     }
     if (BN) {
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = su;
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sq;
+        __syncthreads();                                    // all waves are done with their LDS rows
+        float *s_red = lds;                                 // [4 waves][2][64]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = su[k], q = sq[k];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) {
+                s_red[(wave * 2 + 0) * 64 + 4 * lane + k] = a;
+                s_red[(wave * 2 + 1) * 64 + 4 * lane + k] = q;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+            const float t = (s_red[(0 * 2 + which) * 64 + cc] + s_red[(1 * 2 + which) * 64 + cc]) +
+                            (s_red[(2 * 2 + which) * 64 + cc] + s_red[(3 * 2 + which) * 64 + cc]);
+            partial[((size_t)blockIdx.x * 2 + which) * C + cb + cc] = t;
+        }
     }
 }
 
@@ -562,7 +609,7 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
 
 static int roipool_bwd_grid(int B, int H, int W)
 {
-    const long long ntask = (long long)B * H * ((W + ROI_XS - 1) / ROI_XS);
+    const long long ntask = ((long long)B * H * ((W + ROI_XW - 1) / ROI_XW) + 3) / 4;       // 4 owner waves per block
     return cova_internal_persistent_grid2(ntask > (1 << 30) ? (1 << 30) : (int)ntask, 2);
 }
 
@@ -573,7 +620,7 @@ COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, co
                               float spatial_scale, float *gfeat, void *stream)
 {
     COVA_REQUIRE(gout && rois && argmax && gfeat && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
-    hipLaunchKernelGGL(roipool_bwd_rows_kernel<false>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(64), 0,
+    hipLaunchKernelGGL(roipool_bwd_rows_kernel<false>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
                        (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        nullptr, nullptr, nullptr, nullptr, gfeat, nullptr, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
@@ -594,7 +641,7 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois,
     COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && B > 0 && n_rois >= 0);
     COVA_REQUIRE(act || (x && scale && shift));   // mask: act > 0, or relu argument scale*z + shift + x > 0
     COVA_REQUIRE(C > 0 && C % 64 == 0);
-    hipLaunchKernelGGL(roipool_bwd_rows_kernel<true>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(64), 0,
+    hipLaunchKernelGGL(roipool_bwd_rows_kernel<true>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
                        (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        act, z, mean, invstd, gfeat, partial, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();

@@ -131,11 +131,29 @@ __device__ __forceinline__ int bin_hi(int i, float bin, int rs, int lim) { retur
 //   accumulate: lane = channel; boxes touching the row are found 64 at a time (geometry test + ballot), visited
 //               in ascending order, their arg-max hits added into the LDS row -- program order, so deterministic;
 //   write out : lane = (pixel t*4 + lane/16, channels 4*(lane%16)..+3): one float4 per lane, 1 KB per store.
+// [first, last] box index of every page (boxes of a page are contiguous in the collate layout, datasets.py:
+// 170-178; if they are not, the range merely contains foreign boxes, which the page test rejects)
+__global__ void roipool_page_range_kernel(const float *__restrict__ rois, int n_rois, int B, int *__restrict__ range)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rois) return;
+    const int b = (int)rois[5 * n];
+    if (b < 0 || b >= B) return;
+    atomicMin(range + 2 * b, n);
+    atomicMax(range + 2 * b + 1, n);
+}
+
+__global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { range[2 * b] = 0x7fffffff; range[2 * b + 1] = -1; }
+}
+
 template <bool BN>
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
-    const int32_t *__restrict__ argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
-    float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
+    const int32_t *__restrict__ argmax, const int *__restrict__ page_range, int n_rois, int B, int C, int H,
+    int W, int PH, int PW, float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gfeat,
     float *__restrict__ partial, const LazyFeat lz)
 {
@@ -165,10 +183,11 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
 #pragma unroll
         for (int i = 0; i < ROI_XW * 16 / 64; ++i)
             reinterpret_cast<float4 *>(acc)[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int n0 = 0; n0 < n_rois; n0 += 64) {
+        const int n_lo = page_range[2 * b], n_hi = page_range[2 * b + 1];
+        for (int n0 = n_lo; n0 <= n_hi; n0 += 64) {
             const int n = n0 + lane;
             bool hit = false;
-            if (n < n_rois) {
+            if (n <= n_hi) {
                 const RoiGeo g = roi_geo(rois + 5 * n, spatial_scale, PH, PW);
                 hit = g.b == b && y >= bin_lo(0, g.bin_h, g.rs_h, H) && y < bin_hi(PH - 1, g.bin_h, g.rs_h, H) &&
                       bin_lo(0, g.bin_w, g.rs_w, W) < x1 && bin_hi(PW - 1, g.bin_w, g.rs_w, W) > x0;
@@ -178,15 +197,32 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                 const int nb = n0 + __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
-                for (int ph = 0; ph < PH; ++ph) {
-                    if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
-                    for (int pw = 0; pw < PW; ++pw) {
-                        if (bin_hi(pw, g.bin_w, g.rs_w, W) <= x0 || bin_lo(pw, g.bin_w, g.rs_w, W) >= x1) continue;
-                        const size_t e = (size_t)c * (PH * PW) + ph * PW + pw;
-                        const int mi = argmax[(size_t)nb * C * PH * PW + e];
+                const int32_t *am = argmax + (size_t)nb * C * PH * PW + (size_t)c * (PH * PW);
+                const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
+                if (PH * PW <= 9) {                         // all bins' operands in flight at once
+                    int mi[9];
+                    float gg[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const int qq = q < PH * PW ? q : 0;
+                        mi[q] = am[qq];
+                        gg[q] = gv[qq];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        if (q >= PH * PW) break;
+                        const int ph = q / PW;
+                        if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
+                        const int x = mi[q] - y * W;
+                        if (mi[q] >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gg[q];
+                    }
+                } else {
+                    for (int q = 0; q < PH * PW; ++q) {
+                        const int ph = q / PW;
+                        if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
+                        const int mi = am[q];
                         const int x = mi - y * W;
-                        if (mi >= 0 && x >= x0 && x < x1)
-                            acc[(x - x0) * 64 + lane] += gout[(size_t)nb * ld_g + e];
+                        if (mi >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gv[q];
                     }
                 }
             }
@@ -615,13 +651,26 @@ static int roipool_bwd_grid(int B, int H, int W)
 
 // gfeat NHWC [B,H,W,C] = sum over (box, bin) of gout routed to the arg-max positions; fully written here
 // (no zero-fill, no atomics: every row of the map has one owner wave).  C % 64 == 0.
+static int roipool_page_ranges(const float *rois, int n_rois, int B, int *range, hipStream_t st)
+{
+    hipLaunchKernelGGL(roipool_page_range_init_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, B, range);
+    COVA_LAUNCH_CHECK();
+    if (n_rois > 0) {
+        hipLaunchKernelGGL(roipool_page_range_kernel, dim3(cdiv(n_rois, 256)), dim3(256), 0, st, rois, n_rois, B, range);
+        COVA_LAUNCH_CHECK();
+    }
+    return COVA_OK;
+}
+
 COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                               int n_rois, int B, int C, int H, int W, int PH, int PW,
-                              float spatial_scale, float *gfeat, void *stream)
+                              float spatial_scale, float *gfeat, int *page_range, void *stream)
 {
-    COVA_REQUIRE(gout && rois && argmax && gfeat && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    COVA_REQUIRE(gout && rois && argmax && gfeat && page_range && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
+    if (rc != COVA_OK) return rc;
     hipLaunchKernelGGL(roipool_bwd_rows_kernel<false>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        nullptr, nullptr, nullptr, nullptr, gfeat, nullptr, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -636,13 +685,16 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois,
                                  int n_rois, int B, int C, int H, int W, int PH, int PW,
                                  float spatial_scale, const float *act, const float *x, const float *scale,
                                  const float *shift, const float *z, const float *mean,
-                                 const float *invstd, float *gfeat, float *partial, void *stream)
+                                 const float *invstd, float *gfeat, float *partial, int *page_range,
+                                 void *stream)
 {
-    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && B > 0 && n_rois >= 0);
+    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && page_range && B > 0 && n_rois >= 0);
     COVA_REQUIRE(act || (x && scale && shift));   // mask: act > 0, or relu argument scale*z + shift + x > 0
     COVA_REQUIRE(C > 0 && C % 64 == 0);
+    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
+    if (rc != COVA_OK) return rc;
     hipLaunchKernelGGL(roipool_bwd_rows_kernel<true>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                       (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        act, z, mean, invstd, gfeat, partial, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;

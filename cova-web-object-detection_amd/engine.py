@@ -707,7 +707,7 @@ def roipool_bwd(sv, gout, ld_g):
     PH, PW = sv["roi"]
     gfeat = _empty((B, Hf, Wf, C), gout)
     call("cova_roipool_bwd", gout, ld_g, sv["bboxes"], sv["argmax"], sv["bboxes"].shape[0], B, C, Hf,
-         Wf, PH, PW, float(sv["scale"]), gfeat)
+         Wf, PH, PW, float(sv["scale"]), gfeat, _empty((2 * B,), gout, torch.int32))
     return gfeat
 
 
@@ -725,7 +725,7 @@ def roipool_bwd_bn(sv, gout, ld_g, last):
     lazy = last["out"] is None                    # mask recomputed from (z, x) like the forward did
     call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
          float(sv["scale"]), last["out"], last["x"] if lazy else None, bn.scale if lazy else None,
-         bn.shift if lazy else None, last["z"], bn.mean, bn.invstd, gfeat, part)
+         bn.shift if lazy else None, last["z"], bn.mean, bn.invstd, gfeat, part, _empty((2 * B,), gout, torch.int32))
     return gfeat, (part, npart)
 
 
@@ -762,6 +762,12 @@ def bbox_bwd(sv, g, ldg, gout=None):
 
 
 # ------------------------------------------------------------------------------- GAT
+def _adjacent(a, b):
+    """b starts right where a ends (views of one flat bucket): [a; b] is one row-major matrix"""
+    return (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:] and
+            b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+
+
 def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
     """models.py:171-212.  h rows at h + n*ldh (F values); hprime rows at hprime + n*ldo (D)."""
     _check(ctx, torch.int64)
@@ -769,8 +775,11 @@ def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
     aw, ab = params[prefix + "attention_layer.weight"], params[prefix + "attention_layer.bias"]
     D, K = Wi.shape[0], ctx.shape[1]
     Wh = _empty((N, 2 * D), h)
-    call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wi, F, Wh, 2 * D, None, 0)
-    call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wj, F, Wh[:, D:], 2 * D, None, 0)
+    if _adjacent(Wi, Wj):        # one [2D, F] matrix (flat parameter bucket): both projections in one GEMM
+        call("cova_sgemm", 0, 1, N, 2 * D, F, h, ldh, Wi, F, Wh, 2 * D, None, 0)
+    else:
+        call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wi, F, Wh, 2 * D, None, 0)
+        call("cova_sgemm", 0, 1, N, D, F, h, ldh, Wj, F, Wh[:, D:], 2 * D, None, 0)
     s, t, attn = _empty((N,), h), _empty((N,), h), _empty((N, K), h)
     call("cova_gat_fwd", Wh, 2 * D, aw, ab, ctx, N, K, D, LEAKY_SLOPE, s, t, attn, hprime, ldo)
     return dict(h=h, ldh=ldh, N=N, F=F, D=D, K=K, ctx=ctx, Wh=Wh, s=s, t=t, attn=attn, prefix=prefix)
@@ -805,10 +814,16 @@ def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None, csr=None):
          LEAKY_SLOPE, dWh, 2 * D, ds, dt, daw, dab, csr, du)
     dWi = _gbuf(gout, prefix + "W_i.weight", (D, F), g)
     dWj = _gbuf(gout, prefix + "W_j.weight", (D, F), g)
-    call("cova_sgemm", 1, 0, D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
-    call("cova_sgemm", 1, 0, D, F, N, dWh[:, D:], 2 * D, sv["h"], sv["ldh"], dWj, F, None, 0)
-    call("cova_sgemm", 0, 0, N, F, D, dWh, 2 * D, Wi, F, dh, lddh, None, 1 if accumulate_dh else 0)
-    call("cova_sgemm", 0, 0, N, F, D, dWh[:, D:], 2 * D, Wj, F, dh, lddh, None, 1)
+    if _adjacent(dWi, dWj):
+        call("cova_sgemm", 1, 0, 2 * D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
+    else:
+        call("cova_sgemm", 1, 0, D, F, N, dWh, 2 * D, sv["h"], sv["ldh"], dWi, F, None, 0)
+        call("cova_sgemm", 1, 0, D, F, N, dWh[:, D:], 2 * D, sv["h"], sv["ldh"], dWj, F, None, 0)
+    if _adjacent(Wi, Wj):
+        call("cova_sgemm", 0, 0, N, F, 2 * D, dWh, 2 * D, Wi, F, dh, lddh, None, 1 if accumulate_dh else 0)
+    else:
+        call("cova_sgemm", 0, 0, N, F, D, dWh, 2 * D, Wi, F, dh, lddh, None, 1 if accumulate_dh else 0)
+        call("cova_sgemm", 0, 0, N, F, D, dWh[:, D:], 2 * D, Wj, F, dh, lddh, None, 1)
     return {prefix + "W_i.weight": dWi, prefix + "W_j.weight": dWj,
             prefix + "attention_layer.weight": daw, prefix + "attention_layer.bias": dab}
 

@@ -203,7 +203,7 @@ int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, in
  * ascending box order (the reference's scatter collides constantly: DOM parents contain their children). */
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                      int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
-                     float *gfeat, void *stream);
+                     float *gfeat, int *page_range /*[2*B] scratch*/, void *stream);
 /* same, fused with the ReLU mask (act > 0) and the BatchNorm-backward partial sums of the layer that
  * produced the map: gfeat = masked gradient, partial [cova_roipool_bwd_bn_num_partials][2][C] */
 int cova_roipool_bwd_bn_num_partials(int B, int H, int W);
@@ -212,7 +212,8 @@ int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const in
                         const float *act /*nullable: then x, scale, shift give the mask*/,
                         const float *x /*nullable*/, const float *scale /*nullable*/,
                         const float *shift /*nullable*/, const float *z, const float *mean,
-                        const float *invstd, float *gfeat, float *partial, void *stream);
+                        const float *invstd, float *gfeat, float *partial, int *page_range /*[2*B] scratch*/,
+                        void *stream);
 /* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
 int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
                         const float *rois, int n_rois, int B, int C, int H, int W, int PH, int PW,

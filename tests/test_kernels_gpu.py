@@ -206,7 +206,7 @@ def test_roipool_matches_oracle_bit_exact():
     import ctypes
     O._lib().oracle_roipool_bwd(O._fp(gout), O._fp(rois), O._fp(ref_arg), n, B, C, H, W, 3, 3, O._fp(gref))
     gfeat = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat)
+    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     close(nchw(gfeat), gref, 1e-5, "roipool bwd")
     # fused variant: ReLU mask of the map's producer + BatchNorm-backward sums
     act = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
@@ -217,7 +217,7 @@ def test_roipool_matches_oracle_bit_exact():
     part = torch.empty(npart, 2, C, device=DEV)
     gmask = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, act, None, None,
-         None, z, mean, invstd, gmask, part)
+         None, z, mean, invstd, gmask, part, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     ref_masked = gfeat * (act > 0)
     close(gmask, ref_masked, 1e-5, "roipool bwd masked")
     close(part[:, 0].sum(0), ref_masked.sum((0, 1, 2)), 1e-4, "roipool bwd sum dy")
@@ -236,9 +236,9 @@ def test_roipool_matches_oracle_bit_exact():
     g_m, g_l = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
     p_m, p_l = torch.empty(npart, 2, C, device=DEV), torch.empty(npart, 2, C, device=DEV)
     call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, fmat, None, None,
-         None, z, mean, invstd, g_m, p_m)
+         None, z, mean, invstd, g_m, p_m, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, None, xres, scale,
-         shift, z, mean, invstd, g_l, p_l)
+         shift, z, mean, invstd, g_l, p_l, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     assert torch.equal(g_l == 0, g_m == 0)
     close(g_l, g_m, 1e-6, "lazy roipool bwd")
     close(p_l.sum(0), p_m.sum(0), 1e-5, "lazy roipool bwd sums")
@@ -252,7 +252,7 @@ def test_roipool_matches_oracle_bit_exact():
     assert (out_b.cpu()[isbad] == 0).all() and (arg_b.cpu()[isbad] == -1).all()
     assert torch.equal(out_b.cpu()[~isbad], ref.reshape(n, 576)[~isbad])
     g_b = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, 0.25, g_b)
+    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, 0.25, g_b, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     assert torch.isfinite(g_b).all()
 
 
@@ -713,7 +713,7 @@ def test_roipool_backward_rows_are_deterministic_and_cover_the_map():
     res = []
     for rep in range(2):
         gfeat = torch.full((B, H, W, C), float("nan"), device=DEV)
-        call("cova_roipool_bwd", gout.to(DEV), C * 9, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat)
+        call("cova_roipool_bwd", gout.to(DEV), C * 9, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(2 * B, dtype=torch.int32, device=DEV))
         res.append(gfeat)
     assert torch.isfinite(res[0]).all()
     close(nchw(res[0]), gref, 1e-5, "roipool bwd rows")

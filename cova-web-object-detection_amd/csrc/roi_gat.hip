@@ -193,30 +193,49 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                       bin_lo(0, g.bin_w, g.rs_w, W) < x1 && bin_hi(PW - 1, g.bin_w, g.rs_w, W) > x0;
             }
             unsigned long long m = __ballot(hit);
-            while (m) {                                     // boxes touching this segment, ascending: fixed order
-                const int nb = n0 + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
-                const int32_t *am = argmax + (size_t)nb * C * PH * PW + (size_t)c * (PH * PW);
-                const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
-                if (PH * PW <= 9) {                         // all bins' operands in flight at once
-                    int mi[9];
-                    float gg[9];
+            if (PH * PW <= 9) {
+                // boxes touching this segment, ascending (fixed order); four at a time so that their geometry
+                // and the 4 x 2 x 9 arg-max / gradient operands are one round trip instead of eight
+                while (m) {
+                    int nb[4];
+                    RoiGeo g[4];
+                    int mi[4][9];
+                    float gg[4][9];
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        const int qq = q < PH * PW ? q : 0;
-                        mi[q] = am[qq];
-                        gg[q] = gv[qq];
+                    for (int u = 0; u < 4; ++u) {
+                        nb[u] = m ? n0 + __ffsll((long long)m) - 1 : -1;
+                        m &= m - 1;                          // (0 & anything stays 0)
+                        const int nn = nb[u] >= 0 ? nb[u] : n_lo;
+                        g[u] = roi_geo(rois + 5 * nn, spatial_scale, PH, PW);
+                        const int32_t *am = argmax + (size_t)nn * C * PH * PW + (size_t)c * (PH * PW);
+                        const float *gv = gout + (size_t)nn * ld_g + (size_t)c * (PH * PW);
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) {
+                            const int qq = q < PH * PW ? q : 0;
+                            mi[u][q] = am[qq];
+                            gg[u][q] = gv[qq];
+                        }
                     }
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        if (q >= PH * PW) break;
-                        const int ph = q / PW;
-                        if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
-                        const int x = mi[q] - y * W;
-                        if (mi[q] >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gg[q];
+                    for (int u = 0; u < 4; ++u) {
+                        if (nb[u] < 0) break;
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) {
+                            if (q >= PH * PW) break;
+                            const int ph = q / PW;
+                            if (y < bin_lo(ph, g[u].bin_h, g[u].rs_h, H) || y >= bin_hi(ph, g[u].bin_h, g[u].rs_h, H)) continue;
+                            const int x = mi[u][q] - y * W;
+                            if (mi[u][q] >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gg[u][q];
+                        }
                     }
-                } else {
+                }
+            } else {
+                while (m) {
+                    const int nb = n0 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
+                    const int32_t *am = argmax + (size_t)nb * C * PH * PW + (size_t)c * (PH * PW);
+                    const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
                     for (int q = 0; q < PH * PW; ++q) {
                         const int ph = q / PW;
                         if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
@@ -549,20 +568,29 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
     const int lo = row_ptr[j], deg = row_ptr[j + 1] - lo;
+    // dt[j]: lanes over the row's edges, butterfly sums -- a fixed association, independent of timing
     float dtj = 0.f;
-    for (int q = 0; q < deg; ++q) dtj += du[edges[lo + q]];       // wave-uniform, fixed order
+    for (int c0 = 0; c0 < deg; c0 += 64) dtj += wave_sum(c0 + lane < deg ? du[edges[lo + c0 + lane]] : 0.f);
     if (lane == 0) dt[j] = dtj;
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int d = d0 + lane;
+        const int dd = d < D ? d : 0;
         float accv = 0.f;
         for (int c0 = 0; c0 < deg; c0 += 64) {
             const int e = c0 + lane < deg ? edges[lo + c0 + lane] : 0;
-            const float al = c0 + lane < deg ? attn[e] : 0.f;
+            const float al = c0 + lane < deg ? attn[e] : 0.f;     // 0 weight on the padding lanes
             const int cnt = min(64, deg - c0);
-            for (int q = 0; q < cnt; ++q) {
-                const int i = __shfl(e, q, 64) / K;
-                const float aq = __shfl(al, q, 64);
-                if (d < D) accv += aq * g[(size_t)i * ldg + d];
+            for (int q0 = 0; q0 < cnt; q0 += 8) {                  // 8 neighbour rows in flight, added in edge order
+                float gv[8], aq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int qq = min(q0 + u, 63);
+                    const int i = __shfl(e, qq, 64) / K;
+                    aq[u] = q0 + u < cnt ? __shfl(al, qq, 64) : 0.f;
+                    gv[u] = g[(size_t)i * ldg + dd];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) accv = fmaf(aq[u], gv[u], accv);
             }
         }
         if (d < D) dWh[(size_t)j * lddw + D + d] = accv + dtj * att_w[D + d];

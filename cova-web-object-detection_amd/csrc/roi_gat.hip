@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
 // collide), and writes the finished row -- which also replaces the zero-fill of the gradient map.
 // BN: the row is masked by the ReLU of the map's producer and the BatchNorm-backward sums are taken on the way
 // out (only where the gradient is non-zero: ~1 % of the map).
-constexpr int ROI_XW = 80;                        // pixels per owner wave (20 KB of LDS)
+constexpr int ROI_XW = 40;                        // pixels per owner wave (10 KB of LDS: 16 waves per CU)
 
 struct RoiGeo {
     int b, rs_h, rs_w;
@@ -674,7 +674,7 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
 static int roipool_bwd_grid(int B, int H, int W)
 {
     const long long ntask = ((long long)B * H * ((W + ROI_XW - 1) / ROI_XW) + 3) / 4;       // 4 owner waves per block
-    return cova_internal_persistent_grid2(ntask > (1 << 30) ? (1 << 30) : (int)ntask, 2);
+    return cova_internal_persistent_grid2(ntask > (1 << 30) ? (1 << 30) : (int)ntask, 4);
 }
 
 // gfeat NHWC [B,H,W,C] = sum over (box, bin) of gout routed to the arg-max positions; fully written here

@@ -149,15 +149,16 @@ __global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
     if (b < B) { range[2 * b] = 0x7fffffff; range[2 * b + 1] = -1; }
 }
 
-template <bool BN>
+template <bool BN, bool P33>                      // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
     const int32_t *__restrict__ argmax, const int *__restrict__ page_range, int n_rois, int B, int C, int H,
-    int W, int PH, int PW, float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
+    int W, int PH_, int PW_, float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gfeat,
     float *__restrict__ partial, const LazyFeat lz)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * ROI_XW * 64];
+    const int PH = P33 ? 3 : PH_, PW = P33 ? 3 : PW_;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *acc = lds + wave * ROI_XW * 64;
     const int cb = blockIdx.y * 64;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                       bin_lo(0, g.bin_w, g.rs_w, W) < x1 && bin_hi(PW - 1, g.bin_w, g.rs_w, W) > x0;
             }
             unsigned long long m = __ballot(hit);
-            if (PH * PW <= 9) {
+            if (P33) {
                 // boxes touching this segment, ascending (fixed order); four at a time so that their geometry
                 // and the 4 x 2 x 9 arg-max / gradient operands are one round trip instead of eight
                 while (m) {
@@ -211,21 +212,22 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                         const float *gv = gout + (size_t)nn * ld_g + (size_t)c * (PH * PW);
 #pragma unroll
                         for (int q = 0; q < 9; ++q) {
-                            const int qq = q < PH * PW ? q : 0;
-                            mi[u][q] = am[qq];
-                            gg[u][q] = gv[qq];
+                            mi[u][q] = am[q];
+                            gg[u][q] = gv[q];
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (nb[u] < 0) break;
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) {
-                            if (q >= PH * PW) break;
-                            const int ph = q / PW;
-                            if (y < bin_lo(ph, g[u].bin_h, g[u].rs_h, H) || y >= bin_hi(ph, g[u].bin_h, g[u].rs_h, H)) continue;
-                            const int x = mi[u][q] - y * W;
-                            if (mi[u][q] >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gg[u][q];
+                        for (int ph = 0; ph < 3; ++ph) {
+                            const bool rowhit = nb[u] >= 0 && y >= bin_lo(ph, g[u].bin_h, g[u].rs_h, H) &&
+                                                y < bin_hi(ph, g[u].bin_h, g[u].rs_h, H);
+#pragma unroll
+                            for (int pw = 0; pw < 3; ++pw) {
+                                const int q = ph * 3 + pw;
+                                const int x = mi[u][q] - y * W;
+                                if (rowhit && mi[u][q] >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gg[u][q];
+                            }
                         }
                     }
                 }
@@ -697,8 +699,8 @@ COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, co
     COVA_REQUIRE(gout && rois && argmax && gfeat && page_range && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
     const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
     if (rc != COVA_OK) return rc;
-    hipLaunchKernelGGL(roipool_bwd_rows_kernel<false>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
+    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<false, true> : roipool_bwd_rows_kernel<false, false>),
+                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        nullptr, nullptr, nullptr, nullptr, gfeat, nullptr, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -721,8 +723,8 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois,
     COVA_REQUIRE(C > 0 && C % 64 == 0);
     const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
     if (rc != COVA_OK) return rc;
-    hipLaunchKernelGGL(roipool_bwd_rows_kernel<true>, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0,
-                       (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
+    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true, true> : roipool_bwd_rows_kernel<true, false>),
+                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
                        act, z, mean, invstd, gfeat, partial, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;

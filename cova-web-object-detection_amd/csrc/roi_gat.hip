@@ -249,32 +249,50 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
             }
         }
         const size_t row = ((size_t)b * H + y) * W;
-#pragma unroll 4
-        for (int t = 0; t < ROI_XW / 4; ++t) {
-            const int x = x0 + t * 4 + ps;
-            if (x >= x1) continue;
-            float4 v = *reinterpret_cast<const float4 *>(acc + (t * 4 + ps) * 64 + 4 * (lane & 15));
-            const size_t pos = (row + x) * C + c4;
-            if (BN && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
-                const float4 zv = *reinterpret_cast<const float4 *>(z + pos);
-                float4 a;
-                if (act != nullptr) {
-                    a = *reinterpret_cast<const float4 *>(act + pos);
-                } else {
-                    const float4 xr = *reinterpret_cast<const float4 *>(lz.x + pos);
-                    a.x = fmaf(lsc.x, zv.x, lsh.x) + xr.x; a.y = fmaf(lsc.y, zv.y, lsh.y) + xr.y;
-                    a.z = fmaf(lsc.z, zv.z, lsh.z) + xr.z; a.w = fmaf(lsc.w, zv.w, lsh.w) + xr.w;
-                }
-                if (!(a.x > 0.f)) v.x = 0.f;
-                if (!(a.y > 0.f)) v.y = 0.f;
-                if (!(a.z > 0.f)) v.z = 0.f;
-                if (!(a.w > 0.f)) v.w = 0.f;
-                su[0] += v.x; sq[0] += v.x * ((zv.x - mu.x) * is.x);
-                su[1] += v.y; sq[1] += v.y * ((zv.y - mu.y) * is.y);
-                su[2] += v.z; sq[2] += v.z * ((zv.z - mu.z) * is.z);
-                su[3] += v.w; sq[3] += v.w * ((zv.w - mu.w) * is.w);
+        constexpr int WB = 5;                               // float4 rows per batch: their mask / xhat operands
+        static_assert((ROI_XW / 4) % WB == 0, "segment = whole batches");   // (where the gradient is non-zero)
+#pragma unroll                                              // are requested together, one round trip per batch
+        for (int t0 = 0; t0 < ROI_XW / 4; t0 += WB) {
+            float4 v[WB], zv[WB], av[WB], xr[WB];
+            bool nz[WB];
+#pragma unroll
+            for (int t = 0; t < WB; ++t) {
+                v[t] = *reinterpret_cast<const float4 *>(acc + ((t0 + t) * 4 + ps) * 64 + 4 * (lane & 15));
+                nz[t] = BN && (x0 + (t0 + t) * 4 + ps) < x1 &&
+                        (v[t].x != 0.f || v[t].y != 0.f || v[t].z != 0.f || v[t].w != 0.f);
             }
-            *reinterpret_cast<float4 *>(gfeat + pos) = v;
+            if (BN) {
+#pragma unroll
+                for (int t = 0; t < WB; ++t) {
+                    if (nz[t]) {
+                        const size_t pos = (row + x0 + (t0 + t) * 4 + ps) * C + c4;
+                        zv[t] = *reinterpret_cast<const float4 *>(z + pos);
+                        if (act != nullptr) av[t] = *reinterpret_cast<const float4 *>(act + pos);
+                        else xr[t] = *reinterpret_cast<const float4 *>(lz.x + pos);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < WB; ++t) {
+                const int x = x0 + (t0 + t) * 4 + ps;
+                if (x >= x1) continue;
+                if (nz[t]) {
+                    float4 a = av[t];
+                    if (act == nullptr) {
+                        a.x = fmaf(lsc.x, zv[t].x, lsh.x) + xr[t].x; a.y = fmaf(lsc.y, zv[t].y, lsh.y) + xr[t].y;
+                        a.z = fmaf(lsc.z, zv[t].z, lsh.z) + xr[t].z; a.w = fmaf(lsc.w, zv[t].w, lsh.w) + xr[t].w;
+                    }
+                    if (!(a.x > 0.f)) v[t].x = 0.f;
+                    if (!(a.y > 0.f)) v[t].y = 0.f;
+                    if (!(a.z > 0.f)) v[t].z = 0.f;
+                    if (!(a.w > 0.f)) v[t].w = 0.f;
+                    su[0] += v[t].x; sq[0] += v[t].x * ((zv[t].x - mu.x) * is.x);
+                    su[1] += v[t].y; sq[1] += v[t].y * ((zv[t].y - mu.y) * is.y);
+                    su[2] += v[t].z; sq[2] += v[t].z * ((zv[t].z - mu.z) * is.z);
+                    su[3] += v[t].w; sq[3] += v[t].w * ((zv[t].w - mu.w) * is.w);
+                }
+                *reinterpret_cast<float4 *>(gfeat + (row + x) * C + c4) = v[t];
+            }
         }
     }
     if (BN) {

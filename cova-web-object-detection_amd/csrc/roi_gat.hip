@@ -29,7 +29,7 @@ template <bool LAZY>
 __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int B, int C, int H,
     int W, int PH, int PW, float spatial_scale, float *__restrict__ out, int ld_out,
-    int32_t *__restrict__ argmax, const LazyFeat lz)
+    int32_t *__restrict__ argmax, float *__restrict__ zmax, const LazyFeat lz)
 {
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     const float *fb = feat + (size_t)(bad_page ? 0 : b) * H * W * C;
     const float *xb = LAZY ? lz.x + (size_t)(bad_page ? 0 : b) * H * W * C : nullptr;
     for (int c = lane; c < C; c += 64) {
-        float maxv = empty ? 0.f : -FLT_MAX;
+        float maxv = empty ? 0.f : -FLT_MAX, zbest = 0.f;
         int maxi = -1;
         const int nw = wend - wstart;
         const float sc = LAZY ? lz.scale[c] : 0.f, sh = LAZY ? lz.shift[c] : 0.f;
@@ -70,29 +70,33 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
             const float *zrow = fb + ro;
             const float *xrow = LAZY ? xb + ro : nullptr;
             // element w of the row: the feature value (LAZY: bn2 + residual + ReLU on the fly)
-            auto at = [&](int w) {
-                const float z = zrow[(size_t)w * C];
+            auto val = [&](float z, int w) {
                 if (!LAZY) return z;
                 const float y = fmaf(sc, z, sh) + xrow[(size_t)w * C];
                 return y > 0.f ? y : 0.f;
             };
             int w = 0;
             for (; w + 3 < nw; w += 4) {       // 4 loads in flight; compares in scan order
-                const float v0 = at(w), v1 = at(w + 1);
-                const float v2 = at(w + 2), v3 = at(w + 3);
-                if (v0 > maxv) { maxv = v0; maxi = h * W + wstart + w; }
-                if (v1 > maxv) { maxv = v1; maxi = h * W + wstart + w + 1; }
-                if (v2 > maxv) { maxv = v2; maxi = h * W + wstart + w + 2; }
-                if (v3 > maxv) { maxv = v3; maxi = h * W + wstart + w + 3; }
+                const float z0 = zrow[(size_t)w * C], z1 = zrow[(size_t)(w + 1) * C];
+                const float z2 = zrow[(size_t)(w + 2) * C], z3 = zrow[(size_t)(w + 3) * C];
+                const float v0 = val(z0, w), v1 = val(z1, w + 1), v2 = val(z2, w + 2), v3 = val(z3, w + 3);
+                if (v0 > maxv) { maxv = v0; zbest = z0; maxi = h * W + wstart + w; }
+                if (v1 > maxv) { maxv = v1; zbest = z1; maxi = h * W + wstart + w + 1; }
+                if (v2 > maxv) { maxv = v2; zbest = z2; maxi = h * W + wstart + w + 2; }
+                if (v3 > maxv) { maxv = v3; zbest = z3; maxi = h * W + wstart + w + 3; }
             }
             for (; w < nw; ++w) {
-                const float v = at(w);
-                if (v > maxv) { maxv = v; maxi = h * W + wstart + w; }
+                const float z0 = zrow[(size_t)w * C];
+                const float v = val(z0, w);
+                if (v > maxv) { maxv = v; zbest = z0; maxi = h * W + wstart + w; }
             }
         }
         // reference layout [N, C, PH, PW] flattened per roi: c*(PH*PW) + bin  (models.py:125-127)
         out[(size_t)n * ld_out + c * (PH * PW) + bin] = maxv;
         argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = maxi;
+        // the pre-activation z at the arg-max: with it the backward takes the producer's BatchNorm sums per
+        // pooled entry and never has to read the maps again
+        if (LAZY && zmax != nullptr) zmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = zbest;
     }
 }
 
@@ -126,11 +130,6 @@ __device__ __forceinline__ RoiGeo roi_geo(const float *__restrict__ roi, float s
 __device__ __forceinline__ int bin_lo(int i, float bin, int rs, int lim) { return min(max((int)floorf((float)i * bin) + rs, 0), lim); }
 __device__ __forceinline__ int bin_hi(int i, float bin, int rs, int lim) { return min(max((int)ceilf((float)(i + 1) * bin) + rs, 0), lim); }
 
-// Owner = one wave per (page, feature row, 80-pixel segment), 64 channels (blockIdx.y = channel block); the four
-// waves of a block are independent (own LDS slice, own task stream, no block barrier in the task loop).
-//   accumulate: lane = channel; boxes touching the row are found 64 at a time (geometry test + ballot), visited
-//               in ascending order, their arg-max hits added into the LDS row -- program order, so deterministic;
-//   write out : lane = (pixel t*4 + lane/16, channels 4*(lane%16)..+3): one float4 per lane, 1 KB per store.
 // [first, last] box index of every page (boxes of a page are contiguous in the collate layout, datasets.py:
 // 170-178; if they are not, the range merely contains foreign boxes, which the page test rejects)
 __global__ void roipool_page_range_kernel(const float *__restrict__ rois, int n_rois, int B, int *__restrict__ range)
@@ -149,13 +148,18 @@ __global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
     if (b < B) { range[2 * b] = 0x7fffffff; range[2 * b + 1] = -1; }
 }
 
-template <bool BN, bool P33>                      // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
+// Owner = one wave per (page, feature row, 40-pixel segment), 64 channels (blockIdx.y = channel block); the four
+// waves of a block are independent (own LDS slice, own task stream, no block barrier).
+//   accumulate: lane = channel; boxes touching the row are found 64 at a time (geometry test + ballot), visited
+//               in ascending order, their arg-max hits added into the LDS row -- program order, so deterministic;
+//   write out : lane = (pixel t*4 + lane/16, channels 4*(lane%16)..+3): one float4 per lane, 1 KB per store.
+// pooled != NULL: the contribution of an entry is masked by pooled > 0 -- the pooled value IS the map's value at
+// the arg-max, so this is the ReLU mask of the map's producer without reading the map.
+template <bool P33>                               // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
-    const float *__restrict__ gout, int ld_g, const float *__restrict__ rois,
-    const int32_t *__restrict__ argmax, const int *__restrict__ page_range, int n_rois, int B, int C, int H,
-    int W, int PH_, int PW_, float spatial_scale, const float *__restrict__ act, const float *__restrict__ z,
-    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gfeat,
-    float *__restrict__ partial, const LazyFeat lz)
+    const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
+    const float *__restrict__ rois, const int32_t *__restrict__ argmax, const int *__restrict__ page_range,
+    int n_rois, int B, int C, int H, int W, int PH_, int PW_, float spatial_scale, float *__restrict__ gfeat)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * ROI_XW * 64];
     const int PH = P33 ? 3 : PH_, PW = P33 ? 3 : PW_;
@@ -166,16 +170,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const int ps = lane >> 4, c4 = cb + 4 * (lane & 15);   // write-out phase
     const int nx = (W + ROI_XW - 1) / ROI_XW;
     const long long ntask = (long long)B * H * nx;
-    float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, lsc = mu, lsh = mu;
-    if (BN) {
-        mu = *reinterpret_cast<const float4 *>(mean + c4);
-        is = *reinterpret_cast<const float4 *>(invstd + c4);
-        if (act == nullptr) {
-            lsc = *reinterpret_cast<const float4 *>(lz.scale + c4);
-            lsh = *reinterpret_cast<const float4 *>(lz.shift + c4);
-        }
-    }
+    const bool masked = pooled != nullptr;
     for (long long task = (long long)blockIdx.x * 4 + wave; task < ntask; task += (long long)gridDim.x * 4) {
         const int xs = (int)(task % nx);
         const int y = (int)((task / nx) % H);
@@ -195,29 +190,31 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
             }
             unsigned long long m = __ballot(hit);
             if (P33) {
-                // boxes touching this segment, ascending (fixed order); four at a time so that their geometry
-                // and the 4 x 2 x 9 arg-max / gradient operands are one round trip instead of eight
+                // boxes touching this segment, ascending (fixed order); two at a time so that their geometry
+                // and arg-max / gradient / pooled operands are one round trip
                 while (m) {
-                    int nb[4];
-                    RoiGeo g[4];
-                    int mi[4][9];
-                    float gg[4][9];
+                    int nb[2];
+                    RoiGeo g[2];
+                    int mi[2][9];
+                    float gg[2][9];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 2; ++u) {
                         nb[u] = m ? n0 + __ffsll((long long)m) - 1 : -1;
                         m &= m - 1;                          // (0 & anything stays 0)
                         const int nn = nb[u] >= 0 ? nb[u] : n_lo;
                         g[u] = roi_geo(rois + 5 * nn, spatial_scale, PH, PW);
-                        const int32_t *am = argmax + (size_t)nn * C * PH * PW + (size_t)c * (PH * PW);
-                        const float *gv = gout + (size_t)nn * ld_g + (size_t)c * (PH * PW);
+                        const int32_t *am = argmax + (size_t)nn * C * 9 + (size_t)c * 9;
+                        const float *gv = gout + (size_t)nn * ld_g + (size_t)c * 9;
+                        const float *pv = masked ? pooled + (size_t)nn * ld_p + (size_t)c * 9 : gv;
 #pragma unroll
                         for (int q = 0; q < 9; ++q) {
                             mi[u][q] = am[q];
-                            gg[u][q] = gv[q];
+                            const float p = pv[q];
+                            gg[u][q] = (!masked || p > 0.f) ? gv[q] : 0.f;
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 2; ++u) {
 #pragma unroll
                         for (int ph = 0; ph < 3; ++ph) {
                             const bool rowhit = nb[u] >= 0 && y >= bin_lo(ph, g[u].bin_h, g[u].rs_h, H) &&
@@ -238,83 +235,60 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                     const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
                     const int32_t *am = argmax + (size_t)nb * C * PH * PW + (size_t)c * (PH * PW);
                     const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
+                    const float *pv = masked ? pooled + (size_t)nb * ld_p + (size_t)c * (PH * PW) : gv;
                     for (int q = 0; q < PH * PW; ++q) {
                         const int ph = q / PW;
                         if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
                         const int mi = am[q];
                         const int x = mi - y * W;
-                        if (mi >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gv[q];
+                        if (mi >= 0 && x >= x0 && x < x1 && (!masked || pv[q] > 0.f)) acc[(x - x0) * 64 + lane] += gv[q];
                     }
                 }
             }
         }
         const size_t row = ((size_t)b * H + y) * W;
-        constexpr int WB = 5;                               // float4 rows per batch: their mask / xhat operands
-        static_assert((ROI_XW / 4) % WB == 0, "segment = whole batches");   // (where the gradient is non-zero)
-#pragma unroll                                              // are requested together, one round trip per batch
-        for (int t0 = 0; t0 < ROI_XW / 4; t0 += WB) {
-            float4 v[WB], zv[WB], av[WB], xr[WB];
-            bool nz[WB];
 #pragma unroll
-            for (int t = 0; t < WB; ++t) {
-                v[t] = *reinterpret_cast<const float4 *>(acc + ((t0 + t) * 4 + ps) * 64 + 4 * (lane & 15));
-                nz[t] = BN && (x0 + (t0 + t) * 4 + ps) < x1 &&
-                        (v[t].x != 0.f || v[t].y != 0.f || v[t].z != 0.f || v[t].w != 0.f);
-            }
-            if (BN) {
-#pragma unroll
-                for (int t = 0; t < WB; ++t) {
-                    if (nz[t]) {
-                        const size_t pos = (row + x0 + (t0 + t) * 4 + ps) * C + c4;
-                        zv[t] = *reinterpret_cast<const float4 *>(z + pos);
-                        if (act != nullptr) av[t] = *reinterpret_cast<const float4 *>(act + pos);
-                        else xr[t] = *reinterpret_cast<const float4 *>(lz.x + pos);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < WB; ++t) {
-                const int x = x0 + (t0 + t) * 4 + ps;
-                if (x >= x1) continue;
-                if (nz[t]) {
-                    float4 a = av[t];
-                    if (act == nullptr) {
-                        a.x = fmaf(lsc.x, zv[t].x, lsh.x) + xr[t].x; a.y = fmaf(lsc.y, zv[t].y, lsh.y) + xr[t].y;
-                        a.z = fmaf(lsc.z, zv[t].z, lsh.z) + xr[t].z; a.w = fmaf(lsc.w, zv[t].w, lsh.w) + xr[t].w;
-                    }
-                    if (!(a.x > 0.f)) v[t].x = 0.f;
-                    if (!(a.y > 0.f)) v[t].y = 0.f;
-                    if (!(a.z > 0.f)) v[t].z = 0.f;
-                    if (!(a.w > 0.f)) v[t].w = 0.f;
-                    su[0] += v[t].x; sq[0] += v[t].x * ((zv[t].x - mu.x) * is.x);
-                    su[1] += v[t].y; sq[1] += v[t].y * ((zv[t].y - mu.y) * is.y);
-                    su[2] += v[t].z; sq[2] += v[t].z * ((zv[t].z - mu.z) * is.z);
-                    su[3] += v[t].w; sq[3] += v[t].w * ((zv[t].w - mu.w) * is.w);
-                }
-                *reinterpret_cast<float4 *>(gfeat + (row + x) * C + c4) = v[t];
+        for (int t = 0; t < ROI_XW / 4; ++t) {
+            const int x = x0 + t * 4 + ps;
+            if (x < x1)
+                *reinterpret_cast<float4 *>(gfeat + (row + x) * C + c4) =
+                    *reinterpret_cast<const float4 *>(acc + (t * 4 + ps) * 64 + 4 * (lane & 15));
+        }
+    }
+}
+
+// BatchNorm-backward sums of the map's producer, per pooled ENTRY instead of per map element: both sums are
+// linear in the routed contributions g' = gout * (pooled > 0), and zmax holds the pre-activation at each arg-max:
+//   partial[blk] = (sum g', sum g' * (zmax - mean) * invstd) per channel; rows -> waves by a fixed rule.
+__global__ __launch_bounds__(256) void roipool_bwd_stats_kernel(
+    const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
+    const float *__restrict__ zmax, const int32_t *__restrict__ argmax, int n_rois, int C, int bins,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ partial)
+{
+    __shared__ float s_red[4][2][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.y * 64 + lane;
+    const float mu = mean[c], is = invstd[c];
+    float su = 0.f, sq = 0.f;
+    for (int n = blockIdx.x * 4 + wave; n < n_rois; n += gridDim.x * 4) {
+        const size_t e = (size_t)c * bins;
+        for (int q = 0; q < bins; ++q) {
+            const float p = pooled[(size_t)n * ld_p + e + q];
+            const int mi = argmax[(size_t)n * C * bins + e + q];
+            if (mi >= 0 && p > 0.f) {
+                const float g = gout[(size_t)n * ld_g + e + q];
+                su += g;
+                sq += g * ((zmax[(size_t)n * C * bins + e + q] - mu) * is);
             }
         }
     }
-    if (BN) {
-        __syncthreads();                                    // all waves are done with their LDS rows
-        float *s_red = lds;                                 // [4 waves][2][64]
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float a = su[k], q = sq[k];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-            if (lane < 16) {
-                s_red[(wave * 2 + 0) * 64 + 4 * lane + k] = a;
-                s_red[(wave * 2 + 1) * 64 + 4 * lane + k] = q;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
-            const float t = (s_red[(0 * 2 + which) * 64 + cc] + s_red[(1 * 2 + which) * 64 + cc]) +
-                            (s_red[(2 * 2 + which) * 64 + cc] + s_red[(3 * 2 + which) * 64 + cc]);
-            partial[((size_t)blockIdx.x * 2 + which) * C + cb + cc] = t;
-        }
+    s_red[wave][0][lane] = su;
+    s_red[wave][1][lane] = sq;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6;
+        partial[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * 64 + lane] =
+            (s_red[0][which][lane] + s_red[1][which][lane]) + (s_red[2][which][lane] + s_red[3][which][lane]);
     }
 }
 
@@ -670,7 +644,7 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<false>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, feat, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out,
-                       ld_out, argmax, LazyFeat{nullptr, nullptr, nullptr});
+                       ld_out, argmax, nullptr, LazyFeat{nullptr, nullptr, nullptr});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -680,13 +654,13 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
 COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale,
                                  const float *shift, const float *rois, int n_rois, int B, int C,
                                  int H, int W, int PH, int PW, float spatial_scale, float *out,
-                                 int ld_out, int32_t *argmax, void *stream)
+                                 int ld_out, int32_t *argmax, float *zmax, void *stream)
 {
     COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<true>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, z, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out, ld_out,
-                       argmax, LazyFeat{x, scale, shift});
+                       argmax, zmax, LazyFeat{x, scale, shift});
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -710,42 +684,52 @@ static int roipool_page_ranges(const float *rois, int n_rois, int B, int *range,
     return COVA_OK;
 }
 
+static int launch_roipool_rows(const float *gout, int ld_g, const float *pooled, int ld_p, const float *rois,
+                               const int32_t *argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
+                               float spatial_scale, float *gfeat, int *page_range, hipStream_t st)
+{
+    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, st);
+    if (rc != COVA_OK) return rc;
+    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true> : roipool_bwd_rows_kernel<false>),
+                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gout, ld_g, pooled, ld_p, rois,
+                       argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale, gfeat);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
 COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                               int n_rois, int B, int C, int H, int W, int PH, int PW,
                               float spatial_scale, float *gfeat, int *page_range, void *stream)
 {
     COVA_REQUIRE(gout && rois && argmax && gfeat && page_range && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
-    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
-    if (rc != COVA_OK) return rc;
-    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<false, true> : roipool_bwd_rows_kernel<false, false>),
-                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
-                       nullptr, nullptr, nullptr, nullptr, gfeat, nullptr, LazyFeat{nullptr, nullptr, nullptr});
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    return launch_roipool_rows(gout, ld_g, nullptr, 0, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                               gfeat, page_range, (hipStream_t)stream);
 }
 
-COVA_API int cova_roipool_bwd_bn_num_partials(int B, int H, int W) { return roipool_bwd_grid(B, H, W); }
-
-// cova_roipool_bwd whose gradient is masked by act > 0 (act == NULL: by scale*z + shift + x > 0, the
-// un-materialised map of cova_roipool_fwd_bn) and which also emits the BatchNorm-backward partial sums
-// [num_partials][2][C] of (g', g' * (z - mean) * invstd).  gfeat then holds the ReLU-masked gradient.
-COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                                 int n_rois, int B, int C, int H, int W, int PH, int PW,
-                                 float spatial_scale, const float *act, const float *x, const float *scale,
-                                 const float *shift, const float *z, const float *mean,
-                                 const float *invstd, float *gfeat, float *partial, int *page_range,
-                                 void *stream)
+COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois)
 {
-    COVA_REQUIRE(gout && rois && argmax && z && mean && invstd && gfeat && partial && page_range && B > 0 && n_rois >= 0);
-    COVA_REQUIRE(act || (x && scale && shift));   // mask: act > 0, or relu argument scale*z + shift + x > 0
-    COVA_REQUIRE(C > 0 && C % 64 == 0);
-    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, (hipStream_t)stream);
-    if (rc != COVA_OK) return rc;
-    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true, true> : roipool_bwd_rows_kernel<true, false>),
-                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, (hipStream_t)stream, gout, ld_g, rois, argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale,
-                       act, z, mean, invstd, gfeat, partial, LazyFeat{x, scale, shift});
+    const int g = cdiv(n_rois > 0 ? n_rois : 1, 4);
+    return g < 64 ? g : 64;
+}
+
+// cova_roipool_bwd for a map that is the output of relu(bn(z) + residual) (cova_roipool_fwd_bn): the routed
+// gradient is masked by that ReLU -- pooled > 0, the pooled value being the map's value at the arg-max -- and the
+// BatchNorm-backward partial sums [num_partials][2][C] of (g', g' * (zmax - mean) * invstd) are taken per pooled
+// entry (zmax from cova_roipool_fwd_bn).  No map is read.  gfeat then holds the ReLU-masked gradient.
+COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *pooled, int ld_p,
+                                 const float *zmax, const float *rois, const int32_t *argmax, int n_rois,
+                                 int B, int C, int H, int W, int PH, int PW, float spatial_scale,
+                                 const float *mean, const float *invstd, float *gfeat, float *partial,
+                                 int *page_range, void *stream)
+{
+    COVA_REQUIRE(gout && pooled && zmax && rois && argmax && mean && invstd && gfeat && partial && page_range);
+    COVA_REQUIRE(B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(roipool_bwd_stats_kernel, dim3(cova_roipool_bwd_bn_num_partials(n_rois), C / 64), dim3(256), 0,
+                       st, gout, ld_g, pooled, ld_p, zmax, argmax, n_rois, C, PH * PW, mean, invstd, partial);
     COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    return launch_roipool_rows(gout, ld_g, pooled, ld_p, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
+                               gfeat, page_range, st);
 }
 
 COVA_API int cova_bbox_linear_fwd(const float *bboxes, const float *W, const float *bias, float *raw,

@@ -693,13 +693,16 @@ def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
     N = bboxes.shape[0]
     PH, PW = roi_size
     argmax = _empty((N, C * PH * PW), bboxes, torch.int32)
+    zmax = None
     if isinstance(feat, LazyFeature):
+        zmax = _empty((N, C * PH * PW), bboxes)
         call("cova_roipool_fwd_bn", feat.z, feat.x, feat.scale, feat.shift, bboxes, N, B, C, Hf, Wf, PH, PW,
-             float(spatial_scale), out, ld_out, argmax)
+             float(spatial_scale), out, ld_out, argmax, zmax)
     else:
         call("cova_roipool_fwd", feat, bboxes, N, B, C, Hf, Wf, PH, PW, float(spatial_scale), out, ld_out,
              argmax)
-    return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW), scale=float(spatial_scale))
+    return dict(argmax=argmax, bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW), scale=float(spatial_scale),
+                zmax=zmax, pooled=out, ld_pooled=ld_out)
 
 
 def roipool_bwd(sv, gout, ld_g):
@@ -712,20 +715,19 @@ def roipool_bwd(sv, gout, ld_g):
 
 
 def roipool_bwd_bn(sv, gout, ld_g, last):
-    """RoIPool backward that also applies the ReLU mask of the feature map's producer
-    (out = relu(bn(z) + x)) and takes that BatchNorm's backward sums -> (masked gradient, (partials,
-    count)).  ``last`` = dict(out, x, z, bn) of the block that produced the map (out None = lazy)."""
+    """RoIPool backward for the un-materialised feature map relu(bn(z) + x): the ReLU mask is `pooled > 0`
+    (the pooled value is the map's value at the arg-max) and the BatchNorm-backward sums are taken per
+    pooled entry from the z values the forward kept -> (masked gradient map, (partials, count))."""
     B, Hf, Wf, C = sv["shape"]
     PH, PW = sv["roi"]
     n = sv["bboxes"].shape[0]
     gfeat = _empty((B, Hf, Wf, C), gout)
-    npart = query("cova_roipool_bwd_bn_num_partials", B, Hf, Wf)
+    npart = query("cova_roipool_bwd_bn_num_partials", n)
     part = _empty((npart, 2, C), gout)
     bn = last["bn"]
-    lazy = last["out"] is None                    # mask recomputed from (z, x) like the forward did
-    call("cova_roipool_bwd_bn", gout, ld_g, sv["bboxes"], sv["argmax"], n, B, C, Hf, Wf, PH, PW,
-         float(sv["scale"]), last["out"], last["x"] if lazy else None, bn.scale if lazy else None,
-         bn.shift if lazy else None, last["z"], bn.mean, bn.invstd, gfeat, part, _empty((2 * B,), gout, torch.int32))
+    call("cova_roipool_bwd_bn", gout, ld_g, sv["pooled"], sv["ld_pooled"], sv["zmax"], sv["bboxes"], sv["argmax"],
+         n, B, C, Hf, Wf, PH, PW, float(sv["scale"]), bn.mean, bn.invstd, gfeat, part,
+         _empty((2 * B,), gout, torch.int32))
     return gfeat, (part, npart)
 
 
@@ -981,7 +983,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
         after_head()
     conv = sv["conv"]
     fused = conv["kind"] == "bottleneck" or (USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None)
-    if fused and N > 0:
+    if fused and N > 0 and sv["roi"]["zmax"] is not None:
         dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"])
         grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
     else:

@@ -204,20 +204,21 @@ int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, in
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                      int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
                      float *gfeat, int *page_range /*[2*B] scratch*/, void *stream);
-/* same, fused with the ReLU mask (act > 0) and the BatchNorm-backward partial sums of the layer that
- * produced the map: gfeat = masked gradient, partial [cova_roipool_bwd_bn_num_partials][2][C] */
-int cova_roipool_bwd_bn_num_partials(int B, int H, int W);
-int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
-                        int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
-                        const float *act /*nullable: then x, scale, shift give the mask*/,
-                        const float *x /*nullable*/, const float *scale /*nullable*/,
-                        const float *shift /*nullable*/, const float *z, const float *mean,
-                        const float *invstd, float *gfeat, float *partial, int *page_range /*[2*B] scratch*/,
-                        void *stream);
+/* same for a map produced as relu(bn(z) + residual) and pooled by cova_roipool_fwd_bn: the routed gradient
+ * is masked by that ReLU (pooled > 0: the pooled value is the map's value at the arg-max) and the producer's
+ * BatchNorm-backward partial sums [cova_roipool_bwd_bn_num_partials][2][C] = (sum g', sum g' * xhat(zmax)) are
+ * taken per pooled entry -- no map is read.  gfeat = the ReLU-masked gradient map. */
+int cova_roipool_bwd_bn_num_partials(int n_rois);
+int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *pooled, int ld_p, const float *zmax,
+                        const float *rois, const int32_t *argmax, int n_rois, int B, int C, int H, int W,
+                        int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
+                        float *gfeat, float *partial, int *page_range /*[2*B] scratch*/, void *stream);
 /* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
 int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
                         const float *rois, int n_rois, int B, int C, int H, int W, int PH, int PW,
-                        float spatial_scale, float *out, int ld_out, int32_t *argmax, void *stream);
+                        float spatial_scale, float *out, int ld_out, int32_t *argmax,
+                        float *zmax /*nullable [N, C*PH*PW]: z at each arg-max, for cova_roipool_bwd_bn*/,
+                        void *stream);
 
 /* ------------------------------------------------------------------ positional encoder
  * replaces: CoVA._get_bbox_features up to nn.Linear(5, Hd) (models.py:134-144):

@@ -208,40 +208,40 @@ def test_roipool_matches_oracle_bit_exact():
     gfeat = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(2 * B, dtype=torch.int32, device=DEV))
     close(nchw(gfeat), gref, 1e-5, "roipool bwd")
-    # fused variant: ReLU mask of the map's producer + BatchNorm-backward sums
-    act = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
+    # un-materialised feature map: feat = relu(scale*z + shift + x) formed inside the forward kernel, which
+    # also keeps z at every arg-max; the backward masks by pooled > 0 and takes the BatchNorm-backward sums per
+    # pooled entry -- no map is read
     z = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
-    mean = torch.from_numpy(rs.standard_normal(C).astype(np.float32)).to(DEV) * 0.2
-    invstd = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).to(DEV)
-    npart = query("cova_roipool_bwd_bn_num_partials", B, H, W)
-    part = torch.empty(npart, 2, C, device=DEV)
-    gmask = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, act, None, None,
-         None, z, mean, invstd, gmask, part, torch.empty(2 * B, dtype=torch.int32, device=DEV))
-    ref_masked = gfeat * (act > 0)
-    close(gmask, ref_masked, 1e-5, "roipool bwd masked")
-    close(part[:, 0].sum(0), ref_masked.sum((0, 1, 2)), 1e-4, "roipool bwd sum dy")
-    close(part[:, 1].sum(0), (ref_masked * ((z - mean) * invstd)).sum((0, 1, 2)), 1e-4, "roipool bwd sum dy*xhat")
-    # un-materialised feature map: feat = relu(scale*z + shift + x) formed inside the kernels
     xres = nhwc(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
     scale = torch.from_numpy(rs.uniform(-0.5, 1.5, C).astype(np.float32)).to(DEV)
     shift = torch.from_numpy(rs.standard_normal(C).astype(np.float32)).to(DEV) * 0.3
+    mean = torch.from_numpy(rs.standard_normal(C).astype(np.float32)).to(DEV) * 0.2
+    invstd = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).to(DEV)
     fmat = torch.empty(B, H, W, C, device=DEV)
     call("cova_bn_act_fwd", z, C, scale, shift, xres, C, fmat, C, B * H * W, C, 1)
     out_m, arg_m = torch.empty(n, 576, device=DEV), torch.empty((n, 576), device=DEV, dtype=torch.int32)
     out_l, arg_l = torch.empty(n, 576, device=DEV), torch.empty((n, 576), device=DEV, dtype=torch.int32)
+    zmax = torch.empty(n, 576, device=DEV)
     call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_m, 576, arg_m)
-    call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_l, 576, arg_l)
+    call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_l, 576, arg_l, zmax)
     assert torch.equal(out_l, out_m) and torch.equal(arg_l, arg_m)
-    g_m, g_l = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
-    p_m, p_l = torch.empty(npart, 2, C, device=DEV), torch.empty(npart, 2, C, device=DEV)
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, fmat, None, None,
-         None, z, mean, invstd, g_m, p_m, torch.empty(2 * B, dtype=torch.int32, device=DEV))
-    call("cova_roipool_bwd_bn", gout.to(DEV), 576, rois.to(DEV), arg_m, n, B, C, H, W, 3, 3, 0.25, None, xres, scale,
-         shift, z, mean, invstd, g_l, p_l, torch.empty(2 * B, dtype=torch.int32, device=DEV))
-    assert torch.equal(g_l == 0, g_m == 0)
-    close(g_l, g_m, 1e-6, "lazy roipool bwd")
-    close(p_l.sum(0), p_m.sum(0), 1e-5, "lazy roipool bwd sums")
+    valid = arg_l >= 0
+    pos = arg_l.clamp_min(0).long()
+    page = rois[:, 0].long().to(DEV).view(n, 1)
+    chan = (torch.arange(576, device=DEV) // 9).view(1, 576)
+    assert torch.equal(zmax[valid], z.reshape(B, H * W, C)[page, pos, chan][valid])
+    scratch = torch.empty(2 * B, dtype=torch.int32, device=DEV)
+    g_plain = torch.empty(B, H, W, C, device=DEV)
+    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_plain, scratch)
+    npart = query("cova_roipool_bwd_bn_num_partials", n)
+    part = torch.empty(npart, 2, C, device=DEV)
+    gmask = torch.empty(B, H, W, C, device=DEV)
+    call("cova_roipool_bwd_bn", gout.to(DEV), 576, out_l, 576, zmax, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25,
+         mean, invstd, gmask, part, scratch)
+    ref_masked = g_plain * (fmat > 0)
+    close(gmask, ref_masked, 1e-5, "roipool bwd masked")
+    close(part[:, 0].sum(0), ref_masked.sum((0, 1, 2)), 1e-4, "roipool bwd sum dy")
+    close(part[:, 1].sum(0), (ref_masked * ((z - mean) * invstd)).sum((0, 1, 2)), 1e-4, "roipool bwd sum dy*xhat")
     # memory safety: page indices outside [0, B) pool nothing and scatter nothing
     bad = rois.clone()
     bad[::7, 0] = float(B + 3)

@@ -155,11 +155,13 @@ __global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
 //   write out : lane = (pixel t*4 + lane/16, channels 4*(lane%16)..+3): one float4 per lane, 1 KB per store.
 // pooled != NULL: the contribution of an entry is masked by pooled > 0 -- the pooled value IS the map's value at
 // the arg-max, so this is the ReLU mask of the map's producer without reading the map.
+// gT / amT: the (masked) contributions and arg-max positions in [box][bin][channel] order (roipool_bwd_prep_kernel)
+// so that a wave's loads are 256 contiguous bytes.
 template <bool P33>                               // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
-    const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
-    const float *__restrict__ rois, const int32_t *__restrict__ argmax, const int *__restrict__ page_range,
-    int n_rois, int B, int C, int H, int W, int PH_, int PW_, float spatial_scale, float *__restrict__ gfeat)
+    const float *__restrict__ gT, const int32_t *__restrict__ amT, const float *__restrict__ rois,
+    const int *__restrict__ page_range, int n_rois, int B, int C, int H, int W, int PH_, int PW_,
+    float spatial_scale, float *__restrict__ gfeat)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * ROI_XW * 64];
     const int PH = P33 ? 3 : PH_, PW = P33 ? 3 : PW_;
@@ -170,7 +172,6 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const int ps = lane >> 4, c4 = cb + 4 * (lane & 15);   // write-out phase
     const int nx = (W + ROI_XW - 1) / ROI_XW;
     const long long ntask = (long long)B * H * nx;
-    const bool masked = pooled != nullptr;
     for (long long task = (long long)blockIdx.x * 4 + wave; task < ntask; task += (long long)gridDim.x * 4) {
         const int xs = (int)(task % nx);
         const int y = (int)((task / nx) % H);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
             unsigned long long m = __ballot(hit);
             if (P33) {
                 // boxes touching this segment, ascending (fixed order); two at a time so that their geometry
-                // and arg-max / gradient / pooled operands are one round trip
+                // and arg-max / gradient operands are one round trip
                 while (m) {
                     int nb[2];
                     RoiGeo g[2];
@@ -203,14 +204,12 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                         m &= m - 1;                          // (0 & anything stays 0)
                         const int nn = nb[u] >= 0 ? nb[u] : n_lo;
                         g[u] = roi_geo(rois + 5 * nn, spatial_scale, PH, PW);
-                        const int32_t *am = argmax + (size_t)nn * C * 9 + (size_t)c * 9;
-                        const float *gv = gout + (size_t)nn * ld_g + (size_t)c * 9;
-                        const float *pv = masked ? pooled + (size_t)nn * ld_p + (size_t)c * 9 : gv;
+                        const int32_t *am = amT + (size_t)nn * 9 * C + c;
+                        const float *gv = gT + (size_t)nn * 9 * C + c;
 #pragma unroll
                         for (int q = 0; q < 9; ++q) {
-                            mi[u][q] = am[q];
-                            const float p = pv[q];
-                            gg[u][q] = (!masked || p > 0.f) ? gv[q] : 0.f;
+                            mi[u][q] = am[(size_t)q * C];
+                            gg[u][q] = gv[(size_t)q * C];
                         }
                     }
 #pragma unroll
@@ -233,15 +232,14 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                     const int nb = n0 + __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const RoiGeo g = roi_geo(rois + 5 * nb, spatial_scale, PH, PW);
-                    const int32_t *am = argmax + (size_t)nb * C * PH * PW + (size_t)c * (PH * PW);
-                    const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
-                    const float *pv = masked ? pooled + (size_t)nb * ld_p + (size_t)c * (PH * PW) : gv;
+                    const int32_t *am = amT + (size_t)nb * PH * PW * C + c;
+                    const float *gv = gT + (size_t)nb * PH * PW * C + c;
                     for (int q = 0; q < PH * PW; ++q) {
                         const int ph = q / PW;
                         if (y < bin_lo(ph, g.bin_h, g.rs_h, H) || y >= bin_hi(ph, g.bin_h, g.rs_h, H)) continue;
-                        const int mi = am[q];
+                        const int mi = am[(size_t)q * C];
                         const int x = mi - y * W;
-                        if (mi >= 0 && x >= x0 && x < x1 && (!masked || pv[q] > 0.f)) acc[(x - x0) * 64 + lane] += gv[q];
+                        if (mi >= 0 && x >= x0 && x < x1) acc[(x - x0) * 64 + lane] += gv[(size_t)q * C];
                     }
                 }
             }
@@ -257,38 +255,47 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     }
 }
 
-// BatchNorm-backward sums of the map's producer, per pooled ENTRY instead of per map element: both sums are
-// linear in the routed contributions g' = gout * (pooled > 0), and zmax holds the pre-activation at each arg-max:
-//   partial[blk] = (sum g', sum g' * (zmax - mean) * invstd) per channel; rows -> waves by a fixed rule.
-__global__ __launch_bounds__(256) void roipool_bwd_stats_kernel(
+// Entry pass of the backward: g' = gout (* (pooled > 0): the ReLU mask of the map's producer -- the pooled value
+// IS the map's value at the arg-max) and the arg-max positions, transposed from the reference's [box][c*bins+bin]
+// order into [box][bin][channel] (the rows kernel then reads 256 contiguous bytes per wave), and -- STATS -- the
+// producer's BatchNorm-backward sums per pooled entry instead of per map element: both are linear in the routed
+// contributions, and zmax holds the pre-activation at each arg-max:
+//   partial[blk] = (sum g', sum g' * (zmax - mean) * invstd) per channel; boxes -> waves by a fixed rule.
+template <bool STATS>
+__global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
     const float *__restrict__ zmax, const int32_t *__restrict__ argmax, int n_rois, int C, int bins,
-    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ partial)
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gT,
+    int32_t *__restrict__ amT, float *__restrict__ partial)
 {
     __shared__ float s_red[4][2][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = blockIdx.y * 64 + lane;
-    const float mu = mean[c], is = invstd[c];
+    const float mu = STATS ? mean[c] : 0.f, is = STATS ? invstd[c] : 0.f;
     float su = 0.f, sq = 0.f;
     for (int n = blockIdx.x * 4 + wave; n < n_rois; n += gridDim.x * 4) {
         const size_t e = (size_t)c * bins;
         for (int q = 0; q < bins; ++q) {
-            const float p = pooled[(size_t)n * ld_p + e + q];
             const int mi = argmax[(size_t)n * C * bins + e + q];
-            if (mi >= 0 && p > 0.f) {
-                const float g = gout[(size_t)n * ld_g + e + q];
+            float g = gout[(size_t)n * ld_g + e + q];
+            if (STATS) {
+                if (!(mi >= 0 && pooled[(size_t)n * ld_p + e + q] > 0.f)) g = 0.f;
                 su += g;
                 sq += g * ((zmax[(size_t)n * C * bins + e + q] - mu) * is);
             }
+            gT[((size_t)n * bins + q) * C + c] = g;
+            amT[((size_t)n * bins + q) * C + c] = mi;
         }
     }
-    s_red[wave][0][lane] = su;
-    s_red[wave][1][lane] = sq;
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6;
-        partial[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * 64 + lane] =
-            (s_red[0][which][lane] + s_red[1][which][lane]) + (s_red[2][which][lane] + s_red[3][which][lane]);
+    if (STATS) {
+        s_red[wave][0][lane] = su;
+        s_red[wave][1][lane] = sq;
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6;
+            partial[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * 64 + lane] =
+                (s_red[0][which][lane] + s_red[1][which][lane]) + (s_red[2][which][lane] + s_red[3][which][lane]);
+        }
     }
 }
 
@@ -684,32 +691,51 @@ static int roipool_page_ranges(const float *rois, int n_rois, int B, int *range,
     return COVA_OK;
 }
 
-static int launch_roipool_rows(const float *gout, int ld_g, const float *pooled, int ld_p, const float *rois,
-                               const int32_t *argmax, int n_rois, int B, int C, int H, int W, int PH, int PW,
-                               float spatial_scale, float *gfeat, int *page_range, hipStream_t st)
+COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois)
 {
+    const int g = cdiv(n_rois > 0 ? n_rois : 1, 4);
+    return g < 64 ? g : 64;
+}
+
+// 4-byte words of workspace of cova_roipool_bwd / cova_roipool_bwd_bn: transposed contributions + positions, page ranges
+COVA_API int cova_roipool_bwd_workspace_words(int n_rois, int B, int C, int PH, int PW)
+{
+    return 2 * n_rois * C * PH * PW + 2 * B + 16;
+}
+
+static int launch_roipool_bwd(const float *gout, int ld_g, const float *pooled, int ld_p, const float *zmax,
+                              const float *rois, const int32_t *argmax, int n_rois, int B, int C, int H, int W,
+                              int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
+                              float *gfeat, float *partial, void *ws, hipStream_t st)
+{
+    const size_t ne = (size_t)n_rois * C * PH * PW;
+    float *gT = (float *)ws;
+    int32_t *amT = (int32_t *)ws + ne;
+    int *page_range = (int *)ws + 2 * ne;
     const int rc = roipool_page_ranges(rois, n_rois, B, page_range, st);
     if (rc != COVA_OK) return rc;
+    const dim3 pgrid(cova_roipool_bwd_bn_num_partials(n_rois), C / 64);
+    if (partial)
+        hipLaunchKernelGGL(roipool_bwd_prep_kernel<true>, pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial);
+    else
+        hipLaunchKernelGGL(roipool_bwd_prep_kernel<false>, pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial);
+    COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true> : roipool_bwd_rows_kernel<false>),
-                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gout, ld_g, pooled, ld_p, rois,
-                       argmax, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale, gfeat);
+                       dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gT, amT, rois, page_range, n_rois,
+                       B, C, H, W, PH, PW, spatial_scale, gfeat);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
 
 COVA_API int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                               int n_rois, int B, int C, int H, int W, int PH, int PW,
-                              float spatial_scale, float *gfeat, int *page_range, void *stream)
+                              float spatial_scale, float *gfeat, void *ws, void *stream)
 {
-    COVA_REQUIRE(gout && rois && argmax && gfeat && page_range && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
-    return launch_roipool_rows(gout, ld_g, nullptr, 0, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
-                               gfeat, page_range, (hipStream_t)stream);
-}
-
-COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois)
-{
-    const int g = cdiv(n_rois > 0 ? n_rois : 1, 4);
-    return g < 64 ? g : 64;
+    COVA_REQUIRE(gout && rois && argmax && gfeat && ws && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    return launch_roipool_bwd(gout, ld_g, nullptr, 0, nullptr, rois, argmax, n_rois, B, C, H, W, PH, PW,
+                              spatial_scale, nullptr, nullptr, gfeat, nullptr, ws, (hipStream_t)stream);
 }
 
 // cova_roipool_bwd for a map that is the output of relu(bn(z) + residual) (cova_roipool_fwd_bn): the routed
@@ -720,16 +746,12 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *poole
                                  const float *zmax, const float *rois, const int32_t *argmax, int n_rois,
                                  int B, int C, int H, int W, int PH, int PW, float spatial_scale,
                                  const float *mean, const float *invstd, float *gfeat, float *partial,
-                                 int *page_range, void *stream)
+                                 void *ws, void *stream)
 {
-    COVA_REQUIRE(gout && pooled && zmax && rois && argmax && mean && invstd && gfeat && partial && page_range);
+    COVA_REQUIRE(gout && pooled && zmax && rois && argmax && mean && invstd && gfeat && partial && ws);
     COVA_REQUIRE(B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(roipool_bwd_stats_kernel, dim3(cova_roipool_bwd_bn_num_partials(n_rois), C / 64), dim3(256), 0,
-                       st, gout, ld_g, pooled, ld_p, zmax, argmax, n_rois, C, PH * PW, mean, invstd, partial);
-    COVA_LAUNCH_CHECK();
-    return launch_roipool_rows(gout, ld_g, pooled, ld_p, rois, argmax, n_rois, B, C, H, W, PH, PW, spatial_scale,
-                               gfeat, page_range, st);
+    return launch_roipool_bwd(gout, ld_g, pooled, ld_p, zmax, rois, argmax, n_rois, B, C, H, W, PH, PW,
+                              spatial_scale, mean, invstd, gfeat, partial, ws, (hipStream_t)stream);
 }
 
 COVA_API int cova_bbox_linear_fwd(const float *bboxes, const float *W, const float *bias, float *raw,

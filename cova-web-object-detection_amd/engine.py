@@ -705,12 +705,18 @@ def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
                 zmax=zmax, pooled=out, ld_pooled=ld_out)
 
 
+def _roipool_ws(sv, like):
+    B, Hf, Wf, C = sv["shape"]
+    PH, PW = sv["roi"]
+    return _empty((query("cova_roipool_bwd_workspace_words", sv["bboxes"].shape[0], B, C, PH, PW),), like, torch.int32)
+
+
 def roipool_bwd(sv, gout, ld_g):
     B, Hf, Wf, C = sv["shape"]
     PH, PW = sv["roi"]
     gfeat = _empty((B, Hf, Wf, C), gout)
     call("cova_roipool_bwd", gout, ld_g, sv["bboxes"], sv["argmax"], sv["bboxes"].shape[0], B, C, Hf,
-         Wf, PH, PW, float(sv["scale"]), gfeat, _empty((2 * B,), gout, torch.int32))
+         Wf, PH, PW, float(sv["scale"]), gfeat, _roipool_ws(sv, gout))
     return gfeat
 
 
@@ -726,8 +732,7 @@ def roipool_bwd_bn(sv, gout, ld_g, last):
     part = _empty((npart, 2, C), gout)
     bn = last["bn"]
     call("cova_roipool_bwd_bn", gout, ld_g, sv["pooled"], sv["ld_pooled"], sv["zmax"], sv["bboxes"], sv["argmax"],
-         n, B, C, Hf, Wf, PH, PW, float(sv["scale"]), bn.mean, bn.invstd, gfeat, part,
-         _empty((2 * B,), gout, torch.int32))
+         n, B, C, Hf, Wf, PH, PW, float(sv["scale"]), bn.mean, bn.invstd, gfeat, part, _roipool_ws(sv, gout))
     return gfeat, (part, npart)
 
 

@@ -203,7 +203,8 @@ int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, int B, in
  * ascending box order (the reference's scatter collides constantly: DOM parents contain their children). */
 int cova_roipool_bwd(const float *gout, int ld_g, const float *rois, const int32_t *argmax,
                      int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale,
-                     float *gfeat, int *page_range /*[2*B] scratch*/, void *stream);
+                     float *gfeat, void *ws /*cova_roipool_bwd_workspace_words x 4 bytes*/, void *stream);
+int cova_roipool_bwd_workspace_words(int n_rois, int B, int C, int PH, int PW);
 /* same for a map produced as relu(bn(z) + residual) and pooled by cova_roipool_fwd_bn: the routed gradient
  * is masked by that ReLU (pooled > 0: the pooled value is the map's value at the arg-max) and the producer's
  * BatchNorm-backward partial sums [cova_roipool_bwd_bn_num_partials][2][C] = (sum g', sum g' * xhat(zmax)) are
@@ -212,7 +213,8 @@ int cova_roipool_bwd_bn_num_partials(int n_rois);
 int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *pooled, int ld_p, const float *zmax,
                         const float *rois, const int32_t *argmax, int n_rois, int B, int C, int H, int W,
                         int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
-                        float *gfeat, float *partial, int *page_range /*[2*B] scratch*/, void *stream);
+                        float *gfeat, float *partial, void *ws /*cova_roipool_bwd_workspace_words x 4 bytes*/,
+                        void *stream);
 /* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
 int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
                         const float *rois, int n_rois, int B, int C, int H, int W, int PH, int PW,

@@ -206,7 +206,7 @@ def test_roipool_matches_oracle_bit_exact():
     import ctypes
     O._lib().oracle_roipool_bwd(O._fp(gout), O._fp(rois), O._fp(ref_arg), n, B, C, H, W, 3, 3, O._fp(gref))
     gfeat = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(2 * B, dtype=torch.int32, device=DEV))
+    call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV))
     close(nchw(gfeat), gref, 1e-5, "roipool bwd")
     # un-materialised feature map: feat = relu(scale*z + shift + x) formed inside the forward kernel, which
     # also keeps z at every arg-max; the backward masks by pooled > 0 and takes the BatchNorm-backward sums per
@@ -230,7 +230,7 @@ def test_roipool_matches_oracle_bit_exact():
     page = rois[:, 0].long().to(DEV).view(n, 1)
     chan = (torch.arange(576, device=DEV) // 9).view(1, 576)
     assert torch.equal(zmax[valid], z.reshape(B, H * W, C)[page, pos, chan][valid])
-    scratch = torch.empty(2 * B, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV)
     g_plain = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_plain, scratch)
     npart = query("cova_roipool_bwd_bn_num_partials", n)
@@ -252,7 +252,7 @@ def test_roipool_matches_oracle_bit_exact():
     assert (out_b.cpu()[isbad] == 0).all() and (arg_b.cpu()[isbad] == -1).all()
     assert torch.equal(out_b.cpu()[~isbad], ref.reshape(n, 576)[~isbad])
     g_b = torch.empty(B, H, W, C, device=DEV)
-    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, 0.25, g_b, torch.empty(2 * B, dtype=torch.int32, device=DEV))
+    call("cova_roipool_bwd", gout.to(DEV), 576, bad.to(DEV), arg_b, n, B, C, H, W, 3, 3, 0.25, g_b, torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV))
     assert torch.isfinite(g_b).all()
 
 
@@ -713,7 +713,7 @@ def test_roipool_backward_rows_are_deterministic_and_cover_the_map():
     res = []
     for rep in range(2):
         gfeat = torch.full((B, H, W, C), float("nan"), device=DEV)
-        call("cova_roipool_bwd", gout.to(DEV), C * 9, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(2 * B, dtype=torch.int32, device=DEV))
+        call("cova_roipool_bwd", gout.to(DEV), C * 9, rois.to(DEV), arg, n, B, C, H, W, 3, 3, 0.25, gfeat, torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV))
         res.append(gfeat)
     assert torch.isfinite(res[0]).all()
     close(nchw(res[0]), gref, 1e-5, "roipool bwd rows")

@@ -17,7 +17,7 @@ arg = torch.empty(n, C * 9, device=dev, dtype=torch.int32)
 call("cova_roipool_fwd", feat, rois, n, B, C, H, W, 3, 3, 0.25, out, C * 9, arg)
 gout = torch.randn(n, C * 9, device=dev)
 gfeat = torch.empty(B, H, W, C, device=dev)
-pr = torch.empty(2 * B, dtype=torch.int32, device=dev)
+pr = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=dev)
 z = torch.randn(B, H, W, C, device=dev)
 mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
 part = torch.empty(query("cova_roipool_bwd_bn_num_partials", n), 2, C, device=dev)

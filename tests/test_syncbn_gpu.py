@@ -100,6 +100,7 @@ def test_two_rank_step_with_syncbn_equals_single_process_large_batch(tmp_path):
     scale = float(g_ref.abs().max())
     assert float((r0["grads"] - g_ref).abs().max()) <= 2e-4 * scale
     sd_ref = ref.state_dict()
+    tr_off = ref.gbucket.offsets
     for k, v in sd_ref.items():
         if not v.is_floating_point():
             assert torch.equal(r0["sd"][k], v.cpu()), k
@@ -110,8 +111,19 @@ def test_two_rank_step_with_syncbn_equals_single_process_large_batch(tmp_path):
             #           rounding noise around zero may step the other way (2 * lr per step), the
             #           bulk must agree far better than that
             d = (r0["sd"][k] - v.cpu()).abs()
-            assert float(d.max()) <= 2 * STEPS * 5e-4 + 1e-5, k
-            assert float(d.mean()) <= 0.02 * STEPS * 5e-4 + 1e-6, k
+            # (Adam's per-step move is bounded by lr * (1 - beta1) / sqrt(1 - beta2) = 3.2 lr when a gradient flips sign)
+            off = tr_off[k]
+            gk = g_ref[off[0]:off[0] + off[1]].view(-1)
+            i = int(d.view(-1).argmax())
+            assert float(d.max()) <= 2 * STEPS * 3.2 * 5e-4 + 1e-5, (k, float(d.max()), float(gk[i]), float(gk.abs().max()))
+            if float(d.max()) > 2 * STEPS * 5e-4 + 1e-5:          # only a rounding-noise gradient may do that
+                assert abs(float(gk[i])) <= 1e-4 * scale, (k, float(gk[i]), scale)
+            # the bulk: entries whose gradient is well above the summation noise (the last bn2's bias, e.g., has a
+            # nearly vanishing gradient -- a channel-wise shift of the visual features is removed again by the
+            # decoder's train-mode BatchNorm -- and its Adam steps follow the sign of rounding noise)
+            solid = gk.abs().view(d.shape) > 1e-4 * scale
+            if bool(solid.any()):
+                assert float(d[solid].mean()) <= 0.02 * STEPS * 5e-4 + 1e-6, k
 
 
 def test_two_rank_step_with_local_batchnorm_sums_the_shard_gradients(tmp_path):

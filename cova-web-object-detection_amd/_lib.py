@@ -58,6 +58,16 @@ class _Lib:
             self.fn[name] = f
 
 
+    def load_extra(self, header, lib_path):
+        """Register the entry points of another C-ABI library (tools-only probes) under the same call()."""
+        cdll = ctypes.CDLL(lib_path)
+        for name, types in parse_header(header).items():
+            f = getattr(cdll, name)
+            f.argtypes = types
+            f.restype = ctypes.c_int
+            self.fn[name] = f
+
+
 _LIB = None
 
 

@@ -111,93 +111,6 @@ constexpr int LDS_FLOATS = IN_FLOATS + 2 * W_FLOATS;   // 127,296 B
 constexpr int THREADS = 512;              // 8 waves; wave w owns output row w of the tile
 }  // namespace c3
 
-// wt: [9 taps][64 out][64 in] (in contiguous).  out[p][o] = sum_{tap,c} in[p+off(tap)][c]*wt[tap][o][c]
-template <bool STATS>
-__global__ __launch_bounds__(c3::THREADS) void conv3x3_c64_kernel(
-    const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ addend,
-    float *__restrict__ out, float *__restrict__ stat_part, int H, int W, int tiles_x, int tiles_y)
-{
-    using namespace c3;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    float *s_in = lds;
-    float *s_w = lds + IN_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = blockIdx.x;
-    const int tx = bid % tiles_x;
-    const int ty = (bid / tiles_x) % tiles_y;
-    const int b = bid / (tiles_x * tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
-    const float *in_b = in + (size_t)b * H * W * 64;
-
-    // ---- stage the halo'd input tile (zero outside the image == conv zero padding)
-    for (int idx = tid; idx < PH * PW * 16; idx += THREADS) {
-        const int px = idx >> 4, c4 = idx & 15;
-        const int r = px / PW, c = px - r * PW;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = *reinterpret_cast<const float4 *>(in_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-        *reinterpret_cast<float4 *>(s_in + px * PSTR + c4 * 4) = v;
-    }
-    // ---- tap 0 weights -> buffer 0 (1024 float4 per tap, 2 per thread)
-    {
-        const int co = tid >> 4, c4 = tid & 15;
-        const float4 w0 = *reinterpret_cast<const float4 *>(wt + co * 64 + c4 * 4);
-        const float4 w1 = *reinterpret_cast<const float4 *>(wt + (co + 32) * 64 + c4 * 4);
-        *reinterpret_cast<float4 *>(s_w + co * PSTR + c4 * 4) = w0;
-        *reinterpret_cast<float4 *>(s_w + (co + 32) * PSTR + c4 * 4) = w1;
-    }
-    __syncthreads();
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int li = lane & 31, kh2 = lane >> 5;
-
-    for (int tap = 0; tap < 9; ++tap) {
-        const int kh = tap / 3, kw = tap - kh * 3;
-        // prefetch the next tap's weights into registers while this tap computes
-        float4 wn0 = make_float4(0, 0, 0, 0), wn1 = wn0;
-        const int pco = tid >> 4, pc4 = tid & 15;
-        if (tap < 8) {
-            const float *wsrc = wt + (size_t)(tap + 1) * 4096;
-            wn0 = *reinterpret_cast<const float4 *>(wsrc + pco * 64 + pc4 * 4);
-            wn1 = *reinterpret_cast<const float4 *>(wsrc + (pco + 32) * 64 + pc4 * 4);
-        }
-        // K permutation: in step s the low half-wave holds channels 8s..8s+3 and the high
-        // half-wave 8s+4..8s+7 (one ds_read_b128 each); MFMA t of the step contracts channel
-        // 8s+t (k=0) and 8s+4+t (k=1).  A and B use the same permutation, so the sum is exact.
-        const float *a_base = s_in + ((wave + kh) * PW + (li + kw)) * PSTR + kh2 * 4;
-        const float *b_base = s_w + (tap & 1) * W_FLOATS + li * PSTR + kh2 * 4;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4 *>(a_base + s * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(b_base + s * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(b_base + 32 * PSTR + s * 8);
-            acc0 = mfma32(a.x, b0.x, acc0);
-            acc1 = mfma32(a.x, b1.x, acc1);
-            acc0 = mfma32(a.y, b0.y, acc0);
-            acc1 = mfma32(a.y, b1.y, acc1);
-            acc0 = mfma32(a.z, b0.z, acc0);
-            acc1 = mfma32(a.z, b1.z, acc1);
-            acc0 = mfma32(a.w, b0.w, acc0);
-            acc1 = mfma32(a.w, b1.w, acc1);
-        }
-        if (tap < 8) {
-            float *wdst = s_w + ((tap + 1) & 1) * W_FLOATS;
-            *reinterpret_cast<float4 *>(wdst + pco * PSTR + pc4 * 4) = wn0;
-            *reinterpret_cast<float4 *>(wdst + (pco + 32) * PSTR + pc4 * 4) = wn1;
-        }
-        __syncthreads();
-    }
-
-    const int oy = y0 + wave;
-    float s0, s1, q0, q1;
-    epilogue_store_stats(acc0, acc1, out, addend, ((size_t)b * H + oy) * W + x0, x0, W, oy < H,
-                         lane, s0, s1, q0, q1);
-    if (STATS) block_stats_reduce(s_in, stat_part, bid, tid, lane, wave, 8, s0, s1, q0, q1);
-}
-
 // ------------------------------------------------------------------------------------
 // conv3x3 v2: persistent blocks, software-pipelined.
 //   * one block per CU walks tiles t = blockIdx.x, +gridDim.x, ...; while tile t computes, the
@@ -409,63 +322,6 @@ __host__ __device__ constexpr int tap_off(int k)
 }
 }  // namespace c1
 
-// wk: [154][64], row 2p+h = weights of tap c1::pair_tap(p, h) (zero row if none)
-template <bool STATS>
-__global__ __launch_bounds__(c1::THREADS) void conv1_7x7_kernel(
-    const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
-    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y)
-{
-    using namespace c1;
-    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS];
-    float *s_in = lds;
-    float *s_w = lds + IN_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = blockIdx.x;
-    const int tx = bid % tiles_x;
-    const int ty = (bid / tiles_x) % tiles_y;
-    const int b = bid / (tiles_x * tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
-    const float *img_b = img + (size_t)b * 3 * H * W;
-
-    // input patch: rows 2*y0-3 .. +20, cols 2*x0-3 .. +68; column j of the patch is stored at
-    // [parity j&1][j>>1] so that a stride-2 walk over output columns is contiguous in LDS.
-    for (int idx = tid; idx < 3 * PR * 69; idx += THREADS) {
-        const int c = idx / (PR * 69);
-        const int rem = idx - c * (PR * 69);
-        const int r = rem / 69, j = rem - r * 69;
-        const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img_b[((size_t)c * H + gy) * W + gx];
-        s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = v;
-    }
-    for (int idx = tid; idx < W_FLOATS / 4; idx += THREADS)
-        reinterpret_cast<float4 *>(s_w)[idx] = reinterpret_cast<const float4 *>(wk)[idx];
-    __syncthreads();
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int li = lane & 31, kh2 = lane >> 5;
-    const float *a_base = s_in + (2 * wave) * RSTR + li;   // output (row wave, col li) origin
-    const float *b_base = s_w + kh2 * 64 + li;
-#pragma unroll
-    for (int kk = 0; kk < NPAIR; ++kk) {
-        const int off = kh2 ? tap_off(pair_tap(kk, 1)) : tap_off(pair_tap(kk, 0));
-        const float a = a_base[off];
-        const float b0 = b_base[kk * 128];
-        const float b1 = b_base[kk * 128 + 32];
-        acc0 = mfma32(a, b0, acc0);
-        acc1 = mfma32(a, b1, acc1);
-    }
-    __syncthreads();   // s_in is reused as reduction scratch below
-
-    const int oy = y0 + wave;
-    float s0, s1, q0, q1;
-    epilogue_store_stats(acc0, acc1, out, nullptr, ((size_t)b * H1 + oy) * W1 + x0, x0, W1,
-                         oy < H1, lane, s0, s1, q0, q1);
-    if (STATS) block_stats_reduce(s_in, stat_part, bid, tid, lane, wave, 8, s0, s1, q0, q1);
-}
-
 // ------------------------------------------------------------------------------------
 // conv1 v2: persistent blocks (2 per CU); the 154x64 weight matrix stays resident in LDS for the
 // whole launch, the next tile's image patch is prefetched into registers during the MFMAs.
@@ -637,89 +493,7 @@ __global__ void prep_w7x7_kernel(const float *__restrict__ w, float *__restrict_
 // ------------------------------------------------------------------------------------
 // conv3x3 weight gradient: dW[tap][co][ci] = sum_p dz[p][co] * a[p+off(tap)][ci]
 // GEMM M = co, N = ci (per tap), K = pixels; persistent blocks, partial results per block.
-// wave w: co block (w&1), ci block ((w>>1)&1), pixel half (w>>2); 9 taps x 16 accumulators.
-// ------------------------------------------------------------------------------------
-namespace wg3 {
-constexpr int TH = 4, TW = 32;
-constexpr int PH = TH + 2, PW = TW + 2;
-constexpr int A_FLOATS = PH * PW * 64;      // 13,056 floats = 52,224 B
-constexpr int DZ_FLOATS = TH * TW * 64;     //  8,192 floats = 32,768 B
-constexpr int THREADS = 512;
-}  // namespace wg3
-
-__global__ __launch_bounds__(wg3::THREADS) void conv3x3_wgrad_kernel(
-    const float *__restrict__ act, const float *__restrict__ dz, float *__restrict__ part,
-    int B, int H, int W, int tiles_x, int tiles_y)
-{
-    using namespace wg3;
-    __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + DZ_FLOATS];
-    float *s_a = lds;
-    float *s_dz = lds + A_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh2 = lane >> 5;
-    const int cob = wave & 1, cib = (wave >> 1) & 1, phalf = wave >> 2;
-    const int ntiles = B * tiles_x * tiles_y;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x;
-        const int ty = (tile / tiles_x) % tiles_y;
-        const int b = tile / (tiles_x * tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
-        const float *act_b = act + (size_t)b * H * W * 64;
-        const float *dz_b = dz + (size_t)b * H * W * 64;
-        __syncthreads();   // previous tile fully consumed
-        for (int idx = tid; idx < PH * PW * 16; idx += THREADS) {
-            const int px = idx >> 4, c4 = idx & 15;
-            const int r = px / PW, c = px - r * PW;
-            const int gy = y0 + r - 1, gx = x0 + c - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(act_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-            *reinterpret_cast<float4 *>(s_a + px * 64 + c4 * 4) = v;
-        }
-        for (int idx = tid; idx < TH * TW * 16; idx += THREADS) {
-            const int px = idx >> 4, c4 = idx & 15;
-            const int r = px / TW, c = px - r * TW;
-            const int gy = y0 + r, gx = x0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W)
-                v = *reinterpret_cast<const float4 *>(dz_b + ((size_t)gy * W + gx) * 64 + c4 * 4);
-            *reinterpret_cast<float4 *>(s_dz + px * 64 + c4 * 4) = v;
-        }
-        __syncthreads();
-        // this wave's 64 pixels: tile rows 2*phalf, 2*phalf+1; k-pair t -> pixels 2t, 2t+1
-#pragma unroll 4
-        for (int t = 0; t < 32; ++t) {
-            const int p = 2 * t + kh2;                     // 0..63 within the half
-            const int row = phalf * 2 + (p >> 5), col = p & 31;
-            const float a = s_dz[(row * TW + col) * 64 + cob * 32 + li];
-            const float *bsrc = s_a + (row * PW + col) * 64 + cib * 32 + li;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float bv = bsrc[((tap / 3) * PW + (tap % 3)) * 64];
-                acc[tap] = mfma32(a, bv, acc[tap]);
-            }
-        }
-    }
-    // partial layout: part[(block*2 + phalf)][tap][co][ci]
-    float *dst = part + ((size_t)(blockIdx.x * 2 + phalf)) * (9 * 4096);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cob * 32 + mfma32_row(r, lane);
-            dst[tap * 4096 + co * 64 + cib * 32 + li] = acc[tap][r];
-        }
-}
-
-// ------------------------------------------------------------------------------------
-// conv3x3 weight gradient v2: 12 waves per block.  Wave w owns tap row kh = w/4 (3 taps), output-
+// 12 waves per block.  Wave w owns tap row kh = w/4 (3 taps), output-
 // channel block w&1 and input-channel block (w>>1)&1 over ALL pixels of the tile: 3 accumulators
 // (48 registers) instead of 9, no duplicated partials, and three waves per SIMD to hide LDS
 // latency.  Tiles are 8x32 pixels; the next tile's halo'd activation tile and dz tile are
@@ -889,88 +663,6 @@ constexpr int TH = 8, TW = 32;
 constexpr int THREADS = 512;
 constexpr int DY_FLOATS = TH * TW * 64;     // 16,384 floats = 65,536 B
 }  // namespace wg1
-
-__global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_kernel(
-    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int B, int H, int W, int H1, int W1, int tiles_x, int tiles_y)
-{
-    using namespace c1;
-    __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + wg1::DY_FLOATS];
-    float *s_in = lds;
-    float *s_dy = lds + IN_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh2 = lane >> 5;
-    const int ntiles = B * tiles_x * tiles_y;
-
-    // per-lane LDS offset of this lane's tap in each of the 5 tap blocks
-    int toff[5];
-#pragma unroll
-    for (int tb = 0; tb < 5; ++tb) {
-        const int k = tb * 32 + li;
-        toff[tb] = (k < 147) ? ((k / 49) * CSTR + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH +
-                                ((k % 7) >> 1))
-                             : 0;
-    }
-    f32x16 acc[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x;
-        const int ty = (tile / tiles_x) % tiles_y;
-        const int b = tile / (tiles_x * tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
-        const float *img_b = img + (size_t)b * 3 * H * W;
-        const float *dy_b = dy + (size_t)b * H1 * W1 * 64;
-        __syncthreads();
-        for (int idx = tid; idx < 3 * PR * 69; idx += wg1::THREADS) {
-            const int c = idx / (PR * 69);
-            const int rem = idx - c * (PR * 69);
-            const int r = rem / 69, j = rem - r * 69;
-            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img_b[((size_t)c * H + gy) * W + gx];
-            s_in[c * CSTR + r * RSTR + (j & 1) * PCH + (j >> 1)] = v;
-        }
-        for (int idx = tid; idx < TH * TW * 16; idx += wg1::THREADS) {
-            const int px = idx >> 4, c4 = idx & 15;
-            const int r = px / TW, c = px - r * TW;
-            const int gy = y0 + r, gx = x0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H1 && gx < W1)
-                v = *reinterpret_cast<const float4 *>(dy_b + ((size_t)gy * W1 + gx) * 64 + c4 * 4);
-            *reinterpret_cast<float4 *>(s_dy + px * 64 + c4 * 4) = v;
-        }
-        __syncthreads();
-        // wave = output row of the tile; k-pair t -> output columns 2t, 2t+1
-#pragma unroll 2
-        for (int t = 0; t < 16; ++t) {
-            const int col = 2 * t + kh2;
-            const float a0 = s_dy[(wave * TW + col) * 64 + li];
-            const float a1 = s_dy[(wave * TW + col) * 64 + 32 + li];
-            const float *bsrc = s_in + (2 * wave) * RSTR + col;
-#pragma unroll
-            for (int tb = 0; tb < 5; ++tb) {
-                const float bv = bsrc[toff[tb]];
-                acc[tb] = mfma32(a0, bv, acc[tb]);
-                acc[5 + tb] = mfma32(a1, bv, acc[5 + tb]);
-            }
-        }
-    }
-    // partial layout: part[(block*8 + wave)][co 64][k 160]
-    float *dst = part + ((size_t)(blockIdx.x * 8 + wave)) * (64 * 160);
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int tb = 0; tb < 5; ++tb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb * 32 + mfma32_row(r, lane);
-                dst[co * 160 + tb * 32 + li] = acc[cb * 5 + tb][r];
-            }
-}
 
 // conv1 weight gradient v2: wave w owns output-channel block w&1 and tile rows 2q, 2q+1
 // (q = w>>1): 5 accumulators (80 registers) over 64 pixels, four partials per block; the next
@@ -1299,9 +991,6 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
     return g;
 }
 
-int g_conv3x3_variant = 2;   // 1 = one block per tile, 2 = persistent + software pipelined
-int g_wgrad3_variant = 2;    // 1 = 8 waves x 9 taps, 2 = 12 waves x 3 taps + register prefetch
-int g_conv1_variant = 2;     // conv1 fwd + wgrad: 1 = v1, 2 = persistent + register prefetch
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
 
@@ -1316,13 +1005,11 @@ int cova_internal_ablate() { return g_ablate; }
 // ====================================================================================
 // C ABI
 // ====================================================================================
-// tuning / A-B switches for benchmarking (key 1: conv3x3 fwd kernel variant)
+// test / tool hooks (not part of the path's contract): 2 = cap on persistent grids (tests force many tiles per
+// block), 5 = ablation mask of builds made with -DCOVA_ABLATE (tools/conv_bench.py), 6 = Winograd tile geometry
 COVA_API int cova_set_option(int key, int value)
 {
-    if (key == 1) { g_conv3x3_variant = value; return COVA_OK; }
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
-    if (key == 3) { g_wgrad3_variant = value; return COVA_OK; }
-    if (key == 4) { g_conv1_variant = value; return COVA_OK; }
     if (key == 5) { g_ablate = value; return COVA_OK; }
     if (key == 6) return cova_internal_set_wino_geometry(value);
     return COVA_ERR_BAD_ARG;
@@ -1338,13 +1025,11 @@ COVA_API int cova_conv3x3_num_tiles(int B, int H, int W)
     return B * cdiv(H, c3::TH) * cdiv(W, c3::TW);
 }
 
-// rows of the statistics partials cova_conv1_fwd writes: one per tile (kernel variant 1) or one per
-// persistent block (variant 2, default)
+// rows of the statistics partials cova_conv1_fwd writes: one per persistent block
 COVA_API int cova_conv1_num_tiles(int B, int H, int W);
 COVA_API int cova_conv1_num_partials(int B, int H, int W)
 {
-    const int nt = cova_conv1_num_tiles(B, H, W);
-    return g_conv1_variant == 2 ? persistent_grid(nt, 2) : nt;
+    return persistent_grid(cova_conv1_num_tiles(B, H, W), 2);
 }
 
 COVA_API int cova_conv1_num_tiles(int B, int H, int W)
@@ -1411,21 +1096,8 @@ COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *ad
                               float *stat_part, int B, int H, int W, void *stream)
 {
     COVA_REQUIRE(in && w_t && out && B > 0 && H > 0 && W > 0);
-    const int tiles_x = cdiv(W, c3::TW), tiles_y = cdiv(H, c3::TH);
-    const int ntiles = B * tiles_x * tiles_y;
-    const dim3 block(c3::THREADS);
-    if (g_conv3x3_variant == 2)
-        return launch_conv3x3(in, w_t, addend, out, stat_part, B, H, W,
-                              BnBwdEpi{nullptr, nullptr, nullptr, nullptr}, stream);
-    const dim3 grid(ntiles);
-    if (stat_part)
-        hipLaunchKernelGGL(conv3x3_c64_kernel<true>, grid, block, 0, (hipStream_t)stream, in, w_t,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL(conv3x3_c64_kernel<false>, grid, block, 0, (hipStream_t)stream, in, w_t,
-                           addend, out, stat_part, H, W, tiles_x, tiles_y);
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    return launch_conv3x3(in, w_t, addend, out, stat_part, B, H, W,
+                          BnBwdEpi{nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
 // img NCHW [B,3,H,W]; w_k [154][64]; out NHWC [B,H1,W1,64]
@@ -1436,32 +1108,21 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, c1::TW), tiles_y = cdiv(H1, c1::TH);
     const dim3 block(c1::THREADS);
-    if (g_conv1_variant == 2) {
-        const int ntiles = B * tiles_x * tiles_y;
-        const dim3 pgrid(persistent_grid(ntiles, 2));
-        if (stat_part)
-            hipLaunchKernelGGL(conv1_7x7_v2_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img,
-                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
-        else
-            hipLaunchKernelGGL(conv1_7x7_v2_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img,
-                               w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
-        COVA_LAUNCH_CHECK();
-        return COVA_OK;
-    }
-    const dim3 grid(B * tiles_x * tiles_y);
+    const int ntiles = B * tiles_x * tiles_y;
+    const dim3 pgrid(persistent_grid(ntiles, 2));
     if (stat_part)
-        hipLaunchKernelGGL(conv1_7x7_kernel<true>, grid, block, 0, (hipStream_t)stream, img, w_k,
-                           out, stat_part, H, W, H1, W1, tiles_x, tiles_y);
+        hipLaunchKernelGGL(conv1_7x7_v2_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img,
+                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
     else
-        hipLaunchKernelGGL(conv1_7x7_kernel<false>, grid, block, 0, (hipStream_t)stream, img, w_k,
-                           out, stat_part, H, W, H1, W1, tiles_x, tiles_y);
+        hipLaunchKernelGGL(conv1_7x7_v2_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img,
+                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
 
 COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
 {
-    const int ntiles = B * cdiv(W, wg3::TW) * cdiv(H, wg3::TH);   // v1 bound (>= v2's need)
+    const int ntiles = B * cdiv(W, 32) * cdiv(H, 4);              // upper bound for both weight-gradient forms
     return persistent_grid(ntiles) * 2 * 9 * 4096 + 16 * 4096;   // + Q buffer of the Winograd form
 }
 
@@ -1470,25 +1131,14 @@ COVA_API int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw, fl
                                 int H, int W, void *stream)
 {
     COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
-    if (g_wgrad3_variant == 2) {
-        const int tiles_x = cdiv(W, wg3v2::TW), tiles_y = cdiv(H, wg3v2::TH);
-        const int ntiles = B * tiles_x * tiles_y;
-        const int grid = persistent_grid(ntiles);
-        hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel, dim3(grid), dim3(wg3v2::THREADS), 0,
-                           (hipStream_t)stream, act, dz, ws, H, W, tiles_x, tiles_y, ntiles, g_ablate);
-        COVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 4096 / 64), dim3(1024), 0,
-                           (hipStream_t)stream, ws, grid, dw);
-        COVA_LAUNCH_CHECK();
-        return COVA_OK;
-    }
-    const int tiles_x = cdiv(W, wg3::TW), tiles_y = cdiv(H, wg3::TH);
-    const int grid = persistent_grid(B * tiles_x * tiles_y);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(wg3::THREADS), 0, (hipStream_t)stream,
-                       act, dz, ws, B, H, W, tiles_x, tiles_y);
+    const int tiles_x = cdiv(W, wg3v2::TW), tiles_y = cdiv(H, wg3v2::TH);
+    const int ntiles = B * tiles_x * tiles_y;
+    const int grid = persistent_grid(ntiles);
+    hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel, dim3(grid), dim3(wg3v2::THREADS), 0,
+                       (hipStream_t)stream, act, dz, ws, H, W, tiles_x, tiles_y, ntiles, g_ablate);
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 4096 / 64), dim3(1024), 0,
-                       (hipStream_t)stream, ws, grid * 2, dw);
+                       (hipStream_t)stream, ws, grid, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -1531,21 +1181,12 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
-    if (g_conv1_variant == 2) {
-        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
-                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
-        COVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
-                           (hipStream_t)stream, ws, grid * 4, dw);
-        COVA_LAUNCH_CHECK();
-        return COVA_OK;
-    }
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(grid), dim3(wg1::THREADS), 0, (hipStream_t)stream,
-                       img, dy, ws, B, H, W, H1, W1, tiles_x, tiles_y);
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
-                       (hipStream_t)stream, ws, grid * 8, dw);
+                       (hipStream_t)stream, ws, grid * 4, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

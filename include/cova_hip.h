@@ -38,7 +38,8 @@ extern "C" {
  * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
-/* benchmarking switch (key 1 = conv3x3 kernel variant: 1 block-per-tile, 2 persistent pipelined) */
+/* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
+ * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = Winograd tile geometry (1 | 2) */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
@@ -292,22 +293,6 @@ int cova_collate_boxes(const float *rows, const int *page_offsets, int B, int N,
  * x,y,w,h,label, K x (x,y,w,h) of the context boxes (0 for pads), K attention weights */
 int cova_attn_export_rows(const float *bboxes, const long long *ctx, const float *attn,
                           const long long *labels, int N, int K, float *out, void *stream);
-
-/* ------------------------------------------------------------------ diagnostics (bench tools only)
- * sustained f32-MFMA rate probe: blocks x 8 waves, iters*16 MFMAs (4096 FLOP each) per wave */
-int cova_probe_mfma_f32(float *scratch, int blocks, int iters, void *stream);
-/* MFMA (16x16x4 f32) chain with valu_per_mfma (0,2,4,6) independent FMAs after each MFMA; mfma=0: VALU only */
-int cova_probe_mfma_valu(float *scratch, int blocks, int iters, int valu_per_mfma, int mfma, void *stream);
-/* same-wave probe: per wave iters*16 MFMAs interleaved with iters*loads_per_iter (0..2) float4 loads per lane */
-int cova_probe_mfma_load(float *scratch, const float *buf, long long n4, int blocks, int iters,
-                         int loads_per_iter, void *stream);
-/* mixed probe: mfma_blocks MFMA blocks + stream_blocks blocks streaming buf (n4 float4, `passes` times) */
-int cova_probe_mix(float *scratch, const float *buf, long long n4, int mfma_blocks, int stream_blocks,
-                   int iters, int passes, void *stream);
-/* lane-pattern probe: NHWC-64 copy (or load-only) with the Winograd epilogue's lane mapping (mode 0),
- * fully contiguous lanes (1) or 64-byte segments per 4 lanes (2); lds_bytes limits blocks per CU */
-int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
-                            int blocks, int lds_bytes, void *stream);
 
 #ifdef __cplusplus
 }

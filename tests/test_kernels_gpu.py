@@ -337,7 +337,7 @@ def test_adam_matches_torch():
 
 def test_conv3x3_persistent_multi_tile():
     """More tiles than persistent blocks: exercises the cross-tile prefetch of the v2 kernel
-    (and, with a capped grid, many tiles per block) against the v1 kernel and torch-CPU."""
+    (and, with a capped grid, many tiles per block) against torch-CPU."""
     B, H, W = 3, 100, 200                      # 13 x 7 x 3 = 273 tiles > 256 CUs
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, 64, H, W, generator=g)
@@ -348,18 +348,15 @@ def test_conv3x3_persistent_multi_tile():
     ref = F.conv2d(x, w, padding=1)
     nt = query("cova_conv3x3_num_tiles", B, H, W)
     outs = []
-    for variant, cap in ((2, 0), (2, 7), (1, 0)):
-        query("cova_set_option", 1, variant)
+    for cap in (0, 7, 3):
         query("cova_set_option", 2, cap)
         out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
         call("cova_conv3x3_fwd", xg, wf, None, out, part, B, H, W)
-        close(nchw(out), ref, 1e-4, "conv3x3 v%d cap %d" % (variant, cap))
+        close(nchw(out), ref, 1e-4, "conv3x3 cap %d" % cap)
         close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "stat sum")
         outs.append((out, part))
-    query("cova_set_option", 1, 2)
     query("cova_set_option", 2, 0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])   # same summation order
-    close(outs[0][1], outs[2][1], 1e-6, "stat partials v2 vs v1")
 
 
 def test_conv3x3_wgrad_variants_multi_tile():
@@ -370,13 +367,11 @@ def test_conv3x3_wgrad_variants_multi_tile():
     wr = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).requires_grad_(True)
     (F.conv2d(x, wr, padding=1) * dz).sum().backward()
     ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
-    for variant, cap in ((2, 0), (2, 5), (1, 0), (1, 5)):
-        query("cova_set_option", 3, variant)
+    for cap in (0, 5):
         query("cova_set_option", 2, cap)
         dw = torch.zeros(64, 64, 3, 3, device=DEV)
         call("cova_conv3x3_wgrad", nhwc(x), nhwc(dz), dw, ws, B, H, W)
-        close(dw, wr.grad, 2e-4, "conv3x3 wgrad v%d cap %d" % (variant, cap))
-    query("cova_set_option", 3, 2)
+        close(dw, wr.grad, 2e-4, "conv3x3 wgrad cap %d" % cap)
     query("cova_set_option", 2, 0)
 
 
@@ -393,18 +388,16 @@ def test_conv1_variants_multi_tile():
     call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
     nt = query("cova_conv1_num_partials", B, H, W)
     ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
-    for variant, cap in ((2, 0), (2, 7), (1, 0), (1, 7)):
-        query("cova_set_option", 4, variant)
+    for cap in (0, 7):
         query("cova_set_option", 2, cap)
-        nt = query("cova_conv1_num_partials", B, H, W)        # depends on the kernel variant / grid cap
+        nt = query("cova_conv1_num_partials", B, H, W)        # depends on the grid cap
         out, part = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
         call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
-        close(nchw(out), ref, 1e-4, "conv1 fwd v%d cap %d" % (variant, cap))
+        close(nchw(out), ref, 1e-4, "conv1 fwd cap %d" % cap)
         close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv1 sumsq")
         dw = torch.zeros(64, 3, 7, 7, device=DEV)
         call("cova_conv1_wgrad", x.to(DEV), nhwc(dy), dw, ws, B, H, W)
-        close(dw, wr.grad, 2e-4, "conv1 wgrad v%d cap %d" % (variant, cap))
-    query("cova_set_option", 4, 2)
+        close(dw, wr.grad, 2e-4, "conv1 wgrad cap %d" % cap)
     query("cova_set_option", 2, 0)
 
 

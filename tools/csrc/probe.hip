@@ -1,6 +1,6 @@
 // Diagnostic probes (not on the product path): sustained f32-MFMA rate of this GPU under load,
 // the practical ceiling the conv kernels are compared with besides the 157.3 TFLOP/s spec peak.
-#include "common.h"
+#include "../../cova-web-object-detection_amd/csrc/common.h"
 
 namespace {
 // 8 waves per block, 2 per SIMD; each wave keeps 4 independent accumulators busy.

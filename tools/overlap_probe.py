@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cova_amd  # noqa
 from cova_web_object_detection_amd import _lib
+import probe_lib  # noqa: E402  (tools/probe_lib.py: builds + registers libcova_probe.so)
+probe_lib.load()
 dev = "cuda:0"
 scratch = torch.zeros(16, device=dev)
 buf = torch.randn(1 << 28, device=dev)      # 1 GiB

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cova_amd  # noqa
 from cova_web_object_detection_amd import _lib
+import probe_lib  # noqa: E402  (tools/probe_lib.py: builds + registers libcova_probe.so)
+probe_lib.load()
 dev = "cuda:0"
 npix = 16 * 320 * 320
 x = torch.randn(npix, 64, device=dev)

@@ -141,6 +141,8 @@ class _ReluFn(torch.autograd.Function):
 
 
 def _relu(x, routing, key):
+    if routing and "_tap" in routing:             # tests: keep the pre-activation of every gate
+        routing["_tap"][key] = x.detach()
     return _ReluFn.apply(x, routing.get(key) if routing else None)
 
 
@@ -201,6 +203,8 @@ def convnet(images, sd, training, routing=None):
     routing = routing or {}
     x = F.conv2d(images, sd["convnet.0.weight"], None, stride=2, padding=3)
     x = _relu(_bn(x, sd, "convnet.1.", training), routing, "gate_bn1")
+    if "_tap" in routing:
+        routing["_tap"]["pool_in"] = x.detach()
     x = _MaxPool3x3s2Fn.apply(x, routing.get("pool_idx"))
     if "convnet.4.0.conv3.weight" in sd:
         for blk in (0, 1, 2):

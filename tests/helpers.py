@@ -141,3 +141,37 @@ def compare_grads(grads, grads_ref, rtol, floor_frac=0.01, outlier_frac=2e-3, ou
             "grad %s: %d of %d entries off by > %.1e" % (k, bad, diff.numel(), rtol)
         assert err < outlier_rtol, "grad %s: max err/scale %.3e >= %.1e" % (k, err, outlier_rtol)
     return worst
+
+
+def assert_gate_flips_near_zero(routing, tap, rel_tol=2e-5, max_frac=1e-4):
+    """Discrete decisions of the HIP forward that differ from the UNFORCED oracle's: every flipped ReLU gate
+    must sit on a pre-activation within rel_tol * max|pre-activation| of zero, every max-pool arg-max that
+    differs must point at a value within the same distance of the oracle's maximum, and both must be rare
+    (<= max_frac of the decisions of that layer).  Returns {key: number of flips}."""
+    flips = {}
+    for key, pre in tap.items():
+        if key == "pool_in" or key not in routing:
+            continue
+        gate = routing[key].to(torch.bool).reshape(pre.shape)
+        diff = gate != (pre > 0)
+        n = int(diff.sum())
+        flips[key] = n
+        assert n <= max(2, max_frac * diff.numel()), "%s: %d of %d ReLU gates differ" % (key, n, diff.numel())
+        if n:
+            worst = float(pre[diff].abs().max())
+            assert worst <= rel_tol * float(pre.abs().max()), "%s: a flipped gate sits at %.3e" % (key, worst)
+    if "pool_in" in tap and "pool_idx" in routing:
+        x = tap["pool_in"]
+        B, C, H, W = x.shape
+        ref = torch.nn.functional.max_pool2d(x, 3, 2, 1, return_indices=True)[1]
+        got = routing["pool_idx"].reshape(ref.shape)
+        diff = got != ref
+        n = int(diff.sum())
+        flips["pool_idx"] = n
+        assert n <= max(2, max_frac * diff.numel()), "max-pool: %d of %d arg-maxes differ" % (n, diff.numel())
+        if n:
+            flat = x.reshape(B, C, H * W)
+            a = torch.gather(flat, 2, got.reshape(B, C, -1))[diff.reshape(B, C, -1)]
+            b = torch.gather(flat, 2, ref.reshape(B, C, -1))[diff.reshape(B, C, -1)]
+            assert float((a - b).abs().max()) <= rel_tol * float(x.abs().max())
+    return flips

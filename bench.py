@@ -325,9 +325,11 @@ def main():
     # argmax + .item(), CE-sum + .item(), backward, torch.optim.Adam.step) -- two host reads per step
     dropin = None
     if world == 1 and args.config in (2, 3):
+        import contextlib
         import warnings
         from cova_web_object_detection_amd.models import CoVA
-        with warnings.catch_warnings():
+        # (the constructor prints its parameter count like the reference's does, models.py:92: keep stdout = one JSON line)
+        with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
             warnings.simplefilter("ignore")
             m = CoVA((3, 3), wl["H"], 4, True, 384, 32, 0, 0.2, None, backbone=wl["backbone"],
                      n_heads=wl["n_heads"], n_gat_layers=wl["n_gat_layers"])

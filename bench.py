@@ -65,6 +65,23 @@ def weight_cfg(cfg):
     return {k: v for k, v in cfg.items() if k != "drop_prob"}
 
 
+CFG = model_cfg(WORKLOADS[2])                      # the quoted configuration's model (tools/ import it)
+
+
+def make_device_batch(seed, device, pages=None, config=2):
+    """One synthetic batch of a workload on the device: boxes / neighbour tables from the seeded numpy generator,
+    pixels drawn on the device (uniform [0,1) like datasets.py:41-45's ToTensor output) to keep start-up short."""
+    import torch
+    from cova_web_object_detection_amd import synthetic
+    wl = WORKLOADS[config]
+    pages = pages or wl["pages"]
+    g = torch.Generator(device=device).manual_seed(seed)
+    batch = {k: v.to(device) for k, v in synthetic.make_boxes_only(pages, wl["H"], wl["W"], wl["boxes"], wl["cs"],
+                                                                    seed).items() if torch.is_tensor(v)}
+    batch["images"] = torch.rand((pages, 3, wl["H"], wl["W"]), generator=g, device=device, dtype=torch.float32)
+    return batch
+
+
 # ------------------------------------------------------------------------------------ FLOP accounting
 def flop_model(wl):
     """Algorithmic FLOPs per page (SURVEY.md 8d conventions: 2*MACs, W_j once per node, backward = data +
@@ -262,11 +279,7 @@ def main():
     sd = weights.seeded_state_dict(123, **weight_cfg(cfg))
     trainer = HotPathTrainer(cfg, sd, device, world_size=world, process_group=group, dropout_seed=123 + rank,
                              sync_bn=args.sync_bn)
-    g = torch.Generator(device=device).manual_seed(123 + rank)
-    batch = {k: v.to(device) for k, v in synthetic.make_boxes_only(pages, wl["H"], wl["W"], wl["boxes"], wl["cs"],
-                                                                    123 + rank).items() if torch.is_tensor(v)}
-    # pixels drawn on the device: uniform [0,1) like datasets.py:41-45's ToTensor output
-    batch["images"] = torch.rand((pages, 3, wl["H"], wl["W"]), generator=g, device=device, dtype=torch.float32)
+    batch = make_device_batch(123 + rank, device, pages, args.config)
     n_boxes = batch["bboxes"].shape[0]
 
     def barrier():

@@ -957,297 +957,6 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         }
 }
 
-template <bool POOL, int TH_>
-__global__ __launch_bounds__(64 * TH_, TH_ == 4 ? 2 : 1) void conv1_wgrad_v3_kernel(
-    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
-{
-    // geometry: TH_ x 32 output pixels per tile, 64 * TH_ threads (wave = (output-channel block, row pair));
-    // TH_ = 8: one 512-thread block per CU (109 KB of LDS); TH_ = 4: two independent 256-thread blocks per CU
-    // (60 KB each), so one block's staging / barriers overlap the other's MFMAs
-    using c1::RSTR;
-    using c1::PCH;
-    constexpr int NT = 64 * TH_;                                      // threads
-    constexpr int PRW = 2 * TH_ + 5;                                  // patch rows
-    constexpr int CST = PRW * RSTR;                                   // floats per channel plane
-    constexpr int INF = 3 * CST;
-    constexpr int NSEG = 3 * PRW, NWV = NT / 64;
-    constexpr int NPI = (NSEG + NWV - 1) / NWV + 1;                   // patch slots per thread (last: columns 64..68)
-    constexpr int DYF = TH_ * wg1::TW * 64;
-    constexpr int NPD = DYF / 4 / NT;                                 // 8 float4 of the dy tile per thread
-    constexpr int WIN_W = wg1::TW / 2 + 1, WIN_ITEMS = (TH_ / 2 + 1) * WIN_W * 16;
-    constexpr int NWIN = (TH_ / 2 + 1) * WIN_W;                       // pooling windows that can reach a tile
-    constexpr int NPOOL = POOL ? (WIN_ITEMS + NT - 1) / NT : 0;       // (window, 4-channel group) items per thread
-    static_assert(NSEG * 5 <= NT && NPI + NPD + NPOOL <= 32, "slot budget");
-    __shared__ __attribute__((aligned(16))) float lds[INF + DYF + (POOL ? NWIN * 80 : 0)];
-    float *s_in = lds;
-    float *s_dy = lds + INF;
-    float *s_dpw = lds + INF + DYF;                 // POOL: [window][64] pooled gradient
-    uint32_t *s_ixw = reinterpret_cast<uint32_t *>(s_dpw + NWIN * 64);   // POOL: [window][16] arg-max codes x4
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // wave-uniform copy: scalar index math
-    const int li = lane & 31, kh2 = lane >> 5;
-    const int cob = wave & 1, q = wave >> 1;
-
-    int toff[5];
-#pragma unroll
-    for (int tb = 0; tb < 5; ++tb) {
-        const int k = tb * 32 + li;
-        toff[tb] = (k < 147) ? ((k / 49) * CST + ((k % 49) / 7) * RSTR + ((k % 7) & 1) * PCH +
-                                ((k % 7) >> 1))
-                             : 0;
-    }
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    float pre[NPI];
-    float4 pd[NPD];
-    uint32_t pd_in = 0;                           // POOL: bit it = pixel of slot it lies inside the map
-    float4 pdp[POOL ? NPOOL : 1];
-    uint32_t pix[POOL ? NPOOL : 1];
-    // this thread's 4 channels of A | B | C; fetched where used (kept out of the MFMA loop's registers)
-    auto coef = [&](int which) {
-        int o = which * 64 + (tid & 15) * 4;
-        asm volatile("" : "+v"(o));
-        return *reinterpret_cast<const float4 *>(pool.abc + o);
-    };
-    // slot s < NPRE: image patch element; then NPRE_D float4 of the dy (POOL: y1) tile; then NPOOL
-    // (window, channel group) items of the pooled gradient
-    auto issue_slot = [&](int s, const float *img_b, const float *dy_b, int y0, int x0, int b) {
-        if (s >= NPI + NPD) {
-            if (POOL) {
-                const int k = s - NPI - NPD;
-                int t_ = tid;
-                asm volatile("" : "+v"(t_));      // index math stays here (hoisted, it costs more registers than it saves)
-                const int item = t_ + k * NT;
-                const int wr = item / (WIN_W * 16), wc = (item >> 4) % WIN_W;
-                const int ph = (y0 >> 1) + wr, pw = (x0 >> 1) + wc;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                uint32_t code = 0;
-#if defined(POOL_ABL) && (POOL_ABL & 2)
-                if (false) {
-#else
-                if (item < WIN_ITEMS && ph < pool.H2 && pw < pool.W2) {
-#endif
-                    const size_t o = (((size_t)b * pool.H2 + ph) * pool.W2 + pw) * 64 + (t_ & 15) * 4;
-                    v = *reinterpret_cast<const float4 *>(pool.dp + o);
-                    code = *reinterpret_cast<const uint32_t *>(pool.idx + o);
-                }
-                pdp[k] = v;
-                pix[k] = code;
-            }
-        } else if (s < NPI) {
-            int seg, j;                           // slots 0..NPI-2: columns 0..63 of row segment wave + NWV*s; last: 64..68
-            if (s < NPI - 1) {
-                seg = wave_u + NWV * s;
-                j = lane;
-            } else {
-                seg = tid / 5;
-                j = 64 + tid - 5 * seg;
-            }
-            const int c = seg / PRW, r = seg - c * PRW;
-            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
-            float v = 0.f;
-            if (seg < NSEG && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = img_b[(unsigned)((c * H + gy) * W + gx)];          // 32-bit in-image offset (checked at launch)
-            pre[s] = v;
-        } else {
-            const int it = s - NPI;
-            const int idx = tid + it * NT;
-            const int px = idx >> 4, c4 = idx & 15;
-            const int r = px / wg1::TW, c = px - r * wg1::TW;
-            const int gy = y0 + r, gx = x0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool in = gy < H1 && gx < W1;
-            if (in) v = *reinterpret_cast<const float4 *>(dy_b + (unsigned)(((gy * W1 + gx) << 6) + c4 * 4));
-            pd[it] = v;
-            pd_in = (pd_in & ~(1u << it)) | ((in ? 1u : 0u) << it);
-        }
-    };
-    auto issue_loads = [&](int t) {
-        const int tx = t % tiles_x;
-        const int ty = (t / tiles_x) % tiles_y;
-        const int b = t / (tiles_x * tiles_y);
-#pragma unroll
-        for (int s = 0; s < NPI + NPD + NPOOL; ++s)
-            issue_slot(s, img + (size_t)b * 3 * H * W, dy + (size_t)b * H1 * W1 * 64, ty * TH_,
-                       tx * wg1::TW, b);
-    };
-    auto write_lds = [&]() {
-#pragma unroll
-        for (int it = 0; it < NPI; ++it) {
-            int seg, j;
-            if (it < NPI - 1) {
-                seg = wave_u + NWV * it;
-                j = lane;
-            } else {
-                seg = tid / 5;
-                j = 64 + tid - 5 * seg;
-            }
-            if (seg < NSEG) {
-                const int c = seg / PRW, r = seg - c * PRW;
-                s_in[c * CST + r * RSTR + (j & 1) * PCH + (j >> 1)] = pre[it];
-            }
-        }
-        float4 cB = make_float4(0.f, 0.f, 0.f, 0.f), cC = cB;
-        if (POOL) {
-            cB = coef(1);
-            cC = coef(2);
-        }
-#pragma unroll
-        for (int it = 0; it < NPD; ++it) {
-            float4 v = pd[it];
-            if (POOL) {                                                   // B*y1 + C, 0 outside the map
-                const bool in = (pd_in >> it) & 1u;
-                v.x = in ? fmaf(cB.x, v.x, cC.x) : 0.f;
-                v.y = in ? fmaf(cB.y, v.y, cC.y) : 0.f;
-                v.z = in ? fmaf(cB.z, v.z, cC.z) : 0.f;
-                v.w = in ? fmaf(cB.w, v.w, cC.w) : 0.f;
-            }
-            *reinterpret_cast<float4 *>(s_dy + (tid + it * NT) * 4) = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NPOOL; ++k) {
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int item = t_ + k * NT;                                  // = window * 16 + channel group
-            if (item < WIN_ITEMS) {
-                *reinterpret_cast<float4 *>(s_dpw + item * 4) = pdp[k];
-                s_ixw[item] = pix[k];
-            }
-        }
-    };
-    // POOL: finish dy1 in place.  Thread -> pixel (row it, column cc), channels 4*c4..+3; the column
-    // permutation gives every wave four columns of one parity, so the set of pooling windows that
-    // can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform and rows are
-    // compile-time.  No atomics: each thread gathers into its own pixels.
-    auto scatter_pool = [&]() {
-#if defined(POOL_ABL) && (POOL_ABL & 1)
-        return;
-#endif
-        const int qx = tid >> 4, c4 = tid & 15;
-        const float4 cA = coef(0);
-        const bool codd = (wave & 1) != 0;                                  // == cc & 1
-        const int kx0 = codd ? 2 : 1;                                      // kx of the first candidate; the second (odd only): wc0+1, kx 0
-        constexpr int CHALF = 32 / (NT / 16);                               // column groups per thread (1, or 2 with 256 threads)
-#pragma unroll
-        for (int ch = 0; ch < CHALF; ++ch) {
-        const int cc = (((qx & 3) << 1) | ((qx >> 2) & 1)) + 8 * (qx >> 3) + (NT / 16) * ch;
-        const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
-        // four batches of two rows (2b, 2b+1); all LDS reads of a batch are issued before the first use.
-        // Odd columns have two candidate window columns, even ones a single one (wave-uniform branch).
-        auto batch = [&](const int bq, const int ne) {
-            uint32_t word[3][2];
-            float4 dval[3][2], cur[2];
-            // candidates of rows 2b, 2b+1: (row, window row - b, ky)
-            constexpr int crow[3] = {0, 1, 1}, cwr[3] = {0, 0, 1}, cky[3] = {1, 2, 0};
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (e >= ne) continue;
-                    const int win = (bq + cwr[k]) * WIN_W + wc0 + e;
-                    word[k][e] = s_ixw[win * 16 + c4];
-                    dval[k][e] = *reinterpret_cast<const float4 *>(s_dpw + win * 64 + c4 * 4);
-                }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-                cur[rr] = *reinterpret_cast<const float4 *>(s_dy + ((2 * bq + rr) * wg1::TW + cc) * 64 + c4 * 4);
-            float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (e >= ne) continue;
-                    const uint32_t code = (uint32_t)(cky[k] * 3 + (e == 0 ? kx0 : 0));
-                    const float dv[4] = {dval[k][e].x, dval[k][e].y, dval[k][e].z, dval[k][e].w};
-#pragma unroll
-                    for (int jx = 0; jx < 4; ++jx)
-                        g[crow[k]][jx] += (((word[k][e] >> (8 * jx)) & 255u) == code) ? dv[jx] : 0.f;
-                }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                float4 v = cur[rr];
-                v.x = fmaf(cA.x, g[rr][0], v.x);
-                v.y = fmaf(cA.y, g[rr][1], v.y);
-                v.z = fmaf(cA.z, g[rr][2], v.z);
-                v.w = fmaf(cA.w, g[rr][3], v.w);
-                *reinterpret_cast<float4 *>(s_dy + ((2 * bq + rr) * wg1::TW + cc) * 64 + c4 * 4) = v;
-            }
-            __builtin_amdgcn_sched_barrier(0);       // one batch in flight at a time (registers)
-        };
-        if (codd) {
-#pragma unroll
-            for (int bq = 0; bq < TH_ / 2; ++bq) batch(bq, 2);
-        } else {
-#pragma unroll
-            for (int bq = 0; bq < TH_ / 2; ++bq) batch(bq, 1);
-        }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
-        issue_loads(tile);
-        write_lds();
-        if (POOL) {
-            __syncthreads();
-            scatter_pool();
-        }
-    }
-    __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
-        // next tile's 17 prefetch slots: one per k-pair inside the MFMA loop
-        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
-        const int nb = next / (tiles_x * tiles_y);
-        const float *nimg = img + (size_t)nb * 3 * H * W;
-        const float *ndy = dy + (size_t)nb * H1 * W1 * 64;
-        // this wave: tile rows 2q, 2q+1; k-pair t -> pixels p = 2t + kh2 (row 2q + (p>>5), col p&31)
-        const float *a_ptr = s_dy + (2 * q * wg1::TW + kh2) * 64 + cob * 32 + li;
-        const float *b_ptr = s_in + (4 * q) * RSTR + kh2;
-        float a_op[2], b_op[2][5];                 // operands of k-pair t in slot t & 1 (no copies)
-        a_op[0] = a_ptr[0];
-#pragma unroll
-        for (int tb = 0; tb < 5; ++tb) b_op[0][tb] = b_ptr[toff[tb]];
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            if (t < NPI + NPD + NPOOL && has_next)
-                issue_slot(t, nimg, ndy, nty * TH_, ntx * wg1::TW, nb);
-            if (t < 31) {
-                const int pn = 2 * (t + 1);
-                const int rown = pn >> 5, coln = pn & 31;
-                a_op[(t + 1) & 1] = a_ptr[(rown * wg1::TW + coln) * 64];
-                const float *bn = b_ptr + (2 * rown) * RSTR + coln;
-#pragma unroll
-                for (int tb = 0; tb < 5; ++tb) b_op[(t + 1) & 1][tb] = bn[toff[tb]];
-            }
-#pragma unroll
-            for (int tb = 0; tb < 5; ++tb) acc[tb] = mfma32(a_op[t & 1], b_op[t & 1][tb], acc[tb]);
-        }
-        __syncthreads();
-        if (has_next) write_lds();
-        if (POOL) {
-            __syncthreads();
-            if (has_next) scatter_pool();
-        }
-        __syncthreads();
-    }
-    // partial layout: part[(block*(TH_/2) + q)][co 64][k 160]
-    float *dst = part + ((size_t)(blockIdx.x * (TH_ / 2) + q)) * (64 * 160);
-#pragma unroll
-    for (int tb = 0; tb < 5; ++tb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cob * 32 + mfma32_row(r, lane);
-            dst[co * 160 + tb * 32 + li] = acc[tb][r];
-        }
-}
-
 __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *__restrict__ part,
                                                                   int nparts, float *__restrict__ dw)
 {
@@ -1267,7 +976,6 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *_
 }
 
 extern int g_grid_cap;
-extern int g_wg1_rows;
 inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 {
     static int cus = 0;
@@ -1284,7 +992,6 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 }
 
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
-int g_wg1_rows = 4;          // conv1 weight gradient tile rows: 8 = one 512-thread block per CU, 4 = two 256-thread blocks
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
 
 }  // namespace
@@ -1305,7 +1012,6 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
     if (key == 5) { g_ablate = value; return COVA_OK; }
     if (key == 6) return cova_internal_set_wino_geometry(value);
-    if (key == 7 && (value == 4 || value == 8)) { g_wg1_rows = value; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1437,34 +1143,6 @@ COVA_API int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw, fl
     return COVA_OK;
 }
 
-// conv1 weight gradient launch: 4-row tiles with two independent 256-thread blocks per CU (default: one block's
-// staging and barriers overlap the other's MFMAs) or 8-row tiles with one 512-thread block per CU
-template <bool POOL>
-static int launch_conv1_wgrad(const float *img, const float *dy, float *ws, float *dw, int B, int H, int W, int H1,
-                              int W1, const PoolBwd pool, void *stream)
-{
-    const int tiles_x = cdiv(W1, wg1::TW);
-    if (g_wg1_rows == 4) {
-        const int tiles_y = cdiv(H1, 4);
-        const int grid = persistent_grid(B * tiles_x * tiles_y, 2);
-        hipLaunchKernelGGL((conv1_wgrad_v3_kernel<POOL, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img, dy,
-                           ws, H, W, H1, W1, tiles_x, tiles_y, B * tiles_x * tiles_y, pool);
-        COVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
-                           grid * 2, dw);
-    } else {
-        const int tiles_y = cdiv(H1, wg1::TH);
-        const int grid = persistent_grid(B * tiles_x * tiles_y);
-        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<POOL>, dim3(grid), dim3(wg1::THREADS), 0, (hipStream_t)stream, img,
-                           dy, ws, H, W, H1, W1, tiles_x, tiles_y, B * tiles_x * tiles_y, pool);
-        COVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
-                           grid * 4, dw);
-    }
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
-}
-
 COVA_API int cova_conv1_wgrad_workspace_floats(int B, int H, int W)
 {
     return persistent_grid(cova_conv1_num_tiles(B, H, W)) * 8 * 64 * 160;
@@ -1482,7 +1160,16 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));            // 32-bit in-image offsets in the kernel
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
-    return launch_conv1_wgrad<true>(img, y1, ws, dw, B, H, W, H1, W1, PoolBwd{dp, idx, abc, H2, W2}, stream);
+    const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
+    const int grid = persistent_grid(B * tiles_x * tiles_y);
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
+                       (hipStream_t)stream, ws, grid * 4, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }
 
 // img NCHW [B,3,H,W]; dy NHWC [B,H1,W1,64]; dw OIHW [64,3,7,7]
@@ -1492,5 +1179,14 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     COVA_REQUIRE(img && dy && dw && ws && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));            // 32-bit in-image offsets in the kernel
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
-    return launch_conv1_wgrad<false>(img, dy, ws, dw, B, H, W, H1, W1, PoolBwd{nullptr, nullptr, nullptr, 0, 0}, stream);
+    const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
+    const int grid = persistent_grid(B * tiles_x * tiles_y);
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
+                       (hipStream_t)stream, ws, grid * 4, dw);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }

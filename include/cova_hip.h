@@ -39,8 +39,7 @@ extern "C" {
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 /* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
- * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = Winograd tile geometry (1 | 2),
- * 7 = conv1 weight-gradient tile rows (4 = two 256-thread blocks per CU, default | 8 = one 512-thread block) */
+ * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = Winograd tile geometry (1 | 2) */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */

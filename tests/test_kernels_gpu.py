@@ -388,9 +388,8 @@ def test_conv1_variants_multi_tile():
     call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
     nt = query("cova_conv1_num_partials", B, H, W)
     ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
-    for cap, rows in ((0, 4), (7, 4), (0, 8), (7, 8)):
+    for cap in (0, 7):
         query("cova_set_option", 2, cap)
-        query("cova_set_option", 7, rows)
         nt = query("cova_conv1_num_partials", B, H, W)        # depends on the grid cap
         out, part = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
         call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
@@ -398,9 +397,8 @@ def test_conv1_variants_multi_tile():
         close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv1 sumsq")
         dw = torch.zeros(64, 3, 7, 7, device=DEV)
         call("cova_conv1_wgrad", x.to(DEV), nhwc(dy), dw, ws, B, H, W)
-        close(dw, wr.grad, 2e-4, "conv1 wgrad cap %d rows %d" % (cap, rows))
+        close(dw, wr.grad, 2e-4, "conv1 wgrad cap %d" % cap)
     query("cova_set_option", 2, 0)
-    query("cova_set_option", 7, 4)
 
 
 def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
@@ -598,9 +596,8 @@ def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
         query("cova_set_option", 2, 0)
 
 
-@pytest.mark.parametrize("rows", [4, 8])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 32, 64, 0), (2, 70, 150, 0), (2, 150, 330, 0), (2, 150, 330, 7)])
-def test_conv1_wgrad_with_pool_backward_folded_in(B, H, W, cap, rows):
+def test_conv1_wgrad_with_pool_backward_folded_in(B, H, W, cap):
     """cova_conv1_wgrad_poolbwd == cova_bn_relu_maxpool_bwd_apply followed by cova_conv1_wgrad
     (same partial sums, same coefficients), incl. odd map sizes and windows across tile borders."""
     g = torch.Generator().manual_seed(H * 3 + W)
@@ -625,19 +622,12 @@ def test_conv1_wgrad_with_pool_backward_folded_in(B, H, W, cap, rows):
     ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
     ref, dw = torch.zeros(64, 3, 7, 7, device=DEV), torch.zeros(64, 3, 7, 7, device=DEV)
     query("cova_set_option", 2, cap)
-    query("cova_set_option", 7, rows)          # tile rows: 4 = two 256-thread blocks per CU (default), 8 = one 512-thread block
     try:
         call("cova_conv1_wgrad", x, dy1, ref, ws, B, H, W)
         call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W)
     finally:
         query("cova_set_option", 2, 0)
-        query("cova_set_option", 7, 4)
     close(dw, ref, 2e-5, "conv1 wgrad with folded pool backward")
-    # against the definition as well: dW = dy1^T (*) image (torch-CPU)
-    xr = x.cpu()
-    wr = torch.zeros(64, 3, 7, 7, requires_grad=True)
-    (F.conv2d(xr, wr, stride=2, padding=3) * nchw(dy1)).sum().backward()
-    close(ref, wr.grad, 2e-4, "conv1 wgrad vs torch")
 
 
 # ------------------------------------------------------------------------------------ deterministic backward

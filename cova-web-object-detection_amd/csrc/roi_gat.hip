@@ -18,7 +18,7 @@ int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 namespace {
 
 // ------------------------------------------------------------------------------------ RoIPool
-// one wave per (roi, bin); lane = channel (C multiple of 64 handled by a loop)
+// one wave per (roi, bin); C multiple of 64 handled by a loop over 64-channel blocks
 // LAZY: the feature map is not read but formed on the fly as relu(fma(scale, z, shift) + x) -- the last
 // BasicBlock's bn2 + residual + ReLU (same expression as cova_bn_act_fwd), never written to HBM.
 struct LazyFeat {
@@ -60,43 +60,80 @@ __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     const bool empty = (hend <= hstart) || (wend <= wstart);
     const float *fb = feat + (size_t)(bad_page ? 0 : b) * H * W * C;
     const float *xb = LAZY ? lz.x + (size_t)(bad_page ? 0 : b) * H * W * C : nullptr;
-    for (int c = lane; c < C; c += 64) {
-        float maxv = empty ? 0.f : -FLT_MAX, zbest = 0.f;
-        int maxi = -1;
-        const int nw = wend - wstart;
-        const float sc = LAZY ? lz.scale[c] : 0.f, sh = LAZY ? lz.shift[c] : 0.f;
-        for (int h = hstart; h < hend; ++h) {
-            const size_t ro = ((size_t)h * W + wstart) * C + c;
-            const float *zrow = fb + ro;
-            const float *xrow = LAZY ? xb + ro : nullptr;
-            // element w of the row: the feature value (LAZY: bn2 + residual + ReLU on the fly)
-            auto val = [&](float z, int w) {
-                if (!LAZY) return z;
-                const float y = fmaf(sc, z, sh) + xrow[(size_t)w * C];
-                return y > 0.f ? y : 0.f;
-            };
-            int w = 0;
-            for (; w + 3 < nw; w += 4) {       // 4 loads in flight; compares in scan order
-                const float z0 = zrow[(size_t)w * C], z1 = zrow[(size_t)(w + 1) * C];
-                const float z2 = zrow[(size_t)(w + 2) * C], z3 = zrow[(size_t)(w + 3) * C];
-                const float v0 = val(z0, w), v1 = val(z1, w + 1), v2 = val(z2, w + 2), v3 = val(z3, w + 3);
-                if (v0 > maxv) { maxv = v0; zbest = z0; maxi = h * W + wstart + w; }
-                if (v1 > maxv) { maxv = v1; zbest = z1; maxi = h * W + wstart + w + 1; }
-                if (v2 > maxv) { maxv = v2; zbest = z2; maxi = h * W + wstart + w + 2; }
-                if (v3 > maxv) { maxv = v3; zbest = z3; maxi = h * W + wstart + w + 3; }
+    // lane = (pixel phase ps = lane >> 4, channels 4*(lane & 15)..+3): one float4 per lane covers 4 pixels x 256 B
+    // per load instruction; 4 loads (16 pixels) per map are in flight before the first compare.  Every lane scans
+    // its pixels (linear window index == ps mod 4) in ascending order with a strict >, then the four phases are
+    // merged preferring the larger value and, on ties, the smaller index: exactly the first maximum in row-major
+    // scan order that the reference's sequential loop finds.
+    const int ps = lane >> 4, cq = 4 * (lane & 15);
+    const int nw = wend - wstart, npx = empty ? 0 : (hend - hstart) * nw;
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c4 = cb + cq;
+        float best[4], bz[4];
+        int bi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { best[e] = empty ? 0.f : -FLT_MAX; bz[e] = 0.f; bi[e] = -1; }
+        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+        if (LAZY) {
+            sc = *reinterpret_cast<const float4 *>(lz.scale + c4);
+            sh = *reinterpret_cast<const float4 *>(lz.shift + c4);
+        }
+        for (int i0 = 0; i0 < npx; i0 += 16) {
+            float4 zv[4], xv[4];
+            int pos[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 4 * u + ps;
+                const int ii = i < npx ? i : npx - 1;            // clamped: loads stay unconditional
+                const int hh = ii / nw;
+                pos[u] = (hstart + hh) * W + wstart + (ii - hh * nw);
+                zv[u] = *reinterpret_cast<const float4 *>(fb + (size_t)pos[u] * C + c4);
+                if (LAZY) xv[u] = *reinterpret_cast<const float4 *>(xb + (size_t)pos[u] * C + c4);
+                if (i >= npx) pos[u] = -1;
             }
-            for (; w < nw; ++w) {
-                const float z0 = zrow[(size_t)w * C];
-                const float v = val(z0, w);
-                if (v > maxv) { maxv = v; zbest = z0; maxi = h * W + wstart + w; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (pos[u] < 0) continue;
+                const float z4[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+                float v4[4] = {z4[0], z4[1], z4[2], z4[3]};
+                if (LAZY) {                                       // bn2 + residual + ReLU on the fly
+                    const float x4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                    const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = fmaf(s4[e], z4[e], h4[e]) + x4[e];
+                        v4[e] = y > 0.f ? y : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v4[e] > best[e]) { best[e] = v4[e]; bz[e] = z4[e]; bi[e] = pos[u]; }
             }
         }
-        // reference layout [N, C, PH, PW] flattened per roi: c*(PH*PW) + bin  (models.py:125-127)
-        out[(size_t)n * ld_out + c * (PH * PW) + bin] = maxv;
-        argmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = maxi;
-        // the pre-activation z at the arg-max: with it the backward takes the producer's BatchNorm sums per
-        // pooled entry and never has to read the maps again
-        if (LAZY && zmax != nullptr) zmax[(size_t)n * (C * PH * PW) + c * (PH * PW) + bin] = zbest;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(best[e], o, 64), oz = __shfl_xor(bz[e], o, 64);
+                const int oi = __shfl_xor(bi[e], o, 64);
+                // (a lane that saw no pixel still holds the initial value with index -1: it never wins a tie
+                // against a real pixel, and loses to any larger value)
+                const bool take = ov > best[e] || (ov == best[e] && oi >= 0 && (bi[e] < 0 || oi < bi[e]));
+                if (take) { best[e] = ov; bz[e] = oz; bi[e] = oi; }
+            }
+        }
+        if (ps == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // reference layout [N, C, PH, PW] flattened per roi: c*(PH*PW) + bin  (models.py:125-127)
+                const size_t o = (size_t)(c4 + e) * (PH * PW) + bin;
+                out[(size_t)n * ld_out + o] = best[e];
+                argmax[(size_t)n * (C * PH * PW) + o] = bi[e];
+                // the pre-activation z at the arg-max: with it the backward takes the producer's BatchNorm sums
+                // per pooled entry and never has to read the maps again
+                if (LAZY && zmax != nullptr) zmax[(size_t)n * (C * PH * PW) + o] = bz[e];
+            }
+        }
     }
 }
 
@@ -647,7 +684,7 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
                               int W, int PH, int PW, float spatial_scale, float *out, int ld_out,
                               int32_t *argmax, void *stream)
 {
-    COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
+    COVA_REQUIRE(feat && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && C % 64 == 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<false>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, feat, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out,
@@ -663,7 +700,7 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
                                  int H, int W, int PH, int PW, float spatial_scale, float *out,
                                  int ld_out, int32_t *argmax, float *zmax, void *stream)
 {
-    COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
+    COVA_REQUIRE(z && x && scale && shift && rois && out && argmax && n_rois >= 0 && B > 0 && C > 0 && C % 64 == 0 && PH > 0 && PW > 0);
     if (n_rois == 0) return COVA_OK;
     hipLaunchKernelGGL(roipool_fwd_kernel<true>, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0,
                        (hipStream_t)stream, z, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out, ld_out,

@@ -6,61 +6,66 @@
 //   C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 //   transA = 0: A is [M,K] (lda >= K);  transA = 1: A is stored [K,M] (lda >= M)
 //   transB = 0: B is [K,N] (ldb >= N);  transB = 1: B is stored [N,K] (ldb >= K)
-// Block tile 64x64, BK = 32, 4 waves (2x2), each wave one 32x32 accumulator.  LDS tiles are
+// Block tile 64x64, BK = 64, 4 waves (2x2), each wave one 32x32 accumulator.  LDS tiles are
 // k-major ([k][m]) so that MFMA operand reads are conflict-free ds_read_b32 across lanes; the
-// next k-tile is fetched into registers (2 x float4 per operand per thread) while the current one
-// feeds 16 MFMAs per wave.  ~3 GFLOP per call on this path: latency bound, not roofline relevant.
+// next k-tile is fetched into registers (4 x float4 per operand per thread) while the current one
+// feeds 32 MFMAs per wave (these GEMMs are a few GFLOP each: the loop is latency bound, so fewer, longer
+// k-tiles -- half the barriers and round trips of BK = 32 -- matter more than occupancy).  ~3 GFLOP per call on this path: latency bound, not roofline relevant.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDT = 68;
+constexpr int BM = 64, BN = 64, BK = 64, LDT = 68;
+constexpr int EPT = BK * 64 / 256;      // elements of an operand tile per thread (16)
 
-// Fetch this thread's 8 elements of a (rows x BK) operand tile.
-//  k-contiguous storage (X[row][k]):   thread -> row = tid & 63, k = (tid >> 6) * 8 .. +7
-//  row-contiguous storage (X[k][row]): thread -> k = tid >> 3,   row = (tid & 7) * 8 .. +7
+// Fetch this thread's EPT elements of a (rows x BK) operand tile.
+//  k-contiguous storage (X[row][k]):   thread -> row = tid & 63, k = (tid >> 6) * EPT .. +EPT-1
+//  row-contiguous storage (X[k][row]): thread -> k = tid >> 2,   row = (tid & 3) * EPT .. +EPT-1
 template <bool KCONTIG>
-__device__ __forceinline__ void fetch8(const float *__restrict__ X, int ld, int row0, int nrows,
-                                       int k0, int K, int tid, bool vec_ok, float (&v)[8])
+__device__ __forceinline__ void fetch_tile(const float *__restrict__ X, int ld, int row0, int nrows,
+                                           int k0, int K, int tid, bool vec_ok, float (&v)[EPT])
 {
     if (KCONTIG) {
-        const int r = row0 + (tid & 63), k = k0 + (tid >> 6) * 8;
+        const int r = row0 + (tid & 63), k = k0 + (tid >> 6) * EPT;
         const float *p = X + (size_t)r * ld + k;
-        if (vec_ok && r < nrows && k + 7 < K) {
-            const float4 a = *reinterpret_cast<const float4 *>(p);
-            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (vec_ok && r < nrows && k + EPT - 1 < K) {
+#pragma unroll
+            for (int q = 0; q < EPT / 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4 *>(p + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (r < nrows && k + j < K) ? p[j] : 0.f;
+            for (int j = 0; j < EPT; ++j) v[j] = (r < nrows && k + j < K) ? p[j] : 0.f;
         }
     } else {
-        const int k = k0 + (tid >> 3), r = row0 + (tid & 7) * 8;
+        const int k = k0 + (tid >> 2), r = row0 + (tid & 3) * EPT;
         const float *p = X + (size_t)k * ld + r;
-        if (vec_ok && k < K && r + 7 < nrows) {
-            const float4 a = *reinterpret_cast<const float4 *>(p);
-            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (vec_ok && k < K && r + EPT - 1 < nrows) {
+#pragma unroll
+            for (int q = 0; q < EPT / 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4 *>(p + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (k < K && r + j < nrows) ? p[j] : 0.f;
+            for (int j = 0; j < EPT; ++j) v[j] = (k < K && r + j < nrows) ? p[j] : 0.f;
         }
     }
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void stash8(float (*S)[LDT], int tid, const float (&v)[8])
+__device__ __forceinline__ void stash_tile(float (*S)[LDT], int tid, const float (&v)[EPT])
 {
     if (KCONTIG) {
-        const int r = tid & 63, k = (tid >> 6) * 8;
+        const int r = tid & 63, k = (tid >> 6) * EPT;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) S[k + j][r] = v[j];
+        for (int j = 0; j < EPT; ++j) S[k + j][r] = v[j];
     } else {
-        const int k = tid >> 3, r = (tid & 7) * 8;
-        *reinterpret_cast<float4 *>(&S[k][r]) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(&S[k][r + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+        const int k = tid >> 2, r = (tid & 3) * EPT;
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q)
+            *reinterpret_cast<float4 *>(&S[k][r + 4 * q]) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 }
 
@@ -83,17 +88,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A,
 
     // A tile: rows = m; stored k-contiguous unless transposed.  B tile: rows = n; stored
     // k-contiguous when transB (B is [N,K]).
-    float va[8], vb[8];
-    fetch8<!TA>(A, lda, m0, M, 0, K, tid, vecA != 0, va);
-    fetch8<TB>(Bm, ldb, n0, N, 0, K, tid, vecB != 0, vb);
+    float va[EPT], vb[EPT];
+    fetch_tile<!TA>(A, lda, m0, M, 0, K, tid, vecA != 0, va);
+    fetch_tile<TB>(Bm, ldb, n0, N, 0, K, tid, vecB != 0, vb);
     for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();                    // previous tile fully consumed
-        stash8<!TA>(As, tid, va);
-        stash8<TB>(Bs, tid, vb);
+        stash_tile<!TA>(As, tid, va);
+        stash_tile<TB>(Bs, tid, vb);
         __syncthreads();
         if (k0 + BK < K) {                  // next tile in flight while this one computes
-            fetch8<!TA>(A, lda, m0, M, k0 + BK, K, tid, vecA != 0, va);
-            fetch8<TB>(Bm, ldb, n0, N, k0 + BK, K, tid, vecB != 0, vb);
+            fetch_tile<!TA>(A, lda, m0, M, k0 + BK, K, tid, vecA != 0, va);
+            fetch_tile<TB>(Bm, ldb, n0, N, k0 + BK, K, tid, vecB != 0, vb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {

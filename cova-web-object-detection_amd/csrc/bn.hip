@@ -173,9 +173,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ running_mean, float *__restrict__ running_var, float momentum, float eps,
     float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean,
-    float *__restrict__ invstd)
+    float *__restrict__ invstd, long long *__restrict__ num_batches_tracked)
 {
     __shared__ double s_a[1024], s_b[1024];
+    if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     double sum, sumsq;
     combine_partials(partial, nparts, C, c, slice, s_a, s_b, sum, sumsq);
@@ -703,13 +704,14 @@ COVA_API int cova_colstats(const float *x, int ldx, long long R, int C, float *p
 // when running_mean != NULL)
 COVA_API int cova_bn_finalize_fwd(const float *partial, int nparts, int C, double count,
                                   const float *gamma, const float *beta, float *running_mean,
-                                  float *running_var, float momentum, float eps, float *scale,
-                                  float *shift, float *mean, float *invstd, void *stream)
+                                  float *running_var, long long *num_batches_tracked, float momentum,
+                                  float eps, float *scale, float *shift, float *mean, float *invstd,
+                                  void *stream)
 {
     COVA_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && nparts > 0 && C > 0);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
                        partial, nparts, C, count, gamma, beta, running_mean, running_var, momentum,
-                       eps, scale, shift, mean, invstd);
+                       eps, scale, shift, mean, invstd, num_batches_tracked);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

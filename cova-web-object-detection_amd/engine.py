@@ -129,10 +129,9 @@ def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0
         if STAT_SYNC is not None:
             partial, nparts, count = _global_stats(partial, nparts, 2 * C, count, unit)
             st.count = float(count)
+        nbt = buffers.get(prefix + "num_batches_tracked") if upd else None
         call("cova_bn_finalize_fwd", partial, nparts, C, float(count), g, b, rm if upd else None,
-             rv if upd else None, BN_MOMENTUM, BN_EPS, st.scale, st.shift, st.mean, st.invstd)
-        if upd:
-            buffers[prefix + "num_batches_tracked"] += 1
+             rv if upd else None, nbt, BN_MOMENTUM, BN_EPS, st.scale, st.shift, st.mean, st.invstd)
     else:
         call("cova_bn_eval_params", g, b, rm, rv, BN_EPS, C, st.scale, st.shift, st.mean, st.invstd)
     return st

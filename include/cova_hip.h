@@ -150,6 +150,7 @@ int cova_colstats(const float *x, int ldx, long long R, int C, float *partial /*
                   void *stream);
 int cova_bn_finalize_fwd(const float *partial, int nparts, int C, double count, const float *gamma,
                          const float *beta, float *running_mean /*nullable*/, float *running_var,
+                         long long *num_batches_tracked /*nullable: += 1, like nn.BatchNorm in train mode*/,
                          float momentum, float eps, float *scale, float *shift, float *mean,
                          float *invstd, void *stream);
 int cova_bn_eval_params(const float *gamma, const float *beta, const float *running_mean,

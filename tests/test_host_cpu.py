@@ -114,3 +114,16 @@ def test_shard_batch_and_evaluate_bookkeeping_long_pages():
         tot += n
         assert int(s["context_indices"].max()) < n and int(s["bboxes"][:, 0].max()) == 1
     assert tot == 666
+
+
+def test_bench_flop_accounting_matches_survey_8d():
+    """bench.py's algorithmic-work model reproduces SURVEY.md 8d's per-page figures (the numbers `step.*` and the
+    roofline are derived from): 106.8 GF (R18, 1280^2), 151.3 GF (R50 stem), 484.7 GF (R50, 1280x4096, n=300, K=48)."""
+    import bench
+    for cfg, gf in ((2, 106.8), (3, 151.3), (5, 484.7)):
+        fm = bench.flop_model(bench.WORKLOADS[cfg])
+        assert abs(fm["total"] / 1e9 - gf) < 0.012 * gf, (cfg, fm["total"] / 1e9)
+    fm = bench.flop_model(bench.WORKLOADS[2])
+    assert fm["conv3_launch_per_page"] == 2 * 64 * 64 * 9 * 320 * 320
+    assert fm["wino"] == 12 * fm["conv3_launch_per_page"]
+    assert bench.CFG["backbone"] == "resnet18" and bench.WORKLOADS[4]["pages"] == 32

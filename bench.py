@@ -383,6 +383,7 @@ def main():
         conv_ms, conv_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
         alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
         executed = alg / WINO_RATIO
+        map_bytes = 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4)
         roof = {"bound": "mfma", "kernel": "conv3x3_c64_wino_kernel (forward + data-gradient launches of the step)",
                 "algorithm": "winograd F(2x2,3x3), exact f32 MFMA (v_mfma_f32_16x16x4_f32)",
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches_timed": conv_n}
@@ -395,7 +396,12 @@ def main():
                         algorithmic_achieved=round(alg / conv_ms / 1e9, 2),
                         algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                         traffic=traffic, traffic_unit="B/launch", traffic_source=src,
-                        algorithmic_bytes=2 * 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4))
+                        # compulsory bytes of the launches as they run in the step: besides one input and one
+                        # output map the fused variants read the prologue's second operand, the residual-branch
+                        # gradient and the mask / xhat operands of their epilogues -- per train
+                        # step 27 maps over 8 launches (ResNet-18) or 18 over 6 (ResNet-50 stem)
+                        algorithmic_bytes=int((27 / 8 if wl["backbone"] == "resnet18" else 18 / 6) * map_bytes),
+                        algorithmic_bytes_plain_launch=2 * map_bytes)
         step_alg = fm["total"] * pages                                   # per rank
         step_exec = (fm["total"] - fm["wino"] + fm["wino"] / WINO_RATIO) * pages
         step = {"algorithmic_gflop_per_page": round(fm["total"] / 1e9, 2),

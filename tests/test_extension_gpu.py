@@ -202,6 +202,11 @@ def test_resnet50_two_head_two_layer_nonsquare():                    # configs[4
     run_case(dict(backbone="resnet50", n_heads=2, n_gat_layers=2), 160, 96, [40, 9], 24, 32)
 
 
+def test_resnet50_odd_page_size_ragged_tiles():
+    """100 x 132 pages: 25 x 33 feature map, 1650 pixel rows per batch -- partial tiles in every 1x1 / 3x3 kernel."""
+    run_case(dict(backbone="resnet50", n_heads=2), 100, 132, [12, 7], 6, 35)
+
+
 def test_multi_head_gat_on_reference_backbone():
     run_case(dict(n_heads=4, n_gat_layers=2), 64, 64, [17, 30], 12, 33)
 

@@ -267,3 +267,34 @@ def test_full_size_long_page_train_step_properties():
     ref = O.convnet(crop, O.clone_state_dict(sd), False)[:, :, :64, :64]
     close(feat[0, :64, :64].permute(2, 0, 1).unsqueeze(0), ref, 1e-4, "long-page crop")
     assert feat.shape == (1, 1024, 320, 64)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(backbone="resnet50")])
+def test_piecewise_visual_features_backward(kw):
+    """The members extract_attn_wts_and_visualize.py:117-124 calls piecewise are differentiable on their own:
+    d(sum(visual * g)) through `_get_visual_features` (materialised feature map, stand-alone mask + BatchNorm sums)
+    against autograd of the oracle's conv stack + RoIPool, routing forced to the HIP forward's decisions."""
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(51, **{k: v for k, v in cfg.items() if k != "drop_prob"}, **kw)
+    batch = synthetic.make_batch(2, img_h=64, img_w=96, boxes_per_page=[14, 20], context_size=6, seed=51)
+    m = CoVA((3, 3), 64, 4, True, 48, 16, 0, 0.0, None, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    vis = m._get_visual_features(batch["images"].to(DEV), batch["bboxes"].to(DEV))
+    rs = np.random.RandomState(2)
+    g = torch.from_numpy(rs.standard_normal(tuple(vis.shape)).astype(np.float32))
+    conv_sv, roi_sv = vis.grad_fn.sv, vis.grad_fn.rsv
+    (vis * g.to(DEV)).sum().backward()
+    # oracle with the same discrete decisions
+    fake = dict(conv=conv_sv, roi=roi_sv, n_vis=vis.shape[1], Hd=0, dec=dict(y=torch.zeros(1, 1, device=DEV)))
+    routing = routing_from_saved(fake)
+    routing.pop("gate_dec")
+    work = O.clone_state_dict(sd)
+    leaves = {k: work[k].requires_grad_(True) for k in O.param_keys(work) if k.startswith("convnet.")}
+    feat = O.convnet(batch["images"], work, True, routing)
+    ref = O.roi_pool(feat, batch["bboxes"], (3, 3), 0.25, routing["roi_argmax"]).reshape(vis.shape)
+    close(vis, ref, 1e-4, "visual features")
+    (ref * g).sum().backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if k.startswith("convnet.")}
+    compare_grads(grads, {k: v.grad for k, v in leaves.items()}, rtol=2e-4, outlier_frac=0.0)

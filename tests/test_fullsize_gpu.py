@@ -182,6 +182,45 @@ def test_single_page_train_step_full_resolution_matches_oracle():
             assert rel(buffers[k], after[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("kw,H,W,n,cs", [(dict(backbone="resnet50", n_heads=2), 1280, 1280, 90, 12),
+                                         (dict(backbone="resnet50", n_heads=2, n_gat_layers=2), 2048, 1280, 300, 24)])
+def test_single_page_train_step_full_resolution_extension_matches_self_oracle(kw, H, W, n, cs):
+    """configs[2] (ResNet-50 stem + 2-head GAT, 1280x1280, 90 boxes, K=24) and the configs[4] architecture /
+    box count / K = 48 on a half-length page (2048x1280; the full 4096-row page is covered by
+    tests/test_extension_gpu.py::test_full_size_long_page_train_step_properties), one page, whole train step against
+    the self-oracle with every discrete decision forced: fp32 round-off only."""
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
+               bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.0, **kw)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(9, logit_gain=4.0, **wcfg)
+    batch = synthetic.make_batch(1, img_h=H, img_w=W, boxes_per_page=n, context_size=cs, seed=9)
+    params = {k: v.to(DEV) for k, v in sd.items() if k in O.param_keys(sd)}
+    buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+    args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
+    logits, sv = engine.model_fwd(cfg, params, buffers, *args, True)
+    loss, dl, pred = engine.ce_sum(logits, batch["labels"].to(DEV))
+    routing = routing_from_saved(sv)
+    grads = engine.model_bwd(sv, dl, params)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    ocfg = {k: v for k, v in cfg.items() if k not in kw}
+    loss_ref, logits_ref, grads_ref, after, inter = O.loss_and_grads(
+        sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
+        batch["labels"], ocfg, None, routing)
+    err = rel(logits, logits_ref)
+    assert err < 2e-4, err
+    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    tol = 10 * max(err, 1e-6) * float(logits_ref.abs().max())
+    top2 = torch.topk(logits_ref, 2, dim=1).values
+    ok = (top2[:, 0] - top2[:, 1]) > tol
+    assert torch.equal(pred.cpu()[ok], logits_ref.argmax(1)[ok])          # integer predictions, exact
+    assert set(grads) == set(grads_ref)
+    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
+    for k in buffers:
+        if not k.endswith("num_batches_tracked"):
+            assert rel(buffers[k], after[k]) < 1e-4, k
+
+
 def test_activations_beyond_2_31_elements_index_correctly():
     """96 pages of 1280x1280 (conv1 output 2.5 G elements, 10 GB): six copies of a 16-page batch share
     its BatchNorm statistics, so every copy's logits equal the 16-page logits and the gradient is six

@@ -429,13 +429,21 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
     const float alpha = p / denom;
     if (lane < K) attn[(size_t)n * K + lane] = alpha;
     const int jj = (int)j;
+    const float aw = jj >= 0 ? alpha : 0.f;                 // pads: weight 0 on a valid (clamped) row
     for (int d0 = 0; d0 < D; d0 += 64) {
-        const int d = d0 + lane;
+        const int d = d0 + lane, dd = d < D ? d : 0;
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const int jk = __shfl(jj, k, 64);
-            const float ak = __shfl(alpha, k, 64);
-            if (jk >= 0 && d < D) acc += ak * Wh[(size_t)jk * ldw + D + d];
+        for (int k0 = 0; k0 < K; k0 += 8) {                  // 8 neighbour rows in flight, added in slot order
+            float v[8], a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = min(k0 + u, K - 1);
+                const int jk = __shfl(jj, kk, 64);
+                a[u] = k0 + u < K ? __shfl(aw, kk, 64) : 0.f;
+                v[u] = Wh[(size_t)(jk >= 0 ? jk : 0) * ldw + D + dd];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = a[u] != 0.f ? fmaf(a[u], v[u], acc) : acc;
         }
         if (d < D) hprime[(size_t)n * ldh + d] = acc;
     }

@@ -582,14 +582,24 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
     }
     const int jj = (int)j;
     float dalpha = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const int jk = __shfl(jj, k, 64);
-        float part = 0.f;
-        if (jk >= 0)
-            for (int d = lane; d < D; d += 64)
-                part += g[(size_t)n * ldg + d] * Wh[(size_t)jk * ldw + D + d];
-        part = wave_sum(part);
-        if (lane == k) dalpha = part;
+    for (int k0 = 0; k0 < K; k0 += 4) {                     // four neighbour rows in flight per channel slice
+        int jk[4];
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jk[u] = __shfl(jj, min(k0 + u, K - 1), 64);
+        for (int d = lane; d < D; d += 64) {
+            const float gv = g[(size_t)n * ldg + d];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = Wh[(size_t)(jk[u] >= 0 ? jk[u] : 0) * ldw + D + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] = fmaf(gv, w[u], part[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float tot = wave_sum(part[u]);
+            if (lane == k0 + u && jk[u] >= 0) dalpha = tot;
+        }
     }
     const float dot = wave_sum(alpha * dalpha);
     float du = 0.f;

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void linear_small_bwd_x_kernel(const float *__
 }
 
 // dW[k][c] = sum_n dy[n][k]*x[n][c]; block = 64 columns x 16 row slices; db by block 0
+// V = 4: a thread owns 4 adjacent input columns (one float4 per row): 16 threads cover the block's 64 columns and a
+// wave walks 4 row slices, the block 64 (V = 1: 16 slices, any alignment) -- see colsum_kernel.
+template <int V>
 __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *__restrict__ dy,
                                                                   const float *__restrict__ x, int ldx,
                                                                   float *__restrict__ dW,
@@ -102,26 +105,49 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
                                                                   int Cin, int NC)
 {
     __shared__ float s[16][MAXNC][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
-    float acc[MAXNC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int TX = 64 / V, SPW = 64 / TX;               // column threads; row slices per wave
+    const int tx = lane % TX, slice = wave * SPW + lane / TX;
+    const int c = blockIdx.x * 64 + tx * V;
+    float acc[MAXNC][V];
 #pragma unroll
-    for (int k = 0; k < MAXNC; ++k) acc[k] = 0.f;
+    for (int k = 0; k < MAXNC; ++k)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
     if (c < Cin)
-        for (int n = ty; n < N; n += 16) {
-            const float xv = x[(size_t)n * ldx + c];
+        for (int n = slice; n < N; n += 16 * SPW) {
+            float xv[4];
+            if (V == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)n * ldx + c);
+                xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+            } else {
+                xv[0] = x[(size_t)n * ldx + c];
+            }
 #pragma unroll
             for (int k = 0; k < MAXNC; ++k)
-                if (k < NC) acc[k] += dy[(size_t)n * NC + k] * xv;
+                if (k < NC) {
+                    const float d = dy[(size_t)n * NC + k];
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[k][j] += d * xv[j];
+                }
         }
 #pragma unroll
-    for (int k = 0; k < MAXNC; ++k) s[ty][k][tx] = acc[k];
+    for (int k = 0; k < MAXNC; ++k)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float v = acc[k][j];
+            if (V == 4) {                                   // the wave's 4 row slices
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+            }
+            if (lane < TX) s[wave][k][tx * V + j] = v;
+        }
     __syncthreads();
-    if (ty == 0 && c < Cin)
+    if (wave == 0 && blockIdx.x * 64 + lane < Cin)
         for (int k = 0; k < NC; ++k) {
             float t = 0.f;
-            for (int j = 0; j < 16; ++j) t += s[j][k][tx];
-            dW[(size_t)k * Cin + c] = t;
+            for (int j = 0; j < 16; ++j) t += s[j][k][lane];
+            dW[(size_t)k * Cin + blockIdx.x * 64 + lane] = t;
         }
     if (blockIdx.x == 0) {                  // db[k] = sum_n dy[n][k]: all 1024 threads, LDS tree
         __syncthreads();
@@ -133,13 +159,13 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
             for (int k = 0; k < MAXNC; ++k)
                 if (k < NC) pk[k] += dy[(size_t)n * NC + k];
 #pragma unroll
-        for (int k = 0; k < MAXNC; ++k) s[ty][k][tx] = pk[k];
+        for (int k = 0; k < MAXNC; ++k) s[wave][k][lane] = pk[k];
         __syncthreads();
-        if (ty == 0)
+        if (wave == 0)
             for (int k = 0; k < NC; ++k) {
                 float t = 0.f;
-                for (int j = 0; j < 16; ++j) t += s[j][k][tx];
-                s[0][k][tx] = t;
+                for (int j = 0; j < 16; ++j) t += s[j][k][lane];
+                s[0][k][lane] = t;
             }
         __syncthreads();
         if (threadIdx.x < NC) {
@@ -207,21 +233,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 }
 
 // column sums of x [R, C] -> out [C] (deterministic; small R); 64 columns x 16 row slices
+// V = 4: a thread owns 4 adjacent columns (one float4 per row), so a block covers 64 columns with 16 threads and
+// walks 64 row slices in parallel (the matrices here are ~1.4k x 1k: the launch is latency bound, rows in flight
+// per block are what counts); V = 1: any alignment.
+template <int V>
 __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ x, int ldx, int R,
                                                       int C, float *__restrict__ out)
 {
-    __shared__ float s[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
-    float a = 0.f;
+    constexpr int TX = 64 / V, NS = 1024 / TX;
+    __shared__ float s[NS][64];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = blockIdx.x * 64 + tx * V;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C)
-        for (int r = ty; r < R; r += 16) a += x[(size_t)r * ldx + c];
-    s[ty][tx] = a;
+        for (int r = ty; r < R; r += NS) {
+            if (V == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ldx + c);
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+            } else {
+                a[0] += x[(size_t)r * ldx + c];
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[ty][tx * V + j] = a[j];
     __syncthreads();
-    if (ty == 0 && c < C) {
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
         float t = 0.f;
-        for (int j = 0; j < 16; ++j) t += s[j][tx];
-        out[c] = t;
+        for (int j = 0; j < NS; ++j) t += s[j][threadIdx.x];
+        out[blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
 
@@ -312,7 +351,8 @@ COVA_API int cova_linear_small_bwd(const float *dy, const float *x, int ldx, con
     hipLaunchKernelGGL(linear_small_bwd_x_kernel, dim3(ew_grid((long long)N * Cin)), dim3(256), 0, st,
                        dy, W, dx, lddx, N, Cin, NC);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(linear_small_bwd_w_kernel, dim3(cdiv(Cin, 64)), dim3(1024), 0, st, dy, x, ldx,
+    const bool v4 = (Cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4> : linear_small_bwd_w_kernel<1>), dim3(cdiv(Cin, 64)), dim3(1024), 0, st, dy, x, ldx,
                        dW, db, N, Cin, NC);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -346,7 +386,8 @@ COVA_API int cova_adam_step(float *p, const float *g, float *m, float *v, long l
 COVA_API int cova_colsum(const float *x, int ldx, int R, int C, float *out, void *stream)
 {
     COVA_REQUIRE(x && out && R > 0 && C > 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, R,
+    const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    hipLaunchKernelGGL((v4 ? colsum_kernel<4> : colsum_kernel<1>), dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, R,
                        C, out);
     COVA_LAUNCH_CHECK();
     return COVA_OK;

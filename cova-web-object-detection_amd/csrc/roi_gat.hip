@@ -175,8 +175,10 @@ __global__ void roipool_page_range_kernel(const float *__restrict__ rois, int n_
     if (n >= n_rois) return;
     const int b = (int)rois[5 * n];
     if (b < 0 || b >= B) return;
-    atomicMin(range + 2 * b, n);
-    atomicMax(range + 2 * b + 1, n);
+    // only the first / last box of a run of equal page indices can extend the range: 2 atomics per page for the
+    // sorted collate layout instead of n_rois contended ones (integer min / max: order-independent)
+    if (n == 0 || (int)rois[5 * (n - 1)] != b) atomicMin(range + 2 * b, n);
+    if (n == n_rois - 1 || (int)rois[5 * (n + 1)] != b) atomicMax(range + 2 * b + 1, n);
 }
 
 __global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
@@ -664,30 +666,43 @@ __global__ void gat_bwd_addt_kernel(float *__restrict__ dWh, int lddw, const flo
     dWh[(size_t)n * lddw + D + d] += dt[n] * att_w[D + d];
 }
 
-// block = 64 columns x 16 row slices; column 2D is the bias (sum of ds)
+// block = 64 columns; V = 4: a thread owns 4 adjacent columns (float4 per row) and the block walks 64 row slices
+// (V = 1: 16 slices, any D); the extra block past the 2D columns sums ds (the bias gradient)
+template <int V>
 __global__ __launch_bounds__(1024) void gat_bwd_att_kernel(const float *__restrict__ Wh, int ldw,
                                                            const float *__restrict__ ds,
                                                            const float *__restrict__ dt,
                                                            float *__restrict__ d_att_w,
                                                            float *__restrict__ d_att_b, int N, int D)
 {
-    __shared__ float s_acc[16][64];
-    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + tx;     // 0 .. 2D
-    float acc = 0.f;
+    constexpr int TX = 64 / V, NS = 1024 / TX;
+    __shared__ float s_acc[NS][64];
+    const int tx = threadIdx.x % TX, slice = threadIdx.x / TX;
+    const int col = blockIdx.x * 64 + tx * V;     // 0 .. 2D (+ the bias column)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < 2 * D) {
-        const float *w = col < D ? ds : dt;
-        for (int n = slice; n < N; n += 16) acc += w[n] * Wh[(size_t)n * ldw + col];
+        const float *w = col < D ? ds : dt;       // (D % V == 0: a thread's columns lie on one side)
+        for (int n = slice; n < N; n += NS) {
+            const float wn = w[n];
+            if (V == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(Wh + (size_t)n * ldw + col);
+                acc[0] += wn * v.x; acc[1] += wn * v.y; acc[2] += wn * v.z; acc[3] += wn * v.w;
+            } else {
+                acc[0] += wn * Wh[(size_t)n * ldw + col];
+            }
+        }
     } else if (col == 2 * D) {
-        for (int n = slice; n < N; n += 16) acc += ds[n];
+        for (int n = slice; n < N; n += NS) acc[0] += ds[n];
     }
-    s_acc[slice][tx] = acc;
+#pragma unroll
+    for (int j = 0; j < V; ++j) s_acc[slice][tx * V + j] = acc[j];
     __syncthreads();
-    if (slice == 0 && col <= 2 * D) {
+    const int oc = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && oc <= 2 * D) {
         float t = 0.f;
-        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
-        if (col == 2 * D) d_att_b[0] = t;
-        else d_att_w[col] = t;
+        for (int j = 0; j < NS; ++j) t += s_acc[j][threadIdx.x];
+        if (oc == 2 * D) d_att_b[0] = t;
+        else d_att_w[oc] = t;
     }
 }
 
@@ -902,8 +917,9 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
                            att_w, N, D);
         COVA_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gat_bwd_att_kernel, dim3(cdiv(2 * D + 1, 64)), dim3(1024), 0, st, Wh, ldw, ds,
-                       dt, d_att_w, d_att_b, N, D);
+    const bool v4 = (D % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)Wh & 15) == 0);
+    hipLaunchKernelGGL((v4 ? gat_bwd_att_kernel<4> : gat_bwd_att_kernel<1>), dim3(cdiv(2 * D + 1, 64)), dim3(1024), 0,
+                       st, Wh, ldw, ds, dt, d_att_w, d_att_b, N, D);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -674,8 +674,8 @@ constexpr int NPRE_D = (DY_FLOATS / 4 + THREADS - 1) / THREADS;    // 8 float4
 // POOL: the gradient operand is not read but rebuilt while staging (the BatchNorm+ReLU+MaxPool
 // backward "apply" pass folded in):  dy1 = A*g + B*y1 + C  per channel, where g routes the pooled
 // gradient dp (already ReLU-masked) to each window's arg-max (idx).  The tile is staged as B*y1 + C
-// and each thread then scatters its share of the 5x17 pooling windows that can reach the tile with
-// LDS float atomics (A*dp to the arg-max pixel): dy1 (1.68 GB at the bench size) is never written.
+// and each thread then gathers, into its own pixels, A*dp of the pooling windows (of the 5x17 that can reach the
+// tile) whose arg-max they are: no atomics, and dy1 (1.68 GB at the bench size) is never written.
 struct PoolBwd {
     const float *dp;          // [B,H2,W2,64] pooled gradient, ReLU mask already applied
     const uint8_t *idx;       // [B,H2,W2,64] arg-max position ky*3+kx inside the 3x3/s2 window

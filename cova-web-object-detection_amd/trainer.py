@@ -115,6 +115,30 @@ class HotPathTrainer:
             sd[k] = (self.params[k] if k in self.params else self.buffers[k]).detach().clone()
         return sd
 
+    def load_state_dict(self, state_dict):
+        """Restore parameters and BatchNorm buffers from a reference-layout state_dict -- the save-best /
+        reload-best cycle of train.py:84,94 (`torch.save(model.state_dict())`, `load_state_dict(torch.load(...))`).
+        The flat buffers keep their addresses (views, moments and bucket stay valid)."""
+        missing = [k for k in list(self.params) + list(self.buffers) if k not in state_dict]
+        if missing:
+            raise KeyError("state_dict lacks %s" % missing[:4])
+        for k, p in self.params.items():
+            p.copy_(state_dict[k].to(p.device).view_as(p))
+        for k in self.buffers:
+            self.buffers[k].copy_(state_dict[k].to(self.device))
+
+    def optimizer_state_dict(self):
+        """Adam moments + step count (the reference keeps no optimizer state in its checkpoints, train.py:84;
+        with this a run can be resumed exactly)."""
+        return dict(step=self.step_count, exp_avg=self.exp_avg.detach().clone(),
+                    exp_avg_sq=self.exp_avg_sq.detach().clone(), hp=dict(self.hp))
+
+    def load_optimizer_state_dict(self, state):
+        self.step_count = int(state["step"])
+        self.exp_avg.copy_(state["exp_avg"].to(self.device))
+        self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device))
+        self.hp.update(state.get("hp", {}))
+
     def forward_backward(self, batch, masks=None):
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
         self.step_count += 1

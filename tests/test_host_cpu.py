@@ -127,3 +127,27 @@ def test_bench_flop_accounting_matches_survey_8d():
     assert fm["conv3_launch_per_page"] == 2 * 64 * 64 * 9 * 320 * 320
     assert fm["wino"] == 12 * fm["conv3_launch_per_page"]
     assert bench.CFG["backbone"] == "resnet18" and bench.WORKLOADS[4]["pages"] == 32
+
+
+def test_trainer_checkpoint_round_trip_on_cpu_buffers():
+    """HotPathTrainer's flat buckets are device agnostic: the save-best / reload-best cycle of train.py:84,94 and an
+    optimizer-state round trip can be checked without a GPU (no device work is launched)."""
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=32, bbox_hidden_dim=8,
+               n_additional_feat=0, drop_prob=0.2)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd_a, sd_b = weights.seeded_state_dict(1, **wcfg), weights.seeded_state_dict(2, **wcfg)
+    tr = HotPathTrainer(cfg, sd_a, "cpu")
+    ptr = tr.pbucket.flat.data_ptr()
+    got = tr.state_dict()
+    assert list(got.keys()) != [] and all(torch.equal(got[k], sd_a[k]) for k in sd_a)
+    tr.load_state_dict(sd_b)
+    assert tr.pbucket.flat.data_ptr() == ptr and all(torch.equal(tr.state_dict()[k], sd_b[k]) for k in sd_b)
+    tr.exp_avg.fill_(0.5)
+    tr.step_count = 17
+    st = tr.optimizer_state_dict()
+    tr2 = HotPathTrainer(cfg, sd_b, "cpu")
+    tr2.load_optimizer_state_dict(st)
+    assert tr2.step_count == 17 and torch.equal(tr2.exp_avg, tr.exp_avg)
+    with pytest.raises(KeyError):
+        tr.load_state_dict({"convnet.0.weight": sd_a["convnet.0.weight"]})

@@ -712,3 +712,45 @@ def test_roipool_backward_rows_are_deterministic_and_cover_the_map():
     close(nchw(res[0]), gref, 1e-5, "roipool bwd rows")
     assert torch.equal(res[0], res[1])
     assert int((gref != 0).sum()) < n * C * 9                     # collisions did happen
+
+
+@pytest.mark.parametrize("ph,pw", [(1, 1), (2, 5), (7, 7)])
+def test_roipool_other_output_sizes(ph, pw):
+    """`-r` (roi_output_size, utils.py:20) other than the default 3: forward bit-exact vs the C oracle, backward
+    (generic bin loop of the row-owner kernel) vs its sequential scatter, masked variant consistent."""
+    rs = np.random.RandomState(ph * 10 + pw)
+    B, C, H, W = 2, 64, 30, 45
+    feat = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+    n = 60
+    x1 = rs.uniform(-10, 150, n); y1 = rs.uniform(-10, 100, n)
+    rois = torch.from_numpy(np.stack([rs.randint(0, B, n), x1, y1, x1 + rs.uniform(1, 120, n), y1 + rs.uniform(1, 90, n)], 1)
+                            .astype(np.float32))
+    nb = ph * pw
+    ref, ref_arg = O.roi_pool_argmax(feat, rois, (ph, pw), 0.25)
+    out = torch.empty(n, C * nb, device=DEV)
+    arg = torch.empty((n, C * nb), device=DEV, dtype=torch.int32)
+    call("cova_roipool_fwd", nhwc(feat), rois.to(DEV), n, B, C, H, W, ph, pw, 0.25, out, C * nb, arg)
+    assert torch.equal(out.cpu(), ref.reshape(n, -1)) and torch.equal(arg.cpu(), ref_arg.reshape(n, -1))
+    gout = torch.from_numpy(rs.standard_normal((n, C * nb)).astype(np.float32))
+    gref = torch.empty(B, C, H, W)
+    O._lib().oracle_roipool_bwd(O._fp(gout), O._fp(rois), O._fp(ref_arg), n, B, C, H, W, ph, pw, O._fp(gref))
+    ws = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, ph, pw), dtype=torch.int32, device=DEV)
+    g = torch.full((B, H, W, C), float("nan"), device=DEV)
+    call("cova_roipool_bwd", gout.to(DEV), C * nb, rois.to(DEV), arg, n, B, C, H, W, ph, pw, 0.25, g, ws)
+    close(nchw(g), gref, 1e-5, "roipool bwd %dx%d" % (ph, pw))
+    # whole model with that output size (eval logits vs the oracle)
+    cfg = dict(roi_output_size=(ph, pw), n_classes=4, use_context=True, hidden_dim=32, bbox_hidden_dim=8,
+               n_additional_feat=0, drop_prob=0.0)
+    from cova_web_object_detection_amd import weights
+    sd = weights.seeded_state_dict(3, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    batch = synthetic.make_batch(2, img_h=64, boxes_per_page=[9, 12], context_size=4, seed=3)
+    params = {k: v.to(DEV) for k, v in sd.items() if k in O.param_keys(sd)}
+    buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+    args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
+    logits, sv = engine.model_fwd(cfg, params, buffers, *args, True)
+    loss, dl, _ = engine.ce_sum(logits, batch["labels"].to(DEV))
+    grads = engine.model_bwd(sv, dl, params)
+    ref_l = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"], batch["additional_feats"],
+                      batch["context_indices"], cfg, True)
+    close(logits, ref_l, 2e-4, "logits with %dx%d bins" % (ph, pw))
+    assert all(torch.isfinite(v).all() for v in grads.values())

@@ -338,6 +338,164 @@ __global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ RoIAlign (extension)
+// north_star names RoIAlign; the reference itself calls torchvision.ops.RoIPool (models.py:58), which stays the
+// parity operator.  This is the additional variant: torchvision's RoIAlign (bilinear samples, sampling_ratio^2 per
+// bin or ceil(roi / bin)^2 when sampling_ratio <= 0, `aligned` half-pixel shift), coordinates in float like its
+// C++ / CUDA code.  Self-oracle: oracle/cova_oracle.py::roi_align.
+struct AlignGeo {
+    int b, gh, gw;
+    float sw, sh, bh, bw, inv_count;
+};
+
+__device__ __forceinline__ AlignGeo align_geo(const float *__restrict__ roi, float scale, int PH, int PW,
+                                              int sampling_ratio, int aligned)
+{
+    AlignGeo g;
+    const float off = aligned ? 0.5f : 0.f;
+    g.b = (int)roi[0];
+    g.sw = roi[1] * scale - off;
+    g.sh = roi[2] * scale - off;
+    float rw = (roi[3] * scale - off) - g.sw, rh = (roi[4] * scale - off) - g.sh;
+    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    g.bh = rh / (float)PH;
+    g.bw = rw / (float)PW;
+    g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+    g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+    g.inv_count = 1.f / (float)max(g.gh * g.gw, 1);
+    return g;
+}
+
+struct Bilin {
+    int yl, yh, xl, xh;
+    float hy, ly, hx, lx;
+    bool ok;
+};
+
+__device__ __forceinline__ Bilin bilin_setup(float y, float x, int H, int W)
+{
+    Bilin q;
+    q.ok = !(y < -1.f || y > (float)H || x < -1.f || x > (float)W);
+    y = fmaxf(y, 0.f);
+    x = fmaxf(x, 0.f);
+    q.yl = (int)y;
+    q.xl = (int)x;
+    if (q.yl >= H - 1) { q.yl = q.yh = H - 1; y = (float)q.yl; } else { q.yh = q.yl + 1; }
+    if (q.xl >= W - 1) { q.xl = q.xh = W - 1; x = (float)q.xl; } else { q.xh = q.xl + 1; }
+    q.ly = y - (float)q.yl;
+    q.lx = x - (float)q.xl;
+    q.hy = 1.f - q.ly;
+    q.hx = 1.f - q.lx;
+    return q;
+}
+
+__device__ __forceinline__ float align_coord(float start, int bin, float bsz, int i, int grid)
+{
+    return (start + (float)bin * bsz) + (((float)i + 0.5f) * bsz) / (float)grid;
+}
+
+// one wave per (roi, bin); lanes = channels (256-byte coalesced rows of the NHWC map)
+__global__ __launch_bounds__(256) void roialign_fwd_kernel(
+    const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int B, int C, int H, int W,
+    int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, float *__restrict__ out, int ld_out)
+{
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (task >= n_rois * PH * PW) return;
+    const int n = task / (PH * PW), bin = task - n * (PH * PW);
+    const int ph = bin / PW, pw = bin - ph * PW;
+    const AlignGeo g = align_geo(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio, aligned);
+    const bool bad_page = g.b < 0 || g.b >= B;
+    const float *fb = feat + (size_t)(bad_page ? 0 : g.b) * H * W * C;
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+        if (!bad_page)
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float y = align_coord(g.sh, ph, g.bh, iy, g.gh);
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float x = align_coord(g.sw, pw, g.bw, ix, g.gw);
+                    const Bilin q = bilin_setup(y, x, H, W);
+                    if (!q.ok) continue;
+                    const float v1 = fb[((size_t)q.yl * W + q.xl) * C + c], v2 = fb[((size_t)q.yl * W + q.xh) * C + c];
+                    const float v3 = fb[((size_t)q.yh * W + q.xl) * C + c], v4 = fb[((size_t)q.yh * W + q.xh) * C + c];
+                    acc = acc + (q.hy * q.hx) * v1 + (q.hy * q.lx) * v2 + (q.ly * q.hx) * v3 + (q.ly * q.lx) * v4;
+                }
+            }
+        out[(size_t)n * ld_out + c * (PH * PW) + bin] = acc * g.inv_count;
+    }
+}
+
+// Backward, deterministic like RoIPool's: one owner wave per (page, feature row, 40-pixel segment), lanes = channels;
+// boxes whose sample rows can touch the row are found 64 at a time (ballot) and visited in ascending order, every
+// sample's two row neighbours are tested against the owner row and its column pair added into the LDS row.
+__global__ __launch_bounds__(256) void roialign_bwd_rows_kernel(
+    const float *__restrict__ gout, int ld_g, const float *__restrict__ rois, const int *__restrict__ page_range,
+    int n_rois, int B, int C, int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+    float *__restrict__ gfeat)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * ROI_XW * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *acc = lds + wave * ROI_XW * 64;
+    const int cb = blockIdx.y * 64, c = cb + lane;
+    const int ps = lane >> 4, c4 = cb + 4 * (lane & 15);
+    const int nx = (W + ROI_XW - 1) / ROI_XW;
+    const long long ntask = (long long)B * H * nx;
+    for (long long task = (long long)blockIdx.x * 4 + wave; task < ntask; task += (long long)gridDim.x * 4) {
+        const int xs = (int)(task % nx);
+        const int y = (int)((task / nx) % H);
+        const int b = (int)(task / ((long long)nx * H));
+        const int x0 = xs * ROI_XW, x1 = min(x0 + ROI_XW, W);
+#pragma unroll
+        for (int i = 0; i < ROI_XW * 16 / 64; ++i)
+            reinterpret_cast<float4 *>(acc)[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n_lo = page_range[2 * b], n_hi = page_range[2 * b + 1];
+        for (int n0 = n_lo; n0 <= n_hi; n0 += 64) {
+            const int n = n0 + lane;
+            bool hit = false;
+            if (n <= n_hi) {
+                const AlignGeo g = align_geo(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio, aligned);
+                // rows / columns any sample of the box can touch (conservative: +-1 pixel around the roi)
+                const float ylo = g.sh, yhi = g.sh + (float)PH * g.bh, xlo = g.sw, xhi = g.sw + (float)PW * g.bw;
+                hit = g.b == b && (float)y >= ylo - 2.f && (float)y <= yhi + 2.f && (float)x1 >= xlo - 2.f &&
+                      (float)x0 <= xhi + 2.f;
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int nb = n0 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const AlignGeo g = align_geo(rois + 5 * nb, spatial_scale, PH, PW, sampling_ratio, aligned);
+                const float *gv = gout + (size_t)nb * ld_g + (size_t)c * (PH * PW);
+                for (int ph = 0; ph < PH; ++ph)
+                    for (int iy = 0; iy < g.gh; ++iy) {
+                        const float yy = align_coord(g.sh, ph, g.bh, iy, g.gh);
+                        if (yy < -1.f || yy > (float)H) continue;
+                        const Bilin qy = bilin_setup(yy, 0.f, H, W);
+                        const float wy = (qy.yl == y ? qy.hy : 0.f) + (qy.yh == y ? qy.ly : 0.f);
+                        if (qy.yl != y && qy.yh != y) continue;
+                        for (int pw = 0; pw < PW; ++pw) {
+                            const float gval = gv[ph * PW + pw] * g.inv_count;
+                            for (int ix = 0; ix < g.gw; ++ix) {
+                                const float xx = align_coord(g.sw, pw, g.bw, ix, g.gw);
+                                const Bilin q = bilin_setup(yy, xx, H, W);
+                                if (!q.ok) continue;
+                                if (q.xl >= x0 && q.xl < x1) acc[(q.xl - x0) * 64 + lane] += (wy * q.hx) * gval;
+                                if (q.xh >= x0 && q.xh < x1) acc[(q.xh - x0) * 64 + lane] += (wy * q.lx) * gval;
+                            }
+                        }
+                    }
+            }
+        }
+        const size_t row = ((size_t)b * H + y) * W;
+#pragma unroll
+        for (int t = 0; t < ROI_XW / 4; ++t) {
+            const int x = x0 + t * 4 + ps;
+            if (x < x1)
+                *reinterpret_cast<float4 *>(gfeat + (row + x) * C + c4) =
+                    *reinterpret_cast<const float4 *>(acc + (t * 4 + ps) * 64 + 4 * (lane & 15));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ bbox
 // raw = [x1, y1, w, h, w/h]; z = raw W^T + b  (models.py:134-144 up to the Linear)
 __global__ void bbox_linear_fwd_kernel(const float *__restrict__ bboxes,
@@ -822,6 +980,36 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *poole
     COVA_REQUIRE(B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
     return launch_roipool_bwd(gout, ld_g, pooled, ld_p, zmax, rois, argmax, n_rois, B, C, H, W, PH, PW,
                               spatial_scale, mean, invstd, gfeat, partial, ws, (hipStream_t)stream);
+}
+
+// RoIAlign (extension; see roialign_fwd_kernel): same tensor conventions as cova_roipool_fwd
+COVA_API int cova_roialign_fwd(const float *feat, const float *rois, int n_rois, int B, int C, int H, int W,
+                               int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, float *out,
+                               int ld_out, void *stream)
+{
+    COVA_REQUIRE(feat && rois && out && n_rois >= 0 && B > 0 && C > 0 && PH > 0 && PW > 0);
+    if (n_rois == 0) return COVA_OK;
+    hipLaunchKernelGGL(roialign_fwd_kernel, dim3(cdiv(n_rois * PH * PW, 4)), dim3(256), 0, (hipStream_t)stream,
+                       feat, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, sampling_ratio, aligned, out, ld_out);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// gfeat NHWC [B,H,W,C], fully written, no atomics (one owner wave per feature row); ws >= 2*B + 16 ints
+COVA_API int cova_roialign_bwd(const float *gout, int ld_g, const float *rois, int n_rois, int B, int C, int H,
+                               int W, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+                               float *gfeat, void *ws, void *stream)
+{
+    COVA_REQUIRE(gout && rois && gfeat && ws && B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    int *page_range = (int *)ws;
+    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, st);
+    if (rc != COVA_OK) return rc;
+    hipLaunchKernelGGL(roialign_bwd_rows_kernel, dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gout,
+                       ld_g, rois, page_range, n_rois, B, C, H, W, PH, PW, spatial_scale, sampling_ratio, aligned,
+                       gfeat);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }
 
 COVA_API int cova_bbox_linear_fwd(const float *bboxes, const float *W, const float *bias, float *raw,

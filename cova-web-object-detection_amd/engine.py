@@ -704,6 +704,27 @@ def roipool_fwd(feat, bboxes, roi_size, spatial_scale, out, ld_out):
                 zmax=zmax, pooled=out, ld_pooled=ld_out)
 
 
+def roialign_fwd(feat, bboxes, roi_size, spatial_scale, sampling_ratio, aligned, out, ld_out):
+    """RoIAlign variant of the pooling stage (extension: north_star names RoIAlign, the reference uses RoIPool)."""
+    _check(bboxes)
+    B, Hf, Wf, C = feat.shape
+    N = bboxes.shape[0]
+    PH, PW = roi_size
+    call("cova_roialign_fwd", feat, bboxes, N, B, C, Hf, Wf, PH, PW, float(spatial_scale), int(sampling_ratio),
+         1 if aligned else 0, out, ld_out)
+    return dict(kind="align", bboxes=bboxes, shape=(B, Hf, Wf, C), roi=(PH, PW), scale=float(spatial_scale),
+                sampling_ratio=int(sampling_ratio), aligned=bool(aligned), zmax=None)
+
+
+def roialign_bwd(sv, gout, ld_g):
+    B, Hf, Wf, C = sv["shape"]
+    PH, PW = sv["roi"]
+    gfeat = _empty((B, Hf, Wf, C), gout)
+    call("cova_roialign_bwd", gout, ld_g, sv["bboxes"], sv["bboxes"].shape[0], B, C, Hf, Wf, PH, PW, sv["scale"],
+         sv["sampling_ratio"], 1 if sv["aligned"] else 0, gfeat, _empty((2 * B + 16,), gout, torch.int32))
+    return gfeat
+
+
 def _roipool_ws(sv, like):
     B, Hf, Wf, C = sv["shape"]
     PH, PW = sv["roi"]
@@ -946,11 +967,16 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     F = n_vis + Hd + A
     D = cfg["hidden_dim"] if cfg["use_context"] else 0
     T = F + D
-    feat, sv_conv = convstack_fwd(images, params, buffers, training, save, lazy_out=True)
+    align = cfg.get("roi_op", "pool") == "align"
+    feat, sv_conv = convstack_fwd(images, params, buffers, training, save, lazy_out=not align)
     comb = _empty((N, T), images)
     scale = cfg.get("spatial_scale") or feat.shape[1] / images.shape[2]   # models.py:56
     sv = dict(cfg=cfg, N=N, F=F, D=D, T=T, n_vis=n_vis, Hd=Hd, A=A, conv=sv_conv, comb=comb)
-    sv["roi"] = roipool_fwd(feat, bboxes, (PH, PW), scale, comb, T)
+    if align:
+        sv["roi"] = roialign_fwd(feat, bboxes, (PH, PW), scale, cfg.get("sampling_ratio", 2),
+                                 cfg.get("roi_aligned", False), comb, T)
+    else:
+        sv["roi"] = roipool_fwd(feat, bboxes, (PH, PW), scale, comb, T)
     if Hd > 0:
         sv["bbox"] = bbox_fwd(bboxes, params, buffers, training, comb[:, n_vis:], T)
     if A > 0:
@@ -991,7 +1017,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
         dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"])
         grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
     else:
-        dfeat = roipool_bwd(sv["roi"], dcomb, T)
+        dfeat = roialign_bwd(sv["roi"], dcomb, T) if sv["roi"].get("kind") == "align" else roipool_bwd(sv["roi"], dcomb, T)
         grads.update(convstack_bwd(conv, dfeat, gout, None, params))
     return grads
 

@@ -123,14 +123,20 @@ class _VisualFn(torch.autograd.Function):
         images, bboxes = _f32c(images), _f32c(bboxes)
         feat, sv = engine.convstack_fwd(images, params, buffers, model.training, need_grad)
         out = torch.empty((bboxes.shape[0], model.n_visual_feat), device=images.device)
-        rsv = engine.roipool_fwd(feat, bboxes, model.roi_pool.output_size,
-                                 model.roi_pool.spatial_scale, out, model.n_visual_feat)
+        if model._cfg["roi_op"] == "align":
+            rsv = engine.roialign_fwd(feat, bboxes, model.roi_pool.output_size, model.roi_pool.spatial_scale,
+                                      model._cfg["sampling_ratio"], model._cfg["roi_aligned"], out,
+                                      model.n_visual_feat)
+        else:
+            rsv = engine.roipool_fwd(feat, bboxes, model.roi_pool.output_size,
+                                     model.roi_pool.spatial_scale, out, model.n_visual_feat)
         ctx.sv, ctx.rsv, ctx.keys, ctx.nv, ctx.params = sv, rsv, keys, model.n_visual_feat, params
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        gfeat = engine.roipool_bwd(ctx.rsv, gout.contiguous(), ctx.nv)
+        bwd = engine.roialign_bwd if ctx.rsv.get("kind") == "align" else engine.roipool_bwd
+        gfeat = bwd(ctx.rsv, gout.contiguous(), ctx.nv)
         grads = engine.convstack_bwd(ctx.sv, gfeat, params=ctx.params)
         return (None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
@@ -268,14 +274,19 @@ class MultiHeadGraphAttention(nn.Module):
 class CoVA(nn.Module):
     def __init__(self, roi_output_size, img_H, n_classes, use_context=True, hidden_dim=384,
                  bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.2, class_names=None,
-                 backbone="resnet18", n_heads=1, n_gat_layers=1, backbone_state_dict=None):
+                 backbone="resnet18", n_heads=1, n_gat_layers=1, backbone_state_dict=None, roi_op="pool",
+                 sampling_ratio=2, roi_aligned=False):
         """The first nine arguments exactly as the reference's CoVA (models.py:10-34; called positionally
         at main.py:122-132).  Keyword-only-in-practice extensions, whose defaults are the reference's
         model: ``backbone`` 'resnet18' | 'resnet50' (torchvision ``children()[:-5]`` of either),
         ``n_heads`` / ``n_gat_layers`` (MultiHeadGraphAttention), ``backbone_state_dict`` = a torchvision
         ResNet state_dict (or a path to one) whose conv1 / bn1 / layer1 entries initialise the stack --
         the offline stand-in for the reference's ``pretrained=True`` download (models.py:49).
+        ``roi_op='align'`` swaps RoIPool (the reference's operator and the parity path) for torchvision's RoIAlign
+        (``sampling_ratio``, ``roi_aligned`` as in ``torchvision.ops.RoIAlign``).
         ``img_H`` is only used for the RoIPool scale (models.py:53-56): pages may be any H x W."""
+        if roi_op not in ("pool", "align"):
+            raise ValueError("roi_op must be 'pool' (the reference, models.py:58) or 'align'")
         super(CoVA, self).__init__()
         self.n_classes = n_classes
         self.use_context = use_context
@@ -336,7 +347,8 @@ class CoVA(nn.Module):
                          hidden_dim=hidden_dim, bbox_hidden_dim=bbox_hidden_dim,
                          n_additional_feat=n_additional_feat, drop_prob=float(drop_prob),
                          spatial_scale=self.roi_pool.spatial_scale, backbone=backbone,
-                         n_heads=n_heads, n_gat_layers=n_gat_layers)
+                         n_heads=n_heads, n_gat_layers=n_gat_layers, roi_op=roi_op,
+                         sampling_ratio=int(sampling_ratio), roi_aligned=bool(roi_aligned))
         self._param_keys = [k for k, _ in self.named_parameters()]
         self._conv_keys = [k for k in self._param_keys if k.startswith("convnet.")]
         self._bbox_keys = [k for k in self._param_keys if k.startswith("bbox_feat_encoder.")]

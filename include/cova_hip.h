@@ -224,6 +224,17 @@ int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, cons
                         float *zmax /*nullable [N, C*PH*PW]: z at each arg-max, for cova_roipool_bwd_bn*/,
                         void *stream);
 
+/* RoIAlign -- EXTENSION: north_star names it, the reference calls RoIPool (models.py:58), which stays the parity
+ * operator.  torchvision.ops.RoIAlign semantics (bilinear samples, sampling_ratio^2 per bin, or ceil(roi/bin)^2
+ * when sampling_ratio <= 0; `aligned` half-pixel shift); same tensor conventions as cova_roipool_fwd / _bwd;
+ * backward deterministic (one owner wave per feature row), ws >= (2*B + 16) ints. */
+int cova_roialign_fwd(const float *feat, const float *rois, int n_rois, int B, int C, int H, int W, int PH,
+                      int PW, float spatial_scale, int sampling_ratio, int aligned, float *out, int ld_out,
+                      void *stream);
+int cova_roialign_bwd(const float *gout, int ld_g, const float *rois, int n_rois, int B, int C, int H, int W,
+                      int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, float *gfeat,
+                      void *ws, void *stream);
+
 /* ------------------------------------------------------------------ positional encoder
  * replaces: CoVA._get_bbox_features up to nn.Linear(5, Hd) (models.py:134-144):
  * raw = [x1, y1, x2-x1, y2-y1, (x2-x1)/(y2-y1)], z = raw W^T + b */

@@ -101,6 +101,61 @@ def roi_pool(feat, rois, output_size, spatial_scale, forced_argmax=None):
                             float(spatial_scale), forced_argmax)
 
 
+def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio=2, aligned=False):
+    """EXTENSION (north_star names RoIAlign; the reference itself uses RoIPool, models.py:58): torchvision's
+    `ops.RoIAlign` restated from its published algorithm (Mask R-CNN appendix; torchvision 0.7.0
+    csrc/cpu/ROIAlign_cpu.cpp semantics [from memory -- SELF-ORACLE, parity unpinned]): every bin averages
+    sampling_ratio^2 (or ceil(roi/bin)^2 when sampling_ratio <= 0) bilinear samples; samples more than one pixel
+    outside the map contribute 0, coordinates are clamped at 0 and at the last row / column.
+    feat [B,C,H,W], rois [N,5] -> [N,C,PH,PW]; plain torch ops, so autograd provides the backward."""
+    B, C, H, W = feat.shape
+    PH, PW = int(output_size[0]), int(output_size[1])
+    out = []
+    F = np.float32                                  # the C++ code computes every coordinate in float
+    off, scale = F(0.5 if aligned else 0.0), F(spatial_scale)
+    for r in rois.detach().to(torch.float32).numpy():
+        b = int(r[0])
+        sw, sh = F(r[1] * scale - off), F(r[2] * scale - off)
+        rw, rh = F(F(r[3] * scale - off) - sw), F(F(r[4] * scale - off) - sh)
+        if not aligned:
+            rw, rh = max(rw, F(1.0)), max(rh, F(1.0))
+        bh, bw = F(rh / F(PH)), F(rw / F(PW))
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / F(PH)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / F(PW)))
+        count = F(max(gh * gw, 1))
+        bins = []
+        for ph in range(PH):
+            for pw in range(PW):
+                acc = torch.zeros(C, dtype=torch.float32)
+                for iy in range(gh):
+                    y = F(F(sh + F(F(ph) * bh)) + F(F(F(iy + 0.5) * bh) / F(gh)))
+                    for ix in range(gw):
+                        x = F(F(sw + F(F(pw) * bw)) + F(F(F(ix + 0.5) * bw) / F(gw)))
+                        if y < -1.0 or y > H or x < -1.0 or x > W or b < 0 or b >= B:
+                            continue
+                        yy, xx = max(y, F(0.0)), max(x, F(0.0))
+                        yl, xl = int(yy), int(xx)
+                        if yl >= H - 1:
+                            yl = yh = H - 1
+                            yy = F(yl)
+                        else:
+                            yh = yl + 1
+                        if xl >= W - 1:
+                            xl = xh = W - 1
+                            xx = F(xl)
+                        else:
+                            xh = xl + 1
+                        ly, lx = F(yy - F(yl)), F(xx - F(xl))
+                        hy, hx = F(1.0) - ly, F(1.0) - lx
+                        acc = acc + float(hy * hx) * feat[b, :, yl, xl] + float(hy * lx) * feat[b, :, yl, xh] \
+                            + float(ly * hx) * feat[b, :, yh, xl] + float(ly * lx) * feat[b, :, yh, xh]
+                bins.append(acc / float(count))
+        out.append(torch.stack(bins, dim=1).view(C, PH, PW))
+    if not out:
+        return feat.new_zeros((0, C, PH, PW))
+    return torch.stack(out)
+
+
 class _MaxPool3x3s2Fn(torch.autograd.Function):
     """nn.MaxPool2d(3, 2, 1) (torchvision ResNet stem) with optionally forced argmax routing."""
 
@@ -311,8 +366,12 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     scale = hf / img_h                                      # models.py:56
     routing = routing or {}
     feat = convnet(images, sd, training, routing)
-    visual = roi_pool(feat, bboxes, roi, scale, routing.get("roi_argmax")).reshape(
-        bboxes.shape[0], -1)                                                   # models.py:125
+    if cfg.get("roi_op", "pool") == "align":                                   # extension (see roi_align)
+        visual = roi_align(feat, bboxes, roi, scale, cfg.get("sampling_ratio", 2),
+                           cfg.get("roi_aligned", False)).reshape(bboxes.shape[0], -1)
+    else:
+        visual = roi_pool(feat, bboxes, roi, scale, routing.get("roi_argmax")).reshape(
+            bboxes.shape[0], -1)                                               # models.py:125
     parts = [visual]
     if cfg.get("bbox_hidden_dim", 32) > 0:
         raw = bbox_features_raw(bboxes)

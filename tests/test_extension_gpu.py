@@ -298,3 +298,54 @@ def test_piecewise_visual_features_backward(kw):
     (ref * g).sum().backward()
     grads = {k: p.grad for k, p in m.named_parameters() if k.startswith("convnet.")}
     compare_grads(grads, {k: v.grad for k, v in leaves.items()}, rtol=2e-4, outlier_frac=0.0)
+
+
+# ------------------------------------------------------------------------------------ RoIAlign variant
+@pytest.mark.parametrize("sr,aligned,C", [(2, False, 64), (0, False, 64), (2, True, 256), (3, False, 64)])
+def test_roialign_kernels_match_self_oracle(sr, aligned, C):
+    rs = np.random.RandomState(sr * 7 + aligned + C)
+    B, H, W = 2, 14, 90
+    feat = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)).requires_grad_(True)
+    n = 40
+    x1, y1 = rs.uniform(-20, 340, n), rs.uniform(-12, 50, n)
+    rois = torch.from_numpy(np.stack([rs.randint(0, B, n), x1, y1, x1 + rs.uniform(0.5, 150, n),
+                                      y1 + rs.uniform(0.5, 40, n)], 1).astype(np.float32))
+    rois[0, 1:] = torch.tensor([500., 500., 600., 600.])                 # fully outside: zeros
+    ref = O.roi_align(feat, rois, (3, 3), 0.25, sr, aligned)
+    g = torch.from_numpy(rs.standard_normal((n, C * 9)).astype(np.float32))
+    (ref.reshape(n, -1) * g).sum().backward()
+    fd = feat.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.full((n, C * 9 + 8), -3.0, device=DEV)
+    sv = engine.roialign_fwd(fd, rois.to(DEV), (3, 3), 0.25, sr, aligned, out, C * 9 + 8)
+    close(out[:, :C * 9], ref.detach().reshape(n, -1), 1e-5, "roialign fwd")
+    assert (out[:, C * 9:] == -3.0).all() and (out[0, :C * 9] == 0).all()
+    res = []
+    for rep in range(2):
+        res.append(engine.roialign_bwd(sv, g.to(DEV), C * 9))
+    close(res[0].permute(0, 3, 1, 2), feat.grad, 1e-5, "roialign bwd")
+    assert torch.equal(res[0], res[1])                                    # no atomics: bit-identical reruns
+
+
+@pytest.mark.parametrize("kw", [dict(roi_op="align"), dict(roi_op="align", backbone="resnet50", n_heads=2, sampling_ratio=0)])
+def test_model_with_roialign_matches_self_oracle(kw):
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=64, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.0)
+    wkw = {k: v for k, v in kw.items() if k in ("backbone", "n_heads", "n_gat_layers")}
+    sd = weights.seeded_state_dict(61, logit_gain=4.0, **{k: v for k, v in cfg.items() if k != "drop_prob"}, **wkw)
+    batch = synthetic.make_batch(2, img_h=96, img_w=128, boxes_per_page=[15, 22], context_size=6, seed=61)
+    m = CoVA((3, 3), 96, 4, True, 64, 16, 0, 0.0, None, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
+    logits = m(*args)
+    sv = logits.grad_fn.sv
+    fake = dict(sv, roi=dict(argmax=torch.zeros(1, dtype=torch.int32)))
+    routing = routing_from_saved(fake)
+    routing.pop("roi_argmax")
+    F.cross_entropy(logits, batch["labels"].to(DEV), reduction="sum").backward()
+    ocfg = dict(cfg, roi_op="align", sampling_ratio=kw.get("sampling_ratio", 2))
+    loss_ref, logits_ref, grads_ref, after, _ = O.loss_and_grads(
+        sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"], batch["labels"],
+        ocfg, None, routing)
+    close(logits, logits_ref, 2e-4, "logits (RoIAlign)")
+    compare_grads({k: p.grad for k, p in m.named_parameters()}, grads_ref, rtol=2e-4, outlier_frac=0.0)

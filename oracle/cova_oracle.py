@@ -110,10 +110,11 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio=2, aligned=
     feat [B,C,H,W], rois [N,5] -> [N,C,PH,PW]; plain torch ops, so autograd provides the backward."""
     B, C, H, W = feat.shape
     PH, PW = int(output_size[0]), int(output_size[1])
-    out = []
     F = np.float32                                  # the C++ code computes every coordinate in float
     off, scale = F(0.5 if aligned else 0.0), F(spatial_scale)
-    for r in rois.detach().to(torch.float32).numpy():
+    n_rois = rois.shape[0]
+    slot, bb, ys, xs, ws = [], [], [], [], []       # one entry per (sample, neighbour): output row, page, y, x, weight
+    for n, r in enumerate(rois.detach().to(torch.float32).numpy()):
         b = int(r[0])
         sw, sh = F(r[1] * scale - off), F(r[2] * scale - off)
         rw, rh = F(F(r[3] * scale - off) - sw), F(F(r[4] * scale - off) - sh)
@@ -122,16 +123,16 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio=2, aligned=
         bh, bw = F(rh / F(PH)), F(rw / F(PW))
         gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / F(PH)))
         gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / F(PW)))
-        count = F(max(gh * gw, 1))
-        bins = []
+        inv_count = F(1.0) / F(max(gh * gw, 1))
+        if b < 0 or b >= B:
+            continue
         for ph in range(PH):
             for pw in range(PW):
-                acc = torch.zeros(C, dtype=torch.float32)
                 for iy in range(gh):
                     y = F(F(sh + F(F(ph) * bh)) + F(F(F(iy + 0.5) * bh) / F(gh)))
                     for ix in range(gw):
                         x = F(F(sw + F(F(pw) * bw)) + F(F(F(ix + 0.5) * bw) / F(gw)))
-                        if y < -1.0 or y > H or x < -1.0 or x > W or b < 0 or b >= B:
+                        if y < -1.0 or y > H or x < -1.0 or x > W:
                             continue
                         yy, xx = max(y, F(0.0)), max(x, F(0.0))
                         yl, xl = int(yy), int(xx)
@@ -147,13 +148,14 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio=2, aligned=
                             xh = xl + 1
                         ly, lx = F(yy - F(yl)), F(xx - F(xl))
                         hy, hx = F(1.0) - ly, F(1.0) - lx
-                        acc = acc + float(hy * hx) * feat[b, :, yl, xl] + float(hy * lx) * feat[b, :, yl, xh] \
-                            + float(ly * hx) * feat[b, :, yh, xl] + float(ly * lx) * feat[b, :, yh, xh]
-                bins.append(acc / float(count))
-        out.append(torch.stack(bins, dim=1).view(C, PH, PW))
-    if not out:
-        return feat.new_zeros((0, C, PH, PW))
-    return torch.stack(out)
+                        for (py, px, w) in ((yl, xl, hy * hx), (yl, xh, hy * lx), (yh, xl, ly * hx), (yh, xh, ly * lx)):
+                            slot.append(n * PH * PW + ph * PW + pw)
+                            bb.append(b); ys.append(py); xs.append(px); ws.append(F(w) * inv_count)
+    out = feat.new_zeros((n_rois * PH * PW, C))
+    if slot:
+        vals = feat.permute(0, 2, 3, 1)[torch.tensor(bb), torch.tensor(ys), torch.tensor(xs)]      # [S, C]
+        out = out.index_add(0, torch.tensor(slot), vals * torch.tensor(np.asarray(ws, F)).view(-1, 1))
+    return out.view(n_rois, PH, PW, C).permute(0, 3, 1, 2)
 
 
 class _MaxPool3x3s2Fn(torch.autograd.Function):

@@ -263,3 +263,26 @@ def test_resnet50_oracle_wiring_is_torchvision_bottleneck():
         with torch.no_grad():
             ref = net(x)
         assert got.shape == (2, 256, 12, 20) and torch.allclose(got, ref, atol=1e-6, rtol=1e-5)
+
+
+def test_roialign_self_oracle_properties():
+    """The RoIAlign restatement (extension) on cases with known answers: a constant map pools to the constant, a box
+    more than a pixel outside the map pools to 0, a 1x1-bin box centred on a pixel with one sample returns the
+    bilinear value, and every inside sample distributes a total weight of 1 / count to the map (sum of the gradient)."""
+    c = torch.full((1, 2, 9, 11), 3.25)
+    box = torch.tensor([[0, 4.0, 6.0, 30.0, 28.0]])
+    for sr, al in ((2, False), (0, False), (3, True)):
+        assert torch.allclose(O.roi_align(c, box, (3, 3), 0.25, sr, al), torch.full((1, 2, 3, 3), 3.25), atol=1e-6)
+    assert float(O.roi_align(c, torch.tensor([[0, 100.0, 100.0, 130.0, 120.0]]), (3, 3), 0.25).abs().max()) == 0.0
+    assert float(O.roi_align(c, torch.tensor([[5, 4.0, 4.0, 20.0, 20.0]]), (3, 3), 0.25).abs().max()) == 0.0   # bad page
+    rs = np.random.RandomState(1)
+    f = torch.from_numpy(rs.standard_normal((1, 1, 6, 7)).astype(np.float32)).requires_grad_(True)
+    # box [2.3, 1.6] .. +1 (feature units after scale 1): one 1x1 bin, one sample at its centre (2.8, 2.1)
+    o = O.roi_align(f, torch.tensor([[0, 2.3, 1.6, 3.3, 2.6]]), (1, 1), 1.0, 1, False)
+    x, y = 2.8, 2.1
+    exp = (1 - (y - 2)) * (1 - (x - 2)) * f[0, 0, 2, 2] + (1 - (y - 2)) * (x - 2) * f[0, 0, 2, 3] + \
+        (y - 2) * (1 - (x - 2)) * f[0, 0, 3, 2] + (y - 2) * (x - 2) * f[0, 0, 3, 3]
+    assert abs(float(o) - float(exp)) < 1e-6
+    o = O.roi_align(f, torch.tensor([[0, 0.5, 0.5, 5.0, 4.0]]), (2, 3), 1.0, 2, False)
+    o.sum().backward()
+    assert abs(float(f.grad.sum()) - 6.0) < 1e-5          # 6 bins, each a unit of weight, all samples inside

@@ -567,86 +567,45 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float *__restrict
     if (lane == 0) { s[n] = a + att_b[0]; t[n] = b; }
 }
 
-// LDS-staged neighbour features: a block owns 16 consecutive nodes.  Their neighbour ids are found, and when the
-// id range is compact -- the dataset's +-cs DOM windows overlap in all but one entry between consecutive nodes
-// (datasets.py:121-128), so 16 nodes name at most 16 + 2cs rows -- rows [lo, hi] of W_j h are staged in LDS once
-// (coalesced float4) and every node gathers from there: ~10x less L2 traffic than one 2cs-row gather per node.
-// Any other index table (range too wide for the 96 KB) takes the direct per-node gather from L2, same results.
-constexpr int GAT_NB = 16, GAT_LDS_FLOATS = 24 * 1024;
-
-__global__ __launch_bounds__(256) void gat_fwd_lds_kernel(
+__global__ __launch_bounds__(256) void gat_fwd_kernel(
     const float *__restrict__ Wh, int ldw, const float *__restrict__ s, const float *__restrict__ t,
     const int64_t *__restrict__ ctx, int N, int K, int D, float slope, float *__restrict__ attn,
-    float *__restrict__ hprime, int ldh, int vec_ok)
+    float *__restrict__ hprime, int ldh)
 {
-    __shared__ __attribute__((aligned(16))) float rows[GAT_LDS_FLOATS];
-    __shared__ int s_lo[4], s_hi[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = blockIdx.x * GAT_NB;
-    int lo = 0x7fffffff, hi = -1;
-    for (int i = threadIdx.x; i < GAT_NB * K; i += 256) {
-        const int node = n0 + i / K;
-        if (node < N) {
-            const long long j = ctx[(size_t)node * K + (i % K)];
-            if (j >= 0 && j < N) { lo = min(lo, (int)j); hi = max(hi, (int)j); }
-        }
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float e = -INFINITY;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;                                 // out-of-range id: memory-safe, acts as a pad
+        const float u = s[n] + (j >= 0 ? t[j] : 0.f);
+        const float lr = u > 0.f ? u : slope * u;
+        e = j >= 0 ? lr : -9e15f;                          // models.py:202-203
     }
+    const float m = wave_max(e);
+    const float p = lane < K ? expf(e - m) : 0.f;
+    const float denom = wave_sum(p);
+    const float alpha = p / denom;
+    if (lane < K) attn[(size_t)n * K + lane] = alpha;
+    const int jj = (int)j;
+    const float aw = jj >= 0 ? alpha : 0.f;                 // pads: weight 0 on a valid (clamped) row
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane, dd = d < D ? d : 0;
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 8) {                  // 8 neighbour rows in flight, added in slot order
+            float v[8], a[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, __shfl_xor(lo, o, 64));
-        hi = max(hi, __shfl_xor(hi, o, 64));
-    }
-    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
-    __syncthreads();
-    lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-    hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-    const bool staged = vec_ok && hi >= 0 && (long long)(hi - lo + 1) * D <= GAT_LDS_FLOATS;
-    if (staged) {
-        const int d4 = D >> 2, total = (hi - lo + 1) * d4;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int r = i / d4, c4 = i - r * d4;
-            reinterpret_cast<float4 *>(rows)[i] =
-                *reinterpret_cast<const float4 *>(Wh + (size_t)(lo + r) * ldw + D + 4 * c4);
-        }
-    }
-    __syncthreads();
-    for (int q = 0; q < GAT_NB / 4; ++q) {
-        const int n = n0 + wave * (GAT_NB / 4) + q;
-        if (n >= N) break;
-        long long j = -1;
-        float e = -INFINITY;
-        if (lane < K) {
-            j = ctx[(size_t)n * K + lane];
-            if (j >= N) j = -1;                             // out-of-range id: memory-safe, acts as a pad
-            const float u = s[n] + (j >= 0 ? t[j] : 0.f);
-            const float lr = u > 0.f ? u : slope * u;
-            e = j >= 0 ? lr : -9e15f;                      // models.py:202-203
-        }
-        const float m = wave_max(e);
-        const float p = lane < K ? expf(e - m) : 0.f;
-        const float denom = wave_sum(p);
-        const float alpha = p / denom;
-        if (lane < K) attn[(size_t)n * K + lane] = alpha;
-        const int jj = (int)j;
-        const float aw = jj >= 0 ? alpha : 0.f;             // pads: weight 0 on a valid (clamped) row
-        for (int d0 = 0; d0 < D; d0 += 64) {
-            const int d = d0 + lane, dd = d < D ? d : 0;
-            float acc = 0.f;
-            for (int k0 = 0; k0 < K; k0 += 8) {              // 8 neighbour rows in flight, added in slot order
-                float v[8], a[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int kk = min(k0 + u, K - 1);
-                    const int jk = __shfl(jj, kk, 64);
-                    a[u] = k0 + u < K ? __shfl(aw, kk, 64) : 0.f;
-                    if (staged) v[u] = rows[(size_t)(jk >= 0 ? jk - lo : 0) * D + dd];
-                    else v[u] = Wh[(size_t)(jk >= 0 ? jk : 0) * ldw + D + dd];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = a[u] != 0.f ? fmaf(a[u], v[u], acc) : acc;
+            for (int u = 0; u < 8; ++u) {
+                const int kk = min(k0 + u, K - 1);
+                const int jk = __shfl(jj, kk, 64);
+                a[u] = k0 + u < K ? __shfl(aw, kk, 64) : 0.f;
+                v[u] = Wh[(size_t)(jk >= 0 ? jk : 0) * ldw + D + dd];
             }
-            if (d < D) hprime[(size_t)n * ldh + d] = acc;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = a[u] != 0.f ? fmaf(a[u], v[u], acc) : acc;
         }
+        if (d < D) hprime[(size_t)n * ldh + d] = acc;
     }
 }
 
@@ -1085,9 +1044,8 @@ COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const fl
     hipLaunchKernelGGL(gat_scores_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh,
                        ldw, att_w, att_b, s, t, N, D);
     COVA_LAUNCH_CHECK();
-    const int vec_ok = (D % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)Wh & 15) == 0);
-    hipLaunchKernelGGL(gat_fwd_lds_kernel, dim3(cdiv(N, GAT_NB)), dim3(256), 0, (hipStream_t)stream, Wh, ldw,
-                       s, t, ctx, N, K, D, slope, attn, hprime, ldh, vec_ok);
+    hipLaunchKernelGGL(gat_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh, ldw,
+                       s, t, ctx, N, K, D, slope, attn, hprime, ldh);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

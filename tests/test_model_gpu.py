@@ -288,6 +288,21 @@ def test_trainer_evaluate_matches_oracle_decision_rule():
         ref = np.asarray(O.eval_accuracy(logits.cpu(), batch["bboxes"], batch["labels"], 4, k))
         assert np.array_equal(correct.cpu().numpy().astype(np.int64), ref)
         assert topk.shape == (3, 4, k)
+    # pages that break the "exactly one labelled box per class" habit of the dataset (README.md:17): a class
+    # missing on a page scores False (the reference would raise there), and with two boxes of one class the FIRST
+    # is the ground truth (train.py:146 takes `[0, 0]` of the matching rows)
+    lab = batch["labels"].clone()
+    p1 = slice(counts[0], counts[0] + counts[1])
+    lab[p1][lab[p1] == 2] = 0                                  # page 1 loses its class-2 box
+    p0 = lab[:counts[0]]
+    first1 = int((p0 == 1).nonzero()[0])
+    extra = (first1 + 5) % counts[0]
+    if p0[extra] == 0:
+        p0[extra] = 1                                          # a second class-1 box on page 0, after the first
+    d2 = dict(dbatch, labels=lab.to(DEV))
+    topk, correct = tr.evaluate(d2, start, 1)
+    assert not bool(correct[1, 1])                             # (page 1, class 2)
+    assert bool(correct[0, 0]) == bool(int(topk[0, 1, 0]) == first1)
 
 
 @pytest.mark.parametrize("K", [2, 64])

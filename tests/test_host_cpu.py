@@ -170,3 +170,23 @@ def test_flat_bucket_layout_of_the_extension_model():
     conv = [k for k in pkeys if k.startswith("convnet.")]
     assert head == sum((sd[k].numel() + 3) // 4 * 4 for k in conv)
     assert pkeys[len(conv)].startswith("bbox_feat_encoder.") and "gat.layers.1.heads.1.W_j.weight" in tr.params
+
+
+def test_launch_device_resolution_rejects_cpu_and_mixed_arguments():
+    """_lib.call launches on the device its tensor arguments live on (the reference picks cuda:<-d> without
+    set_device, main.py:17); CPU tensors and mixed devices are refused before anything is launched."""
+    with pytest.raises(_lib.CovaHipError, match="no CPU fallback"):
+        _lib._device_of("cova_x", (torch.zeros(2), 3, None))
+    assert _lib._device_of("cova_x", (3, None, 1.5)) is None
+
+    class Fake:                                   # two "cuda" tensors on different devices, without a GPU
+        def __init__(self, idx):
+            self.is_cuda, self.device = True, torch.device("cuda", idx)
+    orig = torch.Tensor
+    try:
+        _lib.torch.Tensor = Fake                  # isinstance check inside _device_of
+        with pytest.raises(_lib.CovaHipError, match="different devices"):
+            _lib._device_of("cova_x", (Fake(0), Fake(1)))
+        assert _lib._device_of("cova_x", (Fake(1), Fake(1))) == torch.device("cuda", 1)
+    finally:
+        _lib.torch.Tensor = orig

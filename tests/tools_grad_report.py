@@ -12,6 +12,8 @@ seed = int(os.environ.get("SEED", 123))
 dev = "cuda:0"
 cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384,
            bbox_hidden_dim=32, n_additional_feat=0, drop_prob=0.0)
+if os.environ.get("ARCH") == "r50":               # the extension model of BASELINE.json configs[2]
+    cfg.update(backbone="resnet50", n_heads=2)
 wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
 sd = weights.seeded_state_dict(seed, logit_gain=4.0, **wcfg)
 batch = synthetic.make_batch(len(boxes), img_h=img_h, boxes_per_page=boxes, context_size=12, seed=seed)

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void attn_export_rows_kernel(
         } else if (c < 5 + 4 * K) {
             const int k = (c - 5) >> 2, j = (c - 5) & 3;
             const long long n = ctx[(size_t)i * K + k];
-            if (n < 0) {
+            if (n < 0 || n >= N) {          // pads; out-of-range ids are treated like the GAT kernels treat them
                 v = 0.f;
             } else {
                 const float *b = bboxes + (size_t)n * 5 + 1;

@@ -35,6 +35,46 @@ def _check(t, dtype=torch.float32):
     return t
 
 
+def check_batch(cfg, images, bboxes, additional_feats, context_indices, training):
+    """Shape contract of CoVA.forward (models.py:94-122), checked on the host before any launch (the
+    kernels take raw pointers): the errors torch raises inside the reference's forward for malformed
+    input -- conv2d's channel check, the [N,5] roi layout, the cat/Linear width mismatch, gather
+    broadcasting, BatchNorm1d's train-mode batch-size check -- with the same exception types.
+    Index VALUES are not read here (that would cost a device sync): ids outside [0, N) are treated
+    as pads by the kernels, memory-safe; the reference raises IndexError for them on CPU."""
+    if images.dim() != 4 or images.shape[1] != 3:
+        raise RuntimeError("expected images [B, 3, H, W] (conv1 has 3 input channels, models.py:49), got %s"
+                           % (tuple(images.shape),))
+    if bboxes.dim() != 2 or bboxes.shape[1] != 5:
+        raise RuntimeError("expected bboxes [N, 5] = [batch_idx, x1, y1, x2, y2] (models.py:97), got %s"
+                           % (tuple(bboxes.shape),))
+    N, A = bboxes.shape[0], cfg["n_additional_feat"]
+    if additional_feats.dim() != 2 or tuple(additional_feats.shape) != (N, A):
+        raise RuntimeError("expected additional_feats [%d, %d] (n_additional_feat, models.py:98,110), got %s"
+                           % (N, A, tuple(additional_feats.shape)))
+    if cfg["use_context"]:
+        if context_indices.dim() != 2 or context_indices.shape[0] != N:
+            raise RuntimeError("expected context_indices [%d, 2*context_size] (models.py:99), got %s"
+                               % (N, tuple(context_indices.shape)))
+        if context_indices.is_floating_point() or context_indices.dtype == torch.bool:
+            raise IndexError("context_indices must be an integer tensor (models.py:186 indexes with it)")
+        if context_indices.shape[1] > 64:
+            raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
+    if training and N == 1:
+        # torch.nn.functional.batch_norm's _verify_batch_size, hit by the first BatchNorm1d of the forward
+        width = cfg["bbox_hidden_dim"] or A or None
+        if width is None:
+            width = (backbone_feat(cfg) + (cfg["hidden_dim"] if cfg["use_context"] else 0))
+        raise ValueError("Expected more than 1 value per channel when training, got input size "
+                         "torch.Size([1, %d])" % width)
+
+
+def backbone_feat(cfg):
+    PH, PW = cfg["roi_output_size"]
+    from .weights import backbone_channels
+    return backbone_channels(cfg.get("backbone", "resnet18")) * PH * PW
+
+
 def feature_map_size(n):
     """conv1 (7,2,3) then maxpool (3,2,1): models.py:53-56 does this with a dummy forward."""
     return query("cova_conv_out_size", query("cova_conv_out_size", n, 7, 2, 3), 3, 2, 1)

@@ -90,6 +90,25 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _i64c(t):
+    return t.detach().to(torch.int64).contiguous()
+
+
+def _verify_batch_size(training, n, width):
+    """torch.nn.functional.batch_norm's train-mode check (one value per channel has no variance)."""
+    if training and n == 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size "
+                         "torch.Size([1, %d])" % width)
+
+
+def _saved_or_raise(sv):
+    """The saved activations are released by the first backward (like autograd's saved tensors)."""
+    if sv is None:
+        raise RuntimeError("Trying to backward through the graph a second time: the saved activations of "
+                           "this CoVA forward have already been freed (the HIP path does not support "
+                           "retain_graph).")
+
+
 # ------------------------------------------------------------------------------------- autograd
 class _CoVAFn(torch.autograd.Function):
     """Whole forward pass as one autograd node: backward runs engine.model_bwd."""
@@ -102,13 +121,14 @@ class _CoVAFn(torch.autograd.Function):
         _, buffers = _named_tensors(model)
         seeds = model._next_dropout_seeds()
         logits, sv = engine.model_fwd(model._cfg, params, buffers, _f32c(images), _f32c(bboxes),
-                                      _f32c(additional_feats), context_indices.contiguous(),
+                                      _f32c(additional_feats), _i64c(context_indices),
                                       model.training, seeds, model._forced_masks, save=need_grad)
         ctx.sv, ctx.params, ctx.keys = sv, params, keys
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
+        _saved_or_raise(ctx.sv)
         grads = engine.model_bwd(ctx.sv, dlogits.contiguous(), ctx.params)
         ctx.sv = None
         return (None, None, None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
@@ -186,8 +206,11 @@ class _HipBatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x):
         _require_cuda(x)
+        if x.dim() != 2 or x.shape[1] != self.num_features:
+            raise RuntimeError("expected input [N, %d], got %s" % (self.num_features, tuple(x.shape)))
         if x.shape[0] == 0:
             return x
+        _verify_batch_size(self.training, x.shape[0], self.num_features)
         return _BN1dFn.apply(self, x, self.weight, self.bias)
 
 
@@ -200,7 +223,7 @@ class _GATFn(torch.autograd.Function):
                   "gat.attention_layer.weight": att_w.detach(),
                   "gat.attention_layer.bias": att_b.detach()}
         hp = torch.empty((N, layer.hidden_dim), device=h.device)
-        ctx.sv = engine.gat_fwd(h, F, N, F, context_indices.contiguous(), params, hp, layer.hidden_dim)
+        ctx.sv = engine.gat_fwd(h, F, N, F, _i64c(context_indices), params, hp, layer.hidden_dim)
         ctx.params = params
         ctx.mark_non_differentiable(ctx.sv["attn"])
         return hp, ctx.sv["attn"]
@@ -215,6 +238,20 @@ class _GATFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------- modules
+def _check_gat_inputs(h_i, context_indices, in_features):
+    """What the reference's layer would reject inside torch (models.py:180-200), before raw pointers go out."""
+    if h_i.dim() != 2 or h_i.shape[1] != in_features:
+        raise RuntimeError("expected h_i [N, %d] (W_i / W_j input width, models.py:161-162), got %s"
+                           % (in_features, tuple(h_i.shape)))
+    if context_indices.dim() != 2 or context_indices.shape[0] != h_i.shape[0]:
+        raise RuntimeError("expected context_indices [%d, n_context], got %s"
+                           % (h_i.shape[0], tuple(context_indices.shape)))
+    if context_indices.is_floating_point() or context_indices.dtype == torch.bool:
+        raise IndexError("context_indices must be an integer tensor (models.py:186 indexes with it)")
+    if context_indices.shape[1] > 64:
+        raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
+
+
 class GraphAttentionLayer(nn.Module):
     """Single-head additive attention over K padded neighbours (reference models.py:151-212)."""
 
@@ -232,8 +269,7 @@ class GraphAttentionLayer(nn.Module):
     def forward(self, h_i, context_indices, return_attn_wts=False):
         """h_i [N, in_features]; context_indices int64 [N, n_context] with -1 pads."""
         _require_cuda(h_i, context_indices)
-        if context_indices.shape[1] > 64:
-            raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
+        _check_gat_inputs(h_i, context_indices, self.in_features)
         h_prime, attn = _GATFn.apply(self, h_i, context_indices, self.W_i.weight, self.W_j.weight,
                                      self.attention_layer.weight, self.attention_layer.bias)
         if return_attn_wts:
@@ -388,10 +424,12 @@ class CoVA(nn.Module):
         """images [B,3,H,W] f32, bboxes [N,5] f32 = [batch_idx,x1,y1,x2,y2], additional_feats
         [N,A] f32, context_indices int64 [N,K] (-1 pads) -> scores [N,n_classes] (models.py:94-122)."""
         _require_cuda(images, bboxes, additional_feats, context_indices)
+        engine.check_batch(self._cfg, images, bboxes, additional_feats, context_indices, self.training)
+        if torch.is_grad_enabled() and images.requires_grad:
+            raise NotImplementedError("the HIP path does not produce a gradient w.r.t. the page images "
+                                      "(conv1 computes its weight gradient only); detach them")
         if bboxes.shape[0] == 0:
             return torch.empty((0, self.n_classes), device=images.device)
-        if self.use_context and context_indices.shape[1] > 64:
-            raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
         values = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
         return _CoVAFn.apply(self, need_grad, images, bboxes, additional_feats, context_indices,
@@ -399,6 +437,9 @@ class CoVA(nn.Module):
 
     def _get_visual_features(self, images, bboxes):
         _require_cuda(images, bboxes)
+        if images.dim() != 4 or images.shape[1] != 3 or bboxes.dim() != 2 or bboxes.shape[1] != 5:
+            raise RuntimeError("expected images [B, 3, H, W] and bboxes [N, 5], got %s and %s"
+                               % (tuple(images.shape), tuple(bboxes.shape)))
         named = dict(self.named_parameters())
         values = [named[k] for k in self._conv_keys]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
@@ -408,6 +449,9 @@ class CoVA(nn.Module):
         """[x,y,w,h,asp_ratio] -> Linear -> BN -> ReLU (models.py:129-148)."""
         if self.bbox_hidden_dim > 0:
             _require_cuda(bboxes)
+            if bboxes.dim() != 2 or bboxes.shape[1] != 5:
+                raise RuntimeError("expected bboxes [N, 5], got %s" % (tuple(bboxes.shape),))
+            _verify_batch_size(self.training, bboxes.shape[0], self.bbox_hidden_dim)
             named = dict(self.named_parameters())
             return _BBoxFn.apply(self, bboxes, *[named[k] for k in self._bbox_keys])
         return bboxes[:, :0]

@@ -141,6 +141,8 @@ class HotPathTrainer:
 
     def forward_backward(self, batch, masks=None):
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
+        engine.check_batch(self.cfg, batch["images"], batch["bboxes"], batch["additional_feats"],
+                           batch["context_indices"], True)
         self.step_count += 1
         base = (self.dropout_seed * 0x9E3779B1 + 2 * self.step_count) & 0xFFFFFFFFFFFF
         if self.sync_bn:
@@ -234,6 +236,8 @@ class HotPathTrainer:
     @torch.no_grad()
     def predict(self, batch):
         """Eval-mode forward (running statistics) -> (logits, per-box argmax)."""
+        engine.check_batch(self.cfg, batch["images"], batch["bboxes"], batch["additional_feats"],
+                           batch["context_indices"], False)
         logits, _ = engine.model_fwd(self.cfg, self.params, self.buffers, batch["images"],
                                      batch["bboxes"], batch["additional_feats"],
                                      batch["context_indices"], False, save=False)

@@ -190,3 +190,29 @@ def test_launch_device_resolution_rejects_cpu_and_mixed_arguments():
         assert _lib._device_of("cova_x", (Fake(1), Fake(1))) == torch.device("cuda", 1)
     finally:
         _lib.torch.Tensor = orig
+
+
+def test_check_batch_host_contract():
+    """engine.check_batch is pure host logic: the shape errors of the reference's forward, no device read."""
+    from cova_web_object_detection_amd import engine
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384, bbox_hidden_dim=32,
+               n_additional_feat=0, drop_prob=0.2)
+    img, bb, af = torch.zeros(2, 3, 8, 8), torch.zeros(6, 5), torch.zeros(6, 0)
+    ctx = torch.zeros(6, 4, dtype=torch.long)
+    engine.check_batch(cfg, img, bb, af, ctx, True)
+    engine.check_batch(cfg, img, bb, af, ctx.int(), False)
+    engine.check_batch(dict(cfg, use_context=False), img, bb, af, torch.empty(0, 0, dtype=torch.long), True)
+    engine.check_batch(cfg, img, bb[:0], af[:0], ctx[:0], True)                 # empty batch is legal
+    engine.check_batch(cfg, img, bb[:1], af[:1], ctx[:1], False)                # one box in eval mode too
+    for bad in ((img[:, :2], bb, af, ctx), (img, bb[:, :4], af, ctx), (img, bb, torch.zeros(6, 2), ctx),
+                (img, bb, af, ctx[:3]), (img, bb, af, ctx[0])):
+        with pytest.raises(RuntimeError):
+            engine.check_batch(cfg, *bad, True)
+    with pytest.raises(IndexError):
+        engine.check_batch(cfg, img, bb, af, ctx.float(), True)
+    with pytest.raises(ValueError, match=r"torch.Size\(\[1, 32\]\)"):
+        engine.check_batch(cfg, img, bb[:1], af[:1], ctx[:1], True)
+    with pytest.raises(ValueError, match=r"torch.Size\(\[1, 960\]\)"):     # no positional encoder: decoder BN
+        engine.check_batch(dict(cfg, bbox_hidden_dim=0), img, bb[:1], af[:1], ctx[:1], True)
+    with pytest.raises(ValueError):
+        engine.check_batch(cfg, img, bb, af, torch.zeros(6, 65, dtype=torch.long), True)

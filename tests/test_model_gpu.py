@@ -513,3 +513,74 @@ def test_train_steps_are_bit_reproducible(kw):
         assert torch.equal(a, b)
     for k in runs[0][4]:
         assert torch.equal(runs[0][4][k], runs[1][4][k]), k
+
+
+@pytest.mark.gpu
+def test_malformed_input_raises_like_the_reference_forward():
+    """The reference's forward (models.py:94-122) fails inside torch for these (observed by running it on
+    CPU: ValueError from BatchNorm1d's train-mode batch-size check, RuntimeError from conv2d / cat / view,
+    IndexError for a float index tensor, RuntimeError for a second backward); the HIP path takes raw
+    pointers, so the same conditions are caught on the host with the same exception types."""
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(3, logit_gain=2.0, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    batch = synthetic.make_batch(2, img_h=64, boxes_per_page=12, context_size=2, seed=4)
+    m = build(cfg, 64, sd)
+    img, bb, af, ctx = dev_batch(batch)
+    m.train()
+    one = (img, bb[:1], af[:1], torch.full((1, 4), -1, dtype=torch.long, device=DEV))
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(*one)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m._get_bbox_features(bb[:1])
+    m.eval()
+    ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"][:1], batch["additional_feats"][:1],
+                    one[3].cpu(), cfg, False, None)
+    assert relerr(m(*one).detach().cpu(), ref) < 2e-4          # a single box is fine with running statistics
+    m.train()
+    for bad in ((img[:, :1], bb, af, ctx), (img, bb[:, :4], af, ctx), (img, bb, af, ctx[:5]),
+                (img, bb, torch.rand(bb.shape[0], 3, device=DEV), ctx), (img[0], bb, af, ctx)):
+        with pytest.raises(RuntimeError):
+            m(*bad)
+    with pytest.raises(IndexError):
+        m(img, bb, af, ctx.float())
+    with pytest.raises(NotImplementedError):
+        m(img.clone().requires_grad_(True), bb, af, ctx)
+    with pytest.raises(RuntimeError):
+        m.gat(torch.rand(24, 7, device=DEV), ctx)
+    out = m(img, bb, af, ctx)
+    out.sum().backward()
+    with pytest.raises(RuntimeError, match="second time"):
+        out.sum().backward()
+
+
+@pytest.mark.gpu
+def test_input_layout_and_index_dtype_do_not_change_the_result():
+    """Strided / channels_last pages and int32 neighbour ids (both accepted by the reference's torch ops)
+    give the bits of the contiguous int64 call; ids outside [0, N) act as pads (memory-safe; the reference
+    raises IndexError for them on CPU, a device-side assert on a GPU); a page without boxes is legal."""
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(5, logit_gain=2.0, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    batch = synthetic.make_batch(2, img_h=64, boxes_per_page=12, context_size=2, seed=6)
+    m = build(cfg, 64, sd).eval()
+    img, bb, af, ctx = dev_batch(batch)
+    with torch.no_grad():
+        base = m(img, bb, af, ctx)
+        assert torch.equal(m(img.to(memory_format=torch.channels_last), bb, af, ctx), base)
+        wide = torch.rand(2, 3, 64, 128, device=DEV)
+        wide[:, :, :, ::2] = img
+        assert torch.equal(m(wide[:, :, :, ::2], bb, af, ctx), base)
+        assert torch.equal(m(img, bb, af, ctx.int()), base)
+        assert torch.equal(m(img, bb.double(), af, ctx), base)
+        pad = ctx.clone()
+        pad[3, 1] = -1
+        far = ctx.clone()
+        far[3, 1] = 10 ** 6
+        assert torch.equal(m(img, bb, af, far), m(img, bb, af, pad))
+        lone = batch["bboxes"].clone()
+        lone[:, 0] = 1                                        # every box on page 1: page 0 has none
+        got = m(img, lone.to(DEV), af, ctx)
+    ref = O.forward(O.clone_state_dict(sd), batch["images"], lone, batch["additional_feats"],
+                    batch["context_indices"], cfg, False, None)
+    assert relerr(got.cpu(), ref) < 2e-4

@@ -28,6 +28,8 @@ def parse_header(path=HEADER):
         name, args = m.group(1), m.group(2)
         types = []
         for a in [a.strip() for a in args.split(",") if a.strip()]:
+            if a == "void":                          # f(void)
+                continue
             if "*" in a:
                 types.append(ctypes.c_void_p)
                 continue

@@ -43,51 +43,66 @@ struct C11Args {
     float *out, *part, *part2;
     long long R;
     int pro_relu, w_trans;
+    // EXT (linear form of a conv+BatchNorm backward, conv1x1_lin.hip): 64 more K channels
+    // relu?(A3*in3 + C3) with weight w3 [64][Cout], and a per-output-channel constant cvec
+    const float *in3, *pro3, *w3, *cvec;
+    int pro3_relu;
 };
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool EXT = false>
 struct C11Geo {
-    static constexpr int WSTR = CIN + 4;
+    static constexpr int XK = EXT ? 64 : 0;            // extra K channels (second operand tensor)
+    static constexpr int WSTR = CIN + XK + 4;
     static constexpr int KH = CIN / 2;                 // channels per half-wave
     static constexpr int CHUNKS = KH / 32;             // 32-channel register chunks per half
     static constexpr int NT = COUT / 32;               // 32-column accumulators per row tile
     static constexpr int NTP = NT > 4 ? 4 : NT;        // accumulators per pass (register budget)
     static constexpr int PASSES = NT / NTP;
     static constexpr int W_FLOATS = COUT * WSTR;
-    static constexpr int RED_FLOATS = 4 * 3 * COUT;    // aliased onto the weights after the tile loop
-    static constexpr int LDS_FLOATS = W_FLOATS + 3 * CIN;
+    static constexpr int RED_FLOATS = 8 * 3 * COUT;    // aliased onto the weights after the tile loop (<= 8 waves)
+    static constexpr int LDS_FLOATS = W_FLOATS + 3 * CIN + 3 * XK;
 };
 
 // PRO: 0 plain input | 1 f(A*in + C) | 2 f(A*in + B*in2 + C).  EPI: 0 store | 1 store + (sum y, sum y^2)
-// | 2 (acc + addend) * mask, (sum dy, sum dy*xhat[, sum dy*xhat2]).
-template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool HAS_X2>
-__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
+// | 2 (acc + addend) * mask, (sum dy, sum dy*xhat[, sum dy*xhat2]) | 3 (acc + addend) * mask, no sums.
+// NW = waves per block (4: two blocks per CU; 8: one block per CU when the weights need > 80 KB of LDS).
+template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool HAS_X2, bool EXT = false,
+          int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const C11Args a)
 {
-    using G = C11Geo<CIN, COUT>;
+    using G = C11Geo<CIN, COUT, EXT>;
+    constexpr int NTHR = NW * 64;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
-    float *Ws = lds, *s_pro = lds + G::W_FLOATS;
+    float *Ws = lds, *s_pro = lds + G::W_FLOATS, *s_pro3 = lds + G::W_FLOATS + 3 * CIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
 
     // ---- stage the weight [co][WSTR] (+ the prologue table) once per block
     if (!a.w_trans) {
-        for (int i = tid; i < COUT * (CIN / 4); i += 256) {
+        for (int i = tid; i < COUT * (CIN / 4); i += NTHR) {
             const int co = i / (CIN / 4), c4 = i - co * (CIN / 4);
             *reinterpret_cast<float4 *>(Ws + co * G::WSTR + 4 * c4) =
                 *reinterpret_cast<const float4 *>(a.w + (size_t)co * CIN + 4 * c4);
         }
     } else {
-        for (int i = tid; i < CIN * COUT; i += 256) {
+        for (int i = tid; i < CIN * COUT; i += NTHR) {
             const int ci = i / COUT, co = i - ci * COUT;
             Ws[co * G::WSTR + ci] = a.w[i];
         }
     }
+    if (EXT) {
+        for (int i = tid; i < 64 * COUT; i += NTHR) {          // w3 [k 64][COUT]
+            const int k = i / COUT, co = i - k * COUT;
+            Ws[co * G::WSTR + CIN + k] = a.w3[i];
+        }
+        for (int i = tid; i < 3 * 64; i += NTHR) s_pro3[i] = a.pro3[i];
+    }
     if (PRO != 0)
-        for (int i = tid; i < 3 * CIN; i += 256) s_pro[i] = a.pro[i];
+        for (int i = tid; i < 3 * CIN; i += NTHR) s_pro[i] = a.pro[i];
     __syncthreads();
 
     const long long ntiles = (a.R + 31) / 32;
-    const long long stride = (long long)gridDim.x * 4;
+    const long long stride = (long long)gridDim.x * NW;
     float su[G::NT], sq[G::NT], sq2[G::NT];
 #pragma unroll
     for (int n = 0; n < G::NT; ++n) su[n] = sq[n] = sq2[n] = 0.f;
@@ -96,6 +111,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
     auto issue = [&](long long tile, int c, float4 (&v)[8], float4 (&v2)[8]) {
         long long row = tile * 32 + p;
         if (row >= a.R) row = a.R - 1;                       // clamped: loads stay unconditional
+        if (EXT && c == G::CHUNKS) {                         // the extra 64 channels: half h takes 32h .. 32h+31
+            const size_t o3 = (size_t)row * 64 + h * 32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(a.in3 + o3 + 4 * j);
+            return;
+        }
         const size_t o = (size_t)row * CIN + h * G::KH + c * 32;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(a.in + o + 4 * j);
@@ -108,7 +129,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            if (PRO != 0) {
+            if (EXT && c == G::CHUNKS) {
+                int ch = h * 32 + 4 * j;
+                asm volatile("" : "+v"(ch));
+                const float4 A = *reinterpret_cast<const float4 *>(s_pro3 + ch);
+                const float4 C = *reinterpret_cast<const float4 *>(s_pro3 + 128 + ch);
+                const float Aa[4] = {A.x, A.y, A.z, A.w}, Ca[4] = {C.x, C.y, C.z, C.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = fmaf(Aa[k], e[k], Ca[k]);
+                if (a.pro3_relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = e[k] > 0.f ? e[k] : 0.f;
+                }
+            } else if (PRO != 0) {
                 int ch = h * G::KH + c * 32 + 4 * j;
                 asm volatile("" : "+v"(ch));           // keep the table reads here: hoisted, they cost 96 registers
                 const float4 A = *reinterpret_cast<const float4 *>(s_pro + ch);
@@ -137,8 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
     // Cross-tile operand prefetch, except in the 256-channel data-gradient variants: those move ~5x more
     // bytes in their epilogue (addend / mask / xhat operands) than through the MFMA operand, are bound by
     // loads in flight, and need the 64 registers for a second resident wave per SIMD instead.
-    constexpr bool PREFETCH = !(EPI == 2 && COUT == 256);
-    long long tile = (long long)blockIdx.x * 4 + wave;
+    constexpr bool PREFETCH = !((EPI == 2 || EPI == 3) && COUT == 256);
+    constexpr int TC = G::CHUNKS + (EXT ? 1 : 0);          // register chunks per tile incl. the extra operand
+    long long tile = (long long)blockIdx.x * NW + wave;
     float4 nv[8], nv2[8];
     if (PREFETCH && tile < ntiles) issue(tile, 0, nv, nv2);
     for (; tile < ntiles; tile += stride) {
@@ -148,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
         // 256-channel output (so only 4 accumulators are live at a time).  Cin = 256: four chunks stream
         // through a single 64-channel pass.
         float x[32];
-        if (G::CHUNKS == 1) {
+        if (TC == 1) {
             prologue(0, nv, nv2, x);
             if (PREFETCH && tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);      // next tile in flight
         }
@@ -160,21 +194,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 #pragma unroll
-            for (int c = 0; c < G::CHUNKS; ++c) {
-                if (G::CHUNKS > 1) {
+            for (int c = 0; c < TC; ++c) {
+                if (TC > 1) {
                     prologue(c, nv, nv2, x);
                     // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
-                    if (c + 1 < G::CHUNKS) issue(tile, c + 1, nv, nv2);
+                    if (c + 1 < TC) issue(tile, c + 1, nv, nv2);
                     else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
                     __builtin_amdgcn_sched_barrier(0);     // one chunk of loads in flight, not all four
                 }
+                // weight columns of this chunk: the lane's K-half of the main operand, or of the extra one
+                const int wcol = (EXT && c == G::CHUNKS) ? CIN + h * 32 : h * G::KH + c * 32;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float4 b[G::NTP];
 #pragma unroll
                     for (int n = 0; n < G::NTP; ++n)
                         b[n] = *reinterpret_cast<const float4 *>(
-                            Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + h * G::KH + c * 32 + 4 * q);
+                            Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + wcol + 4 * q);
 #pragma unroll
                     for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 0], b[n].x, acc[n]);
 #pragma unroll
@@ -191,17 +227,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
             for (int nn = 0; nn < G::NTP; ++nn) {
                 const int n = ps * G::NTP + nn;
                 const int cn = n * 32 + p;
-                float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f;
+                float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f, cv = 0.f;
                 if (EPI == 2) {
                     mu = a.mean[cn]; is = a.invstd[cn];
                     if (!MASK_ACT) { msc = a.msc[cn]; msh = a.msh[cn]; }
                     if (HAS_X2) { mu2 = a.mean2[cn]; is2 = a.invstd2[cn]; }
                 }
+                if (EXT) cv = a.cvec[cn];
                 constexpr int RB = (HAS_X2 && COUT == 256) ? 4 : 8;    // rows per operand batch
 #pragma unroll
                 for (int rh = 0; rh < 16; rh += RB) {
                     float ad[RB], mk[RB], zz[RB], z2v[RB];
-                    if (EPI == 2) {                        // request every operand first, store last
+                    if (EPI == 2 || EPI == 3) {            // request every operand first, store last
 #pragma unroll
                         for (int r = 0; r < RB; ++r) {
                             long long row = r0 + mfma32_row(rh + r, lane);
@@ -209,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
                             const size_t o = (size_t)row * COUT + cn;
                             if (HAS_ADD) ad[r] = a.addend[o];
                             if (MASK_ACT) mk[r] = a.act[o];
-                            zz[r] = a.z[o];
+                            if (EPI == 2) zz[r] = a.z[o];
                             if (HAS_X2) z2v[r] = a.z2[o];
                         }
                     }
@@ -218,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
                         const long long row = r0 + mfma32_row(rh + r, lane);
                         if (row < a.R) {
                             float v = acc[nn][rh + r];
+                            if (EXT) v += cv;
                             if (EPI == 2) {
                                 if (HAS_ADD) v += ad[r];
                                 const float m = MASK_ACT ? mk[r] : fmaf(msc, zz[r], msh);
@@ -225,6 +263,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
                                 su[n] += v;
                                 sq[n] += v * ((zz[r] - mu) * is);
                                 if (HAS_X2) sq2[n] += v * ((z2v[r] - mu2) * is2);
+                            } else if (EPI == 3) {
+                                if (HAS_ADD) v += ad[r];
+                                if (!(mk[r] > 0.f)) v = 0.f;
                             } else if (EPI == 1) {
                                 su[n] += v;
                                 sq[n] += v * v;
@@ -236,9 +277,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
             }
         }
     }
-    if (EPI != 0) {
+    if (EPI == 1 || EPI == 2) {
         __syncthreads();                                   // every wave is done with the weights
-        float *s_red = lds;                                // [4][3][COUT]
+        float *s_red = lds;                                // [NW][3][COUT]
 #pragma unroll
         for (int n = 0; n < G::NT; ++n) {
             const float s0 = su[n] + __shfl_xor(su[n], 32, 64);
@@ -251,17 +292,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const C11Args a)
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * COUT; i += 256) {
+        for (int i = tid; i < 2 * COUT; i += NTHR) {
             const int which = i / COUT, c = i - which * COUT;
             float t = 0.f;
-            for (int w = 0; w < 4; ++w) t += s_red[(w * 3 + which) * COUT + c];
+            for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + which) * COUT + c];
             a.part[(size_t)blockIdx.x * 2 * COUT + i] = t;
         }
         if (HAS_X2)
-            for (int i = tid; i < 2 * COUT; i += 256) {
+            for (int i = tid; i < 2 * COUT; i += NTHR) {
                 const int which = i / COUT, c = i - which * COUT;
                 float t = 0.f;
-                for (int w = 0; w < 4; ++w) t += s_red[(w * 3 + (which ? 2 : 0)) * COUT + c];
+                for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + (which ? 2 : 0)) * COUT + c];
                 a.part2[(size_t)blockIdx.x * 2 * COUT + i] = t;
             }
     }
@@ -457,6 +498,14 @@ int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_
     }
     // data-gradient epilogue: always with the two-input prologue (dz = A*dy + B*z + C)
     if (pro != 2) return COVA_ERR_BAD_ARG;
+    if (epi == 3) {          // (acc + addend) * mask(act), no sums: the 64->256 block-input gradient
+        if constexpr (COUT == 256) {
+            if (!mask_act || has_x2) return COVA_ERR_BAD_ARG;
+            if (has_add) C11_LAUNCH(2, 3, true, true, false);
+            C11_LAUNCH(2, 3, false, true, false);
+        }
+        return COVA_ERR_BAD_ARG;
+    }
     if (has_add) {
         if (mask_act) {
             if (has_x2) C11_LAUNCH(2, 2, true, true, true);
@@ -508,12 +557,16 @@ COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_ab
         COVA_REQUIRE(mean && invstd && stat_part && (act || (mask_scale && mask_shift)));
         COVA_REQUIRE(!z2 || (mean2 && invstd2 && stat_part2));
         epi = 2;
+    } else if (act) {        // masked data gradient whose BatchNorm sums are taken elsewhere (conv1x1_lin.hip)
+        COVA_REQUIRE(!z2 && !stat_part && Cout == 256);
+        epi = 3;
     } else {
-        COVA_REQUIRE(!addend && !act && !z2);
+        COVA_REQUIRE(!addend && !z2);
         epi = stat_part ? 1 : 0;
     }
     const C11Args a{in, in2, pro_abc, w, addend, act, mask_scale, mask_shift, z, mean, invstd, z2, mean2,
-                    invstd2, out, stat_part, stat_part2, R, pro_relu, w_trans};
+                    invstd2, out, stat_part, stat_part2, R, pro_relu, w_trans,
+                    nullptr, nullptr, nullptr, nullptr, 0};
     const int grid = c11_grid(R);
     hipStream_t st = (hipStream_t)stream;
     int rc = COVA_ERR_BAD_ARG;
@@ -521,6 +574,39 @@ COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_ab
     else if (Cin == 64 && Cout == 256) rc = launch_c11<64, 256>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
     else if (Cin == 256 && Cout == 64) rc = launch_c11<256, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
     if (rc != COVA_OK) return rc;
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// Data gradient of (1x1 conv 64->256, train-mode BatchNorm) in its LINEAR form (conv1x1_lin.hip): with
+// z = a*W^T the BatchNorm-backward apply dz = A*v + B*z + C never has to be formed,
+//   dz*W = (A.v)*W + a*(W^T diag(B) W) + C^T W = (A.v)*W + a*M + cvec,
+// so the 256-channel z is not read: K = 256 channels of v (scaled by `avec` = A | 0 | 0 on load) plus 64
+// channels of a = relu?(act_abc[0]*act + act_abc[2]).  Epilogue as cova_conv1x1's data gradient:
+// (+ addend) * [fma(mask_scale, z, mask_shift) > 0], (sum dy, sum dy*xhat(z)) partials for the 64-channel
+// BatchNorm in front.  w [256][64] (the conv's OIHW weight), m [64][64], cvec [64] from cova_conv1x1_lin_finish.
+COVA_API int cova_conv1x1_lin_dgrad_num_partials(long long R)
+{
+    const long long ntiles = (R + 31) / 32, nb = (ntiles + 7) / 8;
+    return cova_internal_persistent_grid2(nb > (1 << 30) ? (1 << 30) : (int)nb, 1);
+}
+
+COVA_API int cova_conv1x1_lin_dgrad(const float *v, const float *avec, const float *w, const float *act,
+                                    const float *act_abc, int act_relu, const float *m, const float *cvec,
+                                    const float *addend, const float *mask_scale, const float *mask_shift,
+                                    const float *z, const float *mean, const float *invstd, float *out,
+                                    float *stat_part, long long R, void *stream)
+{
+    COVA_REQUIRE(v && avec && w && act && act_abc && m && cvec && out && R > 0);
+    COVA_REQUIRE(mask_scale && mask_shift && z && mean && invstd && stat_part);
+    const C11Args a{v, nullptr, avec, w, addend, nullptr, mask_scale, mask_shift, z, mean, invstd, nullptr,
+                    nullptr, nullptr, out, stat_part, nullptr, R, 0, 1, act, act_abc, m, cvec, act_relu};
+    const int grid = cova_conv1x1_lin_dgrad_num_partials(R);
+    hipStream_t st = (hipStream_t)stream;
+    if (addend)
+        hipLaunchKernelGGL((conv1x1_kernel<256, 64, 1, 2, true, false, false, true, 8>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv1x1_kernel<256, 64, 1, 2, false, false, false, true, 8>), dim3(grid), dim3(512), 0, st, a);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

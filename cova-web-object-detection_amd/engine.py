@@ -427,33 +427,62 @@ def bn_act(z, st, res=None, relu=True):
     return out
 
 
+_IDENT_ABC = {}
+
+
+def _ident_abc(like):
+    """A | B | C = 1 | 0 | 0 for 64 channels (an operand that needs no affine prologue), cached per device."""
+    t = _IDENT_ABC.get(like.device)
+    if t is None:
+        t = torch.zeros((3, C64), device=like.device)
+        t[0].fill_(1.0)
+        _IDENT_ABC[like.device] = t
+    return t
+
+
+def _lin_conv_bn_bwd(v, act, act_abc, act_relu, w, st, R, gout, bn_prefix, w_key, grads, ws):
+    """Backward of (1x1 conv 64->256, BatchNorm ``st``) in linear form (csrc/conv1x1_lin.hip): parameter
+    gradients of both, and (avec, m, cvec) = the operands of cova_conv1x1_lin_dgrad.  ``v`` = masked gradient
+    w.r.t. the BatchNorm output, ``act`` (+ affine/ReLU on load) = the conv's input.  The conv output is not read."""
+    lin = _empty((query("cova_conv1x1_lin_floats"),), v)
+    call("cova_conv1x1_vprod", v, act, act_abc, 1 if act_relu else 0, lin, ws, R)
+    part = _empty((1, 2, C256), v)
+    call("cova_conv1x1_lin_bnsums", lin, w, st.mean, st.invstd, part)
+    dg, db, abc = _bn_abc_from_partials(part, 1, st, R, gout, bn_prefix, v)
+    grads[bn_prefix + "weight"], grads[bn_prefix + "bias"] = dg, db
+    dw = _gbuf(gout, w_key, (C256, C64, 1, 1), v)
+    m, cvec, avec = _empty((C64, C64), v), _empty((C64,), v), _empty((3, C256), v)
+    call("cova_conv1x1_lin_finish", lin, abc, w, dw, m, cvec, avec)
+    grads[w_key] = dw
+    return avec, m, cvec
+
+
 def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
     """Backward of the three Bottlenecks.  ``g`` = gradient w.r.t. the last block's output, already
-    ReLU-masked, ``head_part`` = (partials, rows) of its (sum g, sum g*xhat(z3)) from RoIPool's backward.
+    ReLU-masked.  The two 64->256 convolutions (conv3, downsample) and their BatchNorms run in linear form:
+    sums, weight gradient and data gradient come from v^T a, a^T a, sum a, sum v, so no 256-channel conv
+    output is read in the backward (``head_part``, RoIPool's own sums for the last bn3, is not needed).
     Returns the ReLU-masked gradient w.r.t. the max-pool output (sv['pool_part'] holds the stem's sums)."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     nt = conv3_num_tiles(B, H2, W2)
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
-    ws1 = _empty((query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),), g)
-    pend, pend_d = head_part, None
+    ws1 = _empty((max(query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),
+                      query("cova_conv1x1_vprod_workspace_floats", R)),), g)
+    nd = query("cova_conv1x1_lin_dgrad_num_partials", R)
     stem = sv["bn1"]
     for blk in (2, 1, 0):
         s = sv["blocks"][blk]
         pre, cin, bn1, bn2, bn3 = s["pre"], s["cin"], s["bn1"], s["bn2"], s["bn3"]
         w1, w3 = params[pre + "conv1.weight"], params[pre + "conv3.weight"]
-        dg, db, abc3 = _bn_abc_from_partials(pend[0], pend[1], bn3, R, gout, pre + "bn3.", g)
-        grads[pre + "bn3.weight"], grads[pre + "bn3.bias"] = dg, db
-        # conv3 (64->256): dz3 = abc3 . (g, z3) on load; its input a2 = relu(bn2(z2)) on load
-        dw = _gbuf(gout, pre + "conv3.weight", (C256, C64, 1, 1), g)
-        call("cova_conv1x1_wgrad", g, s["z3"], abc3, s["z2"], bn2.abc, 1, dw, ws1, R, C256, C64)
-        grads[pre + "conv3.weight"] = dw
-        n2 = query("cova_conv1x1_num_partials", R, C256, C64)
-        part = _empty((n2, 2, C64), g)
+        # conv3 (64->256) + bn3; its input a2 = relu(bn2(z2)) on load, bn2's ReLU mask + sums in the epilogue
+        avec, m3, cvec = _lin_conv_bn_bwd(g, s["z2"], bn2.abc, 1, w3, bn3, R, gout, pre + "bn3.",
+                                          pre + "conv3.weight", grads, ws1)
+        part = _empty((nd, 2, C64), g)
         dy2 = _empty((B, H2, W2, C64), g)
-        conv1x1(g, s["z3"], abc3, 0, w3, 1, dy2, part, R, C256, C64, msc=bn2.scale, msh=bn2.shift,
-                z=s["z2"], mean=bn2.mean, invstd=bn2.invstd)
-        dg, db, abc2 = _bn_abc_from_partials(part, n2, bn2, R, gout, pre + "bn2.", g)
+        call("cova_conv1x1_lin_dgrad", g, avec, w3, s["z2"], bn2.abc, 1, m3, cvec, None, bn2.scale, bn2.shift,
+             s["z2"], bn2.mean, bn2.invstd, dy2, part, R)
+        dg, db, abc2 = _bn_abc_from_partials(part, nd, bn2, R, gout, pre + "bn2.", g)
         grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
         # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
         dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
@@ -471,34 +500,23 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "conv1.weight"] = dw
         if blk > 0:
             # gradient w.r.t. the previous block's output = conv1's data gradient + the identity branch,
-            # masked by that output's ReLU; (sum, sum*xhat) for its bn3 (and block 0's downsample BN)
-            prev = sv["blocks"][blk - 1]
-            n1 = query("cova_conv1x1_num_partials", R, C64, C256)
-            pnew = _empty((n1, 2, C256), g)
-            pnew_d = _empty((n1, 2, C256), g) if blk == 1 else None
-            bnd = prev.get("bnd")
+            # masked by that output's ReLU (its BatchNorm sums are taken by the next iteration's v^T a)
             dx = _empty((B, H2, W2, C256), g)
-            conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, pnew, R, C64, C256, addend=g, act=s["x"],
-                    z=prev["z3"], mean=prev["bn3"].mean, invstd=prev["bn3"].invstd,
-                    z2=prev["zd"] if blk == 1 else None, mean2=bnd.mean if blk == 1 else None,
-                    invstd2=bnd.invstd if blk == 1 else None, part2=pnew_d)
-            g, pend, pend_d = dx, (pnew, n1), (pnew_d, n1)
+            conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, None, R, C64, C256, addend=g, act=s["x"])
+            g = dx
         else:
-            bnd, wdn = s["bnd"], params[pre + "downsample.0.weight"]
-            dg, db, abcd = _bn_abc_from_partials(pend_d[0], pend_d[1], bnd, R, gout, pre + "downsample.1.", g)
-            grads[pre + "downsample.1.weight"], grads[pre + "downsample.1.bias"] = dg, db
-            dw = _gbuf(gout, pre + "downsample.0.weight", (C256, C64, 1, 1), g)
-            call("cova_conv1x1_wgrad", g, s["zd"], abcd, s["x"], None, 0, dw, ws1, R, C256, C64)
-            grads[pre + "downsample.0.weight"] = dw
-            # dp1 = conv1's + the downsample conv's data gradients, then the stem's ReLU mask (from the
-            # pooled arg-max pre-activation) and BatchNorm sums
+            # downsample branch (64->256 conv + BatchNorm on the block input p1), linear form as well; then
+            # dp1 = conv1's + the downsample conv's data gradients, the stem's ReLU mask (from the pooled
+            # arg-max pre-activation) and BatchNorm sums
+            wdn = params[pre + "downsample.0.weight"]
+            avd, md, cvd = _lin_conv_bn_bwd(g, s["x"], None, 0, wdn, s["bnd"], R, gout, pre + "downsample.1.",
+                                            pre + "downsample.0.weight", grads, ws1)
             t = _empty((B, H2, W2, C64), g)
             conv1x1(dy1, s["z1"], abc1, 0, w1, 1, t, None, R, C64, C64)
-            n0 = query("cova_conv1x1_num_partials", R, C256, C64)
-            sv["pool_part"], sv["pool_npart"] = _empty((n0, 2, C64), g), n0
+            sv["pool_part"], sv["pool_npart"] = _empty((nd, 2, C64), g), nd
             dp = _empty((B, H2, W2, C64), g)
-            conv1x1(g, s["zd"], abcd, 0, wdn, 1, dp, sv["pool_part"], R, C256, C64, addend=t,
-                    msc=stem.scale, msh=stem.shift, z=sv["ymax"], mean=stem.mean, invstd=stem.invstd)
+            call("cova_conv1x1_lin_dgrad", g, avd, wdn, s["x"], _ident_abc(g), 0, md, cvd, t, stem.scale,
+                 stem.shift, sv["ymax"], stem.mean, stem.invstd, dp, sv["pool_part"], R)
             g = dp
     return g
 

@@ -120,7 +120,8 @@ int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, fl
  * (256,64)}; w [Cout,Cin] row-major (= OIHW), or with w_trans [Cin,Cout] (data gradient of the conv whose
  * weight it is).  Prologue / epilogue arguments as cova_conv3x3_wino_pro; stat_part
  * [cova_conv1x1_num_partials][2][Cout] = (sum y, sum y^2) when z == NULL, else (sum dy, sum dy*xhat);
- * z2/mean2/invstd2 + stat_part2: a second BatchNorm (the downsample branch) fed by the same dy. */
+ * z2/mean2/invstd2 + stat_part2: a second BatchNorm (the downsample branch) fed by the same dy.
+ * z == NULL with act != NULL (Cout = 256): (acc + addend) * [act > 0] without sums (taken by cova_conv1x1_vprod). */
 int cova_conv1x1_num_partials(long long R, int Cin, int Cout);
 int cova_conv1x1(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable [3,Cin]*/,
                  int pro_relu, const float *w, int w_trans, const float *addend /*nullable*/,
@@ -136,6 +137,33 @@ int cova_conv1x1_wgrad_workspace_floats(long long R, int Co, int Ci);
 int cova_conv1x1_wgrad(const float *dz, const float *dz2 /*nullable*/, const float *dz_abc /*nullable [3,Co]*/,
                        const float *act, const float *act_abc /*nullable [3,Ci]*/, int act_relu, float *dw,
                        float *ws, long long R, int Co, int Ci, void *stream);
+
+/* Linear form of the backward of (1x1 conv 64->256, train-mode BatchNorm) -- Bottleneck conv3+bn3 and
+ * downsample[0]+[1]: with z = a W^T, the BatchNorm sums, dW and dz*W are functions of P = v^T a, G = a^T a,
+ * S = sum a, SU = sum v, so the 256-channel z is never read in the backward (csrc/conv1x1_lin.hip).
+ *   cova_conv1x1_vprod      v [R,256], act [R,64] (a = relu?(act_abc[0]*act + act_abc[2]), act_abc nullable)
+ *                           -> lin [cova_conv1x1_lin_floats] = P | G | S | SU
+ *   cova_conv1x1_lin_bnsums lin, w [256,64], mean, invstd -> part [2][256] = (sum v, sum v*xhat(z)): one row of
+ *                           partials for cova_bn_finalize_bwd_abc
+ *   cova_conv1x1_lin_finish lin, abc [3][256] (dz = A*v + B*z + C), w -> dw [256,64], m [64,64] = W^T diag(B) W,
+ *                           cvec [64] = C^T W, avec [3][256] = A | 0 | 0
+ *   cova_conv1x1_lin_dgrad  out [R,64] = ((avec.v) W + a m + cvec (+ addend)) * [fma(mask_scale, z, mask_shift) > 0]
+ *                           and (sum, sum*xhat(z)) partials [cova_conv1x1_lin_dgrad_num_partials][2][64] of the
+ *                           64-channel BatchNorm in front (z, mean, invstd: that layer's) */
+int cova_conv1x1_lin_floats(void);
+int cova_conv1x1_vprod_workspace_floats(long long R);
+int cova_conv1x1_vprod(const float *v, const float *act, const float *act_abc /*nullable [3,64]*/, int act_relu,
+                       float *lin, float *ws, long long R, void *stream);
+int cova_conv1x1_lin_bnsums(const float *lin, const float *w, const float *mean, const float *invstd,
+                            float *part, void *stream);
+int cova_conv1x1_lin_finish(const float *lin, const float *abc, const float *w, float *dw, float *m,
+                            float *cvec, float *avec, void *stream);
+int cova_conv1x1_lin_dgrad_num_partials(long long R);
+int cova_conv1x1_lin_dgrad(const float *v, const float *avec, const float *w, const float *act,
+                           const float *act_abc, int act_relu, const float *m, const float *cvec,
+                           const float *addend /*nullable [R,64]*/, const float *mask_scale,
+                           const float *mask_shift, const float *z, const float *mean, const float *invstd,
+                           float *out, float *stat_part, long long R, void *stream);
 
 /* ------------------------------------------------------------------ BatchNorm / ReLU / MaxPool
  * replaces: nn.BatchNorm2d / nn.BatchNorm1d (train: batch statistics + running-stat update with

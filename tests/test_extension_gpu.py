@@ -135,6 +135,88 @@ def test_conv1x1_weight_gradient(co, ci, R):
         assert torch.equal(dw, dw2)                          # fixed reduction order: bit-identical reruns
 
 
+@pytest.mark.parametrize("R", [1, 2, 777, 60001])
+@pytest.mark.parametrize("pro", [True, False])
+def test_linear_form_of_conv_bn_backward(R, pro):
+    """(1x1 conv 64->256, train-mode BatchNorm) backward without reading the conv output (conv1x1_lin.hip):
+    the four reductions, the BatchNorm sums, dW and the data gradient against torch autograd in fp64."""
+    rs = np.random.RandomState(R + pro)
+    d = lambda t: t.to(DEV)
+    act, v = rnd(rs, R, 64), rnd(rs, R, 256) * (torch.from_numpy(rs.rand(R, 256)) > 0.4)
+    aabc = torch.stack([torch.from_numpy(rs.uniform(0.5, 1.5, 64).astype(np.float32)), rnd(rs, 64), rnd(rs, 64, scale=0.3)])
+    w = rnd(rs, 256, 64, scale=0.15)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 256).astype(np.float32))
+    a = ((aabc[0] * act + aabc[2]).clamp_min(0) if pro else act).double()
+    # ---- the four reductions
+    nl = query("cova_conv1x1_lin_floats")
+    lin, lin2 = torch.empty(nl, device=DEV), torch.empty(nl, device=DEV)
+    ws = torch.empty(query("cova_conv1x1_vprod_workspace_floats", R), device=DEV)
+    for out in (lin, lin2):
+        call("cova_conv1x1_vprod", d(v), d(act), d(aabc) if pro else None, 1 if pro else 0, out, ws, R)
+    assert torch.equal(lin, lin2)                            # fixed reduction order
+    P, G, S, SU = lin[:16384].view(256, 64), lin[16384:20480].view(64, 64), lin[20480:20544], lin[20544:]
+    close(P, v.double().t() @ a, 2e-5, "P")
+    close(G, a.t() @ a, 2e-5, "G")
+    close(S, a.sum(0), 2e-5, "S")
+    close(SU, v.double().sum(0), 1e-4, "SU")
+    if R < 2:
+        return
+    # ---- autograd reference of z = a W^T -> train-mode BatchNorm, upstream gradient v
+    a_r, w_r, g_r = a.clone().requires_grad_(True), w.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    z = a_r @ w_r.t()
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    ((z - mean) * invstd * g_r).backward(v.double())
+    mean32, invstd32 = mean.detach().float(), invstd.detach().float()
+    part = torch.empty((1, 2, 256), device=DEV)
+    call("cova_conv1x1_lin_bnsums", lin, d(w), d(mean32), d(invstd32), part)
+    close(part[0, 1], g_r.grad, 1e-4, "dgamma = sum v*xhat")
+    close(part[0, 0], v.double().sum(0), 1e-4, "dbeta")
+    dg, db, abc = torch.empty(256, device=DEV), torch.empty(256, device=DEV), torch.empty((3, 256), device=DEV)
+    call("cova_bn_finalize_bwd_abc", part, 1, 256, float(R), dg, db, d(mean32), d(invstd32),
+         d((gamma * invstd32)), abc)
+    dw, mm, cvec, avec = (torch.empty((256, 64), device=DEV), torch.empty((64, 64), device=DEV),
+                          torch.empty(64, device=DEV), torch.empty((3, 256), device=DEV))
+    call("cova_conv1x1_lin_finish", lin, abc, d(w), dw, mm, cvec, avec)
+    close(dw, w_r.grad, 1e-4, "dW")
+    assert torch.equal(avec[0], abc[0]) and not avec[1:].any()
+    # ---- data gradient (+ addend), masked by the BatchNorm in front, with that layer's sums
+    z2 = rnd(rs, R, 64)
+    msc, msh = torch.from_numpy(rs.uniform(-1, 1.5, 64).astype(np.float32)), rnd(rs, 64, scale=0.3)
+    mean2, invstd2 = rnd(rs, 64, scale=0.2), torch.from_numpy(rs.uniform(0.5, 1.5, 64).astype(np.float32))
+    addend = rnd(rs, R, 64)
+    ident = torch.stack([torch.ones(64), torch.zeros(64), torch.zeros(64)])
+    n = query("cova_conv1x1_lin_dgrad_num_partials", R)
+    for add in (False, True):
+        out, sp = torch.empty((R, 64), device=DEV), torch.empty((n, 2, 64), device=DEV)
+        call("cova_conv1x1_lin_dgrad", d(v), avec, d(w), d(act), d(aabc) if pro else d(ident), 1 if pro else 0, mm,
+             cvec, d(addend) if add else None, d(msc), d(msh), d(z2), d(mean2), d(invstd2), out, sp, R)
+        ref = a_r.grad + (addend.double() if add else 0.0)
+        m = torch.addcmul(msh, msc, z2) > 0
+        sure = (msc * z2 + msh).abs() > 1e-5
+        ref = ref * m
+        got = out.cpu().double()
+        assert float(((got - ref).abs() * sure).max()) < 1e-4 * float(ref.abs().max()), (add, R)
+        xh = ((z2 - mean2) * invstd2).double()
+        close(sp[:, 0].double().sum(0), got.sum(0), 1e-4, "sum dy")
+        close(sp[:, 1].double().sum(0), (got * xh).sum(0), 1e-4, "sum dy*xhat")
+
+
+def test_conv1x1_masked_gradient_without_sums():
+    """Block-input gradient once its BatchNorm sums come from cova_conv1x1_vprod: (acc + addend) * [act > 0]."""
+    rs = np.random.RandomState(77)
+    R = 3001
+    dy, zin = rnd(rs, R, 64), rnd(rs, R, 64)
+    w = rnd(rs, 64, 256, scale=0.1)
+    abc = torch.stack([rnd(rs, 64), rnd(rs, 64, scale=0.5), rnd(rs, 64, scale=0.3)])
+    addend, act = rnd(rs, R, 256), rnd(rs, R, 256)
+    d = lambda t: t.to(DEV)
+    ref = ((abc[0] * dy + abc[1] * zin + abc[2]).double() @ w.double() + addend.double()) * (act > 0)
+    out = torch.empty((R, 256), device=DEV)
+    engine.conv1x1(d(dy), d(zin), d(abc), 0, d(w), 1, out, None, R, 64, 256, addend=d(addend), act=d(act))
+    close(out, ref, 2e-5, "masked data gradient")
+
+
 def test_bn_act2():
     rs = np.random.RandomState(5)
     R, C = 1000, 256

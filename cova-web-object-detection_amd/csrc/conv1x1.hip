@@ -47,6 +47,9 @@ struct C11Args {
     // relu?(A3*in3 + C3) with weight w3 [64][Cout], and a per-output-channel constant cvec
     const float *in3, *pro3, *w3, *cvec;
     int pro3_relu;
+    // SIDE: the prologue's result f(A*in + B*in2 + C) is also written here ([R][Cin]): the consumer of a
+    // Bottleneck output materialises it (relu(bn3(z3) + x)) while it reads its operands anyway
+    float *side;
 };
 
 template <int CIN, int COUT, bool EXT = false>
@@ -67,7 +70,7 @@ struct C11Geo {
 // | 2 (acc + addend) * mask, (sum dy, sum dy*xhat[, sum dy*xhat2]) | 3 (acc + addend) * mask, no sums.
 // NW = waves per block (4: two blocks per CU; 8: one block per CU when the weights need > 80 KB of LDS).
 template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool HAS_X2, bool EXT = false,
-          int NW = 4>
+          int NW = 4, bool SIDE = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const C11Args a)
 {
     using G = C11Geo<CIN, COUT, EXT>;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             for (int j = 0; j < 8; ++j) v2[j] = *reinterpret_cast<const float4 *>(a.in2 + o + 4 * j);
         }
     };
-    auto prologue = [&](int c, float4 (&v)[8], const float4 (&v2)[8], float (&x)[32]) {
+    auto prologue = [&](long long tile, int c, float4 (&v)[8], const float4 (&v2)[8], float (&x)[32]) {
+        const long long srow = tile * 32 + p;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
@@ -164,6 +168,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[4 * j + k] = e[k];
+            if (SIDE && !(EXT && c == G::CHUNKS) && srow < a.R)
+                *reinterpret_cast<float4 *>(a.side + (size_t)srow * CIN + h * G::KH + c * 32 + 4 * j) =
+                    make_float4(e[0], e[1], e[2], e[3]);
         }
     };
 
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
         // through a single 64-channel pass.
         float x[32];
         if (TC == 1) {
-            prologue(0, nv, nv2, x);
+            prologue(tile, 0, nv, nv2, x);
             if (PREFETCH && tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);      // next tile in flight
         }
 #pragma unroll
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
 #pragma unroll
             for (int c = 0; c < TC; ++c) {
                 if (TC > 1) {
-                    prologue(c, nv, nv2, x);
+                    prologue(tile, c, nv, nv2, x);
                     // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
                     if (c + 1 < TC) issue(tile, c + 1, nv, nv2);
                     else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
@@ -486,6 +493,19 @@ int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_
                            0, st, a);                                                                \
         return COVA_OK;                                                                              \
     } while (0)
+    if (a.side) {           // materialising consumer: 256 -> 64 forward with the two-tensor prologue
+        if constexpr (CIN == 256) {
+            if (pro != 2 || epi > 1) return COVA_ERR_BAD_ARG;
+            if (epi == 1)
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 1, false, false, false, false, 4, true>), dim3(grid),
+                                   dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 0, false, false, false, false, 4, true>), dim3(grid),
+                                   dim3(256), 0, st, a);
+            return COVA_OK;
+        }
+        return COVA_ERR_BAD_ARG;
+    }
     if (epi == 0) {
         if (pro == 0) C11_LAUNCH(0, 0, false, false, false);
         if (pro == 1) C11_LAUNCH(1, 0, false, false, false);
@@ -566,13 +586,29 @@ COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_ab
     }
     const C11Args a{in, in2, pro_abc, w, addend, act, mask_scale, mask_shift, z, mean, invstd, z2, mean2,
                     invstd2, out, stat_part, stat_part2, R, pro_relu, w_trans,
-                    nullptr, nullptr, nullptr, nullptr, 0};
+                    nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     const int grid = c11_grid(R);
     hipStream_t st = (hipStream_t)stream;
     int rc = COVA_ERR_BAD_ARG;
     if (Cin == 64 && Cout == 64) rc = launch_c11<64, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
     else if (Cin == 64 && Cout == 256) rc = launch_c11<64, 256>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
     else if (Cin == 256 && Cout == 64) rc = launch_c11<256, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
+    if (rc != COVA_OK) return rc;
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// cova_conv1x1 (Cin = 256, Cout = 64, forward) whose input is the previous Bottleneck's output
+// relu(A*in + B*in2 + C) = relu(bn3(z3) + identity-or-downsample branch), formed on load AND written to `side`
+// [R,256]: the block output is materialised by its first consumer instead of by an element-wise pass
+// (cova_bn_act_fwd / cova_bn_act2_fwd: one read of the 256-channel map less).
+COVA_API int cova_conv1x1_materialize(const float *in, const float *in2, const float *pro_abc, const float *w,
+                                      float *side, float *out, float *stat_part, long long R, void *stream)
+{
+    COVA_REQUIRE(in && in2 && pro_abc && w && side && out && R > 0);
+    const C11Args a{in, in2, pro_abc, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, out, stat_part, nullptr, R, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, side};
+    const int rc = launch_c11<256, 64>(a, stat_part ? 1 : 0, false, false, false, 2, c11_grid(R), (hipStream_t)stream);
     if (rc != COVA_OK) return rc;
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -600,7 +636,7 @@ COVA_API int cova_conv1x1_lin_dgrad(const float *v, const float *avec, const flo
     COVA_REQUIRE(v && avec && w && act && act_abc && m && cvec && out && R > 0);
     COVA_REQUIRE(mask_scale && mask_shift && z && mean && invstd && stat_part);
     const C11Args a{v, nullptr, avec, w, addend, nullptr, mask_scale, mask_shift, z, mean, invstd, nullptr,
-                    nullptr, nullptr, out, stat_part, nullptr, R, 0, 1, act, act_abc, m, cvec, act_relu};
+                    nullptr, nullptr, out, stat_part, nullptr, R, 0, 1, act, act_abc, m, cvec, act_relu, nullptr};
     const int grid = cova_conv1x1_lin_dgrad_num_partials(R);
     hipStream_t st = (hipStream_t)stream;
     if (addend)

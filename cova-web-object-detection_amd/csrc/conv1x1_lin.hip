@@ -34,9 +34,9 @@ struct VPArgs {
 // GEMM M = 256 (v channels), N = 64 (a channels), K = pixels on v_mfma_f32_32x32x2_f32, operands straight
 // from HBM (conv1x1_wgrad_kernel's layout: a k-step is a pixel pair, half-wave h takes pixel 2s+h, lane p
 // supplies channels {2p, 2p+1}).  Wave u owns v channels 64u..64u+63; the Gram matrix of a (the same
-// operand on both sides) is spread over the four waves by k-step (k & 3 == u), as are the sums of a.
+// operand on both sides) is spread over the four waves by batch of 8 k-steps (batch & 3 == u), as are the sums of a.
 template <bool PRO_ACT>
-__global__ __launch_bounds__(256) void conv1x1_vprod_kernel(const VPArgs a)
+__global__ __launch_bounds__(256, 2) void conv1x1_vprod_kernel(const VPArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,25 +97,33 @@ __global__ __launch_bounds__(256) void conv1x1_vprod_kernel(const VPArgs a)
             sa[1] += x1;
         }
     };
-    auto consume = [&](const float2 (&gg)[U], const float2 (&xx)[U]) {
+    // The Gram matrix of a batch (8 pixel pairs) is taken by wave (batch & 3): one uniform branch per batch.
+    auto consume = [&](const float2 (&gg)[U], const float2 (&xx)[U], long long batch) {
+        const bool gram = (int)(batch & 3) == wave;          // wave-uniform
 #pragma unroll
-        for (int k = 0; k < U; ++k) mac(gg[k].x, gg[k].y, xx[k].x, xx[k].y, true, (k & 3) == wave);
+        for (int k = 0; k < U; ++k) mac(gg[k].x, gg[k].y, xx[k].x, xx[k].y, true, gram);
     };
+    // full batches [s_lo + b*U, +U) inside the block's range AND inside the map.  Every load in the loop is
+    // unconditional (the last batch re-requests itself): a load under a branch would make the compiler wait
+    // for vmcnt(0) at the join, i.e. for the batch that was only just requested.
     long long full_hi = s_hi;
     if (2 * full_hi > a.R) full_hi = a.R / 2;
+    const long long nfull = full_hi > s_lo ? (full_hi - s_lo) / U : 0;
     long long s0 = s_lo;
-    if (s0 + U <= full_hi) issue(s0, g[0], x[0]);
-    while (s0 + U <= full_hi) {
-        const bool more = s0 + 2 * U <= full_hi;
-        if (more) issue(s0 + U, g[1], x[1]);
-        consume(g[0], x[0]);
-        s0 += U;
-        if (!more) break;
-        const bool more2 = s0 + 2 * U <= full_hi;
-        if (more2) issue(s0 + U, g[0], x[0]);
-        consume(g[1], x[1]);
-        s0 += U;
-        if (!more2) break;
+    if (nfull > 0) {
+        issue(s_lo, g[0], x[0]);
+        for (long long b = 0; b < nfull; b += 2) {
+            const long long b1 = b + 1 < nfull ? b + 1 : nfull - 1;
+            issue(s_lo + b1 * U, g[1], x[1]);
+            __builtin_amdgcn_sched_barrier(0);             // keep the requests ahead of the MFMAs (not sunk to their uses)
+            consume(g[0], x[0], b);
+            if (b + 1 >= nfull) break;
+            const long long b2 = b + 2 < nfull ? b + 2 : nfull - 1;
+            issue(s_lo + b2 * U, g[0], x[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(g[1], x[1], b + 1);
+        }
+        s0 = s_lo + nfull * U;
     }
     for (; s0 < s_hi; s0 += U) {           // ragged tail: clamped, predicated
         for (int k = 0; k < U; ++k) {
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void conv1x1_vprod_kernel(const VPArgs a)
             if (row >= a.R) row = a.R - 1;
             const float2 d = *reinterpret_cast<const float2 *>(a.v + (size_t)row * CO + cob + 2 * p);
             const float2 xv = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + 2 * p);
-            mac(d.x, d.y, xv.x, xv.y, valid, (k & 3) == wave);
+            mac(d.x, d.y, xv.x, xv.y, valid, ((int)(s0 / U) & 3) == wave);
         }
     }
     const size_t nb = gridDim.x, b = blockIdx.x;

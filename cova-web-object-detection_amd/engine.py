@@ -376,12 +376,22 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
         return bn_params(prefix, params, buffers, C, p1, training, part, n, R, unit="pages")
 
     x, cin, blocks, feat = p1, C64, [], None
+    pending = None      # (z3, other, abc): the previous block's output relu(abc . (z3, other)), not yet written
     for blk in (0, 1, 2):
         pre = "convnet.4.%d." % blk
-        s = dict(x=x, cin=cin, pre=pre)
+        s = dict(cin=cin, pre=pre)
         part, n = stats(cin, C64)
         s["z1"] = _empty((B, H2, W2, C64), p1)
-        conv1x1(x, None, None, 0, params[pre + "conv1.weight"], 0, s["z1"], part, R, cin, C64)
+        if pending is None:
+            conv1x1(x, None, None, 0, params[pre + "conv1.weight"], 0, s["z1"], part, R, cin, C64)
+        else:
+            # the block input is materialised by its first consumer (one pass over the 256-channel map less
+            # than a separate bn + residual + ReLU kernel)
+            x = _empty((B, H2, W2, C256), p1)
+            call("cova_conv1x1_materialize", pending[0], pending[1], pending[2], params[pre + "conv1.weight"], x,
+                 s["z1"], part, R)
+            blocks[-1]["out"] = x
+        s["x"] = x
         s["bn1"] = bn(pre + "bn1.", C64, part, n)
         uf, s["ud"] = prep_wino(params[pre + "conv2.weight"], p1)
         part = _empty((nt, 2, C64), p1) if training else None
@@ -394,24 +404,28 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
         conv1x1(s["z2"], None, s["bn2"].abc, 1, params[pre + "conv3.weight"], 0, s["z3"], part, R, C64, C256)
         s["bn3"] = bn(pre + "bn3.", C256, part, n)
         bn3 = s["bn3"]
+        s["out"] = None
         if blk == 0:
             part, n = stats(C64, C256)
             s["zd"] = _empty((B, H2, W2, C256), p1)
             conv1x1(x, None, None, 0, params[pre + "downsample.0.weight"], 0, s["zd"], part, R, C64, C256)
             s["bnd"] = bn(pre + "downsample.1.", C256, part, n)
-            s["out"] = _empty((B, H2, W2, C256), p1)
-            call("cova_bn_act2_fwd", s["z3"], bn3.scale, bn3.shift, s["zd"], s["bnd"].scale, s["bnd"].shift,
-                 s["out"], R, C256, 1)
-            feat = s["out"]
-        elif blk == 2 and lazy_out:
-            s["out"] = None
+            abc = _empty((3, C256), p1)          # out = relu(s3*z3 + sd*zd + (h3 + hd))
+            abc[0].copy_(bn3.scale)
+            abc[1].copy_(s["bnd"].scale)
+            torch.add(bn3.shift, s["bnd"].shift, out=abc[2])
+            pending = (s["z3"], s["zd"], abc)
+        elif blk == 1:
+            bn3.abc[1].fill_(1.0)                # out = relu(s3*z3 + 1*x + h3): the unused B row of scale | . | shift
+            pending = (s["z3"], x, bn3.abc)
+        elif lazy_out:
             feat = LazyFeature(s["z3"], x, bn3.scale, bn3.shift)
         else:
             s["out"] = _empty((B, H2, W2, C256), p1)
             call("cova_bn_act_fwd", s["z3"], C256, bn3.scale, bn3.shift, x, C256, s["out"], C256, R, C256, 1)
             feat = s["out"]
         blocks.append(s)
-        x, cin = s["out"], C256
+        cin = C256
     sv["blocks"] = blocks
     last = blocks[2]
     sv["last"] = dict(out=last["out"], x=last["x"], z=last["z3"], bn=last["bn3"])

@@ -131,6 +131,10 @@ int cova_conv1x1(const float *in, const float *in2 /*nullable*/, const float *pr
                  const float *z2 /*nullable*/, const float *mean2 /*nullable*/,
                  const float *invstd2 /*nullable*/, float *out, float *stat_part /*nullable*/,
                  float *stat_part2 /*nullable*/, long long R, int Cin, int Cout, void *stream);
+/* cova_conv1x1 (256 -> 64, forward; stat_part as there, nullable) on relu(A*in + B*in2 + C), which is also
+ * written to side [R,256]: the first consumer of a Bottleneck output materialises it */
+int cova_conv1x1_materialize(const float *in, const float *in2, const float *pro_abc /*[3,256]*/, const float *w,
+                             float *side, float *out, float *stat_part /*nullable*/, long long R, void *stream);
 /* dw [Co,Ci] = sum_r (dz_abc[0]*dz + dz_abc[1]*dz2 + dz_abc[2])[r,co] * relu?(act_abc[0]*act + act_abc[2])[r,ci];
  * (Co,Ci) in {(64,64),(256,64),(64,256)}; ws >= cova_conv1x1_wgrad_workspace_floats */
 int cova_conv1x1_wgrad_workspace_floats(long long R, int Co, int Ci);

@@ -217,6 +217,31 @@ def test_conv1x1_masked_gradient_without_sums():
     close(out, ref, 2e-5, "masked data gradient")
 
 
+@pytest.mark.parametrize("R", [1, 37, 5000 + 3])
+def test_conv1x1_materializing_consumer(R):
+    """256->64 forward on relu(A*in + B*in2 + C) that also writes that input (the previous Bottleneck's output)."""
+    rs = np.random.RandomState(R)
+    z, x = rnd(rs, R, 256), rnd(rs, R, 256)
+    abc = torch.stack([torch.from_numpy(rs.uniform(0.5, 1.5, 256).astype(np.float32)),
+                       torch.from_numpy(rs.uniform(0.5, 1.5, 256).astype(np.float32)), rnd(rs, 256, scale=0.3)])
+    w = rnd(rs, 64, 256, scale=0.1)
+    d = lambda t: t.to(DEV)
+    a = (abc[0] * z + abc[1] * x + abc[2]).clamp_min(0).double()
+    n = query("cova_conv1x1_num_partials", R, 256, 64)
+    for stats in (True, False):
+        side, out = torch.full((R, 256), 9.0, device=DEV), torch.empty((R, 64), device=DEV)
+        part = torch.empty((n, 2, 64), device=DEV) if stats else None
+        call("cova_conv1x1_materialize", d(z), d(x), d(abc), d(w), side, out, part, R)
+        close(side, a, 1e-6, "materialised input")
+        # the product is taken on exactly the values that were written
+        close(out, side.cpu().double() @ w.double().t(), 2e-5, "conv on the materialised input")
+        if stats:
+            close(part[:, 0].double().sum(0), out.cpu().double().sum(0), 1e-4, "sum y")
+        ref = torch.empty((R, 64), device=DEV)
+        engine.conv1x1(d(z), d(x), d(abc), 1, d(w), 0, ref, None, R, 256, 64)
+        assert torch.equal(out, ref)
+
+
 def test_bn_act2():
     rs = np.random.RandomState(5)
     R, C = 1000, 256

@@ -178,6 +178,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
     // bytes in their epilogue (addend / mask / xhat operands) than through the MFMA operand, are bound by
     // loads in flight, and need the 64 registers for a second resident wave per SIMD instead.
     constexpr bool PREFETCH = !((EPI == 2 || EPI == 3) && COUT == 256);
+    // TR: transposed product for the variants without per-channel sums.  With the weights as the MFMA's A
+    // operand the accumulator is D[channel][pixel]: a lane holds pixel p and, per register quad, FOUR
+    // CONSECUTIVE CHANNELS (32n + 8j + 4h ..+3), so the epilogue moves float4s (a quarter of the memory
+    // instructions of the channel-per-lane layout, whose 4-byte accesses bound the 256-channel epilogues).
+    constexpr bool TR = EPI == 3 && COUT == 256 && !EXT;
     constexpr int TC = G::CHUNKS + (EXT ? 1 : 0);          // register chunks per tile incl. the extra operand
     long long tile = (long long)blockIdx.x * NW + wave;
     float4 nv[8], nv2[8];
@@ -219,14 +224,56 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                         b[n] = *reinterpret_cast<const float4 *>(
                             Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + wcol + 4 * q);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 0], b[n].x, acc[n]);
+                    for (int n = 0; n < G::NTP; ++n)
+                        acc[n] = TR ? mfma32(b[n].x, x[4 * q + 0], acc[n]) : mfma32(x[4 * q + 0], b[n].x, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 1], b[n].y, acc[n]);
+                    for (int n = 0; n < G::NTP; ++n)
+                        acc[n] = TR ? mfma32(b[n].y, x[4 * q + 1], acc[n]) : mfma32(x[4 * q + 1], b[n].y, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 2], b[n].z, acc[n]);
+                    for (int n = 0; n < G::NTP; ++n)
+                        acc[n] = TR ? mfma32(b[n].z, x[4 * q + 2], acc[n]) : mfma32(x[4 * q + 2], b[n].z, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n) acc[n] = mfma32(x[4 * q + 3], b[n].w, acc[n]);
+                    for (int n = 0; n < G::NTP; ++n)
+                        acc[n] = TR ? mfma32(b[n].w, x[4 * q + 3], acc[n]) : mfma32(x[4 * q + 3], b[n].w, acc[n]);
                 }
+            }
+            if (TR) {
+                // ---- float4 epilogue: register quad j of accumulator nn = channels 32n + 8j + 4h ..+3 of row r0 + p
+                long long row = r0 + p;
+                const bool ok = row < a.R;
+                if (!ok) row = a.R - 1;
+                const size_t rbase = (size_t)row * COUT + 4 * h;
+#pragma unroll
+                for (int nn = 0; nn < G::NTP; nn += 2) {       // two accumulators = 8 float4 per tensor in flight
+                    float4 ad[2][4], mk[2][4];
+                    if (EPI == 3) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const size_t o = rbase + (ps * G::NTP + nn + u) * 32 + 8 * j;
+                                if (HAS_ADD) ad[u][j] = *reinterpret_cast<const float4 *>(a.addend + o);
+                                mk[u][j] = *reinterpret_cast<const float4 *>(a.act + o);
+                            }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float4 v = make_float4(acc[nn + u][4 * j], acc[nn + u][4 * j + 1], acc[nn + u][4 * j + 2],
+                                                   acc[nn + u][4 * j + 3]);
+                            if (EPI == 3) {
+                                if (HAS_ADD) { v.x += ad[u][j].x; v.y += ad[u][j].y; v.z += ad[u][j].z; v.w += ad[u][j].w; }
+                                if (!(mk[u][j].x > 0.f)) v.x = 0.f;
+                                if (!(mk[u][j].y > 0.f)) v.y = 0.f;
+                                if (!(mk[u][j].z > 0.f)) v.z = 0.f;
+                                if (!(mk[u][j].w > 0.f)) v.w = 0.f;
+                            }
+                            if (ok)
+                                *reinterpret_cast<float4 *>(a.out + rbase + (ps * G::NTP + nn + u) * 32 + 8 * j) = v;
+                        }
+                }
+                continue;                                      // next pass
             }
             // ---- epilogue of this pass: lane owns channel n*32 + p of rows mfma32_row(r, lane); 8 rows at
             // a time so that the operands in flight (up to 4 per row) stay within the register budget

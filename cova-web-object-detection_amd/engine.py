@@ -203,6 +203,7 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 # 3x3 convolutions (forward, data gradient, weight gradient): Winograd F(2x2,3x3) kernels (2.25x
 # fewer MFMAs, same fp32 error) or the direct implicit-GEMM kernels.
 USE_WINOGRAD = True
+USE_WINO4 = os.environ.get("COVA_WINO4", "0") == "1"      # experimental F(4x4,3x3) forward launches
 # With the Winograd kernels, BatchNorm+ReLU between the two convs of a BasicBlock and the
 # BatchNorm-backward "apply" passes are evaluated on load inside the consuming convolutions
 # (cova_conv3x3_wino_pro / cova_conv3x3_wgrad_wino_pro): a1 and dz are never written to HBM.
@@ -322,8 +323,17 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             continue
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
-        conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
-        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
+        if USE_WINO4 and USE_WINOGRAD and training:
+            # experimental F(4x4,3x3) form for the launches whose input is a materialised map (csrc/conv_wino4.hip)
+            u4f, u4d = _empty((16, 4, 64, 36), images), _empty((16, 4, 64, 36), images)
+            call("cova_conv3x3_wino4_prep", params[CONV3_KEYS[2 * blk] + ".weight"], u4f, u4d)
+            n4 = query("cova_conv3x3_wino4_num_partials", B, H2, W2)
+            part4 = _empty((n4, 2, C64), images)
+            call("cova_conv3x3_wino4", x, u4f, z1, part4, B, H2, W2)
+            bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part4, n4, R, unit="pages")
+        else:
+            conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
+            bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
         z2 = _empty((B, H2, W2, C64), images)
         if USE_WINOGRAD and FUSE_AFFINE:            # a1 = relu(bn1(z1)) formed on load
             a1 = None

@@ -114,6 +114,14 @@ int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);
 
+/* Experimental F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs, fp32 error 2.9e-6):
+ * u_fwd / u_dgrad [16][4][64][36]; stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2) */
+int cova_conv3x3_wino4_num_tiles(int B, int H, int W);
+int cova_conv3x3_wino4_num_partials(int B, int H, int W);
+int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
+int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_part /*nullable*/, int B, int H,
+                       int W, void *stream);
+
 /* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
  * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.
  * out[r,co] = sum_ci f(A[ci]*in[r,ci] + B[ci]*in2[r,ci] + C[ci]) * w[co,ci], (Cin,Cout) in {(64,64),(64,256),

@@ -754,3 +754,29 @@ def test_roipool_other_output_sizes(ph, pw):
                       batch["context_indices"], cfg, True)
     close(logits, ref_l, 2e-4, "logits with %dx%d bins" % (ph, pw))
     assert all(torch.isfinite(v).all() for v in grads.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(1, 16, 32), (2, 19, 45), (1, 40, 70), (1, 3, 5)])
+def test_conv3x3_winograd_f4x4(B, H, W):
+    """F(4x4,3x3) form (csrc/conv_wino4.hip): forward with statistics and the data-gradient weights, against
+    torch's conv2d on CPU.  Its fp32 error is ~10x F(2x2,3x3)'s (transform constants up to 8 and 1/24), still
+    two orders inside the 1e-4 gate."""
+    g = torch.Generator().manual_seed(H * W + 1)
+    x = torch.randn(B, 64, H, W, generator=g).clamp_min(0)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    uf, ud = torch.empty(16, 4, 64, 36, device=DEV), torch.empty(16, 4, 64, 36, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
+    n = query("cova_conv3x3_wino4_num_partials", B, H, W)
+    out, part = torch.full((B, H, W, 64), 7.0, device=DEV), torch.empty(n, 2, 64, device=DEV)
+    call("cova_conv3x3_wino4", nhwc(x), uf, out, part, B, H, W)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    close(nchw(out), ref, 2e-5, "wino4 fwd")
+    close(part[:, 0].double().sum(0), ref.sum((0, 2, 3)), 1e-4, "wino4 stat sum")
+    close(part[:, 1].double().sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "wino4 stat sumsq")
+    dz = torch.randn(B, 64, H, W, generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    (F.conv2d(xr, w.double(), padding=1) * dz.double()).sum().backward()
+    dx = torch.empty(B, H, W, 64, device=DEV)
+    call("cova_conv3x3_wino4", nhwc(dz), ud, dx, None, B, H, W)
+    close(nchw(dx), xr.grad, 2e-5, "wino4 dgrad")

@@ -14,6 +14,12 @@
 //   then 36 MFMAs per wave with both operands from LDS (positions contiguous: one ds_read_b128 = 4 positions).
 #include "common.h"
 
+// Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
+// 2 no row stage, 4 no MFMAs, 8 no global -> LDS copies
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
+
 namespace {
 
 namespace w4 {
@@ -213,9 +219,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
         for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#ifndef W4_ABL
-#define W4_ABL 0
-#endif
 #pragma unroll 1
         for (int s = 0; s < 16; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;

@@ -15,7 +15,7 @@
 #include "common.h"
 
 // Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
-// 2 no row stage, 4 no MFMAs, 8 no global -> LDS copies
+// 2 no row stage, 4 no MFMAs, 8 no global -> LDS copies (16: no plane copies, 32: no weight copies)
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -225,8 +225,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             const int slot_nxt = slot == 2 ? 0 : slot + 1;
             // slot `slot` held planes(s), consumed by the previous iteration's column stage -> planes(s+3)
             if (!(W4_ABL & 8)) {
-                copy_u((s + 1) & 15, u_base + nxt * U_FLOATS * 4);
-                copy_planes(s + 3 < 16 ? tile : tile + (int)gridDim.x, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
+                if (!(W4_ABL & 32)) copy_u((s + 1) & 15, u_base + nxt * U_FLOATS * 4);
+                if (!(W4_ABL & 16))
+                    copy_planes(s + 3 < 16 ? tile : tile + (int)gridDim.x, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
             }
             if (!(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);      // planes(s+1)
             wait_weights();                                                     // U(s), requested one iteration ago
@@ -243,6 +244,14 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     acc[4 * q + 1] = mfma16x4(u4.y, v4.y, acc[4 * q + 1]);
                     acc[4 * q + 2] = mfma16x4(u4.z, v4.z, acc[4 * q + 2]);
                     acc[4 * q + 3] = mfma16x4(u4.w, v4.w, acc[4 * q + 3]);
+                }
+                // operand reads run three position quads ahead of the MFMAs that use them (left alone the scheduler
+                // issues each pair right in front of its wait: one LDS latency per 4 MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    if (q + 3 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
             wait_planes();                                                      // planes(s+2), requested two iterations ago

@@ -132,20 +132,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         for (int j = 0; j < 4; ++j) copy16_to_lds(ug + j * THREADS * 4, dst_bytes + (j * 8 + wave) * 1024);
         if (wave < 4) copy16_to_lds(ug + 4 * THREADS * 4, dst_bytes + (32 + wave) * 1024);
     };
-    // Waits on the copies (vmcnt retires in order; per chunk a wave issues U weight instructions, then P plane
-    // instructions: U = 5 on waves 0-3, 4 on waves 4-7; P = 2 on waves 0-1, 1 elsewhere).  Queue inside iteration s
-    // after its requests: [U(s), P(s+2)] from iteration s-1, then [U(s+1), P(s+3)].
-    //   wait_weights: U(s) has landed        <=> at most P + U + P = U + 2P instructions outstanding
-    //   wait_planes:  P(s+2) has landed      <=> at most U + P outstanding            (both: and lgkmcnt(0))
-    auto wait_weights = [&]() {
-        if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0079);          // 5 + 2*2
-        else if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0077);     // 5 + 2
-        else __builtin_amdgcn_s_waitcnt(0x0076);                   // 4 + 2
-    };
-    auto wait_planes = [&]() {
-        if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0077);          // 5 + 2
-        else if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0076);     // 5 + 1
-        else __builtin_amdgcn_s_waitcnt(0x0075);                   // 4 + 1
+    // Wait on the copies (vmcnt retires in order; per chunk a wave issues its weight instructions, then P plane
+    // instructions, P = 2 on waves 0-1 and 1 elsewhere): weights(s+1) -- and planes(s+2), requested one iteration
+    // earlier -- have landed when at most P instructions are outstanding; the planes(s+3) copy stays in flight.
+    auto wait_copies = [&]() {
+        if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0072);
+        else __builtin_amdgcn_s_waitcnt(0x0071);
     };
     // ---- stage items of this thread (e = 0, and e = 1 for threads < 256).
     // column stage: it = (tile*6 + c)*4 + ci -- the channel fastest, as the planes are [px][4];
@@ -229,15 +221,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 if (!(W4_ABL & 16))
                     copy_planes(s + 3 < 16 ? tile : tile + (int)gridDim.x, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
             }
-            if (!(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);      // planes(s+1)
-            wait_weights();                                                     // U(s), requested one iteration ago
-            asm volatile("s_barrier" ::: "memory");
-            if (!(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
-            if (!(W4_ABL & 4)) {   // 36 MFMAs of chunk s: D[co][tile] += U[co][ci] * V[ci][tile] per position
-                const float *ua = s_u + cur * U_FLOATS + (kq * 64 + cog * 16 + l15) * ROW;
-                const float *vb = s_v + cur * V_FLOATS + (kq * 32 + grp * 16 + l15) * ROW;
+            // position quads [q0, q1) of chunk s: D[co][tile] += U[co][ci] * V[ci][tile]
+            const float *ua = s_u + cur * U_FLOATS + (kq * 64 + cog * 16 + l15) * ROW;
+            const float *vb = s_v + cur * V_FLOATS + (kq * 32 + grp * 16 + l15) * ROW;
+            auto mfmas = [&](const int q0, const int q1) {
+                if (W4_ABL & 4) return;
 #pragma unroll
-                for (int q = 0; q < 9; ++q) {
+                for (int q = q0; q < q1; ++q) {
                     const float4 u4 = *reinterpret_cast<const float4 *>(ua + 4 * q);
                     const float4 v4 = *reinterpret_cast<const float4 *>(vb + 4 * q);
                     acc[4 * q + 0] = mfma16x4(u4.x, v4.x, acc[4 * q + 0]);
@@ -245,16 +235,20 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     acc[4 * q + 2] = mfma16x4(u4.z, v4.z, acc[4 * q + 2]);
                     acc[4 * q + 3] = mfma16x4(u4.w, v4.w, acc[4 * q + 3]);
                 }
-                // operand reads run three position quads ahead of the MFMAs that use them (left alone the scheduler
-                // issues each pair right in front of its wait: one LDS latency per 4 MFMAs)
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    if (q + 3 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-            }
-            wait_planes();                                                      // planes(s+2), requested two iterations ago
+            };
+            // The two waves of a SIMD (w and w + 4: tile groups 0 and 1) run the iteration in opposite order, so that
+            // one of them is always in its MFMAs while the other does transform work -- the barriers would otherwise
+            // line all eight waves up in the same phase and leave the matrix pipe idle during both stages.
+            // (the MFMA code exists once; only the stage calls, which do not touch the accumulators, sit under the
+            //  wave-uniform branches -- accumulator updates in both arms of a branch made the allocator spill them)
+            if (grp == 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);      // planes(s+1)
+            mfmas(0, 5);
+            if (grp != 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);
+            lds_barrier();
+            if (grp == 0 && !(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
+            mfmas(5, 9);
+            if (grp != 0 && !(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
+            wait_copies();                      // weights(s+1) and planes(s+2) have landed; planes(s+3) stays in flight
             asm volatile("s_barrier" ::: "memory");
             slot = slot_nxt;
         }

@@ -66,6 +66,8 @@ struct W4Args {
     const float *in, *u;
     float *out, *stat_part;
     int H, W, tiles_x, tiles_y, ntiles;
+    const float *pro_abc;       // PRO: the conv input is relu?(A[c]*in + C[c]) ([3][64] = A | unused | C), zero outside the image
+    int pro_relu;
 };
 
 // 256 zero bytes in global memory: halo pixels outside the image are fetched from here
@@ -94,13 +96,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // land and the planes (HBM) two.  768 stage items on 512 threads: waves 0-3 take two, waves 4-7 one -- the two waves
 // of a SIMD (w, w+4) together always three.  LDS: 3 x 9.8 (planes) + 18.6 (column stage) + 2 x 36.9 (weights)
 // + 2 x 18.4 (V) = 158.6 KB.
-template <bool STATS>
+template <bool STATS, bool PRO>
 __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const W4Args a)
 {
     using namespace w4;
     __shared__ __attribute__((aligned(16))) float s_in[3 * IN_FLOATS], s_tmp[TMP_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_u[2 * U_FLOATS], s_v[2 * V_FLOATS];
     float *s_red = s_tmp;                         // (after the tile loop)
+    __shared__ float s_pro[PRO ? 128 : 1];        // A | C of the affine-on-load prologue
+    if (PRO) {
+        if (threadIdx.x < 64) s_pro[threadIdx.x] = a.pro_abc[threadIdx.x];
+        else if (threadIdx.x < 128) s_pro[threadIdx.x] = a.pro_abc[64 + threadIdx.x];
+        __syncthreads();
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cog = wave & 3, grp = wave >> 2;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // ---- stage items of this thread (e = 0, and e = 1 for threads < 256).
     // column stage: it = (tile*6 + c)*4 + ci -- the channel fastest, as the planes are [px][4];
     // row stage:    it = (ci*32 + tile)*6 + i -- the channel slowest, as V rows are (ci, tile)
-    int col_src[2], col_dst[2], row_src[2], row_dst[2];
+    int col_src[2], col_dst[2], row_src[2], row_dst[2], col_x[2], col_y[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int it = tid + e * THREADS;
@@ -150,6 +158,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             const int ci = it & 3, tc = it >> 2, t = tc / 6, c = tc - t * 6;
             col_src[e] = ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + ci;      // + r * PW * 4
             col_dst[e] = ci * TMP_CI + t * 36 + c * 6;                           // + i (6 contiguous)
+            col_x[e] = 4 * (t & 7) + c - 1;                                      // image column / first row of the item,
+            col_y[e] = 4 * (t >> 3) - 1;                                         // relative to the tile origin
         }
         {
             const int i = it % 6, pt = it / 6, t = pt & 31, ci = pt >> 5;
@@ -157,7 +167,19 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             row_dst[e] = (ci * 32 + t) * ROW + 6 * i;                            // + j (6 contiguous)
         }
     }
-    auto column_stage = [&](const float *slot) {      // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c]
+    // PRO: rows of an item's column that lie inside the image (bit r), for the tile the planes belong to
+    auto row_mask = [&](int tile_, int e) -> unsigned {
+        if (tile_ >= a.ntiles) return 0u;
+        const int tx_ = tile_ % a.tiles_x, ty_ = (tile_ / a.tiles_x) % a.tiles_y;
+        const int gx = tx_ * TW + col_x[e], gy = ty_ * TH + col_y[e];
+        if (gx < 0 || gx >= W) return 0u;
+        unsigned m = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m |= (gy + r >= 0 && gy + r < H) ? (1u << r) : 0u;
+        return m;
+    };
+    // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c];  ch0 = first channel of the chunk, vm = row masks (PRO)
+    auto column_stage = [&](const float *slot, int ch0, const unsigned (&vm)[2]) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (e == 1 && tid >= 256) break;
@@ -165,6 +187,16 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             float d[6], o[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) d[r] = p[r * PW * 4];
+            if (PRO) {
+                const int ch = ch0 + ((tid + e * THREADS) & 3);
+                const float A = s_pro[ch], C = s_pro[64 + ch];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    float v = fmaf(A, d[r], C);
+                    if (a.pro_relu) v = fmaxf(v, 0.f);
+                    d[r] = ((vm[e] >> r) & 1u) ? v : 0.f;
+                }
+            }
             bt6(d, o);
             float *q = s_tmp + col_dst[e];
             *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
@@ -197,7 +229,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     copy_planes(tile, 2, in_base + 2 * IN_FLOATS * 4);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    column_stage(s_in);
+    unsigned vm_cur[2] = {0u, 0u}, vm_nxt[2] = {0u, 0u};
+    if (PRO) {
+        vm_cur[0] = row_mask(tile, 0);
+        vm_cur[1] = row_mask(tile, 1);
+    }
+    column_stage(s_in, 0, vm_cur);
     __syncthreads();
     row_stage(s_v);
     __syncthreads();
@@ -210,6 +247,10 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         f32x4 acc[36];
 #pragma unroll
         for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (PRO) {                                    // chunk 0 of the NEXT tile is transformed in this tile's last iteration
+            vm_nxt[0] = row_mask(tile + (int)gridDim.x, 0);
+            vm_nxt[1] = row_mask(tile + (int)gridDim.x, 1);
+        }
 
 #pragma unroll 1
         for (int s = 0; s < 16; ++s) {
@@ -241,9 +282,10 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             // line all eight waves up in the same phase and leave the matrix pipe idle during both stages.
             // (the MFMA code exists once; only the stage calls, which do not touch the accumulators, sit under the
             //  wave-uniform branches -- accumulator updates in both arms of a branch made the allocator spill them)
-            if (grp == 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);      // planes(s+1)
+            const int ch_nxt = 4 * ((s + 1) & 15);
+            if (grp == 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS, ch_nxt, s == 15 ? vm_nxt : vm_cur);   // planes(s+1)
             mfmas(0, 5);
-            if (grp != 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS);
+            if (grp != 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS, ch_nxt, s == 15 ? vm_nxt : vm_cur);
             lds_barrier();
             if (grp == 0 && !(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
             mfmas(5, 9);
@@ -252,6 +294,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             asm volatile("s_barrier" ::: "memory");
             slot = slot_nxt;
         }
+        if (PRO) { vm_cur[0] = vm_nxt[0]; vm_cur[1] = vm_nxt[1]; }
         // ---- output transform Y = A^T M A in registers: lane = (tile grp*16 + l15, channels cog*16 + kq*4 .. +3)
         const int t = grp * 16 + l15;
         const int oy0 = y0 + 4 * (t >> 3), ox0 = x0 + 4 * (t & 7);
@@ -376,12 +419,29 @@ COVA_API int cova_conv3x3_wino4(const float *in, const float *u, float *out, flo
 {
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
-    const W4Args a{in, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles};
+    const W4Args a{in, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, nullptr, 0};
     const int grid = cova_internal_persistent_grid2(ntiles, 1);
     if (stat_part)
-        hipLaunchKernelGGL(conv3x3_c64_wino4_kernel<true>, dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<true, false>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(conv3x3_c64_wino4_kernel<false>, dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<false, false>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// The same convolution on relu?(A[c]*in + C[c]) formed on load (pro_abc [3][64] = A | unused | C; zero padding stays
+// zero): a BatchNorm(+ReLU) folded into the consuming conv, as cova_conv3x3_wino_pro without a second tensor.
+COVA_API int cova_conv3x3_wino4_pro(const float *in, const float *pro_abc, int pro_relu, const float *u, float *out,
+                                    float *stat_part, int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(in && pro_abc && u && out && B > 0 && H > 0 && W > 0);
+    const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
+    const W4Args a{in, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu};
+    const int grid = cova_internal_persistent_grid2(ntiles, 1);
+    if (stat_part)
+        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<true, true>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<false, true>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

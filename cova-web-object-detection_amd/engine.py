@@ -289,6 +289,20 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     return feat, (sv if save else None)
 
 
+def wino4_conv(x, abc, relu, weight, out, B, H2, W2, want_stats):
+    """Experimental F(4x4,3x3) forward launch (csrc/conv_wino4.hip): conv3x3(relu?(A*x + C)) or conv3x3(x) with abc None.
+    Returns (stat partials or None, number of partial rows)."""
+    u4f, u4d = _empty((16, 4, 64, 36), x), _empty((16, 4, 64, 36), x)
+    call("cova_conv3x3_wino4_prep", weight, u4f, u4d)
+    n4 = query("cova_conv3x3_wino4_num_partials", B, H2, W2)
+    part4 = _empty((n4, 2, C64), x) if want_stats else None
+    if abc is None:
+        call("cova_conv3x3_wino4", x, u4f, out, part4, B, H2, W2)
+    else:
+        call("cova_conv3x3_wino4_pro", x, abc, 1 if relu else 0, u4f, out, part4, B, H2, W2)
+    return part4, n4
+
+
 def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     """layer1 of ResNet-18: two BasicBlocks (the reference's backbone, models.py:49-51)"""
     images = p1
@@ -324,18 +338,18 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
         if USE_WINO4 and USE_WINOGRAD and training:
-            # experimental F(4x4,3x3) form for the launches whose input is a materialised map (csrc/conv_wino4.hip)
-            u4f, u4d = _empty((16, 4, 64, 36), images), _empty((16, 4, 64, 36), images)
-            call("cova_conv3x3_wino4_prep", params[CONV3_KEYS[2 * blk] + ".weight"], u4f, u4d)
-            n4 = query("cova_conv3x3_wino4_num_partials", B, H2, W2)
-            part4 = _empty((n4, 2, C64), images)
-            call("cova_conv3x3_wino4", x, u4f, z1, part4, B, H2, W2)
+            # experimental F(4x4,3x3) form of the forward launches (csrc/conv_wino4.hip)
+            part4, n4 = wino4_conv(x, None, 0, params[CONV3_KEYS[2 * blk] + ".weight"], z1, B, H2, W2, True)
             bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part4, n4, R, unit="pages")
         else:
             conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
             bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
         z2 = _empty((B, H2, W2, C64), images)
-        if USE_WINOGRAD and FUSE_AFFINE:            # a1 = relu(bn1(z1)) formed on load
+        part_b, nt_b = part, nt
+        if USE_WINOGRAD and FUSE_AFFINE and USE_WINO4 and training:
+            a1 = None
+            part_b, nt_b = wino4_conv(z1, bna.abc, 1, params[CONV3_KEYS[2 * blk + 1] + ".weight"], z2, B, H2, W2, True)
+        elif USE_WINOGRAD and FUSE_AFFINE:          # a1 = relu(bn1(z1)) formed on load
             a1 = None
             call("cova_conv3x3_wino_pro", z1, None, bna.abc, 1, wf[2 * blk + 1][1], None, None, None,
                  None, None, None, None, z2, part, B, H2, W2)
@@ -343,7 +357,7 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             a1 = _empty((B, H2, W2, C64), images)
             call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
             conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
-        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R, unit="pages")
+        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part_b, nt_b, R, unit="pages")
         if blk == 1 and lazy_out and USE_WINOGRAD and FUSE_AFFINE:
             out = None
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
@@ -406,9 +420,13 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
         uf, s["ud"] = prep_wino(params[pre + "conv2.weight"], p1)
         part = _empty((nt, 2, C64), p1) if training else None
         s["z2"] = _empty((B, H2, W2, C64), p1)
-        call("cova_conv3x3_wino_pro", s["z1"], None, s["bn1"].abc, 1, uf, None, None, None, None, None, None,
-             None, s["z2"], part, B, H2, W2)
-        s["bn2"] = bn(pre + "bn2.", C64, part, nt)
+        if USE_WINO4 and training:
+            part4, n4 = wino4_conv(s["z1"], s["bn1"].abc, 1, params[pre + "conv2.weight"], s["z2"], B, H2, W2, True)
+            s["bn2"] = bn(pre + "bn2.", C64, part4, n4)
+        else:
+            call("cova_conv3x3_wino_pro", s["z1"], None, s["bn1"].abc, 1, uf, None, None, None, None, None, None,
+                 None, s["z2"], part, B, H2, W2)
+            s["bn2"] = bn(pre + "bn2.", C64, part, nt)
         part, n = stats(C64, C256)
         s["z3"] = _empty((B, H2, W2, C256), p1)
         conv1x1(s["z2"], None, s["bn2"].abc, 1, params[pre + "conv3.weight"], 0, s["z3"], part, R, C64, C256)

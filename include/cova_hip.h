@@ -121,6 +121,9 @@ int cova_conv3x3_wino4_num_partials(int B, int H, int W);
 int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
 int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_part /*nullable*/, int B, int H,
                        int W, void *stream);
+/* ... on relu?(A[c]*in + C[c]) formed on load (pro_abc [3][64] = A | unused | C), zero padding stays zero */
+int cova_conv3x3_wino4_pro(const float *in, const float *pro_abc, int pro_relu, const float *u, float *out,
+                           float *stat_part /*nullable*/, int B, int H, int W, void *stream);
 
 /* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
  * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.

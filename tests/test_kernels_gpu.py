@@ -780,3 +780,15 @@ def test_conv3x3_winograd_f4x4(B, H, W):
     dx = torch.empty(B, H, W, 64, device=DEV)
     call("cova_conv3x3_wino4", nhwc(dz), ud, dx, None, B, H, W)
     close(nchw(dx), xr.grad, 2e-5, "wino4 dgrad")
+    # affine + ReLU on load (zero padding must stay zero although relu(C) != 0)
+    z = torch.randn(B, 64, H, W, generator=g)
+    abc = torch.stack([torch.rand(64, generator=g) + 0.5, torch.zeros(64), torch.randn(64, generator=g) * 0.5 + 0.3])
+    for relu in (1, 0):
+        ain = abc[0].view(1, 64, 1, 1) * z + abc[2].view(1, 64, 1, 1)
+        if relu:
+            ain = ain.clamp_min(0)
+        refp = F.conv2d(ain.double(), w.double(), padding=1)
+        o3, p3 = torch.empty(B, H, W, 64, device=DEV), torch.empty(n, 2, 64, device=DEV)
+        call("cova_conv3x3_wino4_pro", nhwc(z), abc.to(DEV), relu, uf, o3, p3, B, H, W)
+        close(nchw(o3), refp, 2e-5, "wino4 prologue relu=%d" % relu)
+        close(p3[:, 0].double().sum(0), refp.sum((0, 2, 3)), 1e-4, "wino4 prologue stat sum")

@@ -120,19 +120,28 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int px1 = tid + THREADS;
     const int pr0 = tid / PW, pc0 = tid - pr0 * PW, pr1 = px1 / PW, pc1 = px1 - pr1 * PW;
     const unsigned in_base = (unsigned)(size_t)(lds_void *)s_in, u_base = (unsigned)(size_t)(lds_void *)s_u;
-    auto copy_planes = [&](int tile, int s, unsigned slot_bytes) {
-        if (tile >= a.ntiles) tile = a.ntiles - 1;               // past the end: a valid address, result unused
-        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
-        const float *base = a.in + (size_t)b * H * W * 64 + 4 * s;
+    // this thread's source pixels of a tile, channel 0 (out-of-image pixels: the zero page); computed once per tile,
+    // a chunk's copy only adds 16 s bytes
+    struct PlaneSrc { const float *p0, *p1; int step; };          // step = 4 floats per chunk, 0 for the zero page
+    auto plane_src = [&](int tile_) {
+        if (tile_ >= a.ntiles) tile_ = a.ntiles - 1;             // past the end: a valid address, result unused
+        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
+        const float *base = a.in + (size_t)b * H * W * 64;
         const int gy0 = ty * TH + pr0 - 1, gx0 = tx * TW + pc0 - 1;
         const int gy1 = ty * TH + pr1 - 1, gx1 = tx * TW + pc1 - 1;
         const bool in0 = gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W;
         const bool in1 = gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W;
-        const float *p0 = in0 ? base + ((size_t)gy0 * W + gx0) * 64 : g_w4_zero_page;
-        const float *p1 = in1 ? base + ((size_t)gy1 * W + gx1) * 64 : g_w4_zero_page;
+        PlaneSrc r;
+        // (the zero page holds 64 floats: the per-chunk offset 4 s <= 60 stays inside it)
+        r.p0 = in0 ? base + ((size_t)gy0 * W + gx0) * 64 : g_w4_zero_page;
+        r.p1 = in1 ? base + ((size_t)gy1 * W + gx1) * 64 : g_w4_zero_page;
+        r.step = 4;
+        return r;
+    };
+    auto copy_planes = [&](const PlaneSrc &src, int s, unsigned slot_bytes) {
         // lane i of a wave lands at (wave-uniform LDS base) + 16 i
-        copy16_to_lds(p0, slot_bytes + wave * 1024);
-        if (px1 < NPIX) copy16_to_lds(p1, slot_bytes + (8 + wave) * 1024);
+        copy16_to_lds(src.p0 + src.step * s, slot_bytes + wave * 1024);
+        if (px1 < NPIX) copy16_to_lds(src.p1 + src.step * s, slot_bytes + (8 + wave) * 1024);
     };
     auto copy_u = [&](int s, unsigned dst_bytes) {               // 2304 float4: 4.5 per thread, linear
         const float *ug = a.u + (size_t)s * U_FLOATS + tid * 4;
@@ -223,10 +232,11 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     // ---- prime the pipeline: V(0), U(0), planes(1), planes(2) in LDS
-    copy_planes(tile, 0, in_base);
+    PlaneSrc src_cur = plane_src(tile), src_nxt = src_cur;
+    copy_planes(src_cur, 0, in_base);
     copy_u(0, u_base);
-    copy_planes(tile, 1, in_base + IN_FLOATS * 4);
-    copy_planes(tile, 2, in_base + 2 * IN_FLOATS * 4);
+    copy_planes(src_cur, 1, in_base + IN_FLOATS * 4);
+    copy_planes(src_cur, 2, in_base + 2 * IN_FLOATS * 4);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     unsigned vm_cur[2] = {0u, 0u}, vm_nxt[2] = {0u, 0u};
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         f32x4 acc[36];
 #pragma unroll
         for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        src_nxt = plane_src(tile + (int)gridDim.x);
         if (PRO) {                                    // chunk 0 of the NEXT tile is transformed in this tile's last iteration
             vm_nxt[0] = row_mask(tile + (int)gridDim.x, 0);
             vm_nxt[1] = row_mask(tile + (int)gridDim.x, 1);
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             if (!(W4_ABL & 8)) {
                 if (!(W4_ABL & 32)) copy_u((s + 1) & 15, u_base + nxt * U_FLOATS * 4);
                 if (!(W4_ABL & 16))
-                    copy_planes(s + 3 < 16 ? tile : tile + (int)gridDim.x, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
+                    copy_planes(s + 3 < 16 ? src_cur : src_nxt, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
             }
             // position quads [q0, q1) of chunk s: D[co][tile] += U[co][ci] * V[ci][tile]
             const float *ua = s_u + cur * U_FLOATS + (kq * 64 + cog * 16 + l15) * ROW;
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             asm volatile("s_barrier" ::: "memory");
             slot = slot_nxt;
         }
+        src_cur = src_nxt;
         if (PRO) { vm_cur[0] = vm_nxt[0]; vm_cur[1] = vm_nxt[1]; }
         // ---- output transform Y = A^T M A in registers: lane = (tile grp*16 + l15, channels cog*16 + kq*4 .. +3)
         const int t = grp * 16 + l15;

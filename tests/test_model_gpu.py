@@ -584,3 +584,30 @@ def test_input_layout_and_index_dtype_do_not_change_the_result():
     ref = O.forward(O.clone_state_dict(sd), batch["images"], lone, batch["additional_feats"],
                     batch["context_indices"], cfg, False, None)
     assert relerr(got.cpu(), ref) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cova_h64_n90", "cova_h128_ragged"])
+def test_experimental_f4x4_forward_keeps_reference_parity(name, monkeypatch):
+    """The opt-in F(4x4,3x3) forward launches (engine.USE_WINO4, csrc/conv_wino4.hip: plain and affine-on-load
+    inputs, batch statistics) against the same reference fixtures and the forced-routing oracle, at the same
+    bounds as the default path."""
+    monkeypatch.setattr(engine, "USE_WINO4", True)
+    fx, cfg, sd, batch = load_case(name)
+    img_h = int(fx["meta/img_h"])
+    args = dev_batch(batch)
+    m = build(cfg, img_h, sd)
+    m.train()
+    logits = m(*args)
+    routing = routing_from_saved(logits.grad_fn.sv)
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
+    loss.backward()
+    assert relerr(logits.detach().cpu(), fx["train/logits"]) < 2e-4
+    assert abs(loss.item() - float(fx["train/loss"])) <= 2e-4 * abs(float(fx["train/loss"]))
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    _, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
+                                             batch["context_indices"], batch["labels"], cfg, None, routing)
+    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    for k, buf in m.named_buffers():
+        if "buf/" + k in fx:
+            assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k

@@ -5,17 +5,30 @@
 //
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          B^T 6x6, G 6x3, A^T 4x6 (Lavin & Gray 2015)
 //
-// Why this is a different kernel and not a parameter of conv_wino.hip: with 36 transform positions a wave can own
-// 16 output channels x 16 tiles at most (36 accumulators of v_mfma_f32_16x16x4_f32 = 144 registers), so four waves
-// share every tile and forming B^T d B per wave in registers would repeat the 144-FMA patch transform four times.
-// The transformed input is therefore formed ONCE per block and staged through LDS:
-//   block = 512 threads, output tile 16 x 32 px = 4 x 8 Winograd tiles; wave w = (channel group w & 3, tile group w >> 2);
-//   per 4-channel chunk:  planes (18 x 34 px halo tile, 4 channels) -> column stage -> row stage -> V[36][4][32] in LDS,
-//   then 36 MFMAs per wave with both operands from LDS (positions contiguous: one ds_read_b128 = 4 positions).
+// Mapping (round 3; the round-2 kernel kept both MFMA operands in LDS and was bound by LDS bandwidth and by two block
+// barriers per 4-channel chunk):
+//   * block = 512 threads, output tile 8 x 32 px = 2 x 8 Winograd tiles (16 tiles = one MFMA column block);
+//   * the 36 transform positions are SPLIT between the two waves of a SIMD: wave w = (channel group cog = w & 3: 16
+//     output channels, position half ph = w >> 2: transform rows i = 3 ph .. 3 ph + 2) holds 18 accumulators of
+//     v_mfma_f32_16x16x4_f32 = 72 registers.  The output transform is separable, A^T M A = sum over the two row halves,
+//     so each wave transforms its half in registers and the pair swaps half of the 16 partial outputs through LDS once
+//     per tile (8 KB per wave);
+//   * with 72 accumulator registers there is room to keep the transformed WEIGHTS out of LDS altogether: a wave's
+//     operand U[16 co][8 ci][18 positions] is 36 registers per 8-channel chunk, fetched straight from L2
+//     (9 global_load_dwordx4 per wave and chunk, 1 KB contiguous each: the prep kernel writes the register image) with a
+//     lead of TWO chunks (72 registers);
+//   * the transformed input V = B^T d B is formed once per block through LDS in two stages (column stage, row stage:
+//     768 + 768 six-point transforms per 8-channel chunk, three per thread), from planes that arrive as
+//     global -> LDS copies (global_load_lds_dwordx4: no registers);
+//   * ONE block barrier per 8-channel chunk: column stage (chunk g+2), row stage (chunk g+1) and the 36 MFMAs of chunk g
+//     run in the same iteration on double-buffered intermediates.
+// LDS traffic per 8-channel chunk and 16 tiles: 74 KB of V operand reads + 73 KB of stage traffic + 11 KB of copies
+// (round 2: 147 + 73 + 47 KB per 4 channels x 32 tiles).
 #include "common.h"
+#include <type_traits>
 
 // Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
-// 2 no row stage, 4 no MFMAs, 8 no global -> LDS copies (16: no plane copies, 32: no weight copies)
+// 2 no row stage, 4 no MFMAs, 8 no plane copies, 16 no weight loads (stale registers), 32 no tile epilogue
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -23,15 +36,16 @@
 namespace {
 
 namespace w4 {
-constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;      // 612 halo pixels
+constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;      // 340 halo pixels
 constexpr int THREADS = 512;
-constexpr int ROW = 36;                        // floats per operand row = the 36 positions (9 ds_read_b128; 9 x 16 B is an
-                                               // odd slot stride: conflict-free without padding)
-constexpr int U_FLOATS = 4 * 64 * ROW;         // rows (k, co): 9,216 floats = 36.9 KB
-constexpr int V_FLOATS = 4 * 32 * ROW;         // rows (k, tile): 4,608 floats = 18.4 KB
-constexpr int IN_FLOATS = 4 * NPIX;            // one chunk of planes, pixel-major [px][4]
-constexpr int TMP_CI = 32 * 36 + 8;            // column-stage result [ci][tile][c][i]; +8: the four channels of an
-constexpr int TMP_FLOATS = 4 * TMP_CI;         // instruction start 8 banks apart
+constexpr int SUB_FLOATS = NPIX * 4;           // one 4-channel group of a chunk, pixel-major [px][4]
+constexpr int SLOT_FLOATS = 2 * SUB_FLOATS;    // planes of one 8-channel chunk: 10,880 B
+constexpr int TMP_CI = 16 * 36 + 8;            // column-stage result [ci][tile][c][i]; +8: the channels of an
+constexpr int TMP_FLOATS = 8 * TMP_CI;         // instruction start 8 banks apart; 18,688 B
+constexpr int VROW = 44;                       // V row (ci, tile): [i 0..2: 18 floats, 2 pad | i 3..5: 18 floats, 6 pad];
+                                               // 11 x 16 B is an odd slot stride: conflict-free ds_read_b128
+constexpr int V_FLOATS = 8 * 16 * VROW;        // 22,528 B
+constexpr int U_FLOATS = 8 * 8 * 9 * 64 * 4;   // [chunk 8][wave 8][quad 9][lane 64][4]: 147,456 floats
 }  // namespace w4
 
 __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c)
@@ -62,12 +76,20 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
     o[3] = fmaf(8.f, d2, d1) + m[5];
 }
 
+// Epilogue of the data-gradient launches (same contract as conv_wino.hip's BnBwdEpiW): ReLU mask + BatchNorm-backward
+// sums.  The mask is act > 0, or, when the activation was never materialised (act == nullptr),
+// fma(msc, z, msh) > 0 -- the same expression the affine-on-load prologues evaluate.
+struct W4Epi {
+    const float *addend, *act, *z, *mean, *invstd, *msc, *msh;
+};
+
 struct W4Args {
-    const float *in, *u;
+    const float *in, *in2, *u;
     float *out, *stat_part;
     int H, W, tiles_x, tiles_y, ntiles;
-    const float *pro_abc;       // PRO: the conv input is relu?(A[c]*in + C[c]) ([3][64] = A | unused | C), zero outside the image
-    int pro_relu;
+    const float *pro_abc;       // PRO: the conv input is f(A[c]*in + B[c]*in2 + C[c]) ([3][64] = A | B | C), zero outside
+    int pro_relu;               // the image; f = ReLU or identity
+    W4Epi epi;
 };
 
 // 256 zero bytes in global memory: halo pixels outside the image are fetched from here
@@ -85,139 +107,177 @@ __device__ __forceinline__ void copy16_to_lds(const float *gptr, unsigned lds_ba
 }
 
 // Barrier that orders LDS accesses only: this wave's ds_writes are complete (lgkmcnt(0)) while global -> LDS copies
-// stay in flight.  __syncthreads() is a release fence over LDS, and a pending copy IS an LDS store: it waits vmcnt(0).
+// and weight loads stay in flight.  __syncthreads() is a release fence over LDS, and a pending copy IS an LDS store:
+// it waits vmcnt(0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Software pipeline (one iteration = one 4-channel chunk s of a tile; the chunk counter runs across tiles):
-//   request weights(s+1) and planes(s+3) as global -> LDS copies (global_load_lds_dwordx4: no registers; the weight
-//   chunk in global memory IS the LDS image) | column stage(s+1) | LDS barrier | row stage(s+1) -> V[(s+1)&1] ,
-//   36 MFMAs of chunk s from U[s&1], V[s&1] | wait for weights(s+1) -- the planes copy stays in flight | barrier
-// so a wave's transform work runs under the MFMAs of the other wave on its SIMD, the weights (L2) have one chunk to
-// land and the planes (HBM) two.  768 stage items on 512 threads: waves 0-3 take two, waves 4-7 one -- the two waves
-// of a SIMD (w, w+4) together always three.  LDS: 3 x 9.8 (planes) + 18.6 (column stage) + 2 x 36.9 (weights)
-// + 2 x 18.4 (V) = 158.6 KB.
-template <bool STATS, bool PRO>
+// Software pipeline, one iteration = one 8-channel chunk g of the block's chunk stream (8 chunks per tile, the stream
+// runs across tiles):
+//   request planes(g+4) as global -> LDS copies (ring of 3 slots) | column stage(g+2): planes -> tmp[g & 1] |
+//   row stage(g+1): tmp[(g+1) & 1] -> V[(g+1) & 1] | 36 MFMAs of chunk g from V[g & 1] and the weight registers of
+//   chunk g, each weight quad re-requested for chunk g+2 right after its last use | wait for planes(g+3) | barrier.
+// vmcnt retires in order, so waiting for a weight load also waits for every older plane copy: the copies' time of
+// flight equals the weights' lead -- two iterations.  Waves 0-3 (position half 0) run stages then MFMAs, waves 4-7 MFMAs
+// then stages, so that on every SIMD one wave is in its MFMAs while the other does transform work.
+// BN: 0 plain (+ statistics if STATS), 1 = ReLU mask from z + BatchNorm-backward sums, 2 = mask from act + sums.
+template <bool STATS, int PRO, bool ADD, int BN>
 __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const W4Args a)
 {
     using namespace w4;
-    __shared__ __attribute__((aligned(16))) float s_in[3 * IN_FLOATS], s_tmp[TMP_FLOATS];
-    __shared__ __attribute__((aligned(16))) float s_u[2 * U_FLOATS], s_v[2 * V_FLOATS];
-    float *s_red = s_tmp;                         // (after the tile loop)
-    __shared__ float s_pro[PRO ? 128 : 1];        // A | C of the affine-on-load prologue
-    if (PRO) {
-        if (threadIdx.x < 64) s_pro[threadIdx.x] = a.pro_abc[threadIdx.x];
-        else if (threadIdx.x < 128) s_pro[threadIdx.x] = a.pro_abc[64 + threadIdx.x];
-        __syncthreads();
-    }
+    constexpr int NSLOT = 3;
+    constexpr int IN_FLOATS = NSLOT * SLOT_FLOATS;
+    // tmp[0] and V[1] are adjacent: both are idle at a tile boundary and carry the pair exchange of the output transform
+    __shared__ __attribute__((aligned(16))) float lds[(PRO == 2 ? 2 : 1) * IN_FLOATS + 2 * TMP_FLOATS + 2 * V_FLOATS];
+    __shared__ float s_pro[PRO ? 192 : 1];        // A | B | C of the affine-on-load prologue
+    __shared__ float s_red[STATS ? 256 : 1];
+    float *s_in = lds;
+    float *s_in2 = lds + IN_FLOATS;               // (PRO == 2)
+    float *s_tmp1 = lds + (PRO == 2 ? 2 : 1) * IN_FLOATS;
+    float *s_tmp0 = s_tmp1 + TMP_FLOATS;
+    float *s_v1 = s_tmp0 + TMP_FLOATS;
+    float *s_v0 = s_v1 + V_FLOATS;
+    float *s_x = s_tmp0;                          // exchange area: TMP_FLOATS + V_FLOATS = 41 KB >= 32 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cog = wave & 3, grp = wave >> 2;
+    const int cog = wave & 3, ph = wave >> 2;
     const int l15 = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W;
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PRO) {
+        if (tid < 192) s_pro[tid] = a.pro_abc[tid];
+        __syncthreads();
+    }
 
-    // ---- copies.  planes: pixel-major [px][4 channels]; thread px (and px + 512 for threads < 100)
-    const int px1 = tid + THREADS;
-    const int pr0 = tid / PW, pc0 = tid - pr0 * PW, pr1 = px1 / PW, pc1 = px1 - pr1 * PW;
-    const unsigned in_base = (unsigned)(size_t)(lds_void *)s_in, u_base = (unsigned)(size_t)(lds_void *)s_u;
-    // this thread's source pixels of a tile, channel 0 (out-of-image pixels: the zero page); computed once per tile,
-    // a chunk's copy only adds 16 s bytes
-    struct PlaneSrc { const float *p0, *p1; int step; };          // step = 4 floats per chunk, 0 for the zero page
-    auto plane_src = [&](int tile_) {
-        if (tile_ >= a.ntiles) tile_ = a.ntiles - 1;             // past the end: a valid address, result unused
+    // ---- the tiles of this block (XCD-aware order: consecutive blocks of an XCD take consecutive tiles)
+    int first = blockIdx.x;
+    if ((gridDim.x & 7) == 0) first = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (first >= a.ntiles) return;
+    const int nk = (a.ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this block
+    const int G = nk * 8;                                                          // chunks of this block
+    auto tile_of = [&](int k) { return first + (k < nk ? k : nk - 1) * (int)gridDim.x; };   // past the end: a valid tile
+
+    // ---- plane copies.  A chunk = 2 groups of 4 channels x 340 pixels = 12 wave instructions of 64 pixels x 16 B:
+    // instruction j = (group j / 6, pixel block j % 6); wave w issues j = w and, for w < 4, j = w + 8.
+    const int jA = wave, jB = wave + 8;
+    const int kgA = jA / 6, pgA = jA - 6 * kgA, pgB = jB - 6;                      // (kgB = 1)
+    const int pxA = pgA * 64 + lane, pxB = pgB * 64 + lane;
+    const unsigned in_base = (unsigned)(size_t)(lds_void *)s_in, in2_base = (unsigned)(size_t)(lds_void *)s_in2;
+    const unsigned dstA = kgA * (SUB_FLOATS * 4) + pgA * 1024, dstB = SUB_FLOATS * 4 + pgB * 1024;
+    const float *srcA = g_w4_zero_page, *srcB = g_w4_zero_page, *srcA2 = g_w4_zero_page, *srcB2 = g_w4_zero_page;
+    // this thread's source pixels of a tile (channel 0; out-of-image pixels: the zero page)
+    auto plane_src = [&](int k) {
+        const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
-        const float *base = a.in + (size_t)b * H * W * 64;
-        const int gy0 = ty * TH + pr0 - 1, gx0 = tx * TW + pc0 - 1;
-        const int gy1 = ty * TH + pr1 - 1, gx1 = tx * TW + pc1 - 1;
-        const bool in0 = gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W;
-        const bool in1 = gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W;
-        PlaneSrc r;
-        // (the zero page holds 64 floats: the per-chunk offset 4 s <= 60 stays inside it)
-        r.p0 = in0 ? base + ((size_t)gy0 * W + gx0) * 64 : g_w4_zero_page;
-        r.p1 = in1 ? base + ((size_t)gy1 * W + gx1) * 64 : g_w4_zero_page;
-        r.step = 4;
-        return r;
+        const size_t img = (size_t)b * H * W * 64;
+        const int rA = pxA / PW, cA = pxA - rA * PW, rB = pxB / PW, cB = pxB - rB * PW;
+        const int gyA = ty * TH + rA - 1, gxA = tx * TW + cA - 1, gyB = ty * TH + rB - 1, gxB = tx * TW + cB - 1;
+        const bool inA = gyA >= 0 && gyA < H && gxA >= 0 && gxA < W, inB = gyB >= 0 && gyB < H && gxB >= 0 && gxB < W;
+        const size_t oA = img + ((size_t)gyA * W + gxA) * 64 + 4 * kgA, oB = img + ((size_t)gyB * W + gxB) * 64 + 4;
+        // (the zero page holds 64 floats: the per-chunk offset 8 s + 4 <= 60 stays inside it)
+        srcA = inA ? a.in + oA : g_w4_zero_page + 4 * kgA;
+        srcB = inB ? a.in + oB : g_w4_zero_page + 4;
+        if (PRO == 2) {
+            srcA2 = inA ? a.in2 + oA : g_w4_zero_page + 4 * kgA;
+            srcB2 = inB ? a.in2 + oB : g_w4_zero_page + 4;
+        }
     };
-    auto copy_planes = [&](const PlaneSrc &src, int s, unsigned slot_bytes) {
-        // lane i of a wave lands at (wave-uniform LDS base) + 16 i
-        copy16_to_lds(src.p0 + src.step * s, slot_bytes + wave * 1024);
-        if (px1 < NPIX) copy16_to_lds(src.p1 + src.step * s, slot_bytes + (8 + wave) * 1024);
+    auto copy_planes = [&](int s, int slot) {       // chunk s (0..7) of the tile plane_src() was called for
+        if (W4_ABL & 8) return;
+        const unsigned sb = (unsigned)slot * (SLOT_FLOATS * 4);
+        if (pxA < NPIX) copy16_to_lds(srcA + 8 * s, in_base + sb + dstA);
+        if (wave < 4 && pxB < NPIX) copy16_to_lds(srcB + 8 * s, in_base + sb + dstB);
+        if (PRO == 2) {
+            if (pxA < NPIX) copy16_to_lds(srcA2 + 8 * s, in2_base + sb + dstA);
+            if (wave < 4 && pxB < NPIX) copy16_to_lds(srcB2 + 8 * s, in2_base + sb + dstB);
+        }
     };
-    auto copy_u = [&](int s, unsigned dst_bytes) {               // 2304 float4: 4.5 per thread, linear
-        const float *ug = a.u + (size_t)s * U_FLOATS + tid * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) copy16_to_lds(ug + j * THREADS * 4, dst_bytes + (j * 8 + wave) * 1024);
-        if (wave < 4) copy16_to_lds(ug + 4 * THREADS * 4, dst_bytes + (32 + wave) * 1024);
+    // Plane copies issued per iteration: P = 2 on waves 0-3, 1 on waves 4-7 (twice that with a second tensor).  At the end
+    // of iteration g the copy of planes(g+3), issued at the top of iteration g-1, must have landed: behind it in the queue
+    // are the 9 weight loads of iteration g-1, the copies of iteration g and the 9 weight loads of iteration g.
+    auto wait_planes = [&]() {
+        constexpr int M = PRO == 2 ? 2 : 1;
+        if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + 2 * M) & 15) | (((18 + 2 * M) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + M) & 15) | (((18 + M) >> 4) << 14));
     };
-    // Wait on the copies (vmcnt retires in order; per chunk a wave issues its weight instructions, then P plane
-    // instructions, P = 2 on waves 0-1 and 1 elsewhere): weights(s+1) -- and planes(s+2), requested one iteration
-    // earlier -- have landed when at most P instructions are outstanding; the planes(s+3) copy stays in flight.
-    auto wait_copies = [&]() {
-        if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0072);
-        else __builtin_amdgcn_s_waitcnt(0x0071);
-    };
-    // ---- stage items of this thread (e = 0, and e = 1 for threads < 256).
-    // column stage: it = (tile*6 + c)*4 + ci -- the channel fastest, as the planes are [px][4];
-    // row stage:    it = (ci*32 + tile)*6 + i -- the channel slowest, as V rows are (ci, tile)
-    int col_src[2], col_dst[2], row_src[2], row_dst[2], col_x[2], col_y[2];
+
+    // ---- stage items of this thread.
+    // column stage, 768 items it = ((kg*16 + tile)*6 + c)*4 + cl (the channel fastest, as the planes are [px][4]):
+    //   e = 0: it = tid, e = 1: it = 512 + tid (threads < 256)
+    // row stage, 768 items it = ((ci*16 + tile)*6 + i (the channel slowest, as V rows are (ci, tile)):
+    //   e = 0: it = tid, e = 1: it = 256 + tid (threads >= 256)
+    int col_src[2], col_dst[2], col_x[2], col_y[2], col_ch[2], row_src[2], row_dst[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int it = tid + e * THREADS;
         {
-            const int ci = it & 3, tc = it >> 2, t = tc / 6, c = tc - t * 6;
-            col_src[e] = ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + ci;      // + r * PW * 4
-            col_dst[e] = ci * TMP_CI + t * 36 + c * 6;                           // + i (6 contiguous)
-            col_x[e] = 4 * (t & 7) + c - 1;                                      // image column / first row of the item,
-            col_y[e] = 4 * (t >> 3) - 1;                                         // relative to the tile origin
+            const int it = tid + e * THREADS;
+            const int cl = it & 3, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15, kg = tt >> 4;
+            col_src[e] = kg * SUB_FLOATS + ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + cl;      // + r * PW * 4
+            col_dst[e] = (kg * 4 + cl) * TMP_CI + t * 36 + c * 6;                                 // + i (6 contiguous)
+            col_x[e] = 4 * (t & 7) + c - 1;            // image column / first row of the item, relative to the tile origin
+            col_y[e] = 4 * (t >> 3) - 1;
+            col_ch[e] = kg * 4 + cl;
         }
         {
-            const int i = it % 6, pt = it / 6, t = pt & 31, ci = pt >> 5;
-            row_src[e] = ci * TMP_CI + t * 36 + i;                               // + c * 6
-            row_dst[e] = (ci * 32 + t) * ROW + 6 * i;                            // + j (6 contiguous)
+            const int it = tid + e * 256;
+            const int i = it % 6, rt = it / 6, t = rt & 15, ci = rt >> 4;
+            row_src[e] = ci * TMP_CI + t * 36 + i;                                                // + c * 6
+            row_dst[e] = (ci * 16 + t) * VROW + (i < 3 ? 6 * i : 20 + 6 * (i - 3));               // + j (6 contiguous)
         }
     }
+    const bool col2 = tid < 256, row2 = tid >= 256;
     // PRO: rows of an item's column that lie inside the image (bit r), for the tile the planes belong to
-    auto row_mask = [&](int tile_, int e) -> unsigned {
-        if (tile_ >= a.ntiles) return 0u;
+    unsigned vm[2] = {0u, 0u};
+    auto row_masks = [&](int k) {
+        const int tile_ = tile_of(k);
         const int tx_ = tile_ % a.tiles_x, ty_ = (tile_ / a.tiles_x) % a.tiles_y;
-        const int gx = tx_ * TW + col_x[e], gy = ty_ * TH + col_y[e];
-        if (gx < 0 || gx >= W) return 0u;
-        unsigned m = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) m |= (gy + r >= 0 && gy + r < H) ? (1u << r) : 0u;
-        return m;
-    };
-    // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c];  ch0 = first channel of the chunk, vm = row masks (PRO)
-    auto column_stage = [&](const float *slot, int ch0, const unsigned (&vm)[2]) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (e == 1 && tid >= 256) break;
-            const float *p = slot + col_src[e];
+            const int gx = tx_ * TW + col_x[e], gy = ty_ * TH + col_y[e];
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m |= (gy + r >= 0 && gy + r < H) ? (1u << r) : 0u;
+            vm[e] = (gx < 0 || gx >= W) ? 0u : m;
+        }
+    };
+    // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c];  s = chunk of the tile (prologue channel 8 s + ci)
+    auto column_stage = [&](int slot, int s, float *tmp) {
+        if (W4_ABL & 1) return;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && !col2) break;
+            const float *p = s_in + slot * SLOT_FLOATS + col_src[e];
             float d[6], o[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) d[r] = p[r * PW * 4];
             if (PRO) {
-                const int ch = ch0 + ((tid + e * THREADS) & 3);
-                const float A = s_pro[ch], C = s_pro[64 + ch];
+                const int ch = 8 * s + col_ch[e];
+                const float A = s_pro[ch], C = s_pro[128 + ch];
+                float w2[6];
+                if (PRO == 2) {
+                    const float *p2 = s_in2 + slot * SLOT_FLOATS + col_src[e];
+                    const float Bc = s_pro[64 + ch];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) w2[r] = fmaf(Bc, p2[r * PW * 4], C);
+                }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
-                    float v = fmaf(A, d[r], C);
+                    float v = fmaf(A, d[r], PRO == 2 ? w2[r] : C);      // same expression as conv_wino.hip's prologue
                     if (a.pro_relu) v = fmaxf(v, 0.f);
                     d[r] = ((vm[e] >> r) & 1u) ? v : 0.f;
                 }
             }
             bt6(d, o);
-            float *q = s_tmp + col_dst[e];
+            float *q = tmp + col_dst[e];
             *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
             *reinterpret_cast<float2 *>(q + 2) = make_float2(o[2], o[3]);
             *reinterpret_cast<float2 *>(q + 4) = make_float2(o[4], o[5]);
         }
     };
-    auto row_stage = [&](float *vdst) {               // V[(ci, tile)][6i + j] = sum_c tmp[c][i] Bt[j][c]
+    auto row_stage = [&](const float *tmp, float *vdst) {               // V[(ci, tile)][i][j] = sum_c tmp[c][i] Bt[j][c]
+        if (W4_ABL & 2) return;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (e == 1 && tid >= 256) break;
-            const float *p = s_tmp + row_src[e];
+            if (e == 1 && !row2) break;
+            const float *p = tmp + row_src[e];
             float d[6], o[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) d[c] = p[c * 6];
@@ -229,139 +289,240 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
-    // ---- prime the pipeline: V(0), U(0), planes(1), planes(2) in LDS
-    PlaneSrc src_cur = plane_src(tile), src_nxt = src_cur;
-    copy_planes(src_cur, 0, in_base);
-    copy_u(0, u_base);
-    copy_planes(src_cur, 1, in_base + IN_FLOATS * 4);
-    copy_planes(src_cur, 2, in_base + 2 * IN_FLOATS * 4);
+    // ---- weights: 9 float4 per lane and chunk (the prep kernel wrote the register image: wave-contiguous 1 KB rows)
+    const float4 *ug = reinterpret_cast<const float4 *>(a.u) + (size_t)wave * (9 * 64) + lane;
+    auto u_ptr = [&](int s) { return ug + (size_t)(s & 7) * (8 * 9 * 64); };
+    float Ua[36], Ub[36];
+    auto load_u = [&](float (&U)[36], int s) {
+        const float4 *p = u_ptr(s);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float4 t = p[q * 64];
+            U[4 * q] = t.x; U[4 * q + 1] = t.y; U[4 * q + 2] = t.z; U[4 * q + 3] = t.w;
+        }
+    };
+
+    // ---- prime the pipeline: planes(0..2) copied, weights(0), weights(1) requested
+    plane_src(0);
+    copy_planes(0, 0);
+    copy_planes(1, 1);
+    copy_planes(2, 2);
+    load_u(Ua, 0);
+    load_u(Ub, 1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    unsigned vm_cur[2] = {0u, 0u}, vm_nxt[2] = {0u, 0u};
-    if (PRO) {
-        vm_cur[0] = row_mask(tile, 0);
-        vm_cur[1] = row_mask(tile, 1);
-    }
-    column_stage(s_in, 0, vm_cur);
+    if (PRO) row_masks(0);
+    column_stage(0, 0, s_tmp0);
+    column_stage(1, 1, s_tmp1);
     __syncthreads();
-    row_stage(s_v);
+    row_stage(s_tmp0, s_v0);
+    copy_planes(3, 0);                      // slot 0 has been consumed (barrier above)
+    __builtin_amdgcn_s_waitcnt(0);          // (one-time: the steady-state wait counts assume two iterations of history)
     __syncthreads();
 
-    int slot = 0;                                     // planes ring: slot of the current chunk = (chunk counter) mod 3
-    for (; tile < a.ntiles; tile += gridDim.x) {
-        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
-        const size_t img = (size_t)b * H * W * 64;
-        f32x4 acc[36];
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[18];
 #pragma unroll
-        for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        src_nxt = plane_src(tile + (int)gridDim.x);
-        if (PRO) {                                    // chunk 0 of the NEXT tile is transformed in this tile's last iteration
-            vm_nxt[0] = row_mask(tile + (int)gridDim.x, 0);
-            vm_nxt[1] = row_mask(tile + (int)gridDim.x, 1);
-        }
+    for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // V operand rows of this lane: (ci = kg*4 + kq, tile l15), floats ph*20 .. ph*20 + 17
+    const int v_off = (kq * 16 + l15) * VROW + ph * 20;
 
-#pragma unroll 1
-        for (int s = 0; s < 16; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            const int slot_nxt = slot == 2 ? 0 : slot + 1;
-            // slot `slot` held planes(s), consumed by the previous iteration's column stage -> planes(s+3)
-            if (!(W4_ABL & 8)) {
-                if (!(W4_ABL & 32)) copy_u((s + 1) & 15, u_base + nxt * U_FLOATS * 4);
-                if (!(W4_ABL & 16))
-                    copy_planes(s + 3 < 16 ? src_cur : src_nxt, (s + 3) & 15, in_base + slot * IN_FLOATS * 4);
-            }
-            // position quads [q0, q1) of chunk s: D[co][tile] += U[co][ci] * V[ci][tile]
-            const float *ua = s_u + cur * U_FLOATS + (kq * 64 + cog * 16 + l15) * ROW;
-            const float *vb = s_v + cur * V_FLOATS + (kq * 32 + grp * 16 + l15) * ROW;
-            auto mfmas = [&](const int q0, const int q1) {
-                if (W4_ABL & 4) return;
+    // one iteration; PAR = g & 1 (compile time: buffers and weight registers are static)
+    auto iteration = [&](const int g, const int slot, auto par, float (&U)[36]) {
+        constexpr int PAR = decltype(par)::value;
+        float *tmp_w = PAR ? s_tmp1 : s_tmp0;               // column stage (chunk g+2) writes tmp[g & 1]
+        const float *tmp_r = PAR ? s_tmp0 : s_tmp1;         // row stage (chunk g+1) reads tmp[(g+1) & 1]
+        float *v_w = PAR ? s_v0 : s_v1;                     //   and writes V[(g+1) & 1]
+        const float *v_r = (PAR ? s_v1 : s_v0) + v_off;     // MFMAs of chunk g read V[g & 1]
+        const int slot1 = slot == NSLOT - 1 ? 0 : slot + 1, slot2 = slot1 == NSLOT - 1 ? 0 : slot1 + 1;
+        // planes(g+4) -> the slot of planes(g+1), consumed by the previous iteration's column stage
+        if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
+        copy_planes((g + 4) & 7, slot1);
+        if (PRO && ((g + 2) & 7) == 0) row_masks((g + 2) >> 3);
+        auto stages = [&]() {
+            column_stage(slot2, (g + 2) & 7, tmp_w);
+            row_stage(tmp_r, v_w);
+        };
+        if (ph == 0) stages();
+        if (!(W4_ABL & 4)) {
+            const float4 *un = u_ptr(g + 2);
 #pragma unroll
-                for (int q = q0; q < q1; ++q) {
-                    const float4 u4 = *reinterpret_cast<const float4 *>(ua + 4 * q);
-                    const float4 v4 = *reinterpret_cast<const float4 *>(vb + 4 * q);
-                    acc[4 * q + 0] = mfma16x4(u4.x, v4.x, acc[4 * q + 0]);
-                    acc[4 * q + 1] = mfma16x4(u4.y, v4.y, acc[4 * q + 1]);
-                    acc[4 * q + 2] = mfma16x4(u4.z, v4.z, acc[4 * q + 2]);
-                    acc[4 * q + 3] = mfma16x4(u4.w, v4.w, acc[4 * q + 3]);
-                }
-            };
-            // The two waves of a SIMD (w and w + 4: tile groups 0 and 1) run the iteration in opposite order, so that
-            // one of them is always in its MFMAs while the other does transform work -- the barriers would otherwise
-            // line all eight waves up in the same phase and leave the matrix pipe idle during both stages.
-            // (the MFMA code exists once; only the stage calls, which do not touch the accumulators, sit under the
-            //  wave-uniform branches -- accumulator updates in both arms of a branch made the allocator spill them)
-            const int ch_nxt = 4 * ((s + 1) & 15);
-            if (grp == 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS, ch_nxt, s == 15 ? vm_nxt : vm_cur);   // planes(s+1)
-            mfmas(0, 5);
-            if (grp != 0 && !(W4_ABL & 1)) column_stage(s_in + slot_nxt * IN_FLOATS, ch_nxt, s == 15 ? vm_nxt : vm_cur);
-            lds_barrier();
-            if (grp == 0 && !(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
-            mfmas(5, 9);
-            if (grp != 0 && !(W4_ABL & 2)) row_stage(s_v + nxt * V_FLOATS);
-            wait_copies();                      // weights(s+1) and planes(s+2) have landed; planes(s+3) stays in flight
-            asm volatile("s_barrier" ::: "memory");
-            slot = slot_nxt;
-        }
-        src_cur = src_nxt;
-        if (PRO) { vm_cur[0] = vm_nxt[0]; vm_cur[1] = vm_nxt[1]; }
-        // ---- output transform Y = A^T M A in registers: lane = (tile grp*16 + l15, channels cog*16 + kq*4 .. +3)
-        const int t = grp * 16 + l15;
-        const int oy0 = y0 + 4 * (t >> 3), ox0 = x0 + 4 * (t & 7);
-        const int co0 = cog * 16 + kq * 4;
-        float y[4][4][4];                   // [row][col][channel]
+            for (int kg = 0; kg < 2; ++kg) {
+                const float *vr = v_r + kg * 64 * VROW;
+                const float4 v0 = *reinterpret_cast<const float4 *>(vr), v1 = *reinterpret_cast<const float4 *>(vr + 4);
+                const float4 v2 = *reinterpret_cast<const float4 *>(vr + 8), v3 = *reinterpret_cast<const float4 *>(vr + 12);
+                const float2 v4 = *reinterpret_cast<const float2 *>(vr + 16);
+                const float v[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
+                                     v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float tm[4][6];                 // A^T M: [out row][j]
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                float m[6], o[4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) m[i] = acc[6 * i + j][r];
-                at6(m, o);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tm[i][j] = o[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float o[4];
-                at6(tm[i], o);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) y[i][j][r] = o[j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int oy = oy0 + i, ox = ox0 + j;
-                if (oy < H && ox < W) {
-                    *reinterpret_cast<float4 *>(a.out + img + ((size_t)oy * W + ox) * 64 + co0) =
-                        make_float4(y[i][j][0], y[i][j][1], y[i][j][2], y[i][j][3]);
-                    if (STATS) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            ssum[r] += y[i][j][r];
-                            ssq[r] += y[i][j][r] * y[i][j][r];
-                        }
+                for (int p = 0; p < 18; ++p) {
+                    const int idx = kg * 18 + p;
+                    acc[p] = mfma16x4(U[idx], v[p], acc[p]);      // D[co][tile] += U[co][ci] * V[ci][tile]
+                    if ((idx & 3) == 3 && !(W4_ABL & 16)) {       // quad idx >> 2 is done: request it for chunk g + 2
+                        const int q = idx >> 2;
+                        const float4 t = un[q * 64];
+                        U[4 * q] = t.x; U[4 * q + 1] = t.y; U[4 * q + 2] = t.z; U[4 * q + 3] = t.w;
                     }
                 }
             }
+        }
+        if (ph != 0) stages();
+        wait_planes();
+        lds_barrier();
+    };
+
+    // ---- tile epilogue: output transform Y = A^T M A.  This wave holds M[i = 3 ph + il][j] for (channels co0..co0+3,
+    // tile l15); A^T over j in registers, then the partial sums over its three rows i for all four output rows; the
+    // pair (ph 0, ph 1) of a channel group swaps the two output rows the other one owns (ph 0: rows 0-1, ph 1: rows 2-3).
+    const int co0 = cog * 16 + kq * 4;
+    float *xw = s_x + (cog * 8 * 64 + lane) * 4;                 // this pair's exchange area: [slot 8][lane 64] float4
+    // A^T restricted to this position half (columns 3 ph .. 3 ph + 2), as wave-uniform scalars: rows of the outputs this
+    // wave finishes (ph 0: rows 0-1, ph 1: rows 2-3) and of the ones it hands to its partner
+    const float own0[2][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}}, snd0[2][3] = {{0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
+    const float own1[2][3] = {{4.f, 4.f, 0.f}, {8.f, -8.f, 1.f}}, snd1[2][3] = {{1.f, 1.f, 0.f}, {2.f, -2.f, 0.f}};
+    float cfo[2][3], cfs[2][3];
+#pragma unroll
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int il = 0; il < 3; ++il) {
+            cfo[io][il] = ph == 0 ? own0[io][il] : own1[io][il];
+            cfs[io][il] = ph == 0 ? snd0[io][il] : snd1[io][il];
+        }
+    auto tile_epilogue = [&](int k) {
+        if (W4_ABL & 32) {
+#pragma unroll
+            for (int p = 0; p < 18; ++p) { asm volatile("" ::"v"(acc[p])); acc[p] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            return;
+        }
+        const int tile_ = tile_of(k);
+        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
+        float yo[2][4][4], ys[2][4][4];         // partial outputs [output row][column][channel]: kept / handed over
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float tm[3][4];
+#pragma unroll
+            for (int il = 0; il < 3; ++il) {
+                float m[6], o[4];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = acc[il * 6 + j][r];
+                at6(m, o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tm[il][j] = o[j];
+            }
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    yo[io][j][r] = fmaf(cfo[io][0], tm[0][j], fmaf(cfo[io][1], tm[1][j], cfo[io][2] * tm[2][j]));
+                    ys[io][j][r] = fmaf(cfs[io][0], tm[0][j], fmaf(cfs[io][1], tm[1][j], cfs[io][2] * tm[2][j]));
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // exchange (three barriers; the area is idle between two iterations): ph 1 writes, ph 0 reads and writes into the
+        // same slots, ph 1 reads
+        float4 rx[2][4];
+        auto put = [&]() {
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4 *>(xw + (io * 4 + j) * 256) = make_float4(ys[io][j][0], ys[io][j][1], ys[io][j][2], ys[io][j][3]);
+        };
+        auto get = [&]() {
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rx[io][j] = *reinterpret_cast<const float4 *>(xw + (io * 4 + j) * 256);
+        };
+        if (ph == 1) put();
+        lds_barrier();
+        if (ph == 0) { get(); put(); }
+        lds_barrier();
+        if (ph == 1) get();
+        lds_barrier();
+        // own rows: 2 ph + io
+        const int t = l15;
+        const int oy0 = ty * TH + 4 * (t >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t & 7);
+        const size_t img = (size_t)b * H * W * 64;
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (BN) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(a.epi.mean + co0), i4 = *reinterpret_cast<const float4 *>(a.epi.invstd + co0);
+            mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+            is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+            if (BN == 1) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(a.epi.msc + co0), h4 = *reinterpret_cast<const float4 *>(a.epi.msh + co0);
+                msc[0] = s4.x; msc[1] = s4.y; msc[2] = s4.z; msc[3] = s4.w;
+                msh[0] = h4.x; msh[1] = h4.y; msh[2] = h4.z; msh[3] = h4.w;
+            }
+        }
+#pragma unroll
+        for (int io = 0; io < 2; ++io) {
+            // operands of one output row (4 pixels x up to 3 tensors) are requested together
+            const int oy = oy0 + io;
+            float4 ad[4], z4[4], a4[4];
+            bool ok[4];
+            unsigned off[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ox = ox0 + j;
+                ok[j] = oy < H && ox < W;
+                off[j] = (unsigned)((min(oy, H - 1) * W + min(ox, W - 1)) * 64 + co0);
+                ad[j] = z4[j] = a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ADD) ad[j] = *reinterpret_cast<const float4 *>(a.epi.addend + img + off[j]);
+                if (BN) z4[j] = *reinterpret_cast<const float4 *>(a.epi.z + img + off[j]);
+                if (BN == 2) a4[j] = *reinterpret_cast<const float4 *>(a.epi.act + img + off[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float own[4] = {yo[io][j][0], yo[io][j][1], yo[io][j][2], yo[io][j][3]};
+                const float got[4] = {rx[io][j].x, rx[io][j].y, rx[io][j].z, rx[io][j].w};
+                const float adv[4] = {ad[j].x, ad[j].y, ad[j].z, ad[j].w};
+                const float zv[4] = {z4[j].x, z4[j].y, z4[j].z, z4[j].w};
+                const float av[4] = {a4[j].x, a4[j].y, a4[j].z, a4[j].w};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows are summed in the order i = 0..5 on both waves: (rows 0-2) + (rows 3-5)
+                    float v = ph == 0 ? own[r] + got[r] : got[r] + own[r];
+                    if (ADD) v += adv[r];
+                    if (BN) {
+                        const float gate = BN == 2 ? av[r] : fmaf(msc[r], zv[r], msh[r]);
+                        if (!(gate > 0.f) || !ok[j]) v = 0.f;
+                        ssum[r] += v;
+                        ssq[r] += v * ((zv[r] - mu[r]) * is[r]);
+                    } else if (STATS) {
+                        if (!ok[j]) v = 0.f;
+                        ssum[r] += v;
+                        ssq[r] += v * v;
+                    }
+                    o[r] = v;
+                }
+                if (ok[j]) *reinterpret_cast<float4 *>(a.out + img + off[j]) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    };
+
+    int slot = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; g += 2) {
+        iteration(g, slot, std::integral_constant<int, 0>{}, Ua);
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        iteration(g + 1, slot, std::integral_constant<int, 1>{}, Ub);
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        if ((g & 7) == 6) tile_epilogue(g >> 3);
     }
-    if (STATS) {        // one partial row [sum 64 | sum of squares 64] per block
+    if (STATS) {        // one partial row [sum 64 | second kind 64] per block; a channel's two position halves are added
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ssum[r] = row16_sum(ssum[r]);
             ssq[r] = row16_sum(ssq[r]);
         }
-        __syncthreads();
         if (l15 == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s_red[grp * 128 + cog * 16 + kq * 4 + r] = ssum[r];
-                s_red[grp * 128 + 64 + cog * 16 + kq * 4 + r] = ssq[r];
+                s_red[ph * 128 + cog * 16 + kq * 4 + r] = ssum[r];
+                s_red[ph * 128 + 64 + cog * 16 + kq * 4 + r] = ssq[r];
             }
         }
         __syncthreads();
@@ -369,15 +530,20 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     }
 }
 
-// U[s][k][co][pos = i*6 + j] = (G g G^T)[i][j] for input channel 4s+k.
-//  fwd:   g = w[co][ci][:, :];   dgrad: output channel = ci, input channel = co, g = w[co][ci] rotated by 180 degrees
+// Register image of the transformed weights: U[chunk s 8][wave w 8][quad q 9][lane 64][e 4].  Wave w = (cog = w & 3,
+// ph = w >> 2), lane = (kq = lane >> 4, l15 = lane & 15); element n = 4 q + e = kg*18 + p is the MFMA A operand of
+// position (i = 3 ph + p / 6, j = p % 6) for output channel cog*16 + l15 and input channel 8 s + 4 kg + kq:
+// (G g G^T)[i][j].   fwd: g = w[co][ci][:, :];   dgrad: output channel = ci, input channel = co, g rotated by 180 degrees
 __global__ void prep_wino4_kernel(const float *__restrict__ w, float *__restrict__ u_fwd, float *__restrict__ u_dgrad)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;    // over [s 16][row = k*64 + o][pos 36]: the LDS image
-    if (idx >= 16 * 256 * 36) return;
-    const int pos = idx % 36, row = (idx / 36) & 255, s = idx / (36 * 256);
-    const int o = row & 63, k = row >> 6, c = 4 * s + k;
-    const int i = pos / 6, j = pos - 6 * i;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w4::U_FLOATS) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+    const int q = rest % 9, ws = rest / 9, wv = ws & 7, s = ws >> 3;
+    const int n = 4 * q + e, kg = n / 18, p = n - 18 * kg;
+    const int cog = wv & 3, ph = wv >> 2, kq = lane >> 4, l15 = lane & 15;
+    const int o = cog * 16 + l15, c = 8 * s + 4 * kg + kq;
+    const int i = 3 * ph + p / 6, j = p % 6;
     const float G[6][3] = {{0.25f, 0.f, 0.f},
                            {-1.f / 6, -1.f / 6, -1.f / 6},
                            {-1.f / 6, 1.f / 6, -1.f / 6},
@@ -402,7 +568,7 @@ __global__ void prep_wino4_kernel(const float *__restrict__ w, float *__restrict
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 
 // ====================================================================================
-// C ABI (experimental: the F(2x2,3x3) kernels of conv_wino.hip stay the engine's default)
+// C ABI
 // ====================================================================================
 COVA_API int cova_conv3x3_wino4_num_tiles(int B, int H, int W)
 {
@@ -414,31 +580,64 @@ COVA_API int cova_conv3x3_wino4_num_partials(int B, int H, int W)
     return cova_internal_persistent_grid2(cova_conv3x3_wino4_num_tiles(B, H, W), 1);
 }
 
-// u_fwd / u_dgrad: [16 chunks][4 ci][64 co][36 positions] floats each (147,456): a chunk is the LDS image
+// u_fwd / u_dgrad: 147,456 floats each (the per-wave register image, see prep_wino4_kernel)
 COVA_API int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream)
 {
     COVA_REQUIRE(w_oihw && u_fwd && u_dgrad);
-    hipLaunchKernelGGL(prep_wino4_kernel, dim3(cdiv(16 * 256 * 36, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(prep_wino4_kernel, dim3(cdiv(w4::U_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, u_fwd, u_dgrad);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+namespace {
+
+template <bool STATS, int PRO, bool ADD, int BN>
+void launch_w4(const W4Args &a, int grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<STATS, PRO, ADD, BN>), dim3(grid), dim3(w4::THREADS), 0, st, a);
+}
+
+template <int PRO>
+void launch_w4_pro(const W4Args &a, int grid, hipStream_t st)
+{
+    const bool add = a.epi.addend != nullptr;
+    const int bn = a.epi.z == nullptr ? 0 : (a.epi.act == nullptr ? 1 : 2);
+    if (bn == 0) {
+        if (a.stat_part) { if (add) launch_w4<true, PRO, true, 0>(a, grid, st); else launch_w4<true, PRO, false, 0>(a, grid, st); }
+        else             { if (add) launch_w4<false, PRO, true, 0>(a, grid, st); else launch_w4<false, PRO, false, 0>(a, grid, st); }
+    } else if (bn == 1) {
+        if (add) launch_w4<true, PRO, true, 1>(a, grid, st); else launch_w4<true, PRO, false, 1>(a, grid, st);
+    } else {
+        if (add) launch_w4<true, PRO, true, 2>(a, grid, st); else launch_w4<true, PRO, false, 2>(a, grid, st);
+    }
+}
+
+int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu, const float *u, const W4Epi &epi,
+           float *out, float *stat_part, int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
+    COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));          // 32-bit in-image offsets in the epilogue
+    COVA_REQUIRE(epi.z == nullptr || ((epi.act || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
+    const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
+    const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi};
+    const int grid = cova_internal_persistent_grid2(ntiles, 1);
+    if (!pro_abc) launch_w4_pro<0>(a, grid, (hipStream_t)stream);
+    else if (!in2) launch_w4_pro<1>(a, grid, (hipStream_t)stream);
+    else launch_w4_pro<2>(a, grid, (hipStream_t)stream);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+}  // namespace
 
 // out NHWC [B,H,W,64] = conv3x3(in) with the F(4x4,3x3) weights `u`; stat_part (nullable):
 // [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2)
 COVA_API int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_part, int B, int H, int W,
                                 void *stream)
 {
-    COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
-    const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
-    const W4Args a{in, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, nullptr, 0};
-    const int grid = cova_internal_persistent_grid2(ntiles, 1);
-    if (stat_part)
-        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<true, false>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<false, false>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    return run_w4(in, nullptr, nullptr, 0, u, W4Epi{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, out,
+                  stat_part, B, H, W, stream);
 }
 
 // The same convolution on relu?(A[c]*in + C[c]) formed on load (pro_abc [3][64] = A | unused | C; zero padding stays
@@ -446,14 +645,20 @@ COVA_API int cova_conv3x3_wino4(const float *in, const float *u, float *out, flo
 COVA_API int cova_conv3x3_wino4_pro(const float *in, const float *pro_abc, int pro_relu, const float *u, float *out,
                                     float *stat_part, int B, int H, int W, void *stream)
 {
-    COVA_REQUIRE(in && pro_abc && u && out && B > 0 && H > 0 && W > 0);
-    const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
-    const W4Args a{in, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu};
-    const int grid = cova_internal_persistent_grid2(ntiles, 1);
-    if (stat_part)
-        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<true, true>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((conv3x3_c64_wino4_kernel<false, true>), dim3(grid), dim3(w4::THREADS), 0, (hipStream_t)stream, a);
-    COVA_LAUNCH_CHECK();
-    return COVA_OK;
+    COVA_REQUIRE(pro_abc);
+    return run_w4(in, nullptr, pro_abc, pro_relu, u, W4Epi{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                  out, stat_part, B, H, W, stream);
+}
+
+// Full form, same contract as cova_conv3x3_wino_pro (conv_wino.hip): input f(A*in + B*in2 + C) on load (pro_abc / in2
+// nullable), epilogue  (+ addend) (x ReLU mask from act, or from fma(mask_scale, z, mask_shift) when act is NULL)
+// with the BatchNorm-backward sums (sum g, sum g*xhat(z)) in stat_part when z is given, else plain statistics.
+COVA_API int cova_conv3x3_wino4_full(const float *in, const float *in2, const float *pro_abc, int pro_relu,
+                                     const float *u, const float *addend, const float *act, const float *mask_scale,
+                                     const float *mask_shift, const float *z, const float *mean, const float *invstd,
+                                     float *out, float *stat_part, int B, int H, int W, void *stream)
+{
+    return run_w4(in, in2, pro_abc, pro_relu, u,
+                  W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr}, out,
+                  stat_part, B, H, W, stream);
 }

@@ -114,8 +114,9 @@ int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
                        int H, int W, void *stream);
 
-/* Experimental F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs, fp32 error 2.9e-6):
- * u_fwd / u_dgrad [16][4][64][36]; stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2) */
+/* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
+ * the output scale): u_fwd / u_dgrad 147,456 floats each (the per-wave register image written by the prep kernel);
+ * stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2) */
 int cova_conv3x3_wino4_num_tiles(int B, int H, int W);
 int cova_conv3x3_wino4_num_partials(int B, int H, int W);
 int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
@@ -124,6 +125,15 @@ int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_
 /* ... on relu?(A[c]*in + C[c]) formed on load (pro_abc [3][64] = A | unused | C), zero padding stays zero */
 int cova_conv3x3_wino4_pro(const float *in, const float *pro_abc, int pro_relu, const float *u, float *out,
                            float *stat_part /*nullable*/, int B, int H, int W, void *stream);
+/* ... full form, the contract of cova_conv3x3_wino_pro: input f(A*in + B*in2 + C) on load (in2, pro_abc nullable);
+ * epilogue (+ addend) x ReLU mask (act > 0, or fma(mask_scale, z, mask_shift) > 0 when act is NULL) with the
+ * BatchNorm-backward sums (sum g, sum g*xhat(z)) in stat_part when z is given, plain statistics otherwise */
+int cova_conv3x3_wino4_full(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable*/,
+                            int pro_relu, const float *u, const float *addend /*nullable*/,
+                            const float *act /*nullable*/, const float *mask_scale /*nullable*/,
+                            const float *mask_shift /*nullable*/, const float *z /*nullable*/,
+                            const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
+                            float *stat_part /*nullable*/, int B, int H, int W, void *stream);
 
 /* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
  * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.

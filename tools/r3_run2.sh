@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r3b
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "f4x4" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -15 > gpurun_out/r3b/t.log
+timeout 300 python tools/wino4_bench.py > gpurun_out/r3b/bench.log 2>&1

@@ -42,3 +42,10 @@ for n, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
         small[0] += c
         small[1] += t
 print("%-66s %5d %10.1f %6.1f" % ("(all kernels below 40 us in total)", small[0], small[1], 100 * small[1] / busy))
+
+if "--order" in sys.argv:       # launch order of the step: offset from the previous Adam's end, duration, gap in front
+    print("\n# launch order: t_start_us  dur_us  gap_before_us  kernel")
+    t0, prev = rows[adam[which - 1]][1], rows[adam[which - 1]][1]
+    for s, e, k in seg:
+        print("%9.1f %8.1f %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, short(names[k])))
+        prev = e

@@ -28,9 +28,24 @@
 #include <type_traits>
 
 // Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
-// 2 no row stage, 4 no MFMAs, 8 no plane copies, 16 no weight loads (stale registers), 32 no tile epilogue
+// 2 no row stage, 4 no MFMAs, 8 no plane copies, 16 no weight loads (stale registers), 32 no tile epilogue,
+// 64 no wait for the plane copies, 128 weight loads always from chunk 0, 256 no output stores, 512 no exchange barriers
 #ifndef W4_ABL
 #define W4_ABL 0
+#endif
+#ifndef W4_SCHED
+#define W4_SCHED 0
+#endif
+#ifndef W4_LEAD2
+#define W4_LEAD2 0
+#endif
+#ifndef W4_WEAVE
+#define W4_WEAVE 0
+#endif
+#if W4_SCHED
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define W4_SB() do {} while (0)
 #endif
 
 namespace {
@@ -42,7 +57,7 @@ constexpr int SUB_FLOATS = NPIX * 4;           // one 4-channel group of a chunk
 constexpr int SLOT_FLOATS = 2 * SUB_FLOATS;    // planes of one 8-channel chunk: 10,880 B
 constexpr int TMP_CI = 16 * 36 + 8;            // column-stage result [ci][tile][c][i]; +8: the channels of an
 constexpr int TMP_FLOATS = 8 * TMP_CI;         // instruction start 8 banks apart; 18,688 B
-constexpr int VROW = 44;                       // V row (ci, tile): [i 0..2: 18 floats, 2 pad | i 3..5: 18 floats, 6 pad];
+constexpr int VROW = 44;                       // V row (ci, tile): [i 0,1,2: 18 floats, 2 pad | i 5,3,4: 18 floats, 6 pad];
                                                // 11 x 16 B is an odd slot stride: conflict-free ds_read_b128
 constexpr int V_FLOATS = 8 * 16 * VROW;        // 22,528 B
 constexpr int U_FLOATS = 8 * 8 * 9 * 64 * 4;   // [chunk 8][wave 8][quad 9][lane 64][4]: 147,456 floats
@@ -103,7 +118,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 // an explicit s_waitcnt in the kernel.
 __device__ __forceinline__ void copy16_to_lds(const float *gptr, unsigned lds_base_bytes)
 {
+#ifdef W4_NT_LOAD
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_base_bytes), "v"(gptr) : "memory", "m0");
+#else
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base_bytes), "v"(gptr) : "memory", "m0");
+#endif
 }
 
 // Barrier that orders LDS accesses only: this wave's ds_writes are complete (lgkmcnt(0)) while global -> LDS copies
@@ -129,7 +148,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // tmp[0] and V[1] are adjacent: both are idle at a tile boundary and carry the pair exchange of the output transform
     __shared__ __attribute__((aligned(16))) float lds[(PRO == 2 ? 2 : 1) * IN_FLOATS + 2 * TMP_FLOATS + 2 * V_FLOATS];
     __shared__ float s_pro[PRO ? 192 : 1];        // A | B | C of the affine-on-load prologue
-    __shared__ float s_red[STATS ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) float s_epi[BN ? 256 : 4];   // mean | invstd | mask scale | mask shift of the epilogue
+    __shared__ __attribute__((aligned(16))) float s_red[STATS ? 8 * 32 : 4];   // per wave: 16 channels x (sum | second kind), running totals
     float *s_in = lds;
     float *s_in2 = lds + IN_FLOATS;               // (PRO == 2)
     float *s_tmp1 = lds + (PRO == 2 ? 2 : 1) * IN_FLOATS;
@@ -142,10 +162,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int cog = wave & 3, ph = wave >> 2;
     const int l15 = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W;
-    if (PRO) {
-        if (tid < 192) s_pro[tid] = a.pro_abc[tid];
-        __syncthreads();
+    if (PRO && tid < 192) s_pro[tid] = a.pro_abc[tid];
+    if (BN && tid >= 256) {
+        const int c = tid & 63, kind = (tid >> 6) & 3;
+        const float *src = kind == 0 ? a.epi.mean : kind == 1 ? a.epi.invstd : kind == 2 ? a.epi.msc : a.epi.msh;
+        s_epi[kind * 64 + c] = (kind < 2 || BN == 1) ? src[c] : 0.f;
     }
+    if (PRO || BN) __syncthreads();
 
     // ---- the tiles of this block (XCD-aware order: consecutive blocks of an XCD take consecutive tiles)
     int first = blockIdx.x;
@@ -194,16 +217,17 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // of iteration g the copy of planes(g+3), issued at the top of iteration g-1, must have landed: behind it in the queue
     // are the 9 weight loads of iteration g-1, the copies of iteration g and the 9 weight loads of iteration g.
     auto wait_planes = [&]() {
+        if (W4_ABL & 64) return;
         constexpr int M = PRO == 2 ? 2 : 1;
         if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + 2 * M) & 15) | (((18 + 2 * M) >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + M) & 15) | (((18 + M) >> 4) << 14));
     };
 
-    // ---- stage items of this thread.
-    // column stage, 768 items it = ((kg*16 + tile)*6 + c)*4 + cl (the channel fastest, as the planes are [px][4]):
-    //   e = 0: it = tid, e = 1: it = 512 + tid (threads < 256)
-    // row stage, 768 items it = ((ci*16 + tile)*6 + i (the channel slowest, as V rows are (ci, tile)):
-    //   e = 0: it = tid, e = 1: it = 256 + tid (threads >= 256)
+    // ---- stage items of this thread: three per iteration, read in one batch (one LDS round trip per iteration).
+    // column stage, 768 items it = ((kg*16 + tile)*6 + c)*4 + cl (the channel fastest, as the planes are [px][4]);
+    // row stage, 768 items it = ((ci*16 + tile)*6 + i (the channel slowest, as V rows are (ci, tile)).
+    // Waves 0-3: column items tid, 512 + tid and row item tid; waves 4-7: column item tid, row items tid, 256 + tid.
+    const bool lo = wave < 4;                       // (wave-uniform: scalar branches)
     int col_src[2], col_dst[2], col_x[2], col_y[2], col_ch[2], row_src[2], row_dst[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -220,10 +244,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             const int it = tid + e * 256;
             const int i = it % 6, rt = it / 6, t = rt & 15, ci = rt >> 4;
             row_src[e] = ci * TMP_CI + t * 36 + i;                                                // + c * 6
-            row_dst[e] = (ci * 16 + t) * VROW + (i < 3 ? 6 * i : 20 + 6 * (i - 3));               // + j (6 contiguous)
+            row_dst[e] = (ci * 16 + t) * VROW + (i < 3 ? 6 * i : 20 + 6 * ((i - 2) % 3));         // + j (6 contiguous); second half in the order i = 5, 3, 4
         }
     }
-    const bool col2 = tid < 256, row2 = tid >= 256;
     // PRO: rows of an item's column that lie inside the image (bit r), for the tile the planes belong to
     unsigned vm[2] = {0u, 0u};
     auto row_masks = [&](int k) {
@@ -238,89 +261,127 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             vm[e] = (gx < 0 || gx >= W) ? 0u : m;
         }
     };
-    // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c];  s = chunk of the tile (prologue channel 8 s + ci)
-    auto column_stage = [&](int slot, int s, float *tmp) {
-        if (W4_ABL & 1) return;
+    // One stage item in flight: its six inputs (plus the six of the second tensor), where the result goes, and whether
+    // the affine prologue applies (column items).  Reads and transform are separate steps so that MFMAs sit between them.
+    struct Item { float d[6], w[6]; float *q; };
+    auto read_col = [&](int e, int slot, float *tmp_w, Item &it) {
+        const float *p = s_in + slot * SLOT_FLOATS + col_src[e];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (e == 1 && !col2) break;
-            const float *p = s_in + slot * SLOT_FLOATS + col_src[e];
-            float d[6], o[6];
+        for (int r = 0; r < 6; ++r) it.d[r] = p[r * PW * 4];
+        if (PRO == 2) {
+            const float *p2 = s_in2 + slot * SLOT_FLOATS + col_src[e];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = p[r * PW * 4];
-            if (PRO) {
-                const int ch = 8 * s + col_ch[e];
-                const float A = s_pro[ch], C = s_pro[128 + ch];
-                float w2[6];
-                if (PRO == 2) {
-                    const float *p2 = s_in2 + slot * SLOT_FLOATS + col_src[e];
-                    const float Bc = s_pro[64 + ch];
+            for (int r = 0; r < 6; ++r) it.w[r] = p2[r * PW * 4];
+        }
+        it.q = tmp_w + col_dst[e];
+    };
+    auto read_row = [&](int e, const float *tmp_r, float *v_w, Item &it) {
+        const float *p = tmp_r + row_src[e];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) w2[r] = fmaf(Bc, p2[r * PW * 4], C);
-                }
+        for (int c = 0; c < 6; ++c) it.d[c] = p[c * 6];
+        it.q = v_w + row_dst[e];
+    };
+    // affine prologue of column item e (chunk s of its tile: channel 8 s + ci); zero padding stays zero
+    auto pro_apply = [&](int e, int s, Item &it) {
+        const int ch = 8 * s + col_ch[e];
+        const float A = s_pro[ch], C = s_pro[128 + ch];
+        const float Bc = PRO == 2 ? s_pro[64 + ch] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    float v = fmaf(A, d[r], PRO == 2 ? w2[r] : C);      // same expression as conv_wino.hip's prologue
-                    if (a.pro_relu) v = fmaxf(v, 0.f);
-                    d[r] = ((vm[e] >> r) & 1u) ? v : 0.f;
-                }
-            }
-            bt6(d, o);
-            float *q = tmp + col_dst[e];
-            *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2 *>(q + 2) = make_float2(o[2], o[3]);
-            *reinterpret_cast<float2 *>(q + 4) = make_float2(o[4], o[5]);
+        for (int r = 0; r < 6; ++r) {
+            float v = fmaf(A, it.d[r], PRO == 2 ? fmaf(Bc, it.w[r], C) : C);      // same expression as conv_wino.hip's prologue
+            if (a.pro_relu) v = fmaxf(v, 0.f);
+            it.d[r] = ((vm[e] >> r) & 1u) ? v : 0.f;
         }
     };
-    auto row_stage = [&](const float *tmp, float *vdst) {               // V[(ci, tile)][i][j] = sum_c tmp[c][i] Bt[j][c]
-        if (W4_ABL & 2) return;
+    // tmp[ci][tile][c][i] = sum_r Bt[i][r] d[r][c]  /  V[(ci, tile)][i][j] = sum_c tmp[c][i] Bt[j][c]
+    auto transform_store = [&](const Item &it) {
+        float o[6];
+        bt6(it.d, o);
+        *reinterpret_cast<float2 *>(it.q) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2 *>(it.q + 2) = make_float2(o[2], o[3]);
+        *reinterpret_cast<float2 *>(it.q + 4) = make_float2(o[4], o[5]);
+    };
+    // the three items of an iteration: k = 0 column item 0 | k = 1 column item 1 (waves 0-3) or row item 0 (waves 4-7) |
+    // k = 2 row item 0 (waves 0-3) or row item 1.  `lo` is wave-uniform: scalar branches (the empty asm keeps the
+    // compiler from turning the arms into per-lane address selects)
+    auto item_read = [&](const int k, Item &it, int slot, float *tmp_w, const float *tmp_r, float *v_w) {
+        if (W4_ABL & 3) return;
+        if (k == 0) {
+            read_col(0, slot, tmp_w, it);
+        } else if (k == 1) {
+            if (lo) { asm volatile(""); read_col(1, slot, tmp_w, it); }
+            else { asm volatile(""); read_row(0, tmp_r, v_w, it); }
+        } else {
+            if (lo) { asm volatile(""); read_row(0, tmp_r, v_w, it); }
+            else { asm volatile(""); read_row(1, tmp_r, v_w, it); }
+        }
+    };
+    auto item_finish = [&](const int k, Item &it, int s) {
+        if (W4_ABL & 3) return;
+        if (PRO) {
+            if (k == 0) pro_apply(0, s, it);
+            else if (k == 1 && lo) pro_apply(1, s, it);
+        }
+        transform_store(it);
+    };
+
+    // ---- weights: 9 float4 per lane and chunk (the prep kernel wrote the register image: wave-contiguous 1 KB rows);
+    // wave-uniform base (scalar registers) + this lane's fixed 32-bit byte offset + immediate
+    const char *ubase = reinterpret_cast<const char *>(a.u) + (size_t)wave * (9 * 1024);
+    const unsigned ulane = (unsigned)lane * 16u;
+    auto u_ptr = [&](int s) { return ubase + (size_t)((W4_ABL & 128) ? 0 : (s & 7)) * (8 * 9 * 1024); };
+    // Lead of the weights: quads 0-4 (MFMAs 0-19) are requested TWO chunks ahead into Ea / Eb (even / odd chunks), quads
+    // 5-8 one chunk ahead into L: 56 registers instead of 72, and the plane copies -- forced to completion by the first
+    // wait on a younger load, vmcnt being in-order -- still get about one and a half iterations of flight.
+    float Ea[20], Eb[20], L[16];
+    auto load_quads = [&](float *U, int s, const int q0, const int q1, const int base) {
+        const char *p = u_ptr(s);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (e == 1 && !row2) break;
-            const float *p = tmp + row_src[e];
-            float d[6], o[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) d[c] = p[c * 6];
-            bt6(d, o);
-            float *q = vdst + row_dst[e];
-            *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2 *>(q + 2) = make_float2(o[2], o[3]);
-            *reinterpret_cast<float2 *>(q + 4) = make_float2(o[4], o[5]);
+        for (int q = q0; q < q1; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + q * 1024 + ulane);
+            U[4 * q - base] = t.x; U[4 * q + 1 - base] = t.y; U[4 * q + 2 - base] = t.z; U[4 * q + 3 - base] = t.w;
         }
     };
 
-    // ---- weights: 9 float4 per lane and chunk (the prep kernel wrote the register image: wave-contiguous 1 KB rows)
-    const float4 *ug = reinterpret_cast<const float4 *>(a.u) + (size_t)wave * (9 * 64) + lane;
-    auto u_ptr = [&](int s) { return ug + (size_t)(s & 7) * (8 * 9 * 64); };
-    float Ua[36], Ub[36];
-    auto load_u = [&](float (&U)[36], int s) {
-        const float4 *p = u_ptr(s);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const float4 t = p[q * 64];
-            U[4 * q] = t.x; U[4 * q + 1] = t.y; U[4 * q + 2] = t.z; U[4 * q + 3] = t.w;
-        }
-    };
-
+#ifdef W4_STAGGER
+    // start the blocks of an XCD at different phases of a tile, so that the epilogue store bursts (and the copies) of the
+    // 256 CUs do not coincide for the whole launch (persistent blocks with equal tile times stay in lock-step otherwise)
+    for (int i = ((blockIdx.x >> 3) & 7) * W4_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(10);
+#endif
     // ---- prime the pipeline: planes(0..2) copied, weights(0), weights(1) requested
     plane_src(0);
     copy_planes(0, 0);
     copy_planes(1, 1);
     copy_planes(2, 2);
-    load_u(Ua, 0);
-    load_u(Ub, 1);
+    load_quads(Ea, 0, 0, 5, 0);
+    if (W4_LEAD2) load_quads(Eb, 1, 0, 5, 0);
+    load_quads(L, 0, 5, 9, 20);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (PRO) row_masks(0);
-    column_stage(0, 0, s_tmp0);
-    column_stage(1, 1, s_tmp1);
-    __syncthreads();
-    row_stage(s_tmp0, s_v0);
+    {   // column stage of chunks 0 and 1, row stage of chunk 0
+        Item it;
+        for (int c = 0; c < 2; ++c) {
+            float *tw = c ? s_tmp1 : s_tmp0;
+            read_col(0, c, tw, it);
+            if (PRO) pro_apply(0, c, it);
+            transform_store(it);
+            if (lo) {
+                read_col(1, c, tw, it);
+                if (PRO) pro_apply(1, c, it);
+                transform_store(it);
+            }
+        }
+        __syncthreads();
+        read_row(0, s_tmp0, s_v0, it);
+        transform_store(it);
+        if (!lo) { read_row(1, s_tmp0, s_v0, it); transform_store(it); }
+    }
     copy_planes(3, 0);                      // slot 0 has been consumed (barrier above)
     __builtin_amdgcn_s_waitcnt(0);          // (one-time: the steady-state wait counts assume two iterations of history)
     __syncthreads();
 
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (STATS && tid < 256) s_red[tid] = 0.f;       // (ordered before its first use by the barriers of the first tile)
     f32x4 acc[18];
 #pragma unroll
     for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -328,7 +389,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int v_off = (kq * 16 + l15) * VROW + ph * 20;
 
     // one iteration; PAR = g & 1 (compile time: buffers and weight registers are static)
-    auto iteration = [&](const int g, const int slot, auto par, float (&U)[36]) {
+    auto iteration = [&](const int g, const int slot, auto par, float (&E)[20]) {
         constexpr int PAR = decltype(par)::value;
         float *tmp_w = PAR ? s_tmp1 : s_tmp0;               // column stage (chunk g+2) writes tmp[g & 1]
         const float *tmp_r = PAR ? s_tmp0 : s_tmp1;         // row stage (chunk g+1) reads tmp[(g+1) & 1]
@@ -339,34 +400,88 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
         copy_planes((g + 4) & 7, slot1);
         if (PRO && ((g + 2) & 7) == 0) row_masks((g + 2) >> 3);
-        auto stages = [&]() {
-            column_stage(slot2, (g + 2) & 7, tmp_w);
-            row_stage(tmp_r, v_w);
+        const int s2 = (g + 2) & 7;
+        // wave-uniform weight bases in scalar registers (global_load with an SGPR base + this lane's offset): chunk g + 2
+        // for the early quads, chunk g + 1 for the late ones; one base per 4 KB of immediate-offset range
+        // (the opaque offsets keep the compiler from re-associating the bases into one base + offsets beyond the
+        //  immediate range; the pointers themselves stay derived from the kernel argument: global, not flat, loads)
+        unsigned o4k = 4096, o8k = 8192;
+        asm volatile("" : "+s"(o4k), "+s"(o8k));
+        const char *ue = u_ptr(g + (W4_LEAD2 ? 2 : 1)), *ue1 = ue + o4k, *ul1 = u_ptr(g + 1) + o4k, *ul2 = u_ptr(g + 1) + o8k;
+        unsigned ul = ulane;
+        asm volatile("" : "+v"(ul));         // keeps (uniform base) + (lane offset) apart: LICM would fold the lane offset into
+                                             // a 64-bit VGPR base and every load would need vector address arithmetic
+        float v[2][18];
+        auto read_v = [&](int kg) {
+            if (W4_ABL & 4) return;
+            const float *vr = v_r + kg * 64 * VROW;
+            const float4 v0 = *reinterpret_cast<const float4 *>(vr), v1 = *reinterpret_cast<const float4 *>(vr + 4);
+            const float4 v2 = *reinterpret_cast<const float4 *>(vr + 8), v3 = *reinterpret_cast<const float4 *>(vr + 12);
+            const float2 v4 = *reinterpret_cast<const float2 *>(vr + 16);
+            const float t[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
+                                 v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
+#pragma unroll
+            for (int p = 0; p < 18; ++p) v[kg][p] = t[p];
         };
-        if (ph == 0) stages();
-        if (!(W4_ABL & 4)) {
-            const float4 *un = u_ptr(g + 2);
+        // MFMAs idx0 .. idx1-1 of the chunk (idx = kg*18 + p); a weight quad is re-requested right after its last use.  The
+        // scheduling barriers keep the weight loads SPREAD between the MFMAs: clustered (the compiler's choice) the 72
+        // loads of a CU queue up on its address path and every wave stalls behind them.
+        auto mfma_range = [&](const int idx0, const int idx1) {
+            if (W4_ABL & 4) return;
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                const float *vr = v_r + kg * 64 * VROW;
-                const float4 v0 = *reinterpret_cast<const float4 *>(vr), v1 = *reinterpret_cast<const float4 *>(vr + 4);
-                const float4 v2 = *reinterpret_cast<const float4 *>(vr + 8), v3 = *reinterpret_cast<const float4 *>(vr + 12);
-                const float2 v4 = *reinterpret_cast<const float2 *>(vr + 16);
-                const float v[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
-                                     v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
-#pragma unroll
-                for (int p = 0; p < 18; ++p) {
-                    const int idx = kg * 18 + p;
-                    acc[p] = mfma16x4(U[idx], v[p], acc[p]);      // D[co][tile] += U[co][ci] * V[ci][tile]
-                    if ((idx & 3) == 3 && !(W4_ABL & 16)) {       // quad idx >> 2 is done: request it for chunk g + 2
-                        const int q = idx >> 2;
-                        const float4 t = un[q * 64];
-                        U[4 * q] = t.x; U[4 * q + 1] = t.y; U[4 * q + 2] = t.z; U[4 * q + 3] = t.w;
-                    }
+            for (int idx = idx0; idx < idx1; ++idx) {
+                const int kg = idx / 18, p = idx - 18 * kg;
+                acc[p] = mfma16x4(idx < 20 ? E[idx] : L[idx - 20], v[kg][p], acc[p]);      // D[co][tile] += U[co][ci] * V[ci][tile]
+                if ((idx & 3) == 3 && !(W4_ABL & 16)) {
+                    const int q = idx >> 2;
+                    const char *bp = q < 4 ? ue : q == 4 ? ue1 : q < 8 ? ul1 : ul2;
+                    const float4 t = *reinterpret_cast<const float4 *>(bp + (q & 3) * 1024 + ul);
+                    float *U = q < 5 ? &E[4 * q] : &L[4 * q - 20];
+                    U[0] = t.x; U[1] = t.y; U[2] = t.z; U[3] = t.w;
+                    W4_SB();
                 }
             }
-        }
-        if (ph != 0) stages();
+        };
+        // Order (pinned by the scheduling barriers; register pressure decides it): one stage item in flight at a time, its
+        // reads issued four MFMAs before its transform; the second V group is requested before the last item's transform,
+        // whose vector instructions cover its latency.
+#if W4_WEAVE
+        Item it;
+        read_v(0);
+        W4_SB();
+        mfma_range(0, 4);
+        item_read(0, it, slot2, tmp_w, tmp_r, v_w);
+        W4_SB();
+        mfma_range(4, 8);
+        item_finish(0, it, s2);
+        item_read(1, it, slot2, tmp_w, tmp_r, v_w);
+        W4_SB();
+        mfma_range(8, 12);
+        item_finish(1, it, s2);
+        item_read(2, it, slot2, tmp_w, tmp_r, v_w);
+        W4_SB();
+        mfma_range(12, 16);
+        read_v(1);
+        W4_SB();
+        item_finish(2, it, s2);
+        W4_SB();
+        mfma_range(16, 36);
+#else
+        Item it0, it1, it2;
+        item_read(0, it0, slot2, tmp_w, tmp_r, v_w);
+        item_read(1, it1, slot2, tmp_w, tmp_r, v_w);
+        item_read(2, it2, slot2, tmp_w, tmp_r, v_w);
+        read_v(0);
+        W4_SB();
+        mfma_range(0, 16);
+        read_v(1);
+        mfma_range(16, 18);
+        item_finish(0, it0, s2);
+        item_finish(1, it1, s2);
+        item_finish(2, it2, s2);
+        W4_SB();
+        mfma_range(18, 36);
+#endif
         wait_planes();
         lds_barrier();
     };
@@ -376,18 +491,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // pair (ph 0, ph 1) of a channel group swaps the two output rows the other one owns (ph 0: rows 0-1, ph 1: rows 2-3).
     const int co0 = cog * 16 + kq * 4;
     float *xw = s_x + (cog * 8 * 64 + lane) * 4;                 // this pair's exchange area: [slot 8][lane 64] float4
-    // A^T restricted to this position half (columns 3 ph .. 3 ph + 2), as wave-uniform scalars: rows of the outputs this
-    // wave finishes (ph 0: rows 0-1, ph 1: rows 2-3) and of the ones it hands to its partner
-    const float own0[2][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}}, snd0[2][3] = {{0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
-    const float own1[2][3] = {{4.f, 4.f, 0.f}, {8.f, -8.f, 1.f}}, snd1[2][3] = {{1.f, 1.f, 0.f}, {2.f, -2.f, 0.f}};
-    float cfo[2][3], cfs[2][3];
-#pragma unroll
-    for (int io = 0; io < 2; ++io)
-#pragma unroll
-        for (int il = 0; il < 3; ++il) {
-            cfo[io][il] = ph == 0 ? own0[io][il] : own1[io][il];
-            cfs[io][il] = ph == 0 ? snd0[io][il] : snd1[io][il];
-        }
+    const float cf_s = ph == 0 ? 1.f : 4.f, cf_t0 = ph == 0 ? 1.f : 0.f;       // (wave-uniform scalars)
+    const float cf_d = ph == 0 ? 1.f : 8.f, cf_t1 = ph == 0 ? 0.f : 1.f, cf_h = ph == 0 ? 1.f : 2.f;
     auto tile_epilogue = [&](int k) {
         if (W4_ABL & 32) {
 #pragma unroll
@@ -397,6 +502,10 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
         float yo[2][4][4], ys[2][4][4];         // partial outputs [output row][column][channel]: kept / handed over
+        // A^T restricted to this position half.  ph 0 holds rows (m0, m1, m2), ph 1 holds rows (m5, m3, m4) -- in that
+        // order, so that with s = t1 + t2, d = t1 - t2 both halves evaluate the same expressions with wave-uniform
+        // coefficients:   ph 0 finishes Y0 = t0 + s, Y1 = d           and hands over Y2 = s, Y3 = d
+        //                 ph 1 finishes Y2 = 4 s,    Y3 = 8 d + t0    and hands over Y0 = s, Y1 = 2 d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float tm[3][4];
@@ -410,15 +519,37 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 for (int j = 0; j < 4; ++j) tm[il][j] = o[j];
             }
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    yo[io][j][r] = fmaf(cfo[io][0], tm[0][j], fmaf(cfo[io][1], tm[1][j], cfo[io][2] * tm[2][j]));
-                    ys[io][j][r] = fmaf(cfs[io][0], tm[0][j], fmaf(cfs[io][1], tm[1][j], cfs[io][2] * tm[2][j]));
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float sm = tm[1][j] + tm[2][j], df = tm[1][j] - tm[2][j];
+                yo[0][j][r] = fmaf(cf_s, sm, cf_t0 * tm[0][j]);
+                yo[1][j][r] = fmaf(cf_d, df, cf_t1 * tm[0][j]);
+                ys[0][j][r] = sm;
+                ys[1][j][r] = cf_h * df;
+            }
         }
 #pragma unroll
         for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // own output rows 2 ph + io; the operands of one output row (4 pixels x up to 3 tensors) are requested together, the
+        // first row's before the exchange so that the exchange hides part of their round trip
+        const int t = l15;
+        const int oy0 = ty * TH + 4 * (t >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t & 7);
+        const size_t img = (size_t)b * H * W * 64;
+        struct Ops { float4 ad[4], z4[4], a4[4]; };
+        auto offs = [&](int io, int j) {        // in-image element offset of the pixel's channels (clamped: loads are unconditional)
+            return (unsigned)((min(oy0 + io, H - 1) * W + min(ox0 + j, W - 1)) * 64 + co0);
+        };
+        auto load_ops = [&](int io, Ops &o) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = offs(io, j);
+                o.ad[j] = o.z4[j] = o.a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ADD) o.ad[j] = *reinterpret_cast<const float4 *>(a.epi.addend + img + off);
+                if (BN) o.z4[j] = *reinterpret_cast<const float4 *>(a.epi.z + img + off);
+                if (BN == 2) o.a4[j] = *reinterpret_cast<const float4 *>(a.epi.act + img + off);
+            }
+        };
+        Ops ops;
+        if (ADD || BN) load_ops(0, ops);
         // exchange (three barriers; the area is idle between two iterations): ph 1 writes, ph 0 reads and writes into the
         // same slots, ph 1 reads
         float4 rx[2][4];
@@ -436,50 +567,34 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 for (int j = 0; j < 4; ++j) rx[io][j] = *reinterpret_cast<const float4 *>(xw + (io * 4 + j) * 256);
         };
         if (ph == 1) put();
-        lds_barrier();
+        if (!(W4_ABL & 512)) lds_barrier();
         if (ph == 0) { get(); put(); }
-        lds_barrier();
+        if (!(W4_ABL & 512)) lds_barrier();
         if (ph == 1) get();
-        lds_barrier();
-        // own rows: 2 ph + io
-        const int t = l15;
-        const int oy0 = ty * TH + 4 * (t >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t & 7);
-        const size_t img = (size_t)b * H * W * 64;
-        float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
-        if (BN) {
-            const float4 m4 = *reinterpret_cast<const float4 *>(a.epi.mean + co0), i4 = *reinterpret_cast<const float4 *>(a.epi.invstd + co0);
-            mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
-            is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
-            if (BN == 1) {
-                const float4 s4 = *reinterpret_cast<const float4 *>(a.epi.msc + co0), h4 = *reinterpret_cast<const float4 *>(a.epi.msh + co0);
-                msc[0] = s4.x; msc[1] = s4.y; msc[2] = s4.z; msc[3] = s4.w;
-                msh[0] = h4.x; msh[1] = h4.y; msh[2] = h4.z; msh[3] = h4.w;
-            }
-        }
+        if (!(W4_ABL & 512)) lds_barrier();
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int io = 0; io < 2; ++io) {
-            // operands of one output row (4 pixels x up to 3 tensors) are requested together
             const int oy = oy0 + io;
-            float4 ad[4], z4[4], a4[4];
-            bool ok[4];
-            unsigned off[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ox = ox0 + j;
-                ok[j] = oy < H && ox < W;
-                off[j] = (unsigned)((min(oy, H - 1) * W + min(ox, W - 1)) * 64 + co0);
-                ad[j] = z4[j] = a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ADD) ad[j] = *reinterpret_cast<const float4 *>(a.epi.addend + img + off[j]);
-                if (BN) z4[j] = *reinterpret_cast<const float4 *>(a.epi.z + img + off[j]);
-                if (BN == 2) a4[j] = *reinterpret_cast<const float4 *>(a.epi.act + img + off[j]);
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BN) {           // per-channel constants from LDS, just before their use
+                const float4 m4 = *reinterpret_cast<const float4 *>(s_epi + co0), i4 = *reinterpret_cast<const float4 *>(s_epi + 64 + co0);
+                mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+                is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+                if (BN == 1) {
+                    const float4 s4 = *reinterpret_cast<const float4 *>(s_epi + 128 + co0), h4 = *reinterpret_cast<const float4 *>(s_epi + 192 + co0);
+                    msc[0] = s4.x; msc[1] = s4.y; msc[2] = s4.z; msc[3] = s4.w;
+                    msh[0] = h4.x; msh[1] = h4.y; msh[2] = h4.z; msh[3] = h4.w;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const bool ok = oy < H && ox0 + j < W;
                 const float own[4] = {yo[io][j][0], yo[io][j][1], yo[io][j][2], yo[io][j][3]};
                 const float got[4] = {rx[io][j].x, rx[io][j].y, rx[io][j].z, rx[io][j].w};
-                const float adv[4] = {ad[j].x, ad[j].y, ad[j].z, ad[j].w};
-                const float zv[4] = {z4[j].x, z4[j].y, z4[j].z, z4[j].w};
-                const float av[4] = {a4[j].x, a4[j].y, a4[j].z, a4[j].w};
+                const float adv[4] = {ops.ad[j].x, ops.ad[j].y, ops.ad[j].z, ops.ad[j].w};
+                const float zv[4] = {ops.z4[j].x, ops.z4[j].y, ops.z4[j].z, ops.z4[j].w};
+                const float av[4] = {ops.a4[j].x, ops.a4[j].y, ops.a4[j].z, ops.a4[j].w};
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -488,17 +603,40 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     if (ADD) v += adv[r];
                     if (BN) {
                         const float gate = BN == 2 ? av[r] : fmaf(msc[r], zv[r], msh[r]);
-                        if (!(gate > 0.f) || !ok[j]) v = 0.f;
+                        if (!(gate > 0.f) || !ok) v = 0.f;
                         ssum[r] += v;
                         ssq[r] += v * ((zv[r] - mu[r]) * is[r]);
                     } else if (STATS) {
-                        if (!ok[j]) v = 0.f;
+                        if (!ok) v = 0.f;
                         ssum[r] += v;
                         ssq[r] += v * v;
                     }
                     o[r] = v;
                 }
-                if (ok[j]) *reinterpret_cast<float4 *>(a.out + img + off[j]) = make_float4(o[0], o[1], o[2], o[3]);
+                if (W4_ABL & 1024) {        // (timing experiment: same bytes, every wave store 1 KB contiguous; wrong placement)
+                    *reinterpret_cast<float4 *>(a.out + ((((size_t)tile_ * 8 + wave) * 8 + (io * 4 + j)) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                } else if (ok && !(W4_ABL & 256)) {
+                    *reinterpret_cast<float4 *>(a.out + img + (unsigned)(((oy0 + io) * W + ox0 + j) * 64 + co0)) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            if ((ADD || BN) && io == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_ops(1, ops);
+            }
+        }
+        if (STATS) {        // this tile's sums over the wave's 16 tiles -> the wave's running totals (lanes l15 == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ssum[r] = row16_sum(ssum[r]);
+                ssq[r] = row16_sum(ssq[r]);
+            }
+            if (l15 == 0) {
+                float4 *ps = reinterpret_cast<float4 *>(s_red + wave * 32 + kq * 4), *pq = ps + 4;
+                float4 x = *ps, y = *pq;
+                x.x += ssum[0]; x.y += ssum[1]; x.z += ssum[2]; x.w += ssum[3];
+                y.x += ssq[0]; y.y += ssq[1]; y.z += ssq[2]; y.w += ssq[3];
+                *ps = x;
+                *pq = y;
             }
         }
     };
@@ -506,27 +644,18 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     int slot = 0;
 #pragma unroll 1
     for (int g = 0; g < G; g += 2) {
-        iteration(g, slot, std::integral_constant<int, 0>{}, Ua);
+        iteration(g, slot, std::integral_constant<int, 0>{}, Ea);
         slot = slot == NSLOT - 1 ? 0 : slot + 1;
-        iteration(g + 1, slot, std::integral_constant<int, 1>{}, Ub);
+        iteration(g + 1, slot, std::integral_constant<int, 1>{}, W4_LEAD2 ? Eb : Ea);
         slot = slot == NSLOT - 1 ? 0 : slot + 1;
         if ((g & 7) == 6) tile_epilogue(g >> 3);
     }
     if (STATS) {        // one partial row [sum 64 | second kind 64] per block; a channel's two position halves are added
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ssum[r] = row16_sum(ssum[r]);
-            ssq[r] = row16_sum(ssq[r]);
-        }
-        if (l15 == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s_red[ph * 128 + cog * 16 + kq * 4 + r] = ssum[r];
-                s_red[ph * 128 + 64 + cog * 16 + kq * 4 + r] = ssq[r];
-            }
-        }
         __syncthreads();
-        if (tid < 128) a.stat_part[(size_t)blockIdx.x * 128 + tid] = s_red[tid] + s_red[128 + tid];
+        if (tid < 128) {
+            const int kind = tid >> 6, ch = tid & 63, cg = ch >> 4, c = ch & 15;
+            a.stat_part[(size_t)blockIdx.x * 128 + tid] = s_red[cg * 32 + kind * 16 + c] + s_red[(4 + cg) * 32 + kind * 16 + c];
+        }
     }
 }
 
@@ -543,7 +672,8 @@ __global__ void prep_wino4_kernel(const float *__restrict__ w, float *__restrict
     const int n = 4 * q + e, kg = n / 18, p = n - 18 * kg;
     const int cog = wv & 3, ph = wv >> 2, kq = lane >> 4, l15 = lane & 15;
     const int o = cog * 16 + l15, c = 8 * s + 4 * kg + kq;
-    const int i = 3 * ph + p / 6, j = p % 6;
+    const int il = p / 6, j = p % 6;
+    const int i = ph == 0 ? il : (il == 0 ? 5 : 2 + il);      // second half in the order i = 5, 3, 4 (see the tile epilogue)
     const float G[6][3] = {{0.25f, 0.f, 0.f},
                            {-1.f / 6, -1.f / 6, -1.f / 6},
                            {-1.f / 6, 1.f / 6, -1.f / 6},

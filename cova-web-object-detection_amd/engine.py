@@ -200,35 +200,16 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 
 
 # ------------------------------------------------------------------------------- conv stack
-# 3x3 convolutions (forward, data gradient, weight gradient): Winograd F(2x2,3x3) kernels (2.25x
-# fewer MFMAs, same fp32 error) or the direct implicit-GEMM kernels.
-USE_WINOGRAD = True
-USE_WINO4 = os.environ.get("COVA_WINO4", "0") == "1"      # experimental F(4x4,3x3) forward launches
-# With the Winograd kernels, BatchNorm+ReLU between the two convs of a BasicBlock and the
-# BatchNorm-backward "apply" passes are evaluated on load inside the consuming convolutions
-# (cova_conv3x3_wino_pro / cova_conv3x3_wgrad_wino_pro): a1 and dz are never written to HBM.
-FUSE_AFFINE = os.environ.get("COVA_FUSE_AFFINE", "1") != "0"
+# 3x3 convolutions: Winograd kernels only.  The weight gradient is F(2x2,3x3) (csrc/conv_wino.hip); forward and data
+# gradient run as F(4x4,3x3) (csrc/conv_wino4.hip: 1.78x fewer MFMAs again) or F(2x2,3x3).  BatchNorm+ReLU between
+# the two convs of a block and the BatchNorm-backward "apply" passes are evaluated on load inside the consuming
+# convolutions: a1 and dz are never written to HBM.
+class Options:
+    """The one set of run-time switches of the path (process-wide; read at call time)."""
+    wino4 = os.environ.get("COVA_WINO4", "1") != "0"     # F(4x4,3x3) forward / data-gradient launches in training steps
 
 
-if os.environ.get("COVA_WINO_GEO"):         # A/B switch: 1 (default) = 8x32 tiles, one block per CU; 2 = 8x16, two per CU
-    query("cova_set_option", 6, int(os.environ["COVA_WINO_GEO"]))
-
-
-def conv3_num_tiles(B, H, W):
-    """rows of the statistics partials of the active 3x3 conv kernels"""
-    return query("cova_conv3x3_wino_num_partials" if USE_WINOGRAD else "cova_conv3x3_num_tiles", B, H, W)
-
-
-def conv3x3(x, wts, addend, out, part, B, H, W, bn=None):
-    """wts = (direct layout, winograd layout) of either the forward or the dgrad weights.
-    bn = (act, z, mean, invstd): fused ReLU mask + BatchNorm-backward sums in the epilogue."""
-    if USE_WINOGRAD:
-        a, z, m, i = bn if bn is not None else (None, None, None, None)
-        call("cova_conv3x3_wino", x, wts[1], addend, a, z, m, i, out, part, B, H, W)
-    elif bn is not None:
-        call("cova_conv3x3_dgrad_bnbwd", x, wts[0], addend, bn[0], bn[1], bn[2], bn[3], out, part, B, H, W)
-    else:
-        call("cova_conv3x3_fwd", x, wts[0], addend, out, part, B, H, W)
+OPTIONS = Options()
 
 
 CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "convnet.4.1.conv2"]
@@ -264,8 +245,6 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
     bottleneck = is_bottleneck(params)
-    if bottleneck and not (USE_WINOGRAD and FUSE_AFFINE):
-        raise RuntimeError("the resnet50 extension is built on the fused Winograd path only")
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
     w1k = _empty((154, 64), images)
     call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
@@ -278,7 +257,7 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     p1 = _empty((B, H2, W2, C64), images)
     idx = _empty((B, H2, W2, C64), images, torch.uint8)
     # ymax = y1 at each window's arg-max: lets the last data-gradient conv take bn1's backward sums
-    want_ymax = save and USE_WINOGRAD and FUSE_AFFINE and (training or bottleneck)
+    want_ymax = save and (training or bottleneck)
     ymax = _empty((B, H2, W2, C64), images) if want_ymax else None
     call("cova_bn_relu_maxpool_fwd", y1, bn1.scale, bn1.shift, p1, idx, ymax, B, H1, W1)
     sv.update(y1=y1, bn1=bn1, idx=idx, ymax=ymax)
@@ -289,42 +268,55 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     return feat, (sv if save else None)
 
 
-def wino4_conv(x, abc, relu, weight, out, B, H2, W2, want_stats):
-    """Experimental F(4x4,3x3) forward launch (csrc/conv_wino4.hip): conv3x3(relu?(A*x + C)) or conv3x3(x) with abc None.
-    Returns (stat partials or None, number of partial rows)."""
-    u4f, u4d = _empty((16, 4, 64, 36), x), _empty((16, 4, 64, 36), x)
-    call("cova_conv3x3_wino4_prep", weight, u4f, u4d)
-    n4 = query("cova_conv3x3_wino4_num_partials", B, H2, W2)
-    part4 = _empty((n4, 2, C64), x) if want_stats else None
-    if abc is None:
-        call("cova_conv3x3_wino4", x, u4f, out, part4, B, H2, W2)
+def prep_wino4(w, like):
+    """conv3x3 OIHW weight -> F(4x4,3x3) forward / data-gradient operands (the per-wave register image)"""
+    a, b = _empty((147456,), like), _empty((147456,), like)
+    call("cova_conv3x3_wino4_prep", w, a, b)
+    return a, b
+
+
+def conv3_num_partials(B, H, W, wino4):
+    return query("cova_conv3x3_wino4_num_partials" if wino4 else "cova_conv3x3_wino_num_partials", B, H, W)
+
+
+def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W):
+    """conv3x3 of f(A*inp + B*in2 + C) (abc / in2 nullable) with the fused epilogue of cova_conv3x3_wino_pro.
+    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3)."""
+    kind, uw = u
+    if kind == "w4":
+        call("cova_conv3x3_wino4_full", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
+             B, H, W)
     else:
-        call("cova_conv3x3_wino4_pro", x, abc, 1 if relu else 0, u4f, out, part4, B, H2, W2)
-    return part4, n4
+        call("cova_conv3x3_wino_pro", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
+             B, H, W)
+
+
+def conv3_weights(w, like, wino4):
+    """-> (forward operand, data-gradient operand) of one 3x3 convolution, each tagged with its kernel family"""
+    if wino4:
+        a, b = prep_wino4(w, like)
+        return ("w4", a), ("w4", b)
+    a, b = prep_wino(w, like)
+    return ("w2", a), ("w2", b)
 
 
 def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     """layer1 of ResNet-18: two BasicBlocks (the reference's backbone, models.py:49-51)"""
     images = p1
     B, H, W, H1, W1, H2, W2 = sv["dims"]
+    w4 = OPTIONS.wino4 and training       # (inference keeps the BatchNorm-in-epilogue F(2x2) form)
     wf, wd = [], []
     for k in CONV3_KEYS:
-        if USE_WINOGRAD:
-            a, b = prep_wino(params[k + ".weight"], images)
-            wf.append((None, a))
-            wd.append((None, b))
-        else:
-            a, b = _empty((9, 64, 64), images), _empty((9, 64, 64), images)
-            call("cova_conv3x3_prep_weights", params[k + ".weight"], a, b)
-            wf.append((a, None))
-            wd.append((b, None))
-    sv["wd"] = wd
+        f, d = conv3_weights(params[k + ".weight"], images, w4)
+        wf.append(f)
+        wd.append(d)
+    sv["wd"], sv["w4"] = wd, w4
     R = B * H2 * W2
-    nt = conv3_num_tiles(B, H2, W2)
+    nt = conv3_num_partials(B, H2, W2, w4)
     x = p1
     blocks = []
     for blk in (0, 1):
-        if not training and not save and USE_WINOGRAD and FUSE_AFFINE:
+        if not training and not save:
             # inference: running statistics are known up front, so BatchNorm (+ residual) + ReLU sit in
             # the conv epilogues -- two launches per BasicBlock, nothing else touches the maps
             bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, False)
@@ -337,35 +329,21 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             continue
         part = _empty((nt, 2, C64), images) if training else None
         z1 = _empty((B, H2, W2, C64), images)
-        if USE_WINO4 and USE_WINOGRAD and training:
-            # experimental F(4x4,3x3) form of the forward launches (csrc/conv_wino4.hip)
-            part4, n4 = wino4_conv(x, None, 0, params[CONV3_KEYS[2 * blk] + ".weight"], z1, B, H2, W2, True)
-            bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part4, n4, R, unit="pages")
-        else:
-            conv3x3(x, wf[2 * blk], None, z1, part, B, H2, W2)
-            bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
+        conv3x3_pro(wf[2 * blk], x, None, None, 0, None, None, None, None, None, None, None, z1, part, B, H2, W2)
+        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
         z2 = _empty((B, H2, W2, C64), images)
-        part_b, nt_b = part, nt
-        if USE_WINOGRAD and FUSE_AFFINE and USE_WINO4 and training:
-            a1 = None
-            part_b, nt_b = wino4_conv(z1, bna.abc, 1, params[CONV3_KEYS[2 * blk + 1] + ".weight"], z2, B, H2, W2, True)
-        elif USE_WINOGRAD and FUSE_AFFINE:          # a1 = relu(bn1(z1)) formed on load
-            a1 = None
-            call("cova_conv3x3_wino_pro", z1, None, bna.abc, 1, wf[2 * blk + 1][1], None, None, None,
-                 None, None, None, None, z2, part, B, H2, W2)
-        else:
-            a1 = _empty((B, H2, W2, C64), images)
-            call("cova_bn_act_fwd", z1, C64, bna.scale, bna.shift, None, 0, a1, C64, R, C64, 1)
-            conv3x3(a1, wf[2 * blk + 1], None, z2, part, B, H2, W2)
-        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part_b, nt_b, R, unit="pages")
-        if blk == 1 and lazy_out and USE_WINOGRAD and FUSE_AFFINE:
+        # a1 = relu(bn1(z1)) formed on load
+        conv3x3_pro(wf[2 * blk + 1], z1, None, bna.abc, 1, None, None, None, None, None, None, None, z2, part,
+                    B, H2, W2)
+        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R, unit="pages")
+        if blk == 1 and lazy_out:
             out = None
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
         else:
             out = _empty((B, H2, W2, C64), images)
             call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
             feat = out
-        blocks.append(dict(x=x, z1=z1, a1=a1, z2=z2, out=out, bna=bna, bnb=bnb))
+        blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=out, bna=bna, bnb=bnb))
         x = out
     sv["blocks"] = blocks
     # what RoIPool's backward needs of the block that produced the feature map
@@ -390,7 +368,9 @@ def conv1x1(inp, in2, abc, relu, w, w_trans, out, part, R, cin, cout, addend=Non
 def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    nt = conv3_num_tiles(B, H2, W2)
+    w4 = OPTIONS.wino4 and training
+    sv["w4"] = w4
+    nt = conv3_num_partials(B, H2, W2, w4)
 
     def stats(cin, cout):
         n = query("cova_conv1x1_num_partials", R, cin, cout)
@@ -417,16 +397,12 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
             blocks[-1]["out"] = x
         s["x"] = x
         s["bn1"] = bn(pre + "bn1.", C64, part, n)
-        uf, s["ud"] = prep_wino(params[pre + "conv2.weight"], p1)
+        uf, s["ud"] = conv3_weights(params[pre + "conv2.weight"], p1, w4)
         part = _empty((nt, 2, C64), p1) if training else None
         s["z2"] = _empty((B, H2, W2, C64), p1)
-        if USE_WINO4 and training:
-            part4, n4 = wino4_conv(s["z1"], s["bn1"].abc, 1, params[pre + "conv2.weight"], s["z2"], B, H2, W2, True)
-            s["bn2"] = bn(pre + "bn2.", C64, part4, n4)
-        else:
-            call("cova_conv3x3_wino_pro", s["z1"], None, s["bn1"].abc, 1, uf, None, None, None, None, None, None,
-                 None, s["z2"], part, B, H2, W2)
-            s["bn2"] = bn(pre + "bn2.", C64, part, nt)
+        conv3x3_pro(uf, s["z1"], None, s["bn1"].abc, 1, None, None, None, None, None, None, None, s["z2"], part,
+                    B, H2, W2)
+        s["bn2"] = bn(pre + "bn2.", C64, part, nt)
         part, n = stats(C64, C256)
         s["z3"] = _empty((B, H2, W2, C256), p1)
         conv1x1(s["z2"], None, s["bn2"].abc, 1, params[pre + "conv3.weight"], 0, s["z3"], part, R, C64, C256)
@@ -507,7 +483,7 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
     Returns the ReLU-masked gradient w.r.t. the max-pool output (sv['pool_part'] holds the stem's sums)."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    nt = conv3_num_tiles(B, H2, W2)
+    nt = conv3_num_partials(B, H2, W2, sv["w4"])
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
     ws1 = _empty((max(query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),
                       query("cova_conv1x1_vprod_workspace_floats", R)),), g)
@@ -532,8 +508,8 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "conv2.weight"] = dw
         dy1 = _empty((B, H2, W2, C64), g)
         part = _empty((nt, 2, C64), g)
-        call("cova_conv3x3_wino_pro", dy2, s["z2"], abc2, 0, s["ud"], None, None, bn1.scale, bn1.shift,
-             s["z1"], bn1.mean, bn1.invstd, dy1, part, B, H2, W2)
+        conv3x3_pro(s["ud"], dy2, s["z2"], abc2, 0, None, None, bn1.scale, bn1.shift, s["z1"], bn1.mean, bn1.invstd,
+                    dy1, part, B, H2, W2)
         dg, db, abc1 = _bn_abc_from_partials(part, nt, bn1, R, gout, pre + "bn1.", g)
         grads[pre + "bn1.weight"], grads[pre + "bn1.bias"] = dg, db
         # conv1 (Cin->64): dz1 = abc1 . (dy1, z1) on load
@@ -612,7 +588,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
-    nt = conv3_num_tiles(B, H2, W2)
+    nt = conv3_num_partials(B, H2, W2, sv["w4"])
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
     # the last bn2 were taken by cova_roipool_bwd_bn
     dA, pend, npend = dfeat, None, nt
@@ -640,8 +616,8 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         # ---- dgrad of conv2 with bn1's ReLU mask (recomputed from z1) + backward sums in the epilogue
         dy_a = torch.empty_like(dA)
         part = _empty((nt, 2, C64), dfeat)
-        call("cova_conv3x3_wino_pro", g_in, g_in2, g_abc, 0, sv["wd"][2 * blk + 1][1], None, None,
-             bna.scale, bna.shift, s["z1"], bna.mean, bna.invstd, dy_a, part, B, H2, W2)
+        conv3x3_pro(sv["wd"][2 * blk + 1], g_in, g_in2, g_abc, 0, None, None, bna.scale, bna.shift, s["z1"], bna.mean,
+                    bna.invstd, dy_a, part, B, H2, W2)
         dg, db, abc_a = _bn_abc_from_partials(part, nt, bna, R, gout, pa, dfeat)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
@@ -652,66 +628,17 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         if blk == 1:
             prev = sv["blocks"][0]
             pend, npend = _empty((nt, 2, C64), dfeat), nt
-            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres,
-                 prev["out"], None, None, prev["z2"], prev["bnb"].mean, prev["bnb"].invstd, dx, pend,
-                 B, H2, W2)
+            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, prev["out"], None, None, prev["z2"],
+                        prev["bnb"].mean, prev["bnb"].invstd, dx, pend, B, H2, W2)
         elif sv.get("ymax") is not None:
             # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
             bn1 = sv["bn1"]
             sv["pool_part"], sv["pool_npart"] = _empty((nt, 2, C64), dfeat), nt
-            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
-                 bn1.scale, bn1.shift, sv["ymax"], bn1.mean, bn1.invstd, dx, sv["pool_part"], B, H2, W2)
+            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, bn1.scale, bn1.shift, sv["ymax"],
+                        bn1.mean, bn1.invstd, dx, sv["pool_part"], B, H2, W2)
         else:
-            call("cova_conv3x3_wino_pro", dy_a, s["z1"], abc_a, 0, sv["wd"][2 * blk][1], dres, None,
-                 None, None, None, None, None, dx, None, B, H2, W2)
-        dA = dx
-    return dA
-
-
-def _layer1_bwd_unfused(sv, dfeat, gout, grads):
-    B, H, W, H1, W1, H2, W2 = sv["dims"]
-    R = B * H2 * W2
-    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
-    WGRAD3 = "cova_conv3x3_wgrad_wino" if USE_WINOGRAD else "cova_conv3x3_wgrad"
-    nt = conv3_num_tiles(B, H2, W2)
-    dA, pend = dfeat, None          # pend: partials of the fused reduction for dA (already masked)
-    for blk in (1, 0):
-        s = sv["blocks"][blk]
-        ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
-        pa, pb = BN3_KEYS[2 * blk], BN3_KEYS[2 * blk + 1]
-        # ---- out = relu(bn2(z2) + x)
-        dz2 = torch.empty_like(dA)
-        if pend is None:
-            dres = torch.empty_like(dA)
-            dg, db = bn_backward(dA, C64, block_out(s), C64, s["z2"], C64, s["bnb"], R, dz2, C64, dres,
-                                 C64, gout, pb, unit="pages")
-        else:
-            dres = dA                                 # masked dy doubles as the residual gradient
-            dg, db = bn_bwd_from_partials(pend, nt, dA, s["z2"], s["bnb"], R, dz2, gout, pb)
-        grads[pb + "weight"], grads[pb + "bias"] = dg, db
-        dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
-        call(WGRAD3, s["a1"], dz2, dw, ws3, B, H2, W2)
-        grads[kb + ".weight"] = dw
-        # ---- a1 = relu(bn1(z1)): dgrad of conv2 fused with bn1's mask + reduction
-        dy_a = torch.empty_like(dA)
-        part = _empty((nt, 2, C64), dfeat)
-        bna = s["bna"]
-        conv3x3(dz2, sv["wd"][2 * blk + 1], None, dy_a, part, B, H2, W2,
-                (s["a1"], s["z1"], bna.mean, bna.invstd))
-        dz1 = dz2                                     # reuse
-        dg, db = bn_bwd_from_partials(part, nt, dy_a, s["z1"], bna, R, dz1, gout, pa)
-        grads[pa + "weight"], grads[pa + "bias"] = dg, db
-        dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
-        call(WGRAD3, s["x"], dz1, dw, ws3, B, H2, W2)
-        grads[ka + ".weight"] = dw
-        dx = dy_a                                     # reuse
-        if blk == 1:
-            prev = sv["blocks"][0]                    # this block's input is prev's relu(bn2 + x)
-            pend = _empty((nt, 2, C64), dfeat)
-            conv3x3(dz1, sv["wd"][2 * blk], dres, dx, pend, B, H2, W2,
-                    (prev["out"], prev["z2"], prev["bnb"].mean, prev["bnb"].invstd))
-        else:
-            conv3x3(dz1, sv["wd"][2 * blk], dres, dx, None, B, H2, W2)
+            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, None, None, None, None, None, dx,
+                        None, B, H2, W2)
         dA = dx
     return dA
 
@@ -749,12 +676,8 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
             dfeat, head_part = masked_grad_and_sums(dfeat, sv["last"], R)
         dA = _layer1_bottleneck_bwd(sv, dfeat, params, gout, grads, head_part)
     else:
-        fused = USE_WINOGRAD and FUSE_AFFINE and sv["blocks"][0]["a1"] is None
-        if fused:
-            dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
-        else:
-            assert head_part is None
-            dA = _layer1_bwd_unfused(sv, dfeat, gout, grads)
+        fused = True
+        dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
     if fused and sv.get("pool_part") is not None:
@@ -1112,8 +1035,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     if after_head is not None:
         after_head()
     conv = sv["conv"]
-    fused = conv["kind"] == "bottleneck" or (USE_WINOGRAD and FUSE_AFFINE and conv["blocks"][0]["a1"] is None)
-    if fused and N > 0 and sv["roi"]["zmax"] is not None:
+    if N > 0 and sv["roi"]["zmax"] is not None:
         dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"])
         grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
     else:

@@ -541,6 +541,67 @@ def test_conv3x3_winograd_affine_on_load(B, H, W, cap, geo):
         query("cova_set_option", 6, 1)
 
 
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5), (1, 3, 5, 0)])
+def test_conv3x3_winograd_f4x4_full_form(B, H, W, cap):
+    """cova_conv3x3_wino4_full (F(4x4,3x3): one- and two-tensor affine prologue, addend, ReLU mask from z or from the
+    materialised activation, BatchNorm-backward sums) against the F(2x2,3x3) kernel on the same inputs -- the ReLU
+    masks must be IDENTICAL (same fma as cova_bn_act_fwd), values and sums agree to F(4x4)'s fp32 error -- and against
+    torch in fp64.  cap forces several tiles per persistent block (the pipeline crosses tile boundaries)."""
+    g = torch.Generator().manual_seed(13 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    xc, x2c, addc = rnd(B, 64, H, W), rnd(B, 64, H, W), rnd(B, 64, H, W)
+    x, x2, add = nhwc(xc), nhwc(x2c), nhwc(addc)
+    w = rnd(64, 64, 3, 3) * 0.05
+    abc = rnd(3, 64)
+    u2f, u2d = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
+    call("cova_conv3x3_prep_weights_wino", w.to(DEV), u2f, u2d)
+    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
+    query("cova_set_option", 2, cap)
+    n2, n4 = query("cova_conv3x3_wino_num_partials", B, H, W), query("cova_conv3x3_wino4_num_partials", B, H, W)
+    R = B * H * W
+    abcd = abc.to(DEV)
+    try:
+        z = nhwc(rnd(B, 64, H, W))
+        msc, msh = rnd(64).to(DEV), rnd(64).to(DEV) * 0.3
+        act = torch.empty_like(z)
+        call("cova_bn_act_fwd", z, 64, msc, msh, None, 0, act, 64, R, 64, 1)
+        mean, invstd = rnd(64).to(DEV) * 0.2, (torch.rand(64, generator=g) + 0.5).to(DEV)
+        pre = abc[0].view(1, -1, 1, 1) * xc + abc[1].view(1, -1, 1, 1) * x2c + abc[2].view(1, -1, 1, 1)
+        dref = F.conv2d(pre.double(), w.double().flip(2, 3).transpose(0, 1), padding=1)       # data-gradient form
+        cases = [  # (in2, abc, relu, weights 2/4, addend, act, msc/msh, z)
+            ("two-tensor prologue, mask from z", x2, abcd, 0, (u2d, u4d), None, None, (msc, msh), z),
+            ("two-tensor prologue, addend, mask from z", x2, abcd, 0, (u2d, u4d), add, None, (msc, msh), z),
+            ("two-tensor prologue, addend, mask from act", x2, abcd, 0, (u2d, u4d), add, act, (None, None), z),
+            ("relu prologue, statistics", None, abcd, 1, (u2f, u4f), None, None, (None, None), None),
+            ("plain, addend, no statistics", None, None, 0, (u2f, u4f), add, None, (None, None), None),
+        ]
+        for name, in2, pabc, relu, (u2, u4), ad, ac, (sc, sh), zz in cases:
+            want_part = zz is not None or "statistics" in name and "no statistics" not in name
+            ref, out = torch.empty_like(x), torch.full_like(x, 7.0)
+            pref = torch.empty(n2, 2, 64, device=DEV) if want_part else None
+            part = torch.empty(n4, 2, 64, device=DEV) if want_part else None
+            mm = (mean, invstd) if zz is not None else (None, None)
+            call("cova_conv3x3_wino_pro", x, in2, pabc, relu, u2, ad, ac, sc, sh, zz, mm[0], mm[1], ref, pref, B, H, W)
+            call("cova_conv3x3_wino4_full", x, in2, pabc, relu, u4, ad, ac, sc, sh, zz, mm[0], mm[1], out, part, B, H, W)
+            if zz is not None:
+                assert torch.equal(out == 0, ref == 0), name + ": ReLU masks differ"
+            close(out, ref, 2e-5, name)
+            if want_part:
+                close(part.double().sum(0), pref.double().sum(0), 2e-4, name + " sums")
+        # against torch (fp64): the two-tensor prologue + addend with the mask from z
+        out, part = torch.empty_like(x), torch.empty(n4, 2, 64, device=DEV)
+        call("cova_conv3x3_wino4_full", x, x2, abcd, 0, u4d, add, None, msc, msh, z, mean, invstd, out, part, B, H, W)
+        gate = (nchw(act) > 0)
+        t = (dref + addc.double()) * gate
+        close(nchw(out), t, 2e-5, "wino4 full vs torch")
+        xhat = (nchw(z).double() - mean.cpu().double().view(1, -1, 1, 1)) * invstd.cpu().double().view(1, -1, 1, 1)
+        close(part[:, 0].double().sum(0), t.sum((0, 2, 3)), 2e-4, "wino4 full sum g")
+        close(part[:, 1].double().sum(0), (t * xhat).sum((0, 2, 3)), 2e-4, "wino4 full sum g*xhat")
+    finally:
+        query("cova_set_option", 2, 0)
+
+
 @pytest.mark.parametrize("geo", [1, 2])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 5)])
 def test_conv3x3_winograd_inference_epilogue(B, H, W, cap, geo):
@@ -757,7 +818,7 @@ def test_roipool_other_output_sizes(ph, pw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,W", [(1, 16, 32), (2, 19, 45), (1, 40, 70), (1, 3, 5)])
+@pytest.mark.parametrize("B,H,W", [(1, 16, 32), (2, 19, 45), (1, 40, 70), (1, 3, 5), (3, 100, 200)])
 def test_conv3x3_winograd_f4x4(B, H, W):
     """F(4x4,3x3) form (csrc/conv_wino4.hip): forward with statistics and the data-gradient weights, against
     torch's conv2d on CPU.  Its fp32 error is ~10x F(2x2,3x3)'s (transform constants up to 8 and 1/24), still
@@ -765,8 +826,10 @@ def test_conv3x3_winograd_f4x4(B, H, W):
     g = torch.Generator().manual_seed(H * W + 1)
     x = torch.randn(B, 64, H, W, generator=g).clamp_min(0)
     w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
-    uf, ud = torch.empty(16, 4, 64, 36, device=DEV), torch.empty(16, 4, 64, 36, device=DEV)
+    uf, ud = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
+    if B == 3:
+        query("cova_set_option", 2, 5)          # several tiles per persistent block
     n = query("cova_conv3x3_wino4_num_partials", B, H, W)
     out, part = torch.full((B, H, W, 64), 7.0, device=DEV), torch.empty(n, 2, 64, device=DEV)
     call("cova_conv3x3_wino4", nhwc(x), uf, out, part, B, H, W)
@@ -792,3 +855,4 @@ def test_conv3x3_winograd_f4x4(B, H, W):
         call("cova_conv3x3_wino4_pro", nhwc(z), abc.to(DEV), relu, uf, o3, p3, B, H, W)
         close(nchw(o3), refp, 2e-5, "wino4 prologue relu=%d" % relu)
         close(p3[:, 0].double().sum(0), refp.sum((0, 2, 3)), 1e-4, "wino4 prologue stat sum")
+    query("cova_set_option", 2, 0)

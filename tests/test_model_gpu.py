@@ -588,11 +588,11 @@ def test_input_layout_and_index_dtype_do_not_change_the_result():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cova_h64_n90", "cova_h128_ragged"])
-def test_experimental_f4x4_forward_keeps_reference_parity(name, monkeypatch):
-    """The opt-in F(4x4,3x3) forward launches (engine.USE_WINO4, csrc/conv_wino4.hip: plain and affine-on-load
-    inputs, batch statistics) against the same reference fixtures and the forced-routing oracle, at the same
-    bounds as the default path."""
-    monkeypatch.setattr(engine, "USE_WINO4", True)
+def test_f2x2_conv_path_keeps_reference_parity(name, monkeypatch):
+    """The F(2x2,3x3) forward / data-gradient launches (engine.OPTIONS.wino4 = False; the default is F(4x4,3x3),
+    csrc/conv_wino4.hip, which every other model test runs) against the same reference fixtures and the
+    forced-routing oracle, at the same bounds."""
+    monkeypatch.setattr(engine.OPTIONS, "wino4", False)
     fx, cfg, sd, batch = load_case(name)
     img_h = int(fx["meta/img_h"])
     args = dev_batch(batch)

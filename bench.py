@@ -17,8 +17,10 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- the dominant kernel family (Winograd conv3x3 64->64 on exact-f32 MFMA), timed live with HIP
                   events on the launching stream inside the timed steps.  `frac` = EXECUTED MFMA FLOP/s over
                   the 157.3 TFLOP/s f32-MFMA peak (<= 1 by construction); the algorithmic (direct-convolution,
-                  SURVEY.md 8d) rate of the same launches is reported beside it -- Winograd F(2x2,3x3)
-                  executes 2.25x fewer multiplies, so that rate may exceed the direct-form peak.
+                  SURVEY.md 8d) rate of the same launches is reported beside it -- Winograd F(4x4,3x3)
+                  executes 4x fewer multiplies, so that rate may exceed the direct-form peak.
+  sustained    -- >= 5 s of back-to-back train steps after the headline measurement (same batch), reported
+                  separately: long enough for an external utilisation sampler to see the GPU work.
   step         -- whole-step FLOP accounting: algorithmic TFLOP/s, fraction of the direct-convolution MFMA
                   ceiling, fraction of the executed-MFMA floor.
   cpu_baseline -- the CPU oracle (oracle/cova_oracle.py, a restatement of the reference's torch-CPU path)
@@ -40,8 +42,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-input MFMA
 PEAK_HBM_TBS = 8.0
-WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3)
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3): the weight gradients
+WINO4_RATIO = 4.0                                  # ... / Winograd F(4x4,3x3): forward and data-gradient launches
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 
 WORKLOADS = {
     2: dict(name="configs[1]", H=1280, W=1280, pages=16, boxes=90, cs=12, backbone="resnet18", n_heads=1,
@@ -155,7 +158,7 @@ def cpu_baseline(wl, full=False):
     out = {"unit": "webpages/s", "cores": torch.get_num_threads(), "physical_cores": phys, "cpu_model": model,
            "kind": "port", "statistic": "median"}
     legs = []
-    for pages, warm, timed in ((2, 3, 5), (16, 3 if full else 1, 5 if full else 3)):
+    for pages, warm, timed in ((2, 3, 5), (16, 3 if full else 1, 5 if full else 3)):      # default: full
         sd = weights.seeded_state_dict(123, **weight_cfg(cfg))
         b = synthetic.make_boxes_only(pages, wl["H"], wl["W"], wl["boxes"], wl["cs"], 123)
         images = torch.rand((pages, 3, wl["H"], wl["W"]), generator=torch.Generator().manual_seed(123))
@@ -239,7 +242,10 @@ def main():
     ap.add_argument("--roi-op", choices=("pool", "align"), default="pool",
                     help="pool = the reference's RoIPool (the metric's configuration); align = the RoIAlign variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="3 warm-up + 5 timed steps for the 16-page leg too")
+    ap.add_argument("--cpu-baseline-quick", action="store_true",
+                    help="16-page CPU leg with 1 warm-up + 3 timed steps (default: 3 + 5 as SURVEY.md 8d asks)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="length of the `sustained` leg after the headline measurement (0 = skip)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm statistics over the whole data-parallel batch (default: per rank, as DDP)")
     args = ap.parse_args()
@@ -307,7 +313,8 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    timed = ["cova_conv3x3_wino", "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
+    timed = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv1_fwd_tail", "cova_conv3x3_wino", "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro",
+             "cova_conv3x3_wgrad_wino",
              "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad", "cova_bn_relu_maxpool_fwd",
              "cova_conv1x1", "cova_conv1x1_wgrad", "cova_bn_act_fwd", "cova_bn_act2_fwd", "cova_roipool_fwd_bn",
              "cova_roipool_bwd_bn", "cova_sgemm", "cova_gat_fwd", "cova_gat_bwd"]
@@ -318,8 +325,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, _lib.PROFILE = _lib.PROFILE, None
+    dt_rank = dt
     dt = max_over_ranks(dt)
     loss_val = float(loss.item())
+    per_rank_ms, exposed_ms = [round(1e3 * dt_rank / args.steps, 3)], [round(trainer.exposed_allreduce_ms(), 4)]
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (per_rank_ms[0], exposed_ms[0]))
+        per_rank_ms, exposed_ms = [g[0] for g in gathered], [g[1] for g in gathered]
 
     def mean_ms(names, pred=None):
         ev = [p for n in names for p in prof.get(n, []) if pred is None or pred(p[2])]
@@ -330,6 +344,19 @@ def main():
         for ms, n, k in sorted(rows, reverse=True):
             print("%-36s %5.1f calls/step %8.3f ms/step" % (k, n, ms), file=sys.stderr)
         print("sum %.3f ms/step" % sum(r[0] for r in rows), file=sys.stderr)
+
+    # sustained leg: >= N seconds of back-to-back train steps (reported separately from the headline)
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_s = max(args.steps, int(args.sustained_seconds / max(dt / args.steps, 1e-4)) + 1)
+        barrier()
+        t_s = time.perf_counter()
+        for _ in range(n_s):
+            trainer.train_step(batch)
+        barrier()
+        dt_s = max_over_ranks(time.perf_counter() - t_s)
+        sustained = {"value": round(global_pages * n_s / dt_s, 2), "unit": "webpages/s", "steps": n_s,
+                     "seconds": round(dt_s, 2), "ms_per_step": round(1e3 * dt_s / n_s, 3)}
 
     # forward only (eval mode, running statistics): the second number SURVEY.md section 8d asks for
     for _ in range(2):
@@ -387,18 +414,22 @@ def main():
         value = global_pages * args.steps / dt
         fm = flop_model(wl)
         px_pages = pages
-        conv_ms, conv_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
+        w4_ms, w4_n = mean_ms(["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail"])
+        w2_ms, w2_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
+        use4 = w4_n > 0
+        conv_ms, conv_n, ratio = (w4_ms, w4_n, WINO4_RATIO) if use4 else (w2_ms, w2_n, WINO_RATIO)
+        kname = "conv3x3_c64_wino4_kernel" if use4 else "conv3x3_c64_wino_kernel"
         alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
-        executed = alg / WINO_RATIO
+        executed = alg / ratio
         map_bytes = 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4)
-        roof = {"bound": "mfma", "kernel": "conv3x3_c64_wino_kernel (forward + data-gradient launches of the step)",
-                "algorithm": "winograd F(2x2,3x3), exact f32 MFMA (v_mfma_f32_16x16x4_f32)",
+        roof = {"bound": "mfma", "kernel": kname + " (forward + data-gradient launches of the step)",
+                "algorithm": "winograd %s, exact f32 MFMA (v_mfma_f32_16x16x4_f32)" % ("F(4x4,3x3)" if use4 else "F(2x2,3x3)"),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches_timed": conv_n}
         if conv_n:
             ach = executed / conv_ms / 1e9
-            traffic, src = read_traffic("conv3x3_c64_wino_kernel", px_pages)
+            traffic, src = read_traffic(kname, px_pages)
             roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        achieved_is="EXECUTED MFMA FLOP/s (algorithmic / 2.25)", avg_launch_ms=round(conv_ms, 4),
+                        achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio, avg_launch_ms=round(conv_ms, 4),
                         executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
                         algorithmic_achieved=round(alg / conv_ms / 1e9, 2),
                         algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -410,17 +441,19 @@ def main():
                         algorithmic_bytes=int((27 / 8 if wl["backbone"] == "resnet18" else 18 / 6) * map_bytes),
                         algorithmic_bytes_plain_launch=2 * map_bytes)
         step_alg = fm["total"] * pages                                   # per rank
-        step_exec = (fm["total"] - fm["wino"] + fm["wino"] / WINO_RATIO) * pages
+        # executed multiplies: weight gradients as F(2x2,3x3), forward + data gradients as F(4x4,3x3) when those kernels ran
+        step_exec = (fm["total"] - fm["wino"] + fm["wino"] / 3 / WINO_RATIO + 2 * fm["wino"] / 3 / ratio) * pages
         step = {"algorithmic_gflop_per_page": round(fm["total"] / 1e9, 2),
                 "algorithmic_tflops": round(step_alg / (ms_per_step * 1e-3) / 1e12, 2),
                 "frac_of_direct_ceiling": round(step_alg / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "executed_gflop_per_page": round(step_exec / pages / 1e9, 2),
                 "frac_of_executed_floor": round(step_exec / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "per GPU; executed = 3x3 convolutions counted at Winograd's 1/2.25 of the direct multiplies"}
+                "note": "per GPU; executed = 3x3 convolutions counted at Winograd's share of the direct multiplies "
+                        "(weight gradient 1/2.25, forward and data gradient 1/%g)" % ratio}
         others = {}
         hw = (wl["H"] // 4) * (wl["W"] // 4)
         f_conv1 = 2 * 64 * 147 * pages * (wl["H"] // 2) * (wl["W"] // 2)
-        specs = [("conv1_7x7_fwd", ["cova_conv1_fwd"], None, f_conv1, 0),
+        specs = [("conv1_7x7_fwd", ["cova_conv1_fwd", "cova_conv1_fwd_tail"], None, f_conv1, 0),
                  ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0),
                  ("conv3x3_wgrad_winograd", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino"], None,
                   fm["conv3_launch_per_page"] * pages / WINO_RATIO, 0),
@@ -460,10 +493,15 @@ def main():
                              "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),
                              "mode": "eval forward (running statistics) + per-box argmax, same batch"},
         }
+        if sustained:
+            out["sustained"] = sustained
+        out["per_rank"] = {"ms_per_step": per_rank_ms, "allreduce_exposed_ms": exposed_ms,
+                           "note": "allreduce_exposed_ms = HIP-event time of optimizer_step's collective waits per step "
+                                   "(0 on one rank)"}
         if dropin:
             out["dropin_module_loop"] = dropin
         if world == 1 and not args.no_cpu_baseline and args.roi_op == "pool":
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_full)
+            out["cpu_baseline"] = cpu_baseline(wl, not args.cpu_baseline_quick)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -11,6 +11,7 @@
 // by the conv epilogues), then a finalize kernel that combines the partials in fp64.
 // These kernels are HBM-bound: algorithmic bytes = 4 B per element read or written.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -180,22 +181,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     double sum, sumsq;
     combine_partials(partial, nparts, C, c, slice, s_a, s_b, sum, sumsq);
-    if (slice == 0 && c < C) {
-        const double mu = sum / count;
-        double var = sumsq / count - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * is;
-        mean[c] = (float)mu;
-        invstd[c] = is;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mu * sc;
-        if (running_mean != nullptr) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
+    if (slice == 0 && c < C)
+        bn_fwd_channel(sum, sumsq, count, c, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
+                       invstd);
 }
 
 __global__ void bn_eval_params_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -243,15 +231,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_abc_kernel(
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     double s1, s2;
     combine_partials(partial, nparts, C, c, slice, s_a, s_b, s1, s2);
-    if (slice == 0 && c < C) {
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dgamma) dgamma[c] = (float)s2;
-        const double c1 = s1 / count, c2 = s2 / count;
-        const double sc = scale[c], is = invstd[c], mu = mean[c];
-        abc[c] = (float)sc;
-        abc[C + c] = (float)(-sc * is * c2);
-        abc[2 * C + c] = (float)(sc * (mu * is * c2 - c1));
-    }
+    if (slice == 0 && c < C) bn_bwd_abc_channel(s1, s2, count, c, C, dgamma, dbeta, mean, invstd, scale, abc);
 }
 
 // out = act(z*scale + shift (+ res));  V = vector width (1 or 4)

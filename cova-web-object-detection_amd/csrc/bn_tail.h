@@ -1,0 +1,96 @@
+// BatchNorm finalize as the TAIL of the kernel that produced the statistics partials: the last block to finish (ticket
+// counter) folds the partial rows and writes what cova_bn_finalize_fwd / cova_bn_finalize_bwd_abc would have written
+// in a separate launch (same fp64 arithmetic, same summation order: bit-identical results).  Used by the 3x3 / 7x7
+// convolution kernels with 64 channels; SyncBN and frozen BatchNorm keep the separate kernels (a collective / a host
+// decision sits between the partials and the finalize there).
+#pragma once
+#include "common.h"
+
+#include "../../include/cova_hip.h"
+typedef cova_bn_tail BnTail;      // (a plain C struct of device pointers; passed to the kernels by value)
+
+// per-channel results from the fp64 totals -- shared with bn.hip's stand-alone kernels
+__device__ __forceinline__ void bn_fwd_channel(double sum, double sumsq, double count, int c, const float *gamma,
+                                               const float *beta, float *running_mean, float *running_var,
+                                               float momentum, float eps, float *scale, float *shift, float *mean,
+                                               float *invstd)
+{
+    const double mu = sum / count;
+    double var = sumsq / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * is;
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__device__ __forceinline__ void bn_bwd_abc_channel(double s1, double s2, double count, int c, int C, float *dgamma,
+                                                   float *dbeta, const float *mean, const float *invstd,
+                                                   const float *scale, float *abc)
+{
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    const double c1 = s1 / count, c2 = s2 / count;
+    const double sc = scale[c], is = invstd[c], mu = mean[c];
+    abc[c] = (float)sc;
+    abc[C + c] = (float)(-sc * is * c2);
+    abc[2 * C + c] = (float)(sc * (mu * is * c2 - c1));
+}
+
+// A block's partial row is written with device-scope (agent) relaxed atomic stores and read back by the last block with
+// device-scope atomic loads: per-access coherence across the eight XCDs' L2s.  A __threadfence() instead would write
+// back and invalidate the whole L2 of the XCD at the end of every block -- measured: +0.6 ms per train step, because
+// the next kernel then finds neither the output map nor the weights in L2.
+__device__ __forceinline__ void bn_tail_store(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Call at the very end of the kernel, by ALL threads of every block, after this block's partial row(s) have been
+// written with bn_tail_store (`partial` = [nparts][2][64]).  `s_dbl` = at least 2048 doubles of shared memory that is
+// free by now.  blockDim.x must be a multiple of 64.
+__device__ __forceinline__ void bn_tail_run(const BnTail &t, float *partial, int nparts, double *s_dbl)
+{
+    if (t.mode == 0) return;
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);        // this thread's row stores have been acknowledged at device scope ...
+    __syncthreads();                      // ... all of the block's have ...
+    if (threadIdx.x == 0)                 // ... before its ticket is taken
+        s_last = __hip_atomic_fetch_add(t.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    double *s_a = s_dbl, *s_b = s_dbl + 1024;
+    const int c = threadIdx.x & 63, nsl = blockDim.x >> 6;
+    for (int slice = threadIdx.x >> 6; slice < 16; slice += nsl) {      // bn.hip's combine_partials: 16 slices of rows
+        double a = 0.0, b = 0.0;
+        for (int p = slice; p < nparts; p += 16) {
+            a += (double)__hip_atomic_load(partial + ((size_t)p * 2 + 0) * 64 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b += (double)__hip_atomic_load(partial + ((size_t)p * 2 + 1) * 64 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_a[slice * 64 + c] = a;
+        s_b[slice * 64 + c] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double ta = 0.0, tb = 0.0;
+        for (int j = 0; j < 16; ++j) {
+            ta += s_a[j * 64 + c];
+            tb += s_b[j * 64 + c];
+        }
+        if (t.mode == 1) {
+            if (threadIdx.x == 0 && t.num_batches_tracked != nullptr) *t.num_batches_tracked += 1;
+            bn_fwd_channel(ta, tb, t.count, c, t.gamma, t.beta, t.running_mean, t.running_var, t.momentum, t.eps,
+                           t.scale, t.shift, t.mean, t.invstd);
+        } else {
+            bn_bwd_abc_channel(ta, tb, t.count, c, 64, t.dgamma, t.dbeta, t.mean, t.invstd, t.scale, t.abc);
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(t.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}

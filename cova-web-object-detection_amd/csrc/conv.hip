@@ -12,6 +12,7 @@
 // Roofline bookkeeping: 2*64*64*9 = 73,728 FLOP per output pixel
 // for conv3x3 (fwd, dgrad and wgrad each), 2*64*147 = 18,816 FLOP per output pixel for conv1.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -335,7 +336,7 @@ template <bool STATS>
 __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
     float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
-    int abl_arg)
+    int abl_arg, int w_oihw, const BnTail tail)
 {
     const int abl = COVA_ABL(abl_arg);
     using namespace c1;
@@ -397,8 +398,16 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
         }
     };
     issue_loads(tile);
-    for (int idx = tid; idx < W_FLOATS / 4; idx += THREADS)
-        reinterpret_cast<float4 *>(s_w)[idx] = reinterpret_cast<const float4 *>(wk)[idx];
+    if (w_oihw) {                // wk is the OIHW weight itself [64][3][7][7]: the K-pair layout is formed here (no prep launch)
+        for (int idx = tid; idx < W_FLOATS; idx += THREADS) {
+            const int row = idx >> 6, co = idx & 63;
+            const int tap = c1::pair_tap(row >> 1, row & 1);
+            s_w[idx] = tap >= 0 ? wk[co * 147 + tap] : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < W_FLOATS / 4; idx += THREADS)
+            reinterpret_cast<float4 *>(s_w)[idx] = reinterpret_cast<const float4 *>(wk)[idx];
+    }
     write_lds();
     __syncthreads();
 
@@ -461,8 +470,10 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
     if (STATS && tid < 128) {            // (the loop's last barrier orders the waves' final updates)
         float t = 0.f;
         for (int w = 0; w < 8; ++w) t += s_red[w * 128 + tid];
-        stat_part[(size_t)blockIdx.x * 128 + tid] = t;
+        bn_tail_store(stat_part + (size_t)blockIdx.x * 128 + tid, t);
     }
+    // BatchNorm finalize by the last block to finish (mode 0: a separate cova_bn_finalize_fwd launch follows)
+    if (STATS) bn_tail_run(tail, stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1101,10 +1112,16 @@ COVA_API int cova_conv3x3_fwd(const float *in, const float *w_t, const float *ad
 }
 
 // img NCHW [B,3,H,W]; w_k [154][64]; out NHWC [B,H1,W1,64]
-COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part,
-                            int B, int H, int W, void *stream)
+static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, float *out, float *stat_part, int B, int H,
+                           int W, const cova_bn_tail *tail, void *stream)
 {
     COVA_REQUIRE(img && w_k && out && B > 0 && H > 0 && W > 0);
+    BnTail t{};
+    if (tail != nullptr && tail->mode != 0) {
+        t = *tail;
+        COVA_REQUIRE(t.mode == 1 && stat_part && t.counter && t.count > 0 && t.gamma && t.beta && t.scale && t.shift &&
+                     t.mean && t.invstd);
+    }
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, c1::TW), tiles_y = cdiv(H1, c1::TH);
     const dim3 block(c1::THREADS);
@@ -1112,12 +1129,26 @@ COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, floa
     const dim3 pgrid(persistent_grid(ntiles, 2));
     if (stat_part)
         hipLaunchKernelGGL(conv1_7x7_v2_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img,
-                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
+                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate, w_oihw, t);
     else
         hipLaunchKernelGGL(conv1_7x7_v2_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img,
-                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate);
+                           w_k, out, stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, g_ablate, w_oihw, t);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
+}
+
+COVA_API int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part,
+                            int B, int H, int W, void *stream)
+{
+    return conv1_fwd_launch(img, w_k, 0, out, stat_part, B, H, W, nullptr, stream);
+}
+
+// w_oihw: the [64,3,7,7] weight as the reference stores it (every block forms the kernel's K-pair layout itself while it
+// stages the weights: no cova_conv1_prep_weights launch); tail (nullable): the BatchNorm finalize of the statistics
+COVA_API int cova_conv1_fwd_tail(const float *img, const float *w_oihw, float *out, float *stat_part, int B, int H,
+                                 int W, const cova_bn_tail *tail, void *stream)
+{
+    return conv1_fwd_launch(img, w_oihw, 1, out, stat_part, B, H, W, tail, stream);
 }
 
 COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)

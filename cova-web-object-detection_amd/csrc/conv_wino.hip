@@ -1043,48 +1043,51 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
 }
 
 // sum the per-block partials (fp64) : q[16*4096]
-__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float *__restrict__ part,
-                                                                 int nparts, float *__restrict__ q)
+// Fold of the per-block partials and the final transform in ONE launch (they were two):
+//   Q[pos][co][ci] = sum over blocks of part[block][pos][co][ci]                 (fp64, fixed order)
+//   dW[co][ci][r][t] = sum_{a,b} G[a][r] * Q[a*4+b][co][ci] * G[b][t]            (OIHW)
+// block = 16 (co, ci) pairs x 16 slices of partial rows; 256 blocks.
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float *__restrict__ part, int nparts,
+                                                                float *__restrict__ dw)
 {
-    __shared__ double s_acc[16][64];
-    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + tx;
-    double s = 0.0;
-    for (int p = slice; p < nparts; p += 16) s += (double)part[(size_t)p * (16 * 4096) + idx];
-    s_acc[slice][tx] = s;
+    __shared__ double s_acc[16][16][16];         // [position][slice][pair]
+    const int tx = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + tx;        // (co, ci) pair
+    double acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = 0.0;
+    for (int r = slice; r < nparts; r += 16) {
+        const float *row = part + (size_t)r * (16 * 4096) + idx;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc[p] += (double)row[p * 4096];
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s_acc[p][slice][tx] = acc[p];
     __syncthreads();
     if (slice == 0) {
-        double t = 0.0;
-        for (int j = 0; j < 16; ++j) t += s_acc[j][tx];
-        q[idx] = (float)t;
-    }
-}
-
-// dW[co][ci][r][t] = sum_{a,b} G[a][r] * Q[a*4+b][co][ci] * G[b][t]   (OIHW)
-__global__ void wgrad_wino_final_kernel(const float *__restrict__ q, float *__restrict__ dw)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over [co][ci]
-    if (idx >= 4096) return;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-    float Q[16];
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+        float Q[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        // sign flips left open by the operand formation of conv3x3_wgrad_wino_kernel
-        const int a = p >> 2, b = p & 3;
-        const float sgn = ((a == 3) != (b == 3)) != (a == 2) ? -1.f : 1.f;
-        Q[p] = sgn * q[p * 4096 + idx];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            float s = 0.f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) s += G[a][r] * G[b][t] * Q[a * 4 + b];
-            dw[idx * 9 + r * 3 + t] = s;
+        for (int p = 0; p < 16; ++p) {
+            double t = 0.0;
+            for (int j = 0; j < 16; ++j) t += s_acc[p][j][tx];
+            // sign flips left open by the operand formation of conv3x3_wgrad_wino_kernel
+            const int a = p >> 2, b = p & 3;
+            const float sgn = ((a == 3) != (b == 3)) != (a == 2) ? -1.f : 1.f;
+            Q[p] = sgn * (float)t;
         }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float sm = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sm += G[a][r] * G[b][t] * Q[a * 4 + b];
+                dw[idx * 9 + r * 3 + t] = sm;
+            }
+    }
 }
 
 }  // namespace
@@ -1110,10 +1113,7 @@ static int launch_wgrad_wino(const float *act, const float *dz, float *dw, float
         hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<false, false>), g, blk, 0, st, act, dz, ws, H, W,
                            tiles_x, tiles_y, ntiles, proa, prod);
     COVA_LAUNCH_CHECK();
-    float *q = ws + (size_t)grid * (16 * 4096);
-    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(16 * 4096 / 64), dim3(1024), 0, st, ws, grid, q);
-    COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_wino_final_kernel, dim3(16), dim3(256), 0, st, q, dw);
+    hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(4096 / 16), dim3(256), 0, st, ws, grid, dw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

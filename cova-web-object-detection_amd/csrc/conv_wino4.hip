@@ -25,6 +25,7 @@
 // LDS traffic per 8-channel chunk and 16 tiles: 74 KB of V operand reads + 73 KB of stage traffic + 11 KB of copies
 // (round 2: 147 + 73 + 47 KB per 4 channels x 32 tiles).
 #include "common.h"
+#include "bn_tail.h"
 #include <type_traits>
 
 // Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
@@ -105,6 +106,7 @@ struct W4Args {
     const float *pro_abc;       // PRO: the conv input is f(A[c]*in + B[c]*in2 + C[c]) ([3][64] = A | B | C), zero outside
     int pro_relu;               // the image; f = ReLU or identity
     W4Epi epi;
+    BnTail tail;                // BatchNorm finalize of stat_part by the last block (mode 0: none)
 };
 
 // 256 zero bytes in global memory: halo pixels outside the image are fetched from here
@@ -118,11 +120,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // an explicit s_waitcnt in the kernel.
 __device__ __forceinline__ void copy16_to_lds(const float *gptr, unsigned lds_base_bytes)
 {
-#ifdef W4_NT_LOAD
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_base_bytes), "v"(gptr) : "memory", "m0");
-#else
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base_bytes), "v"(gptr) : "memory", "m0");
-#endif
 }
 
 // Barrier that orders LDS accesses only: this wave's ds_writes are complete (lgkmcnt(0)) while global -> LDS copies
@@ -143,6 +141,16 @@ template <bool STATS, int PRO, bool ADD, int BN>
 __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const W4Args a)
 {
     using namespace w4;
+    // Arguments that are needed once per tile (epilogue operands, output) or once per launch (BatchNorm tail) are read
+    // from the kernel-argument segment WHERE they are used, through a pointer the compiler cannot see through: loaded
+    // at entry like the rest they would pin ~50 scalar registers for the whole kernel, and the scalar spills that follow
+    // cost vector registers in the main loop.
+    typedef const W4Args __attribute__((address_space(4))) *KArgs;
+    auto late_args = [&]() -> KArgs {
+        unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return (KArgs)kp;
+    };
     constexpr int NSLOT = 3;
     constexpr int IN_FLOATS = NSLOT * SLOT_FLOATS;
     // tmp[0] and V[1] are adjacent: both are idle at a tile boundary and carry the pair exchange of the output transform
@@ -162,10 +170,11 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int cog = wave & 3, ph = wave >> 2;
     const int l15 = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W;
-    if (PRO && tid < 192) s_pro[tid] = a.pro_abc[tid];
+    if (PRO && tid < 192) s_pro[tid] = late_args()->pro_abc[tid];
     if (BN && tid >= 256) {
         const int c = tid & 63, kind = (tid >> 6) & 3;
-        const float *src = kind == 0 ? a.epi.mean : kind == 1 ? a.epi.invstd : kind == 2 ? a.epi.msc : a.epi.msh;
+        const KArgs la = late_args();
+        const float *src = kind == 0 ? la->epi.mean : kind == 1 ? la->epi.invstd : kind == 2 ? la->epi.msc : la->epi.msh;
         s_epi[kind * 64 + c] = (kind < 2 || BN == 1) ? src[c] : 0.f;
     }
     if (PRO || BN) __syncthreads();
@@ -185,32 +194,33 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int pxA = pgA * 64 + lane, pxB = pgB * 64 + lane;
     const unsigned in_base = (unsigned)(size_t)(lds_void *)s_in, in2_base = (unsigned)(size_t)(lds_void *)s_in2;
     const unsigned dstA = kgA * (SUB_FLOATS * 4) + pgA * 1024, dstB = SUB_FLOATS * 4 + pgB * 1024;
-    const float *srcA = g_w4_zero_page, *srcB = g_w4_zero_page, *srcA2 = g_w4_zero_page, *srcB2 = g_w4_zero_page;
-    // this thread's source pixels of a tile (channel 0; out-of-image pixels: the zero page)
+    // Source of this thread's pixels: (tile base: wave-uniform, scalar registers) + (the pixel's fixed element offset from
+    // the tile's halo origin: one register per pixel) when the pixel lies inside the image, the zero page otherwise.  The
+    // in-image flags are per tile (lane masks); no 64-bit per-thread pointers stay live across the loop.
+    const int rA = pxA / PW, cA = pxA - rA * PW, rB = pxB / PW, cB = pxB - rB * PW;
+    const int relA = (rA * W + cA) * 64 + 4 * kgA, relB = (rB * W + cB) * 64 + 4;       // floats
+    const float *tbase = a.in, *tbase2 = a.in;         // element (ty*TH - 1, tx*TW - 1, channel 0) of the current tile's image
+    bool inA = false, inB = false;
     auto plane_src = [&](int k) {
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
-        const size_t img = (size_t)b * H * W * 64;
-        const int rA = pxA / PW, cA = pxA - rA * PW, rB = pxB / PW, cB = pxB - rB * PW;
+        const long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
+        tbase = a.in + org;
+        if (PRO == 2) tbase2 = a.in2 + org;
         const int gyA = ty * TH + rA - 1, gxA = tx * TW + cA - 1, gyB = ty * TH + rB - 1, gxB = tx * TW + cB - 1;
-        const bool inA = gyA >= 0 && gyA < H && gxA >= 0 && gxA < W, inB = gyB >= 0 && gyB < H && gxB >= 0 && gxB < W;
-        const size_t oA = img + ((size_t)gyA * W + gxA) * 64 + 4 * kgA, oB = img + ((size_t)gyB * W + gxB) * 64 + 4;
-        // (the zero page holds 64 floats: the per-chunk offset 8 s + 4 <= 60 stays inside it)
-        srcA = inA ? a.in + oA : g_w4_zero_page + 4 * kgA;
-        srcB = inB ? a.in + oB : g_w4_zero_page + 4;
-        if (PRO == 2) {
-            srcA2 = inA ? a.in2 + oA : g_w4_zero_page + 4 * kgA;
-            srcB2 = inB ? a.in2 + oB : g_w4_zero_page + 4;
-        }
+        inA = gyA >= 0 && gyA < H && gxA >= 0 && gxA < W;
+        inB = gyB >= 0 && gyB < H && gxB >= 0 && gxB < W;
     };
     auto copy_planes = [&](int s, int slot) {       // chunk s (0..7) of the tile plane_src() was called for
         if (W4_ABL & 8) return;
         const unsigned sb = (unsigned)slot * (SLOT_FLOATS * 4);
-        if (pxA < NPIX) copy16_to_lds(srcA + 8 * s, in_base + sb + dstA);
-        if (wave < 4 && pxB < NPIX) copy16_to_lds(srcB + 8 * s, in_base + sb + dstB);
+        // (the zero page holds 64 floats: the per-chunk offset 8 s + 4 <= 60 stays inside it)
+        const float *zA = g_w4_zero_page + 4 * kgA + 8 * s, *zB = g_w4_zero_page + 4 + 8 * s;
+        if (pxA < NPIX) copy16_to_lds(inA ? tbase + relA + 8 * s : zA, in_base + sb + dstA);
+        if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase + relB + 8 * s : zB, in_base + sb + dstB);
         if (PRO == 2) {
-            if (pxA < NPIX) copy16_to_lds(srcA2 + 8 * s, in2_base + sb + dstA);
-            if (wave < 4 && pxB < NPIX) copy16_to_lds(srcB2 + 8 * s, in2_base + sb + dstB);
+            if (pxA < NPIX) copy16_to_lds(inA ? tbase2 + relA + 8 * s : zA, in2_base + sb + dstA);
+            if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase2 + relB + 8 * s : zB, in2_base + sb + dstB);
         }
     };
     // Plane copies issued per iteration: P = 2 on waves 0-3, 1 on waves 4-7 (twice that with a second tensor).  At the end
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // row stage, 768 items it = ((ci*16 + tile)*6 + i (the channel slowest, as V rows are (ci, tile)).
     // Waves 0-3: column items tid, 512 + tid and row item tid; waves 4-7: column item tid, row items tid, 256 + tid.
     const bool lo = wave < 4;                       // (wave-uniform: scalar branches)
-    int col_src[2], col_dst[2], col_x[2], col_y[2], col_ch[2], row_src[2], row_dst[2];
+    int col_src[2], col_dst[2], col_ch[2], row_src[2], row_dst[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         {
@@ -236,8 +246,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             const int cl = it & 3, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15, kg = tt >> 4;
             col_src[e] = kg * SUB_FLOATS + ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + cl;      // + r * PW * 4
             col_dst[e] = (kg * 4 + cl) * TMP_CI + t * 36 + c * 6;                                 // + i (6 contiguous)
-            col_x[e] = 4 * (t & 7) + c - 1;            // image column / first row of the item, relative to the tile origin
-            col_y[e] = 4 * (t >> 3) - 1;
             col_ch[e] = kg * 4 + cl;
         }
         {
@@ -254,7 +262,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const int tx_ = tile_ % a.tiles_x, ty_ = (tile_ / a.tiles_x) % a.tiles_y;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int gx = tx_ * TW + col_x[e], gy = ty_ * TH + col_y[e];
+            // image column / first row of column item e (recomputed from the thread index: once per tile)
+            const int it = tid + e * THREADS, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15;
+            const int gx = tx_ * TW + 4 * (t & 7) + c - 1, gy = ty_ * TH + 4 * (t >> 3) - 1;
             unsigned m = 0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) m |= (gy + r >= 0 && gy + r < H) ? (1u << r) : 0u;
@@ -343,11 +353,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         }
     };
 
-#ifdef W4_STAGGER
-    // start the blocks of an XCD at different phases of a tile, so that the epilogue store bursts (and the copies) of the
-    // 256 CUs do not coincide for the whole launch (persistent blocks with equal tile times stay in lock-step otherwise)
-    for (int i = ((blockIdx.x >> 3) & 7) * W4_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(10);
-#endif
     // ---- prime the pipeline: planes(0..2) copied, weights(0), weights(1) requested
     plane_src(0);
     copy_planes(0, 0);
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         // Order (pinned by the scheduling barriers; register pressure decides it): one stage item in flight at a time, its
         // reads issued four MFMAs before its transform; the second V group is requested before the last item's transform,
         // whose vector instructions cover its latency.
-#if W4_WEAVE
+        if constexpr (PRO != 0 || W4_WEAVE) {      // one stage item in flight (prologue variants: register pressure)
         Item it;
         read_v(0);
         W4_SB();
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         item_finish(2, it, s2);
         W4_SB();
         mfma_range(16, 36);
-#else
+        } else {                                    // all three items' reads up front
         Item it0, it1, it2;
         item_read(0, it0, slot2, tmp_w, tmp_r, v_w);
         item_read(1, it1, slot2, tmp_w, tmp_r, v_w);
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         item_finish(2, it2, s2);
         W4_SB();
         mfma_range(18, 36);
-#endif
+        }
         wait_planes();
         lds_barrier();
     };
@@ -501,6 +506,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         }
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
+        const KArgs la = late_args();
+        const float *e_addend = la->epi.addend, *e_z = la->epi.z, *e_act = la->epi.act;
+        float *e_out = la->out;
         float yo[2][4][4], ys[2][4][4];         // partial outputs [output row][column][channel]: kept / handed over
         // A^T restricted to this position half.  ph 0 holds rows (m0, m1, m2), ph 1 holds rows (m5, m3, m4) -- in that
         // order, so that with s = t1 + t2, d = t1 - t2 both halves evaluate the same expressions with wave-uniform
@@ -543,9 +551,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             for (int j = 0; j < 4; ++j) {
                 const unsigned off = offs(io, j);
                 o.ad[j] = o.z4[j] = o.a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ADD) o.ad[j] = *reinterpret_cast<const float4 *>(a.epi.addend + img + off);
-                if (BN) o.z4[j] = *reinterpret_cast<const float4 *>(a.epi.z + img + off);
-                if (BN == 2) o.a4[j] = *reinterpret_cast<const float4 *>(a.epi.act + img + off);
+                if (ADD) o.ad[j] = *reinterpret_cast<const float4 *>(e_addend + img + off);
+                if (BN) o.z4[j] = *reinterpret_cast<const float4 *>(e_z + img + off);
+                if (BN == 2) o.a4[j] = *reinterpret_cast<const float4 *>(e_act + img + off);
             }
         };
         Ops ops;
@@ -614,9 +622,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     o[r] = v;
                 }
                 if (W4_ABL & 1024) {        // (timing experiment: same bytes, every wave store 1 KB contiguous; wrong placement)
-                    *reinterpret_cast<float4 *>(a.out + ((((size_t)tile_ * 8 + wave) * 8 + (io * 4 + j)) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4 *>(e_out + ((((size_t)tile_ * 8 + wave) * 8 + (io * 4 + j)) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
                 } else if (ok && !(W4_ABL & 256)) {
-                    *reinterpret_cast<float4 *>(a.out + img + (unsigned)(((oy0 + io) * W + ox0 + j) * 64 + co0)) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4 *>(e_out + img + (unsigned)(((oy0 + io) * W + ox0 + j) * 64 + co0)) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
             if ((ADD || BN) && io == 0) {
@@ -651,11 +659,20 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         if ((g & 7) == 6) tile_epilogue(g >> 3);
     }
     if (STATS) {        // one partial row [sum 64 | second kind 64] per block; a channel's two position halves are added
+        const KArgs la = late_args();
         __syncthreads();
         if (tid < 128) {
             const int kind = tid >> 6, ch = tid & 63, cg = ch >> 4, c = ch & 15;
-            a.stat_part[(size_t)blockIdx.x * 128 + tid] = s_red[cg * 32 + kind * 16 + c] + s_red[(4 + cg) * 32 + kind * 16 + c];
+            bn_tail_store(la->stat_part + (size_t)blockIdx.x * 128 + tid, s_red[cg * 32 + kind * 16 + c] + s_red[(4 + cg) * 32 + kind * 16 + c]);
         }
+        BnTail tl;
+        tl.mode = la->tail.mode; tl.counter = la->tail.counter; tl.count = la->tail.count;
+        tl.gamma = la->tail.gamma; tl.beta = la->tail.beta;
+        tl.running_mean = la->tail.running_mean; tl.running_var = la->tail.running_var;
+        tl.num_batches_tracked = la->tail.num_batches_tracked; tl.momentum = la->tail.momentum; tl.eps = la->tail.eps;
+        tl.scale = la->tail.scale; tl.shift = la->tail.shift; tl.mean = la->tail.mean; tl.invstd = la->tail.invstd;
+        tl.dgamma = la->tail.dgamma; tl.dbeta = la->tail.dbeta; tl.abc = la->tail.abc;
+        bn_tail_run(tl, la->stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
     }
 }
 
@@ -663,10 +680,14 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 // ph = w >> 2), lane = (kq = lane >> 4, l15 = lane & 15); element n = 4 q + e = kg*18 + p is the MFMA A operand of
 // position (i = 3 ph + p / 6, j = p % 6) for output channel cog*16 + l15 and input channel 8 s + 4 kg + kq:
 // (G g G^T)[i][j].   fwd: g = w[co][ci][:, :];   dgrad: output channel = ci, input channel = co, g rotated by 180 degrees
-__global__ void prep_wino4_kernel(const float *__restrict__ w, float *__restrict__ u_fwd, float *__restrict__ u_dgrad)
+struct PrepW { const float *w[4]; };
+__global__ void prep_wino4_kernel(const PrepW pw, float *__restrict__ u_fwd, float *__restrict__ u_dgrad)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= w4::U_FLOATS) return;
+    const float *__restrict__ w = pw.w[blockIdx.y];          // convolution blockIdx.y of the launch
+    u_fwd += (size_t)blockIdx.y * w4::U_FLOATS;
+    u_dgrad += (size_t)blockIdx.y * w4::U_FLOATS;
     const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
     const int q = rest % 9, ws = rest / 9, wv = ws & 7, s = ws >> 3;
     const int n = 4 * q + e, kg = n / 18, p = n - 18 * kg;
@@ -711,13 +732,21 @@ COVA_API int cova_conv3x3_wino4_num_partials(int B, int H, int W)
 }
 
 // u_fwd / u_dgrad: 147,456 floats each (the per-wave register image, see prep_wino4_kernel)
-COVA_API int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream)
+COVA_API int cova_conv3x3_wino4_prep_multi(const float *w0, const float *w1, const float *w2, const float *w3,
+                                           float *u_fwd, float *u_dgrad, void *stream)
 {
-    COVA_REQUIRE(w_oihw && u_fwd && u_dgrad);
-    hipLaunchKernelGGL(prep_wino4_kernel, dim3(cdiv(w4::U_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, u_fwd, u_dgrad);
+    COVA_REQUIRE(w0 && u_fwd && u_dgrad);
+    const PrepW pw{{w0, w1, w2, w3}};
+    const int n = w1 == nullptr ? 1 : w2 == nullptr ? 2 : w3 == nullptr ? 3 : 4;
+    hipLaunchKernelGGL(prep_wino4_kernel, dim3(cdiv(w4::U_FLOATS, 256), n), dim3(256), 0, (hipStream_t)stream, pw, u_fwd,
+                       u_dgrad);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
+}
+
+COVA_API int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream)
+{
+    return cova_conv3x3_wino4_prep_multi(w_oihw, nullptr, nullptr, nullptr, u_fwd, u_dgrad, stream);
 }
 
 namespace {
@@ -744,13 +773,20 @@ void launch_w4_pro(const W4Args &a, int grid, hipStream_t st)
 }
 
 int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu, const float *u, const W4Epi &epi,
-           float *out, float *stat_part, int B, int H, int W, void *stream)
+           float *out, float *stat_part, int B, int H, int W, void *stream, const cova_bn_tail *tail = nullptr)
 {
+    BnTail t{};
+    if (tail != nullptr && tail->mode != 0) {
+        t = *tail;
+        COVA_REQUIRE(stat_part && t.counter && t.count > 0 && (t.mode == 1 || t.mode == 2));
+        COVA_REQUIRE(t.mode != 1 || (epi.z == nullptr && t.gamma && t.beta && t.scale && t.shift && t.mean && t.invstd));
+        COVA_REQUIRE(t.mode != 2 || (epi.z != nullptr && t.mean && t.invstd && t.scale && t.abc));
+    }
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));          // 32-bit in-image offsets in the epilogue
     COVA_REQUIRE(epi.z == nullptr || ((epi.act || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
-    const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi};
+    const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi, t};
     const int grid = cova_internal_persistent_grid2(ntiles, 1);
     if (!pro_abc) launch_w4_pro<0>(a, grid, (hipStream_t)stream);
     else if (!in2) launch_w4_pro<1>(a, grid, (hipStream_t)stream);
@@ -791,4 +827,15 @@ COVA_API int cova_conv3x3_wino4_full(const float *in, const float *in2, const fl
     return run_w4(in, in2, pro_abc, pro_relu, u,
                   W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr}, out,
                   stat_part, B, H, W, stream);
+}
+
+COVA_API int cova_conv3x3_wino4_full_tail(const float *in, const float *in2, const float *pro_abc, int pro_relu,
+                                          const float *u, const float *addend, const float *act,
+                                          const float *mask_scale, const float *mask_shift, const float *z,
+                                          const float *mean, const float *invstd, float *out, float *stat_part, int B,
+                                          int H, int W, const cova_bn_tail *tail, void *stream)
+{
+    return run_w4(in, in2, pro_abc, pro_relu, u,
+                  W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr}, out,
+                  stat_part, B, H, W, stream, tail);
 }

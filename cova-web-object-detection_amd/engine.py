@@ -6,6 +6,7 @@ Stages: conv stack R1, RoIPool R2, positional encode
 additional-feature BN R4, GAT G1-G6, decoder D, loss/predictions L/P, optimizer U.
 ``params`` maps the reference's state_dict keys (weights.state_dict_spec) to device tensors.
 """
+import ctypes
 import os
 
 import torch
@@ -154,13 +155,47 @@ def bn_finalize_bwd(part, nparts, C, count, dgamma, dbeta, unit, abc_from=None, 
     return out
 
 
-def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
-              update_running=True, unit="boxes"):
+def bn_state(C, like, count, training):
     st = BNState()
     st.C, st.count, st.frozen = C, float(count), not training
     st.abc = _empty((3, C), like)               # scale | (unused) | shift: the prologue's A | B | C
     st.scale, st.shift = st.abc[0], st.abc[2]
     st.mean, st.invstd = _empty((C,), like), _empty((C,), like)
+    return st
+
+
+def tails_on(C=C64):
+    """in-launch BatchNorm finalize: 64-channel producers, no SyncBN (a collective sits between partials and finalize)"""
+    return OPTIONS.bn_tail and STAT_SYNC is None and C == C64
+
+
+def bn_tail_fwd(prefix, params, buffers, C, like, count, update_running=True):
+    """(BNState, BnTail) for a train-mode BatchNorm whose statistics the NEXT launch produces: the tail writes
+    scale / shift / mean / invstd and the running statistics, as cova_bn_finalize_fwd would."""
+    st = bn_state(C, like, count, True)
+    upd = update_running
+    tail = BnTail(1, like, count, gamma=params[prefix + "weight"], beta=params[prefix + "bias"],
+                  running_mean=buffers[prefix + "running_mean"] if upd else None,
+                  running_var=buffers[prefix + "running_var"] if upd else None,
+                  num_batches_tracked=buffers.get(prefix + "num_batches_tracked") if upd else None,
+                  scale=st.scale, shift=st.shift, mean=st.mean, invstd=st.invstd)
+    return st, tail
+
+
+def bn_tail_bwd(st, count, gout, prefix, like):
+    """(dgamma, dbeta, abc, BnTail): the launch that produces the (sum g, sum g*xhat) partials of BatchNorm `st` also
+    writes its parameter gradients and the dz = abc[0]*dy + abc[1]*z + abc[2] coefficients."""
+    C = st.C
+    dgamma = _gbuf(gout, prefix + "weight", (C,), like)
+    dbeta = _gbuf(gout, prefix + "bias", (C,), like)
+    abc = _empty((3, C), like)
+    tail = BnTail(2, like, count, mean=st.mean, invstd=st.invstd, scale=st.scale, dgamma=dgamma, dbeta=dbeta, abc=abc)
+    return dgamma, dbeta, abc, tail
+
+
+def bn_params(prefix, params, buffers, C, like, training, partial=None, nparts=0, count=0,
+              update_running=True, unit="boxes"):
+    st = bn_state(C, like, count, training)
     g, b = params[prefix + "weight"], params[prefix + "bias"]
     rm, rv = buffers[prefix + "running_mean"], buffers[prefix + "running_var"]
     if training:
@@ -204,9 +239,46 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 # gradient run as F(4x4,3x3) (csrc/conv_wino4.hip: 1.78x fewer MFMAs again) or F(2x2,3x3).  BatchNorm+ReLU between
 # the two convs of a block and the BatchNorm-backward "apply" passes are evaluated on load inside the consuming
 # convolutions: a1 and dz are never written to HBM.
+class _BnTailStruct(ctypes.Structure):
+    """cova_bn_tail of include/cova_hip.h (a HOST struct of device pointers, read by the launch call)"""
+    _fields_ = [("mode", ctypes.c_int), ("counter", ctypes.c_void_p), ("count", ctypes.c_double),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("running_mean", ctypes.c_void_p),
+                ("running_var", ctypes.c_void_p), ("num_batches_tracked", ctypes.c_void_p),
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("scale", ctypes.c_void_p),
+                ("shift", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p),
+                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("abc", ctypes.c_void_p)]
+
+
+class BnTail:
+    """BatchNorm finalize riding on the launch that produces the statistics partials (csrc/bn_tail.h): the struct
+    plus the tensors it points to (kept alive until the launch call has returned)."""
+    _COUNTERS = {}
+
+    def __init__(self, mode, like, count, **ptrs):
+        key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+        ctr = BnTail._COUNTERS.get(key)
+        if ctr is None:                      # one ticket counter per (device, stream): launches on a stream are ordered,
+            ctr = BnTail._COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=like.device)   # the kernel leaves it 0
+        self.keep = [ctr] + [v for v in ptrs.values() if isinstance(v, torch.Tensor)]
+        c = _BnTailStruct()
+        c.mode, c.counter, c.count = mode, ctr.data_ptr(), float(count)
+        c.momentum, c.eps = BN_MOMENTUM, BN_EPS
+        for k, v in ptrs.items():
+            setattr(c, k, v.data_ptr() if isinstance(v, torch.Tensor) else None)
+        self.c = c
+
+    @property
+    def ptr(self):
+        return ctypes.addressof(self.c)
+
+
 class Options:
     """The one set of run-time switches of the path (process-wide; read at call time)."""
     wino4 = os.environ.get("COVA_WINO4", "1") != "0"     # F(4x4,3x3) forward / data-gradient launches in training steps
+    # data-parallel steps: the head's gradient all-reduce is issued under the conv-stack backward (trainer.py)
+    overlap_allreduce = os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
+    # BatchNorm finalize as the tail of the producing convolution launch (no separate finalize launches)
+    bn_tail = os.environ.get("COVA_BN_TAIL", "1") != "0"
 
 
 OPTIONS = Options()
@@ -246,14 +318,17 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
     bottleneck = is_bottleneck(params)
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
-    w1k = _empty((154, 64), images)
-    call("cova_conv1_prep_weights", params["convnet.0.weight"], w1k)
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
     nt1 = query("cova_conv1_num_partials", B, H, W)
     part = _empty((nt1, 2, C64), images) if training else None
-    call("cova_conv1_fwd", images, w1k, y1, part, B, H, W)
-    bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1, unit="pages")
+    # (the kernel reads the OIHW weight itself: no layout-prep launch)
+    if training and tails_on():
+        bn1, tail = bn_tail_fwd("convnet.1.", params, buffers, C64, images, B * H1 * W1)
+        call("cova_conv1_fwd_tail", images, params["convnet.0.weight"], y1, part, B, H, W, tail.ptr)
+    else:
+        call("cova_conv1_fwd_tail", images, params["convnet.0.weight"], y1, part, B, H, W, None)
+        bn1 = bn_params("convnet.1.", params, buffers, C64, images, training, part, nt1, B * H1 * W1, unit="pages")
     p1 = _empty((B, H2, W2, C64), images)
     idx = _empty((B, H2, W2, C64), images, torch.uint8)
     # ymax = y1 at each window's arg-max: lets the last data-gradient conv take bn1's backward sums
@@ -268,22 +343,19 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     return feat, (sv if save else None)
 
 
-def prep_wino4(w, like):
-    """conv3x3 OIHW weight -> F(4x4,3x3) forward / data-gradient operands (the per-wave register image)"""
-    a, b = _empty((147456,), like), _empty((147456,), like)
-    call("cova_conv3x3_wino4_prep", w, a, b)
-    return a, b
-
-
 def conv3_num_partials(B, H, W, wino4):
     return query("cova_conv3x3_wino4_num_partials" if wino4 else "cova_conv3x3_wino_num_partials", B, H, W)
 
 
-def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W):
+def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W, tail=None):
     """conv3x3 of f(A*inp + B*in2 + C) (abc / in2 nullable) with the fused epilogue of cova_conv3x3_wino_pro.
-    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3)."""
+    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3); tail (F(4x4) only): BnTail."""
     kind, uw = u
-    if kind == "w4":
+    if tail is not None:
+        assert kind == "w4"
+        call("cova_conv3x3_wino4_full_tail", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out,
+             part, B, H, W, tail.ptr)
+    elif kind == "w4":
         call("cova_conv3x3_wino4_full", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
              B, H, W)
     else:
@@ -291,13 +363,33 @@ def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, 
              B, H, W)
 
 
-def conv3_weights(w, like, wino4):
-    """-> (forward operand, data-gradient operand) of one 3x3 convolution, each tagged with its kernel family"""
+def conv3_weights(ws, like, wino4):
+    """3x3 weights (a list of up to four OIHW tensors) -> ([forward operands], [data-gradient operands]), each tagged
+    with its kernel family; the F(4x4) operands of all of them come from ONE launch."""
     if wino4:
-        a, b = prep_wino4(w, like)
-        return ("w4", a), ("w4", b)
-    a, b = prep_wino(w, like)
-    return ("w2", a), ("w2", b)
+        n = len(ws)
+        uf, ud = _empty((n, 147456), like), _empty((n, 147456), like)
+        call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
+        return [("w4", uf[i]) for i in range(n)], [("w4", ud[i]) for i in range(n)]
+    pairs = [prep_wino(w, like) for w in ws]
+    return [("w2", a) for a, _ in pairs], [("w2", b) for _, b in pairs]
+
+
+def conv_bn_fwd(u, inp, abc, relu, out, prefix, params, buffers, training, part, nt, R, B, H, W):
+    """3x3 conv (input relu?(abc . inp) on load) followed by a BatchNorm whose statistics it produces -> BNState"""
+    if training and u[0] == "w4" and tails_on():
+        st, tail = bn_tail_fwd(prefix, params, buffers, C64, inp, R)
+        conv3x3_pro(u, inp, None, abc, relu, None, None, None, None, None, None, None, out, part, B, H, W, tail)
+        return st
+    conv3x3_pro(u, inp, None, abc, relu, None, None, None, None, None, None, None, out, part, B, H, W)
+    return bn_params(prefix, params, buffers, C64, inp, training, part, nt, R, unit="pages")
+
+
+def conv_bn_pair_fwd(ua, ub, x, z1, z2, pa, pb, params, buffers, training, part, nt, R, B, H, W):
+    """z1 = conv_a(x), bn_a;  z2 = conv_b(relu(bn_a(z1))) with a1 formed on load, bn_b  -> (BNState a, BNState b)"""
+    bna = conv_bn_fwd(ua, x, None, 0, z1, pa, params, buffers, training, part, nt, R, B, H, W)
+    bnb = conv_bn_fwd(ub, z1, bna.abc, 1, z2, pb, params, buffers, training, part, nt, R, B, H, W)
+    return bna, bnb
 
 
 def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
@@ -305,11 +397,7 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     images = p1
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     w4 = OPTIONS.wino4 and training       # (inference keeps the BatchNorm-in-epilogue F(2x2) form)
-    wf, wd = [], []
-    for k in CONV3_KEYS:
-        f, d = conv3_weights(params[k + ".weight"], images, w4)
-        wf.append(f)
-        wd.append(d)
+    wf, wd = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4)
     sv["wd"], sv["w4"] = wd, w4
     R = B * H2 * W2
     nt = conv3_num_partials(B, H2, W2, w4)
@@ -328,14 +416,9 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             x = feat = out
             continue
         part = _empty((nt, 2, C64), images) if training else None
-        z1 = _empty((B, H2, W2, C64), images)
-        conv3x3_pro(wf[2 * blk], x, None, None, 0, None, None, None, None, None, None, None, z1, part, B, H2, W2)
-        bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, training, part, nt, R, unit="pages")
-        z2 = _empty((B, H2, W2, C64), images)
-        # a1 = relu(bn1(z1)) formed on load
-        conv3x3_pro(wf[2 * blk + 1], z1, None, bna.abc, 1, None, None, None, None, None, None, None, z2, part,
-                    B, H2, W2)
-        bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, training, part, nt, R, unit="pages")
+        z1, z2 = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
+        bna, bnb = conv_bn_pair_fwd(wf[2 * blk], wf[2 * blk + 1], x, z1, z2, BN3_KEYS[2 * blk], BN3_KEYS[2 * blk + 1],
+                                    params, buffers, training, part, nt, R, B, H2, W2)
         if blk == 1 and lazy_out:
             out = None
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
@@ -379,6 +462,7 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     def bn(prefix, C, part, n):
         return bn_params(prefix, params, buffers, C, p1, training, part, n, R, unit="pages")
 
+    ufs, uds = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], p1, w4)
     x, cin, blocks, feat = p1, C64, [], None
     pending = None      # (z3, other, abc): the previous block's output relu(abc . (z3, other)), not yet written
     for blk in (0, 1, 2):
@@ -397,12 +481,11 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
             blocks[-1]["out"] = x
         s["x"] = x
         s["bn1"] = bn(pre + "bn1.", C64, part, n)
-        uf, s["ud"] = conv3_weights(params[pre + "conv2.weight"], p1, w4)
+        uf, s["ud"] = ufs[blk], uds[blk]
         part = _empty((nt, 2, C64), p1) if training else None
         s["z2"] = _empty((B, H2, W2, C64), p1)
-        conv3x3_pro(uf, s["z1"], None, s["bn1"].abc, 1, None, None, None, None, None, None, None, s["z2"], part,
-                    B, H2, W2)
-        s["bn2"] = bn(pre + "bn2.", C64, part, nt)
+        s["bn2"] = conv_bn_fwd(uf, s["z1"], s["bn1"].abc, 1, s["z2"], pre + "bn2.", params, buffers, training, part, nt,
+                               R, B, H2, W2)
         part, n = stats(C64, C256)
         s["z3"] = _empty((B, H2, W2, C256), p1)
         conv1x1(s["z2"], None, s["bn2"].abc, 1, params[pre + "conv3.weight"], 0, s["z3"], part, R, C64, C256)
@@ -508,9 +591,8 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "conv2.weight"] = dw
         dy1 = _empty((B, H2, W2, C64), g)
         part = _empty((nt, 2, C64), g)
-        conv3x3_pro(s["ud"], dy2, s["z2"], abc2, 0, None, None, bn1.scale, bn1.shift, s["z1"], bn1.mean, bn1.invstd,
-                    dy1, part, B, H2, W2)
-        dg, db, abc1 = _bn_abc_from_partials(part, nt, bn1, R, gout, pre + "bn1.", g)
+        dg, db, abc1 = dgrad_bn_bwd(s["ud"], dy2, s["z2"], abc2, None, None, bn1.scale, bn1.shift, s["z1"], bn1, dy1, part,
+                                    nt, R, gout, pre + "bn1.", B, H2, W2)
         grads[pre + "bn1.weight"], grads[pre + "bn1.bias"] = dg, db
         # conv1 (Cin->64): dz1 = abc1 . (dy1, z1) on load
         dw = _gbuf(gout, pre + "conv1.weight", (C64, cin, 1, 1), g)
@@ -572,6 +654,22 @@ def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
     return dgamma, dbeta
 
 
+def dgrad_bn_bwd(u, g_in, g_in2, g_abc, addend, act, msc, msh, z, st, out, part, nt, count, gout, prefix, B, H, W):
+    """Data-gradient conv3x3 (input g_abc . (g_in, g_in2) on load, + addend) whose epilogue masks with the ReLU of
+    BatchNorm `st` and takes its backward sums; -> (dgamma, dbeta, abc) of that BatchNorm (finalized by the launch's tail
+    or by a separate cova_bn_finalize_bwd_abc).  ``count`` = elements per channel of that BatchNorm."""
+    if u[0] == "w4" and tails_on() and not st.frozen:
+        dg, db, abc, tail = bn_tail_bwd(st, count, gout, prefix, out)
+        conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W, tail)
+        return dg, db, abc
+    conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W)
+    C = st.C
+    dg = _gbuf(gout, prefix + "weight", (C,), out)
+    db = _gbuf(gout, prefix + "bias", (C,), out)
+    abc = bn_finalize_bwd(part, nt, C, count, dg, db, "pages", abc_from=st, frozen=st.frozen)
+    return dg, db, abc
+
+
 def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
     """(dgamma, dbeta, abc) with dz = abc[0]*dy + abc[1]*z + abc[2] (applied on load downstream)."""
     C = st.C
@@ -584,16 +682,17 @@ def _bn_abc_from_partials(part, nparts, st, R, gout, prefix, like):
 def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     """Backward of the two BasicBlocks with every BatchNorm-backward apply (except the one fed by
     RoIPool's scatter) and both a1 = relu(bn1(z1)) recomputations folded into the Winograd kernels.
-    Returns the gradient w.r.t. the max-pool output."""
+    Returns the gradient w.r.t. the max-pool output; sv['pool_abc'] = (dgamma, dbeta, abc) of the stem's BatchNorm."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
     nt = conv3_num_partials(B, H2, W2, sv["w4"])
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
     # the last bn2 were taken by cova_roipool_bwd_bn
-    dA, pend, npend = dfeat, None, nt
+    dA, pend = dfeat, None                  # pend = (dgamma, dbeta, abc) of the bn2 in front of dA, when already known
     if head_part is not None:
-        pend, npend = head_part
+        last = sv["blocks"][1]["bnb"]
+        pend = _bn_abc_from_partials(head_part[0], head_part[1], last, R, gout, BN3_KEYS[3], dfeat)
     for blk in (1, 0):
         s = sv["blocks"][blk]
         ka, kb = CONV3_KEYS[2 * blk], CONV3_KEYS[2 * blk + 1]
@@ -607,7 +706,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
             g_in, g_in2, g_abc = dz2, None, None
         else:
             dres = dA
-            dg, db, g_abc = _bn_abc_from_partials(pend, npend, bnb, R, gout, pb, dfeat)
+            dg, db, g_abc = pend
             g_in, g_in2 = dA, s["z2"]
         grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
@@ -616,9 +715,8 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         # ---- dgrad of conv2 with bn1's ReLU mask (recomputed from z1) + backward sums in the epilogue
         dy_a = torch.empty_like(dA)
         part = _empty((nt, 2, C64), dfeat)
-        conv3x3_pro(sv["wd"][2 * blk + 1], g_in, g_in2, g_abc, 0, None, None, bna.scale, bna.shift, s["z1"], bna.mean,
-                    bna.invstd, dy_a, part, B, H2, W2)
-        dg, db, abc_a = _bn_abc_from_partials(part, nt, bna, R, gout, pa, dfeat)
+        dg, db, abc_a = dgrad_bn_bwd(sv["wd"][2 * blk + 1], g_in, g_in2, g_abc, None, None, bna.scale, bna.shift, s["z1"],
+                                     bna, dy_a, part, nt, R, gout, pa, B, H2, W2)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
         call("cova_conv3x3_wgrad_wino_pro", s["x"], None, 0, dy_a, s["z1"], abc_a, dw, ws3, B, H2, W2)
@@ -627,15 +725,14 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         dx = torch.empty_like(dA)
         if blk == 1:
             prev = sv["blocks"][0]
-            pend, npend = _empty((nt, 2, C64), dfeat), nt
-            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, prev["out"], None, None, prev["z2"],
-                        prev["bnb"].mean, prev["bnb"].invstd, dx, pend, B, H2, W2)
+            pend = dgrad_bn_bwd(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, dres, prev["out"], None, None, prev["z2"],
+                                prev["bnb"], dx, _empty((nt, 2, C64), dfeat), nt, R, gout, BN3_KEYS[1], B, H2, W2)
         elif sv.get("ymax") is not None:
             # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
             bn1 = sv["bn1"]
-            sv["pool_part"], sv["pool_npart"] = _empty((nt, 2, C64), dfeat), nt
-            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, bn1.scale, bn1.shift, sv["ymax"],
-                        bn1.mean, bn1.invstd, dx, sv["pool_part"], B, H2, W2)
+            sv["pool_abc"] = dgrad_bn_bwd(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, dres, None, bn1.scale, bn1.shift,
+                                          sv["ymax"], bn1, dx, _empty((nt, 2, C64), dfeat), nt, B * H1 * W1, gout,
+                                          "convnet.1.", B, H2, W2)
         else:
             conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, None, None, None, None, None, dx,
                         None, B, H2, W2)
@@ -664,39 +761,40 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
     """dfeat NHWC [B,Hf,Wf,C] -> {state_dict key: grad} for the convs and BatchNorms of the stack.
 
     The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
-    in front of them in their epilogue (cova_conv3x3_dgrad_bnbwd), so only the last block's bn2
-    (whose incoming gradient is RoIPool's scatter) needs the stand-alone reduction pass.
+    in front of them in their epilogue (and its finalize in their tail), so only the last block's bn2
+    (whose incoming gradient is RoIPool's scatter) needs a stand-alone reduction / finalize.
     ``params`` is needed by the resnet50 extension only (its 1x1 convs read the weights directly)."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     grads = {}
     if sv["kind"] == "bottleneck":
-        fused = True
         if head_part is None:          # piecewise API (_get_visual_features): mask + sums stand-alone
             dfeat, head_part = masked_grad_and_sums(dfeat, sv["last"], R)
         dA = _layer1_bottleneck_bwd(sv, dfeat, params, gout, grads, head_part)
     else:
-        fused = True
         dA = _layer1_bwd_fused(sv, dfeat, gout, grads, head_part)
     # maxpool + relu + bn1, then conv1's weight gradient
     bn1 = sv["bn1"]
-    if fused and sv.get("pool_part") is not None:
-        part, npart = sv["pool_part"], sv["pool_npart"]
+    ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
+    dw1 = _gbuf(gout, "convnet.0.weight", (64, 3, 7, 7), dfeat)
+    pool_abc = sv.get("pool_abc")
+    if pool_abc is None and sv.get("pool_part") is not None:        # (resnet50 stack: its last launch left the partials)
+        dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
+        db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
+        pool_abc = (dg, db, bn_finalize_bwd(sv["pool_part"], sv["pool_npart"], C64, B * H1 * W1, dg, db, "pages",
+                                            abc_from=bn1, frozen=bn1.frozen))
+    if pool_abc is not None:
+        # dA is already ReLU-masked (epilogue of the last data-gradient conv): the pooling/BN backward
+        # apply is folded into conv1's weight-gradient kernel, dy1 is never written
+        dg, db, abc = pool_abc
+        call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
     else:
         npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
         part = _empty((npart, 2, C64), dfeat)
         call("cova_bn_relu_maxpool_bwd_reduce", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
              bn1.invstd, part, B, H1, W1)
-    dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
-    db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
-    ws1 = _empty((query("cova_conv1_wgrad_workspace_floats", B, H, W),), dfeat)
-    dw1 = _gbuf(gout, "convnet.0.weight", (64, 3, 7, 7), dfeat)
-    if fused and sv.get("pool_part") is not None:
-        # dA is already ReLU-masked (epilogue of the last data-gradient conv): the pooling/BN backward
-        # apply is folded into conv1's weight-gradient kernel, dy1 is never written
-        abc = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", abc_from=bn1, frozen=bn1.frozen)
-        call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
-    else:
+        dg = _gbuf(gout, "convnet.1.weight", (C64,), dfeat)
+        db = _gbuf(gout, "convnet.1.bias", (C64,), dfeat)
         coef = bn_finalize_bwd(part, npart, C64, B * H1 * W1, dg, db, "pages", frozen=bn1.frozen)
         dy1 = torch.empty_like(sv["y1"])
         call("cova_bn_relu_maxpool_bwd_apply", dA, sv["idx"], sv["y1"], bn1.scale, bn1.shift, bn1.mean,
@@ -835,11 +933,7 @@ def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
     return dict(h=h, ldh=ldh, N=N, F=F, D=D, K=K, ctx=ctx, Wh=Wh, s=s, t=t, attn=attn, prefix=prefix)
 
 
-# Backward of the neighbour gather: deterministic gather through the transposed index (default) or the
-# scatter with float atomics (COVA_GAT_ATOMICS=1, kept for A/B timing).
-GAT_ATOMICS = os.environ.get("COVA_GAT_ATOMICS", "0") == "1"
-
-
+# Backward of the neighbour gather: a deterministic gather through the transposed index (no float atomics).
 def gat_transpose(ctx):
     """Transposed neighbour index of one batch (shared by every head / layer / backward call of the step)."""
     N, K = ctx.shape
@@ -851,9 +945,9 @@ def gat_transpose(ctx):
 def gat_bwd(sv, g, ldg, params, dh, lddh, accumulate_dh, gout=None, csr=None):
     """g = dL/dh' (rows at g + n*ldg).  Writes / accumulates dL/dh into dh; returns param grads."""
     N, F, D, K, prefix = sv["N"], sv["F"], sv["D"], sv["K"], sv["prefix"]
-    if csr is None and not GAT_ATOMICS:
+    if csr is None:
         csr = gat_transpose(sv["ctx"])
-    du = _empty((N, K), g) if csr is not None else None
+    du = _empty((N, K), g)
     Wi, Wj = params[prefix + "W_i.weight"], params[prefix + "W_j.weight"]
     aw = params[prefix + "attention_layer.weight"]
     dWh = _empty((N, 2 * D), g)
@@ -900,7 +994,7 @@ def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
     """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F]."""
     grads = {}
     g, ldg = dcomb[:, F:], T
-    csr = None if GAT_ATOMICS else gat_transpose(layers[0]["heads"][0]["ctx"])
+    csr = gat_transpose(layers[0]["heads"][0]["ctx"])
     for l in reversed(range(len(layers))):
         heads = layers[l]["heads"]
         dh = D // len(heads)

@@ -108,6 +108,29 @@ class HotPathTrainer:
         self.world_size, self.group = world_size, process_group
         self.step_count, self.dropout_seed = 0, int(dropout_seed)
         self.sync_bn = bool(sync_bn) and world_size > 1
+        self._ar_events = []              # (start, end) HIP events around the collective waits of optimizer_step
+        if world_size > 1:
+            self.broadcast_state(src=0)
+
+    def broadcast_state(self, src=0):
+        """Rank `src`'s parameters, BatchNorm buffers, Adam moments and step count to every rank: replicas start (and
+        resume) from ONE state even when the ranks were built from rank-local checkpoints."""
+        import torch.distributed as dist
+        for t in [self.pbucket.flat, self.exp_avg, self.exp_avg_sq] + [self.buffers[k] for k in sorted(self.buffers)]:
+            dist.broadcast(t, src=src, group=self.group)
+        step = torch.tensor([self.step_count], dtype=torch.int64, device=self.device)
+        dist.broadcast(step, src=src, group=self.group)
+        self.step_count = int(step.item())
+
+    def exposed_allreduce_ms(self):
+        """Mean time per step the stream spent in optimizer_step's gradient collectives (HIP events on the compute
+        stream around the all-reduce calls / waits: what the overlap did not hide); 0 on a single rank."""
+        if not self._ar_events:
+            return 0.0
+        torch.cuda.synchronize(self.device)
+        ms = sum(a.elapsed_time(b) for a, b in self._ar_events) / len(self._ar_events)
+        self._ar_events = []
+        return ms
 
     def state_dict(self):
         sd = OrderedDict()
@@ -141,8 +164,12 @@ class HotPathTrainer:
 
     def forward_backward(self, batch, masks=None):
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
+        # With SyncBN a one-box shard is legal (the statistics are over the whole batch, as torch.nn.SyncBatchNorm
+        # accepts it): the train-mode "more than 1 value per channel" check then applies to the GLOBAL box count, which
+        # _stat_sync has from its all-reduce -- every rank raises together instead of one rank leaving the others
+        # blocked in a collective.
         engine.check_batch(self.cfg, batch["images"], batch["bboxes"], batch["additional_feats"],
-                           batch["context_indices"], True)
+                           batch["context_indices"], not self.sync_bn)
         self.step_count += 1
         base = (self.dropout_seed * 0x9E3779B1 + 2 * self.step_count) & 0xFFFFFFFFFFFF
         if self.sync_bn:
@@ -153,7 +180,7 @@ class HotPathTrainer:
                                           batch["context_indices"], True, (base, base + 1), masks)
             loss, dl, pred = engine.ce_sum(logits, batch["labels"])
             self._head_work = None
-            overlap = self.world_size > 1 and os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
+            overlap = self.world_size > 1 and engine.OPTIONS.overlap_allreduce
             engine.model_bwd(sv, dl, self.params, self.grads,
                              after_head=self._reduce_head if overlap else None)
         finally:
@@ -168,7 +195,10 @@ class HotPathTrainer:
                              device=self.device)
         total = local.clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
-        r = (total / local.clamp_min(1.0)).tolist()
+        tot = total.tolist()
+        r = [tot[0] / max(float(local[0].item()), 1.0), tot[1] / max(float(local[1].item()), 1.0)]
+        if tot[1] == 1.0:
+            raise ValueError("Expected more than 1 value per channel when training (1 box in the whole batch)")
         return engine.StatSync(self.group, r[0], r[1])
 
     # Gradient exchange: the head (positional encoder, GAT, decoder = 96 % of the 6.5 MB bucket, the
@@ -190,12 +220,17 @@ class HotPathTrainer:
 
     def optimizer_step(self):
         if self.world_size > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             if getattr(self, "_head_work", None) is not None:
                 self.gbucket.all_reduce_range(0, self._head_offset(), self.group)
                 self._head_work.wait()
                 self._head_work = None
             else:
                 self.gbucket.all_reduce_sum(self.group)
+            e1.record()
+            if len(self._ar_events) < 4096:
+                self._ar_events.append((e0, e1))
         b1, b2 = self.hp["betas"]
         engine.call("cova_adam_step", self.pbucket.flat, self.gbucket.flat, self.exp_avg,
                     self.exp_avg_sq, self.pbucket.flat.numel(), self.step_count, self.hp["lr"], b1, b2,

@@ -33,6 +33,23 @@ extern "C" {
 
 #define COVA_ERR_BAD_ARG 10001
 
+/* BatchNorm finalize as the TAIL of the launch that produced the statistics partials (cova_conv1_fwd_tail,
+ * cova_conv3x3_wino4_full_tail): the last block to finish folds the partial rows and writes what
+ * cova_bn_finalize_fwd (mode 1) or cova_bn_finalize_bwd_abc (mode 2) would write in a launch of its own -- same
+ * fp64 arithmetic.  A HOST struct of device pointers, read at launch time.  `counter`: one device int, zero before the
+ * first launch; the kernel leaves it zero.  64 channels. */
+typedef struct cova_bn_tail {
+    int mode;                                   /* 0 none | 1 forward statistics | 2 backward sums */
+    int *counter;
+    double count;                               /* elements per channel */
+    const float *gamma, *beta;                  /* mode 1 */
+    float *running_mean, *running_var;          /* mode 1, nullable: momentum update */
+    long long *num_batches_tracked;             /* mode 1, nullable: += 1 */
+    float momentum, eps;
+    float *scale, *shift, *mean, *invstd;       /* mode 1: outputs | mode 2: inputs (mean, invstd, scale) */
+    float *dgamma, *dbeta, *abc;                /* mode 2 outputs: dgamma / dbeta (nullable), abc [3][64] */
+} cova_bn_tail;
+
 /* ------------------------------------------------------------------ conv stack (models.py:49-51)
  * replaces: torchvision resnet18 children()[:-5] = nn.Conv2d(3,64,7,2,3), nn.BatchNorm2d(64),
  * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
@@ -55,6 +72,10 @@ int cova_conv1_num_tiles(int B, int H, int W);
 int cova_conv1_num_partials(int B, int H, int W);
 int cova_conv1_fwd(const float *img, const float *w_k, float *out, float *stat_part, int B, int H,
                    int W, void *stream);
+/* ... reading the [64,3,7,7] OIHW weight directly (no cova_conv1_prep_weights launch), and with the BatchNorm finalize
+ * of its statistics as the launch's tail (tail: host pointer, mode 1; nullable) */
+int cova_conv1_fwd_tail(const float *img, const float *w_oihw, float *out, float *stat_part, int B, int H, int W,
+                        const cova_bn_tail *tail, void *stream);
 /* gradient of conv1's weight (the image needs no gradient): dw OIHW [64,3,7,7] */
 int cova_conv1_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv1_wgrad(const float *img, const float *dy /*NHWC*/, float *dw, float *ws, int B, int H,
@@ -120,6 +141,9 @@ int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, fl
 int cova_conv3x3_wino4_num_tiles(int B, int H, int W);
 int cova_conv3x3_wino4_num_partials(int B, int H, int W);
 int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
+/* ... of up to four convolutions in ONE launch (w1..w3 nullable): u_fwd / u_dgrad hold n x 147,456 floats */
+int cova_conv3x3_wino4_prep_multi(const float *w0, const float *w1, const float *w2, const float *w3, float *u_fwd,
+                                  float *u_dgrad, void *stream);
 int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_part /*nullable*/, int B, int H,
                        int W, void *stream);
 /* ... on relu?(A[c]*in + C[c]) formed on load (pro_abc [3][64] = A | unused | C), zero padding stays zero */
@@ -134,6 +158,14 @@ int cova_conv3x3_wino4_full(const float *in, const float *in2 /*nullable*/, cons
                             const float *mask_shift /*nullable*/, const float *z /*nullable*/,
                             const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
                             float *stat_part /*nullable*/, int B, int H, int W, void *stream);
+/* ... with the BatchNorm finalize of stat_part as the launch's tail (tail: host pointer; mode 1 for plain statistics,
+ * mode 2 for the BatchNorm-backward sums of the z epilogue) */
+int cova_conv3x3_wino4_full_tail(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable*/,
+                                 int pro_relu, const float *u, const float *addend /*nullable*/,
+                                 const float *act /*nullable*/, const float *mask_scale /*nullable*/,
+                                 const float *mask_shift /*nullable*/, const float *z /*nullable*/,
+                                 const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
+                                 float *stat_part, int B, int H, int W, const cova_bn_tail *tail, void *stream);
 
 /* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
  * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.

@@ -602,6 +602,90 @@ def test_conv3x3_winograd_f4x4_full_form(B, H, W, cap):
         query("cova_set_option", 2, 0)
 
 
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
+def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
+    """The BatchNorm finalize riding on the producing launch (csrc/bn_tail.h: last block, ticket counter) writes exactly
+    what the separate cova_bn_finalize_fwd / cova_bn_finalize_bwd_abc launches write -- bit for bit, launch after launch
+    (the counter resets itself) -- for the F(4x4,3x3) forward (statistics) and data-gradient (backward sums) forms."""
+    from cova_web_object_detection_amd import engine
+    g = torch.Generator().manual_seed(17 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x, x2, z = nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W))
+    w = rnd(64, 64, 3, 3) * 0.05
+    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), rnd(64).to(DEV)
+    query("cova_set_option", 2, cap)
+    n4 = query("cova_conv3x3_wino4_num_partials", B, H, W)
+    R = float(B * H * W)
+    try:
+        for rep in range(3):
+            # ---- forward statistics
+            rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+            rm2, rv2, nbt2 = rm.clone(), rv.clone(), nbt.clone()
+            out, part = torch.empty_like(x), torch.empty(n4, 2, 64, device=DEV)
+            call("cova_conv3x3_wino4_full", x, None, None, 0, u4f, None, None, None, None, None, None, None, out, part, B, H, W)
+            ref = [torch.empty(64, device=DEV) for _ in range(4)]
+            call("cova_bn_finalize_fwd", part, n4, 64, R, gamma, beta, rm, rv, nbt, 0.1, 1e-5, *ref)
+            got = [torch.full((64,), 7.0, device=DEV) for _ in range(4)]
+            tail = engine.BnTail(1, x, R, gamma=gamma, beta=beta, running_mean=rm2, running_var=rv2, num_batches_tracked=nbt2,
+                                 scale=got[0], shift=got[1], mean=got[2], invstd=got[3])
+            out2, part2 = torch.empty_like(x), torch.empty(n4, 2, 64, device=DEV)
+            call("cova_conv3x3_wino4_full_tail", x, None, None, 0, u4f, None, None, None, None, None, None, None, out2, part2,
+                 B, H, W, tail.ptr)
+            assert torch.equal(out, out2) and torch.equal(part, part2)
+            for a, b_ in zip(got + [rm2, rv2], ref + [rm, rv]):
+                assert torch.equal(a, b_), "forward tail differs (launch %d)" % rep
+            assert int(nbt2) == 1 == int(nbt)
+            # ---- backward sums (two-tensor prologue, mask from z)
+            abc = rnd(3, 64).to(DEV)
+            msc, msh = rnd(64).to(DEV), rnd(64).to(DEV) * 0.3
+            mean, invstd, scale = ref[2], ref[3], ref[0]
+            call("cova_conv3x3_wino4_full", x, x2, abc, 0, u4d, None, None, msc, msh, z, mean, invstd, out, part, B, H, W)
+            dg, db, abc_ref = torch.empty(64, device=DEV), torch.empty(64, device=DEV), torch.empty(3, 64, device=DEV)
+            call("cova_bn_finalize_bwd_abc", part, n4, 64, R, dg, db, mean, invstd, scale, abc_ref)
+            dg2, db2, abc2 = torch.empty(64, device=DEV), torch.empty(64, device=DEV), torch.empty(3, 64, device=DEV)
+            tail = engine.BnTail(2, x, R, mean=mean, invstd=invstd, scale=scale, dgamma=dg2, dbeta=db2, abc=abc2)
+            call("cova_conv3x3_wino4_full_tail", x, x2, abc, 0, u4d, None, None, msc, msh, z, mean, invstd, out2, part2,
+                 B, H, W, tail.ptr)
+            assert torch.equal(out, out2) and torch.equal(part, part2)
+            assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(abc_ref, abc2), "backward tail differs"
+    finally:
+        query("cova_set_option", 2, 0)
+
+
+def test_conv1_forward_with_batchnorm_tail():
+    """cova_conv1_fwd_tail (OIHW weight read directly, BatchNorm finalize as the launch's tail) == cova_conv1_prep_weights +
+    cova_conv1_fwd + cova_bn_finalize_fwd: same outputs and partial rows bit for bit, BatchNorm parameters to fp32 round-off."""
+    from cova_web_object_detection_amd import engine
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 150, 330
+    img = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    wk = torch.empty(154, 64, device=DEV)
+    call("cova_conv1_prep_weights", w, wk)
+    H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
+    n = query("cova_conv1_num_partials", B, H, W)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
+    cnt = float(B * H1 * W1)
+    y, part = torch.empty(B, H1, W1, 64, device=DEV), torch.empty(n, 2, 64, device=DEV)
+    call("cova_conv1_fwd", img, wk, y, part, B, H, W)
+    ref = [torch.empty(64, device=DEV) for _ in range(4)]
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    call("cova_bn_finalize_fwd", part, n, 64, cnt, gamma, beta, rm, rv, None, 0.1, 1e-5, *ref)
+    for _ in range(2):
+        got = [torch.empty(64, device=DEV) for _ in range(4)]
+        rm2, rv2 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        tail = engine.BnTail(1, img, cnt, gamma=gamma, beta=beta, running_mean=rm2, running_var=rv2, num_batches_tracked=None,
+                             scale=got[0], shift=got[1], mean=got[2], invstd=got[3])
+        y2, part2 = torch.empty_like(y), torch.empty_like(part)
+        call("cova_conv1_fwd_tail", img, w, y2, part2, B, H, W, tail.ptr)      # (the OIHW weight: no prep launch)
+        assert torch.equal(y, y2) and torch.equal(part, part2)
+        for a, b_ in zip(got + [rm2, rv2], ref + [rm, rv]):
+            close(a, b_, 1e-6, "conv1 tail")
+
+
 @pytest.mark.parametrize("geo", [1, 2])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 5)])
 def test_conv3x3_winograd_inference_epilogue(B, H, W, cap, geo):

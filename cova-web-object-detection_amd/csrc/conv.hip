@@ -989,13 +989,17 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *_
 extern int g_grid_cap;
 inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 {
-    static int cus = 0;
+    // compute units of the CURRENT device (the caller launches under the device guard of its tensors; the host
+    // queries run under the same guard): cached per device id, not once per process
+    static int cus_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cus_of[dev];
     if (cus == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
+        cus_of[dev] = cus;
     }
     int g = ntiles < cus * blocks_per_cu ? ntiles : cus * blocks_per_cu;
     if (g_grid_cap > 0 && g > g_grid_cap) g = g_grid_cap;

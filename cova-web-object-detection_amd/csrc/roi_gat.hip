@@ -803,7 +803,8 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
                     const int qq = min(q0 + u, 63);
                     const int i = __shfl(e, qq, 64) / K;
                     aq[u] = q0 + u < cnt ? __shfl(al, qq, 64) : 0.f;
-                    gv[u] = g[(size_t)i * ldg + dd];
+                    const float gl = g[(size_t)i * ldg + dd];      // (unconditional load; padding slots read row 0 ...)
+                    gv[u] = q0 + u < cnt ? gl : 0.f;               // ... and must not turn a non-finite g[0] into NaN: 0 * inf
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) accv = fmaf(aq[u], gv[u], accv);

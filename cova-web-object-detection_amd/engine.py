@@ -18,6 +18,25 @@ call, query = _lib.call, _lib.query
 BN_MOMENTUM, BN_EPS, LEAKY_SLOPE = 0.1, 1e-5, 0.2   # nn.BatchNorm defaults; models.py:156
 
 
+def on_device_of(argpos):
+    """Run an engine entry point under the device guard of its tensors (argument `argpos`): the host-side size
+    queries (persistent-grid sizes, workspace sizes) then consult the SAME device the launches go to -- the reference
+    picks `cuda:<-d>` without ever calling set_device (main.py:17), so the process' current device may be another GPU."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*args, **kw):
+            t = args[argpos]
+            t = t.get("images") if isinstance(t, dict) else t
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != torch.cuda.current_device():
+                with torch.cuda.device(t.device):
+                    return fn(*args, **kw)
+            return fn(*args, **kw)
+        return wrapped
+    return deco
+
+
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -309,6 +328,7 @@ def prep_wino(w, like):
     return a, b
 
 
+@on_device_of(0)
 def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,C]  (models.py:49-51,125);
     with ``lazy_out`` (Winograd path) a LazyFeature instead of the tensor."""
@@ -757,6 +777,7 @@ def masked_grad_and_sums(dout, last, R):
     return g, (part, n)
 
 
+@on_device_of(1)
 def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
     """dfeat NHWC [B,Hf,Wf,C] -> {state_dict key: grad} for the convs and BatchNorms of the stack.
 
@@ -1074,6 +1095,7 @@ def decoder_bwd(sv, dlogits, params, gout=None):
 
 
 # ------------------------------------------------------------------------------- whole model
+@on_device_of(3)
 def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_indices, training,
               seeds=(0, 0), masks=None, save=True):
     """CoVA.forward (models.py:94-122) -> (logits [N,n_classes], saved-for-backward or None)."""
@@ -1109,6 +1131,7 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     return logits, (sv if save else None)
 
 
+@on_device_of(1)
 def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     """-> {state_dict key: gradient} for every trainable parameter.  ``gout`` (optional) maps
     keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket.

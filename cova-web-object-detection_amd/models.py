@@ -335,8 +335,8 @@ class CoVA(nn.Module):
 
         # ---- representation network.  ImageNet weights (models.py:49 pretrained=True) cannot be
         # fetched offline: convs get torchvision's kaiming-normal(fan_out) init unless a torchvision
-        # state_dict is supplied (backbone_state_dict / $COVA_BACKBONE_WEIGHTS) or a reference
-        # checkpoint is loaded afterwards with load_state_dict.
+        # state_dict is supplied (the explicit backbone_state_dict= argument: a dict or a path; no hidden
+        # environment state) or a reference checkpoint is loaded afterwards with load_state_dict.
         c = engine.C64
         c_out = backbone_channels(backbone)
         conv1 = nn.Conv2d(3, c, 7, 2, 3, bias=False)
@@ -351,7 +351,7 @@ class CoVA(nn.Module):
         for m in self.convnet.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-        self._init_backbone(backbone_state_dict or os.environ.get("COVA_BACKBONE_WEIGHTS"))
+        self._init_backbone(backbone_state_dict)
         c = c_out
         # models.py:53-56 reads the output size off a dummy forward; it is a closed form
         feat_h = engine.feature_map_size(img_H)
@@ -392,16 +392,23 @@ class CoVA(nn.Module):
         self._forced_masks = None      # parity tests inject keep-masks here
         print("Model Parameters:", sum(p.numel() for p in self.parameters() if p.requires_grad))
 
+    _warned_random_init = set()
+
     def _init_backbone(self, source):
         """conv1 / bn1 / layer1 of a torchvision ResNet state_dict -> convnet.0 / .1 / .4 (keys map 1:1).
         Without one the stack keeps its random init, which the reference never does: say so."""
         if source is None:
-            warnings.warn("CoVA: no ImageNet weights for the %s stack (the reference downloads them, "
-                          "models.py:49); it starts from a random init.  Pass backbone_state_dict= / set "
-                          "COVA_BACKBONE_WEIGHTS to a torchvision state_dict, or load a checkpoint."
-                          % self.backbone, stacklevel=3)
+            if self.backbone not in CoVA._warned_random_init:          # once per process and architecture
+                CoVA._warned_random_init.add(self.backbone)
+                warnings.warn("CoVA: no ImageNet weights for the %s stack (the reference downloads them, "
+                              "models.py:49); it starts from a random init.  Pass backbone_state_dict= (a torchvision "
+                              "state_dict or a path to one), or load a checkpoint." % self.backbone, stacklevel=3)
             return
-        sd = torch.load(source, map_location="cpu") if isinstance(source, (str, bytes, os.PathLike)) else source
+        if isinstance(source, (str, bytes, os.PathLike)):
+            print("CoVA: backbone weights from", source)
+            sd = torch.load(source, map_location="cpu")
+        else:
+            sd = source
         mapped = {}
         for k, v in sd.items():
             for src, dst in (("conv1.", "0."), ("bn1.", "1."), ("layer1.", "4.")):

@@ -253,14 +253,14 @@ def test_bn_act2():
 
 
 # ------------------------------------------------------------------------------------ whole model
-def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4):
-    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=hidden, bbox_hidden_dim=32,
+def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4, bbox_hidden=32):
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=hidden, bbox_hidden_dim=bbox_hidden,
                n_additional_feat=0, drop_prob=0.0)
     sd = weights.seeded_state_dict(seed, logit_gain=4.0, **{k: v for k, v in cfg.items() if k != "drop_prob"},
                                    **cfg_kw)
     batch = synthetic.make_batch(len(boxes), img_h=img_h, img_w=img_w, boxes_per_page=boxes, context_size=cs,
                                  seed=seed)
-    m = CoVA((3, 3), img_h, 4, True, hidden, 32, 0, 0.0, None, **cfg_kw)
+    m = CoVA((3, 3), img_h, 4, True, hidden, bbox_hidden, 0, 0.0, None, **cfg_kw)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV)
     args = [batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")]
@@ -324,6 +324,20 @@ def test_reference_model_on_config5_geometry():
     run_case(dict(), 256, 80, [300], 24, 34, hidden=384)
 
 
+def test_without_positional_encoder_bbox_hidden_dim_zero():
+    """`-bbhd 0` (/root/reference utils.py:21, models.py:145-146: _get_bbox_features returns an empty [N, 0] tensor and
+    the concatenation is visual || additional only) on the reference architecture, against the reference-pinned oracle:
+    eval logits + decisions, train loss, all gradients, running statistics."""
+    m, _ = run_case(dict(), 64, 64, [31, 18], 12, 51, hidden=384, bbox_hidden=0)
+    assert not any(k.startswith("bbox_feat_encoder") for k in m.state_dict())
+
+
+def test_context_size_32_fills_the_wave_wide_neighbour_table():
+    """`-cs 32` => K = 64 neighbour slots, the most one wavefront-per-node GAT kernel takes (64 lanes = 64 slots):
+    pages of 70 / 9 boxes, so rows mix full windows, -1 padding and (second page) rows that are mostly padding."""
+    run_case(dict(), 64, 64, [70, 9], 32, 52, hidden=384)
+
+
 def test_eval_mode_backward_uses_frozen_batchnorm():
     """model.eval() + backward (frozen-BN fine-tuning, saliency): BatchNorm is a fixed affine map, so
     dz = scale*dy (torch's eval-mode batch_norm backward), not the train-mode formula."""
@@ -374,6 +388,107 @@ def test_full_size_long_page_train_step_properties():
     ref = O.convnet(crop, O.clone_state_dict(sd), False)[:, :, :64, :64]
     close(feat[0, :64, :64].permute(2, 0, 1).unsqueeze(0), ref, 1e-4, "long-page crop")
     assert feat.shape == (1, 1024, 320, 64)
+
+
+def _bn_moment_checks(conv, keys_bn):
+    """BatchNorm identities of a train step (size independent): the normalised output of every conv-stack BatchNorm has
+    per-channel mean 0 and variance 1 over the batch (checked through the saved pre-activations and the saved
+    mean / invstd, in fp64)."""
+    for z, st in keys_bn:
+        zz = z.reshape(-1, st.C)
+        mu = torch.zeros(st.C, dtype=torch.float64, device=zz.device)
+        sq = torch.zeros(st.C, dtype=torch.float64, device=zz.device)
+        for r0 in range(0, zz.shape[0], 1 << 22):           # fp64 sums in slabs (the maps are up to 3.4 GB)
+            zd = zz[r0:r0 + (1 << 22)].double()
+            mu += zd.sum(0)
+            sq += (zd * zd).sum(0)
+        mu /= zz.shape[0]
+        var = (sq / zz.shape[0] - mu * mu).clamp_min(0)
+        assert float((mu - st.mean.double()).abs().max() / (mu.abs().max() + 1e-6)) < 1e-4
+        assert float((1.0 / torch.sqrt(var + 1e-5) - st.invstd.double()).abs().max() / st.invstd.double().abs().max()) < 1e-4
+
+
+def test_config5_model_on_a_full_length_page():
+    """BASELINE.json configs[4] with ITS OWN model (ResNet-50 stem, 2 heads x 2 layers, 300 boxes, K = 48) on one
+    full 4096 x 1280 page: finite train step, BatchNorm moment identities at full size, bit-identical rerun, and the
+    top 512 pixel rows against the self-oracle's conv stack with the step's batch statistics frozen in (eval-mode
+    crop property: the first 96 feature rows depend on the first ~400 pixel rows only)."""
+    H, W = 4096, 1280
+    kw = dict(backbone="resnet50", n_heads=2, n_gat_layers=2)
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384, bbox_hidden_dim=32,
+               n_additional_feat=0, drop_prob=0.0, **kw)
+    sd = weights.seeded_state_dict(9, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    boxes = synthetic.make_boxes_only(1, H, W, 300, 24, 9)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    images = torch.rand((1, 3, H, W), generator=g, device=DEV)
+    params = {k: sd[k].to(DEV) for k in O.param_keys(sd)}
+
+    def step():
+        buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+        logits, sv = engine.model_fwd(cfg, params, buffers, images, boxes["bboxes"].to(DEV),
+                                      boxes["additional_feats"].to(DEV), boxes["context_indices"].to(DEV), True)
+        loss, dl, _ = engine.ce_sum(logits, boxes["labels"].to(DEV))
+        grads = engine.model_bwd(sv, dl, params)
+        return logits, loss, grads, sv, buffers
+
+    logits, loss, grads, sv, buffers = step()
+    assert logits.shape == (300, 4) and torch.isfinite(logits).all() and torch.isfinite(loss).all()
+    assert set(grads) == set(params)
+    for k, gk in grads.items():
+        assert torch.isfinite(gk).all(), k
+    conv = sv["conv"]
+    pairs = [(conv["y1"], conv["bn1"])]
+    for blk in conv["blocks"]:
+        pairs += [(blk["z1"], blk["bn1"]), (blk["z2"], blk["bn2"]), (blk["z3"], blk["bn3"])]
+    _bn_moment_checks(conv, pairs)
+    logits2, loss2, grads2, _, _ = step()
+    assert torch.equal(logits, logits2) and torch.equal(loss, loss2)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+    # eval-mode forward with the statistics this step left in the running buffers after ONE update from (0, 1):
+    # running = 0.9 * init + 0.1 * batch; compare the top crop against the self-oracle given the same buffers
+    feat, _ = engine.convstack_fwd(images, params, buffers, False, save=False)
+    assert feat.shape == (1, 1024, 320, 256)
+    sd_eval = O.clone_state_dict(sd)
+    for k, v in buffers.items():
+        sd_eval[k] = v.cpu()
+    ref = O.convnet(images[:, :, :512, :].cpu(), sd_eval, False)[:, :, :96, :]
+    close(feat[0, :96].permute(2, 0, 1).unsqueeze(0), ref, 2e-4, "configs[4] full-length page, top crop vs self-oracle")
+
+
+def test_config3_batch_of_32_pages_reproducible_with_batchnorm_identities():
+    """BASELINE.json configs[2] at its full batch (32 pages of 1280 x 1280, ResNet-50 stem + 2-head GAT): the
+    256-channel maps have 0.84 G elements each (32 * 320 * 320 * 256 > 2^29 floats: 64-bit image bases), two train steps
+    from the same state are bit-identical, and every conv-stack BatchNorm's saved statistics are the exact moments of
+    its saved pre-activation."""
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    kw = dict(backbone="resnet50", n_heads=2, n_gat_layers=1)
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=384, bbox_hidden_dim=32,
+               n_additional_feat=0, drop_prob=0.2, **kw)
+    sd = weights.seeded_state_dict(123, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    pages = 32
+    b = synthetic.make_boxes_only(pages, 1280, 1280, 90, 12, 123)
+    batch = {k: v.to(DEV) for k, v in b.items() if torch.is_tensor(v)}
+    g = torch.Generator(device=DEV).manual_seed(123)
+    batch["images"] = torch.rand((pages, 3, 1280, 1280), generator=g, device=DEV)
+    outs = []
+    for _ in range(2):
+        tr = HotPathTrainer(cfg, sd, DEV)
+        loss, pred = tr.train_step(batch)
+        outs.append((loss.clone(), pred.clone(), tr.pbucket.flat.clone(), tr.gbucket.flat.clone()))
+        del tr
+        torch.cuda.empty_cache()
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][3]).all()
+    # BatchNorm identities on one forward of the same batch (drop_prob does not touch the conv stack)
+    params = {k: sd[k].to(DEV) for k in O.param_keys(sd)}
+    buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+    feat, conv = engine.convstack_fwd(batch["images"], params, buffers, True, save=True, lazy_out=True)
+    pairs = [(conv["y1"], conv["bn1"])]
+    for blk in conv["blocks"]:
+        pairs += [(blk["z1"], blk["bn1"]), (blk["z2"], blk["bn2"]), (blk["z3"], blk["bn3"])]
+    _bn_moment_checks(conv, pairs)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(backbone="resnet50")])

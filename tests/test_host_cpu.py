@@ -89,7 +89,11 @@ def test_extension_modules_keep_the_reference_surface():
         assert sum(p.numel() for p in m.parameters()) == nparam
         assert m.n_visual_feat == 2304 and m.n_total_feat == 2720
         m.load_state_dict(weights.seeded_state_dict(1, **kw))
+    CoVA._warned_random_init.clear()                 # the warning is issued once per process and architecture
     with pytest.warns(UserWarning, match="ImageNet"):
+        CoVA((3, 3), 64, 4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")               # ... and not again
         CoVA((3, 3), 64, 4)
     # torchvision-style backbone weights initialise conv1 / bn1 / layer1 (offline stand-in for pretrained=True)
     sd = weights.seeded_state_dict(4)

@@ -6,6 +6,8 @@ gradients 1e-3 of each tensor's scale (floored at 1% of the largest gradient: se
 have analytically zero gradient); integer outputs exact on rows whose top-2 logit margin exceeds
 10x the observed fp error.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -238,6 +240,94 @@ def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
     assert abs(losses[0] - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
     logits, pred = tr.predict(dbatch)
     assert logits.shape == (39, 4) and torch.equal(pred, logits.argmax(1))
+
+
+def test_training_trajectory_follows_the_cpu_oracle():
+    """Stand-in for the reference's accuracy claim (README.md:41-42; the CoVA dataset is not available offline):
+    80 Adam steps (lr 5e-4, weight_decay 1e-3: /root/reference main.py:133-139) of the HIP trainer against the CPU oracle
+    (oracle.loss_and_grads + torch.optim.Adam) on a memorisable synthetic task -- three batches of two 96-pixel pages
+    cycling, the same dropout keep-masks injected on both sides.  The two runs are chaotic in the last bits (ReLU gates
+    near zero), so the check is a band on the loss curve and equal decisions at the end: per-box arg-max on margin
+    rows and the per-page / per-class top-1 box of train.py:144-153.  The curve goes to profiles/ when COVA_WRITE_CURVE
+    names a file."""
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=96,
+               bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.2)
+    wcfg = {k: v for k, v in cfg.items() if k != "drop_prob"}
+    sd = weights.seeded_state_dict(77, logit_gain=2.0, **wcfg)
+    batches = [synthetic.make_batch(2, img_h=96, boxes_per_page=[30 + 3 * i, 21 + 2 * i], context_size=12, seed=700 + i)
+               for i in range(3)]
+    T = sd["decoder.1.weight"].shape[0]
+    steps = 80
+    gen = torch.Generator().manual_seed(5)
+    keys = O.param_keys(sd)
+    tr = HotPathTrainer(cfg, sd, DEV)
+    ref_sd, state = O.clone_state_dict(sd), None
+    curve = []
+    for it in range(steps):
+        b = batches[it % 3]
+        n = b["bboxes"].shape[0]
+        masks = [(torch.rand(n, T, generator=gen) > cfg["drop_prob"]) for _ in range(2)]
+        db = {k: v.to(DEV) for k, v in b.items() if torch.is_tensor(v)}
+        loss, _ = tr.train_step(db, masks=[m.to(torch.uint8).to(DEV) for m in masks])
+        loss_ref, _, grads, after, _ = O.loss_and_grads(ref_sd, b["images"], b["bboxes"], b["additional_feats"],
+                                                        b["context_indices"], b["labels"], cfg,
+                                                        [m.float() for m in masks])
+        new_p, state = O.adam_reference([ref_sd[k] for k in keys], [grads[k] for k in keys], state)
+        for k, p in zip(keys, new_p):
+            after[k] = p
+        ref_sd = after
+        curve.append((it, float(loss.item()), float(loss_ref)))
+        if it == steps // 2 - 1:          # half-way snapshot of both sides for the decision check
+            mid_sd = O.clone_state_dict(ref_sd)
+            mid_tr = HotPathTrainer(cfg, tr.state_dict(), DEV)
+    path = os.environ.get("COVA_WRITE_CURVE")
+    if path:
+        with open(path, "w") as f:
+            f.write("# 80 Adam steps, HIP trainer vs CPU oracle (tests/test_model_gpu.py::test_training_trajectory_follows_the_cpu_oracle)\n")
+            f.write("# step  loss_hip  loss_oracle  rel_diff\n")
+            for it, a, r in curve:
+                f.write("%3d %12.5f %12.5f %9.2e\n" % (it, a, r, abs(a - r) / max(abs(r), 1e-9)))
+    first, last = curve[0], curve[-1]
+    assert abs(first[1] - first[2]) <= 2e-4 * abs(first[2])                    # same start
+    assert last[2] < 0.5 * first[2], "the oracle run did not learn: not a meaningful trajectory"
+    # band: 5 % of the current loss + 0.2 % of the initial one.  The two runs are chaotic once the weights have separated
+    # by Adam's +-lr steps on noise-level gradients (and the multi-threaded CPU side is not bit-reproducible itself):
+    # measured 1e-7 at step 0, 1e-4 around step 15 at 1/4 of the initial loss, 1-5 % of the CURRENT loss from step ~45 on,
+    # where the loss is 20-100x below its start (profiles/r03_trajectory.txt)
+    for it, a, r in curve:
+        assert abs(a - r) <= 0.05 * abs(r) + 2e-3 * first[2], "loss curves drifted apart at step %d: %.5f vs %.5f" % (it, a, r)
+    assert max(abs(a - r) / abs(r) for _, a, r in curve[:4]) < 5e-5        # the first steps agree to fp32 round-off,
+    assert max(abs(a - r) / abs(r) for _, a, r in curve[:12]) < 2e-3       # the early ones tightly
+    # decisions, eval mode, on every batch: half-way (step 40, where the two parameter sets are still within ~1 % in
+    # logit space) on rows whose margin exceeds 10x the observed difference, and at the end on the rows that are still
+    # decided by a clear margin
+    def decisions(hip_tr, oracle_sd, min_frac):
+        for b in batches:
+            db = {k: v.to(DEV) for k, v in b.items() if torch.is_tensor(v)}
+            logits, pred = hip_tr.predict(db)
+            ref = O.forward(O.clone_state_dict(oracle_sd), b["images"], b["bboxes"], b["additional_feats"],
+                            b["context_indices"], cfg, False)
+            err = float((logits.cpu() - ref).abs().max())
+            top2 = ref.topk(2, dim=1).values
+            ok = (top2[:, 0] - top2[:, 1]) > 10 * err
+            assert int(ok.sum()) >= min_frac * ok.numel(), ("too few margin rows for a decision check", int(ok.sum()), ok.numel(), err)
+            assert torch.equal(pred.cpu()[ok], ref.argmax(1)[ok])
+            # per page and class: the top-1 box (train.py:144-153) where the winner's margin exceeds the difference
+            page = b["bboxes"][:, 0].long()
+            for pg in page.unique():
+                sel = page == pg
+                lr, lh = ref[sel], logits.cpu()[sel]
+                for c in range(1, 4):
+                    col = lr[:, c].sort(descending=True).values
+                    if col[0] - col[1] > 10 * err:
+                        assert int(lh[:, c].argmax()) == int(lr[:, c].argmax())
+        return err
+
+    decisions(mid_tr, mid_sd, 0.5)
+    decisions(tr, ref_sd, 0.0)
+    hip_sd = tr.state_dict()
+    assert all(torch.isfinite(v).all() for v in hip_sd.values())
 
 
 def test_eval_decision_kernel_matches_reference_rule():

@@ -1,5 +1,6 @@
-"""Data-parallel step with real HIP kernels in TWO processes (both on cuda:0; collectives through gloo,
-which stages device tensors through the host -- a 1-GPU box cannot host a 2-rank RCCL group).
+"""Data-parallel step with real HIP kernels in TWO processes: both on cuda:0 with the collectives through gloo
+(which stages device tensors through the host -- a 1-GPU box cannot host a 2-rank RCCL group), and, wherever two GPUs
+are visible, one rank per GPU over RCCL.
 
 With sync_bn=True a 2-rank step over page shards must equal the single-process step over the whole
 batch ("exact large-batch mode"): loss, every parameter after Adam, every
@@ -49,111 +50,145 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, sync_bn, arch="resnet18"):
+def _worker(rank, world, port, out_dir, sync_bn, arch="resnet18", backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:%d" % rank if backend == "nccl" else "cuda:0"       # RCCL: one GPU per rank; gloo: both on cuda:0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = "cuda:0"
         cfg, wcfg = _cfgs(arch)
         shard = {k: v.to(dev) for k, v in shard_batch(_batch(), rank, world).items()}
-        tr = HotPathTrainer(cfg, weights.seeded_state_dict(23, **wcfg), dev, world_size=world,
+        # rank 1 starts from DIFFERENT weights: the trainer's start-up broadcast must make the replicas equal
+        tr = HotPathTrainer(cfg, weights.seeded_state_dict(23 + 100 * rank, **wcfg), dev, world_size=world,
                             sync_bn=sync_bn)
         # this rank's own gradient (no exchange): a single-process trainer on the shard
         solo = HotPathTrainer(cfg, weights.seeded_state_dict(23, **wcfg), dev)
         solo.forward_backward(shard)
         local = solo.gbucket.flat.clone()
-        losses, grads = [], None
+        ref_states = os.path.join(out_dir, "ref_state_%d.pt")
+        losses, grads = [], []
         for i in range(STEPS):
+            if os.path.exists(ref_states % i):
+                # every step starts from the single-process run's state at that step: the comparison of step i is then
+                # not blurred by Adam's +-lr moves on noise-level gradients in the steps before it
+                st = torch.load(ref_states % i)
+                tr.load_state_dict(st["sd"])
+                tr.load_optimizer_state_dict(st["opt"])
             loss, _ = tr.forward_backward(shard)
             tr.optimizer_step()
-            if i == 0:
-                grads = tr.gbucket.flat.clone()          # after the exchange: sum over ranks
+            grads.append(tr.gbucket.flat.clone().cpu())          # after the exchange: sum over ranks
             losses.append(float(loss))
         torch.cuda.synchronize()
-        torch.save(dict(losses=losses, local=local.cpu(), grads=grads.cpu(),
-                        sd={k: v.cpu() for k, v in tr.state_dict().items()}),
+        torch.save(dict(losses=losses, local=local.cpu(), grads=grads,
+                        sd={k: v.cpu() for k, v in tr.state_dict().items()},
+                        exposed_ms=tr.exposed_allreduce_ms()),
                    os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
 
-def _run(tmp_path, sync_bn, arch="resnet18"):
+def _run(tmp_path, sync_bn, arch="resnet18", backend="gloo"):
     port = _free_port()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    mp.spawn(_worker, args=(2, port, str(tmp_path), sync_bn, arch), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), sync_bn, arch, backend), nprocs=2, join=True)
     return [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2)]
 
 
-@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
-def test_two_rank_step_with_syncbn_equals_single_process_large_batch(tmp_path, arch):
-    r0, r1 = _run(tmp_path, True, arch)
+def _reference_run(tmp_path, arch):
+    """The single-process run on the concatenated batch; its state BEFORE every step goes to files the ranks load."""
     dev = "cuda:0"
     cfg, wcfg = _cfgs(arch)
     full = {k: v.to(dev) for k, v in _batch().items() if torch.is_tensor(v)}
     ref = HotPathTrainer(cfg, weights.seeded_state_dict(23, **wcfg), dev)
-    ref_losses = []
+    out = dict(losses=[], grads=[])
     for i in range(STEPS):
+        torch.save(dict(sd={k: v.cpu() for k, v in ref.state_dict().items()},
+                        opt={k: (v.cpu() if torch.is_tensor(v) else v) for k, v in ref.optimizer_state_dict().items()}),
+                   os.path.join(str(tmp_path), "ref_state_%d.pt" % i))
         loss, _ = ref.forward_backward(full)
-        if i == 0:
-            g_ref = ref.gbucket.flat.clone().cpu()
+        out["grads"].append(ref.gbucket.flat.clone().cpu())
         ref.optimizer_step()
-        ref_losses.append(float(loss))
+        out["losses"].append(float(loss))
+    out["sd"] = {k: v.cpu() for k, v in ref.state_dict().items()}
+    out["offsets"] = ref.gbucket.offsets
+    return out
+
+
+def _check_syncbn(r0, r1, ref, arch):
     # the ranks agree with each other exactly (same all-reduced gradient, same Adam) ...
-    assert torch.equal(r0["grads"], r1["grads"])
+    for g0, g1 in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(g0, g1)
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
-    # ... and with the single-process step on the concatenated batch to fp32 re-association accuracy
+    # ... and EVERY step (started from the single-process run's state) with the single-process step on the concatenated
+    # batch to fp32 re-association accuracy: a wrong count ratio in any step is an O(1) error
     for i in range(STEPS):
         tot = r0["losses"][i] + r1["losses"][i]
-        # (from the second step on the two runs' weights differ by Adam's +-lr steps on noise-level gradients)
-        assert abs(tot - ref_losses[i]) <= (2e-4 if i == 0 else 1e-3) * abs(ref_losses[i]), (i, tot, ref_losses[i])
-    scale = float(g_ref.abs().max())
-    if arch == "resnet18":
-        assert float((r0["grads"] - g_ref).abs().max()) <= 2e-4 * scale
-    else:
-        # The deeper stack takes ~4x more ReLU decisions, and the two runs' BatchNorm parameters differ in the
-        # last bit (all-reduced fp32 rows vs one fp64 fold): a pre-activation within 1e-7 of zero may gate
-        # differently and moves single gradient entries by ~1e-3 of the scale (with
-        # IDENTICAL shards on both ranks blocks 1-2 agree to 3e-7 and one flipped gate of block 0 shows as 5e-4).
-        # A wrong count ratio or a missed exchange is an O(1) error: bound the bulk tightly, the peak loosely.
-        d = (r0["grads"] - g_ref).double()
-        assert float(d.abs().max()) <= 5e-3 * scale
-        assert float(d.norm() / g_ref.double().norm()) <= 2e-3
-        return        # (the post-Adam state comparison below amplifies those entries by lr / sqrt(v): resnet18 only)
-    sd_ref = ref.state_dict()
-    tr_off = ref.gbucket.offsets
-    for k, v in sd_ref.items():
+        assert abs(tot - ref["losses"][i]) <= 2e-4 * abs(ref["losses"][i]), (i, tot, ref["losses"][i])
+        g_ref = ref["grads"][i]
+        scale = float(g_ref.abs().max())
+        d = (r0["grads"][i] - g_ref).double().abs()
+        if arch == "resnet18":
+            assert float(d.max()) <= 2e-4 * scale, (i, float(d.max()) / scale)
+        else:
+            # The deeper stack takes ~4x more ReLU decisions, and the two runs' BatchNorm parameters differ in the last
+            # bit (all-reduced fp32 rows vs one fp64 fold): a pre-activation within 1e-7 of zero may gate differently
+            # and moves a handful of gradient entries by ~1e-3 of the scale (DESIGN.md section 5).  The bulk (99 % of the
+            # entries) is held to the tight bound, 99.9 % to 1e-3 (measured 2.2e-4), the peak to a loose one.
+            assert float(torch.quantile(d[::7].float(), 0.99)) <= 2e-4 * scale, i
+            assert float(torch.quantile(d[::7].float(), 0.999)) <= 1e-3 * scale, i
+            assert float(d.max()) <= 5e-3 * scale, i
+    # state after the last step: each step started from identical parameters, so one Adam step separates the runs
+    for k, v in ref["sd"].items():
         if not v.is_floating_point():
-            assert torch.equal(r0["sd"][k], v.cpu()), k
+            assert torch.equal(r0["sd"][k], v), k
         elif k.endswith(("running_mean", "running_var")):
-            # (after the first Adam step the two runs' weights differ by the +-lr noise above)
-            assert torch.allclose(r0["sd"][k], v.cpu(), rtol=1e-3, atol=2e-4), k
-        else:     # Adam's first steps move every weight by ~lr * sign(g): an entry whose gradient is
-            #           rounding noise around zero may step the other way (2 * lr per step), the
-            #           bulk must agree far better than that
-            d = (r0["sd"][k] - v.cpu()).abs()
-            # (Adam's per-step move is bounded by lr * (1 - beta1) / sqrt(1 - beta2) = 3.2 lr when a gradient flips sign)
-            off = tr_off[k]
-            gk = g_ref[off[0]:off[0] + off[1]].view(-1)
-            i = int(d.view(-1).argmax())
-            assert float(d.max()) <= 2 * STEPS * 3.2 * 5e-4 + 1e-5, (k, float(d.max()), float(gk[i]), float(gk.abs().max()))
-            if float(d.max()) > 2 * STEPS * 5e-4 + 1e-5:          # only a rounding-noise gradient may do that
-                assert abs(float(gk[i])) <= 1e-4 * scale, (k, float(gk[i]), scale)
-            # the bulk: entries whose gradient is well above the summation noise (the last bn2's bias, e.g., has a
-            # nearly vanishing gradient -- a channel-wise shift of the visual features is removed again by the
-            # decoder's train-mode BatchNorm -- and its Adam steps follow the sign of rounding noise)
-            solid = gk.abs().view(d.shape) > 1e-4 * scale
+            assert torch.allclose(r0["sd"][k], v, rtol=2e-4, atol=2e-5), k
+        else:
+            # Adam moves a weight by <= 3.2 lr per step; entries whose gradient is rounding noise around zero may step
+            # the other way, the ones with a solid gradient must agree far better
+            dd = (r0["sd"][k] - v).abs()
+            assert float(dd.max()) <= 2 * 3.2 * 5e-4 + 1e-5, (k, float(dd.max()))
+            off = ref["offsets"][k]
+            gk = ref["grads"][-1][off[0]:off[0] + off[1]].view(dd.shape)
+            solid = gk.abs() > 1e-3 * float(ref["grads"][-1].abs().max())
             if bool(solid.any()):
-                assert float(d[solid].mean()) <= 0.02 * STEPS * 5e-4 + 1e-6, k
+                assert float(dd[solid].mean()) <= 0.02 * 5e-4 + 1e-6, k
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_two_rank_step_with_syncbn_equals_single_process_large_batch(tmp_path, arch):
+    ref = _reference_run(tmp_path, arch)
+    r0, r1 = _run(tmp_path, True, arch)
+    _check_syncbn(r0, r1, ref, arch)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: a 2-rank RCCL group, one rank per device")
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_two_rank_step_over_rccl(tmp_path, sync_bn):
+    """The same two assertions with the collectives on RCCL (backend "nccl"), one rank per GPU over xGMI -- runs
+    wherever `pytest -m gpu` finds two devices; the 1-GPU boxes skip it and keep the gloo variants."""
+    if sync_bn:
+        ref = _reference_run(tmp_path, "resnet18")
+        r0, r1 = _run(tmp_path, True, "resnet18", backend="nccl")
+        _check_syncbn(r0, r1, ref, "resnet18")
+    else:
+        r0, r1 = _run(tmp_path, False, backend="nccl")
+        assert torch.equal(r0["grads"][0], r1["grads"][0])
+        assert torch.equal(r0["local"] + r1["local"], r0["grads"][0])
+    assert r0["exposed_ms"] >= 0.0
 
 
 def test_two_rank_step_with_local_batchnorm_sums_the_shard_gradients(tmp_path):
     from oracle import cova_oracle as O
     r0, r1 = _run(tmp_path, False)
-    assert torch.equal(r0["grads"], r1["grads"])
+    assert torch.equal(r0["grads"][0], r1["grads"][0])
     summed = r0["local"] + r1["local"]
     # no float atomics anywhere in the step (RoIPool / GAT backward gather in a fixed order): exact
-    assert torch.equal(summed, r0["grads"])
+    assert torch.equal(summed, r0["grads"][0])
     # each rank's local gradient against the oracle on its shard
     sd = weights.seeded_state_dict(23, **WCFG)
     tr = HotPathTrainer(CFG, sd, "cpu")            # (flat layout only; no device work)

@@ -580,6 +580,16 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         if (!(W4_ABL & 512)) lds_barrier();
         if (ph == 1) get();
         if (!(W4_ABL & 512)) lds_barrier();
+        // complete the own rows right away (the received values die here): rows are summed in the order i = 0..5 on both
+        // waves, (rows 0-2) + (rows 3-5)
+#pragma unroll
+        for (int io = 0; io < 2; ++io)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float got[4] = {rx[io][j].x, rx[io][j].y, rx[io][j].z, rx[io][j].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yo[io][j][r] = ph == 0 ? yo[io][j][r] + got[r] : got[r] + yo[io][j][r];
+            }
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int io = 0; io < 2; ++io) {
@@ -599,15 +609,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             for (int j = 0; j < 4; ++j) {
                 const bool ok = oy < H && ox0 + j < W;
                 const float own[4] = {yo[io][j][0], yo[io][j][1], yo[io][j][2], yo[io][j][3]};
-                const float got[4] = {rx[io][j].x, rx[io][j].y, rx[io][j].z, rx[io][j].w};
                 const float adv[4] = {ops.ad[j].x, ops.ad[j].y, ops.ad[j].z, ops.ad[j].w};
                 const float zv[4] = {ops.z4[j].x, ops.z4[j].y, ops.z4[j].z, ops.z4[j].w};
                 const float av[4] = {ops.a4[j].x, ops.a4[j].y, ops.a4[j].z, ops.a4[j].w};
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // rows are summed in the order i = 0..5 on both waves: (rows 0-2) + (rows 3-5)
-                    float v = ph == 0 ? own[r] + got[r] : got[r] + own[r];
+                    float v = own[r];
                     if (ADD) v += adv[r];
                     if (BN) {
                         const float gate = BN == 2 ? av[r] : fmaf(msc[r], zv[r], msh[r]);
@@ -621,10 +629,22 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     }
                     o[r] = v;
                 }
-                if (W4_ABL & 1024) {        // (timing experiment: same bytes, every wave store 1 KB contiguous; wrong placement)
-                    *reinterpret_cast<float4 *>(e_out + ((((size_t)tile_ * 8 + wave) * 8 + (io * 4 + j)) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
-                } else if (ok && !(W4_ABL & 256)) {
-                    *reinterpret_cast<float4 *>(e_out + img + (unsigned)(((oy0 + io) * W + ox0 + j) * 64 + co0)) = make_float4(o[0], o[1], o[2], o[3]);
+                // Store through a lane transpose: lane (kq, l15) computed channels kq*4.. of tile l15, but four ADJACENT
+                // lanes should write one pixel's 64 contiguous bytes (the memory pipeline merges a lane quad's 16-byte
+                // pieces into one request; with lane = kq*16 + l15 every piece was a request of its own: measured -5 %
+                // on the whole launch).  Lane L' = (tile L' >> 2, channel quad L' & 3) takes its float4 from lane
+                // (L' & 3) * 16 + (L' >> 2): four ds_bpermute_b32.
+                if (!(W4_ABL & 256)) {
+                    const int src = ((lane & 3) * 16 + (lane >> 2)) * 4;
+                    float4 ov;
+                    ov.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[0])));
+                    ov.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[1])));
+                    ov.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[2])));
+                    ov.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[3])));
+                    const int t2 = lane >> 2;
+                    const int oy2 = ty * TH + 4 * (t2 >> 3) + 2 * ph + io, ox2 = tx * TW + 4 * (t2 & 7) + j;
+                    if (oy2 < H && ox2 < W)
+                        *reinterpret_cast<float4 *>(e_out + img + (unsigned)((oy2 * W + ox2) * 64 + cog * 16 + (lane & 3) * 4)) = ov;
                 }
             }
             if ((ADD || BN) && io == 0) {

@@ -56,13 +56,11 @@ typedef struct cova_bn_tail {
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 /* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
- * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = Winograd tile geometry (1 | 2) */
+ * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2) */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
 int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[154,64]*/, void *stream);
-int cova_conv3x3_prep_weights(const float *w_oihw /*[64,64,3,3]*/, float *w_fwd /*[9,64,64]*/,
-                              float *w_dgrad /*[9,64,64]*/, void *stream);
 
 /* nn.Conv2d(3,64,7,stride 2,pad 3,bias=False): img NCHW -> out NHWC [B,H1,W1,64].
  * stat_part (nullable) [cova_conv1_num_tiles][2][64]: per-tile channel sum / sum of squares of
@@ -86,21 +84,14 @@ int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const float *dp,
                              const float *abc, float *dw, float *ws, int B, int H, int W,
                              void *stream);
 
-/* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC; with w_dgrad it is the data gradient.
- * addend (nullable, NHWC) is added to the result (residual-branch gradient). */
-int cova_conv3x3_num_tiles(int B, int H, int W);
-int cova_conv3x3_fwd(const float *in, const float *w_t, const float *addend, float *out,
-                     float *stat_part, int B, int H, int W, void *stream);
-/* data gradient fused with the ReLU mask + BatchNorm-backward reduction of the layer in front of
- * the conv: out = dy = (conv(dz,w_dgrad) + addend) * (act > 0); stat_part[tile][2][64] =
- * (sum dy, sum dy*xhat).  Follow with cova_bn_finalize_bwd + cova_bn_bwd_apply(dout=dy, act=NULL). */
-int cova_conv3x3_dgrad_bnbwd(const float *dz, const float *w_dgrad, const float *addend,
-                             const float *act, const float *z, const float *mean, const float *invstd,
-                             float *dy, float *stat_part, int B, int H, int W, void *stream);
-/* Winograd F(2x2,3x3) form of the same convolution (2.25x fewer MFMAs, same fp32 error): weights
- * are transformed once per step into u_fwd / u_dgrad [16,16,4,64]; cova_conv3x3_wino has the
- * semantics of cova_conv3x3_fwd (act = z = mean = invstd = NULL) or cova_conv3x3_dgrad_bnbwd,
- * except that stat_part has one row per persistent block: [cova_conv3x3_wino_num_partials][2][64]. */
+/* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC [B,H,W,64] (torchvision BasicBlock / Bottleneck conv2; models.py:49-51), as
+ * Winograd convolutions in exact f32 arithmetic (the direct implicit-GEMM kernels of round 1 live in tools/csrc).
+ * F(2x2,3x3) form (2.25x fewer MFMAs than direct, same fp32 error): weights are transformed once per step into
+ * u_fwd / u_dgrad [16,16,4,64]; with u_dgrad it is the data gradient; addend (nullable, NHWC) is added to the result
+ * (residual-branch gradient).  With act / z / mean / invstd the data gradient is fused with the ReLU mask and the
+ * BatchNorm-backward reduction of the layer in front of the conv: out = dy = (conv + addend) * (act > 0), stat_part =
+ * (sum dy, sum dy*xhat); otherwise stat_part (nullable) = (sum y, sum y^2).  stat_part has one row per persistent
+ * block: [cova_conv3x3_wino_num_partials][2][64]. */
 /* rows of the statistics partials of cova_conv3x3_wino(_pro): one per persistent block (depends on the
  * device's CU count and on cova_set_option 2 / 6: query it right before allocating) */
 int cova_conv3x3_wino_num_partials(int B, int H, int W);
@@ -126,14 +117,12 @@ int cova_conv3x3_wino_pro(const float *in, const float *in2 /*nullable*/,
                           const float *invstd /*nullable*/, float *out, float *stat_part /*nullable*/,
                           int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
-                            int H, int W, void *stream);   /* Winograd form of cova_conv3x3_wgrad */
+                            int H, int W, void *stream);   /* weight gradient, Winograd F(2x2,3x3) form */
 int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc /*nullable*/, int act_relu,
                                 const float *dz, const float *dz2 /*nullable*/,
                                 const float *dz_abc /*nullable*/, float *dw, float *ws, int B, int H,
                                 int W, void *stream);
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
-int cova_conv3x3_wgrad(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
-                       int H, int W, void *stream);
 
 /* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
  * the output scale): u_fwd / u_dgrad 147,456 floats each (the per-wave register image written by the prep kernel);

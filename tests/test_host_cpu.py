@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     # pure host queries work without a GPU
     assert _lib.query("cova_conv_out_size", 1280, 7, 2, 3) == 640
     assert _lib.query("cova_conv_out_size", 640, 3, 2, 1) == 320
-    assert _lib.query("cova_conv3x3_num_tiles", 16, 320, 320) == 16 * 40 * 10
+    assert _lib.query("cova_conv3x3_wino4_num_tiles", 16, 320, 320) == 16 * 40 * 10
 
 
 def test_header_has_no_torch_types():

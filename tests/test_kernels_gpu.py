@@ -53,37 +53,6 @@ def test_sgemm(ta, tb, M, N, K):
     close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 8, 32), (2, 19, 45), (1, 40, 70)])
-def test_conv3x3_fwd_dgrad_wgrad(B, H, W):
-    g = torch.Generator().manual_seed(H * W)
-    x = torch.randn(B, 64, H, W, generator=g)
-    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
-    add = torch.randn(B, 64, H, W, generator=g)
-    wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
-    call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
-    xg = nhwc(x)
-    nt = query("cova_conv3x3_num_tiles", B, H, W)
-    out, part = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
-    call("cova_conv3x3_fwd", xg, wf, None, out, part, B, H, W)
-    ref = F.conv2d(x, w, padding=1)
-    close(nchw(out), ref, 1e-4, "conv3x3 fwd")
-    close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "conv3x3 stat sum")
-    close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv3x3 stat sumsq")
-    # data gradient + addend
-    dz = torch.randn(B, 64, H, W, generator=g)
-    xr = x.clone().requires_grad_(True)
-    wr = w.clone().requires_grad_(True)
-    (F.conv2d(xr, wr, padding=1) * dz).sum().backward()
-    dx = torch.empty(B, H, W, 64, device=DEV)
-    call("cova_conv3x3_fwd", nhwc(dz), wd, nhwc(add), dx, None, B, H, W)
-    close(nchw(dx), xr.grad + add, 1e-4, "conv3x3 dgrad")
-    # weight gradient
-    ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
-    dw = torch.empty(64, 64, 3, 3, device=DEV)
-    call("cova_conv3x3_wgrad", xg, nhwc(dz), dw, ws, B, H, W)
-    close(dw, wr.grad, 2e-4, "conv3x3 wgrad")
-
-
 @pytest.mark.parametrize("B,H,W", [(1, 16, 64), (2, 37, 50), (1, 64, 64)])
 def test_conv1_fwd_wgrad(B, H, W):
     g = torch.Generator().manual_seed(H + W)
@@ -335,46 +304,6 @@ def test_adam_matches_torch():
         close(p, ref_p[0], 1e-6, "adam step %d" % step)
 
 
-def test_conv3x3_persistent_multi_tile():
-    """More tiles than persistent blocks: exercises the cross-tile prefetch of the v2 kernel
-    (and, with a capped grid, many tiles per block) against torch-CPU."""
-    B, H, W = 3, 100, 200                      # 13 x 7 x 3 = 273 tiles > 256 CUs
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(B, 64, H, W, generator=g)
-    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
-    wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
-    call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
-    xg = nhwc(x)
-    ref = F.conv2d(x, w, padding=1)
-    nt = query("cova_conv3x3_num_tiles", B, H, W)
-    outs = []
-    for cap in (0, 7, 3):
-        query("cova_set_option", 2, cap)
-        out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
-        call("cova_conv3x3_fwd", xg, wf, None, out, part, B, H, W)
-        close(nchw(out), ref, 1e-4, "conv3x3 cap %d" % cap)
-        close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "stat sum")
-        outs.append((out, part))
-    query("cova_set_option", 2, 0)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])   # same summation order
-
-
-def test_conv3x3_wgrad_variants_multi_tile():
-    B, H, W = 3, 100, 200
-    g = torch.Generator().manual_seed(6)
-    x = torch.randn(B, 64, H, W, generator=g)
-    dz = torch.randn(B, 64, H, W, generator=g)
-    wr = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).requires_grad_(True)
-    (F.conv2d(x, wr, padding=1) * dz).sum().backward()
-    ws = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=DEV)
-    for cap in (0, 5):
-        query("cova_set_option", 2, cap)
-        dw = torch.zeros(64, 64, 3, 3, device=DEV)
-        call("cova_conv3x3_wgrad", nhwc(x), nhwc(dz), dw, ws, B, H, W)
-        close(dw, wr.grad, 2e-4, "conv3x3 wgrad cap %d" % cap)
-    query("cova_set_option", 2, 0)
-
-
 def test_conv1_variants_multi_tile():
     B, H, W = 2, 150, 330                     # 10 x 6 x 2 = 120 tiles; capped grid -> many per block
     g = torch.Generator().manual_seed(8)
@@ -402,8 +331,8 @@ def test_conv1_variants_multi_tile():
 
 
 def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
-    """Fused dgrad epilogue (ReLU mask + BN-backward sums) == plain dgrad followed by
-    cova_bn_bwd_reduce, on a multi-tile problem."""
+    """Fused data-gradient epilogue (ReLU mask + BatchNorm-backward sums) == plain data gradient followed by
+    cova_bn_bwd_reduce, on a multi-tile problem, for both Winograd kernel families."""
     B, H, W = 2, 37, 70
     g = torch.Generator().manual_seed(11)
     dz = nhwc(torch.randn(B, 64, H, W, generator=g))
@@ -413,26 +342,36 @@ def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     mean = (torch.randn(64, generator=g) * 0.2).to(DEV)
     invstd = (torch.rand(64, generator=g) + 0.5).to(DEV)
     w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
-    wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
-    call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
+    u2f, u2d = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
+    call("cova_conv3x3_prep_weights_wino", w.to(DEV), u2f, u2d)
+    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
     R = B * H * W
-    plain = torch.empty(B, H, W, 64, device=DEV)
-    call("cova_conv3x3_fwd", dz, wd, add, plain, None, B, H, W)
     n = query("cova_colreduce_num_chunks", R, 64)
-    part_ref = torch.empty(n, 2, 64, device=DEV)
-    call("cova_bn_bwd_reduce", plain, 64, act, 64, z, 64, mean, invstd, R, 64, part_ref)
-    nt = query("cova_conv3x3_num_tiles", B, H, W)
-    dy, part = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
-    call("cova_conv3x3_dgrad_bnbwd", dz, wd, add, act, z, mean, invstd, dy, part, B, H, W)
-    assert torch.equal(dy, plain * (act > 0))
-    close(part.sum(0), part_ref.sum(0), 1e-5, "fused bn-bwd sums")
+    for fam in ("w2", "w4"):
+        plain = torch.empty(B, H, W, 64, device=DEV)
+        if fam == "w2":
+            nt = query("cova_conv3x3_wino_num_partials", B, H, W)
+            call("cova_conv3x3_wino", dz, u2d, add, None, None, None, None, plain, None, B, H, W)
+        else:
+            nt = query("cova_conv3x3_wino4_num_partials", B, H, W)
+            call("cova_conv3x3_wino4_full", dz, None, None, 0, u4d, add, None, None, None, None, None, None, plain, None, B, H, W)
+        part_ref = torch.empty(n, 2, 64, device=DEV)
+        call("cova_bn_bwd_reduce", plain, 64, act, 64, z, 64, mean, invstd, R, 64, part_ref)
+        dy, part = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
+        if fam == "w2":
+            call("cova_conv3x3_wino", dz, u2d, add, act, z, mean, invstd, dy, part, B, H, W)
+        else:
+            call("cova_conv3x3_wino4_full", dz, None, None, 0, u4d, add, act, None, None, z, mean, invstd, dy, part, B, H, W)
+        assert torch.equal(dy, plain * (act > 0)), fam
+        close(part.sum(0), part_ref.sum(0), 1e-5, "fused bn-bwd sums " + fam)
 
 
 @pytest.mark.parametrize("geo", [1, 2])
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
-def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap, geo):
+def test_conv3x3_winograd_matches_cpu(B, H, W, cap, geo):
     """Winograd F(2x2,3x3) kernel: forward (+statistics), data gradient (+addend) and the fused
-    ReLU-mask / BN-backward epilogue against torch-CPU and the direct kernel."""
+    ReLU-mask / BN-backward epilogue against torch-CPU."""
     g = torch.Generator().manual_seed(H * W + B)
     x = torch.randn(B, 64, H, W, generator=g)
     w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
@@ -443,7 +382,6 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap, geo):
     query("cova_set_option", 2, cap)
     query("cova_set_option", 6, geo)          # 8x32 tiles / 1 block per CU | 8x16 tiles / 2 blocks per CU
     try:
-        nt = query("cova_conv3x3_num_tiles", B, H, W)
         ntw = query("cova_conv3x3_wino_num_partials", B, H, W)
         out, part = torch.zeros(B, H, W, 64, device=DEV), torch.zeros(ntw, 2, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(x), uf, None, None, None, None, None, out, part, B, H, W)
@@ -456,18 +394,19 @@ def test_conv3x3_winograd_matches_direct_and_cpu(B, H, W, cap, geo):
         dx = torch.zeros(B, H, W, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(dz), ud, nhwc(add), None, None, None, None, dx, None, B, H, W)
         close(nchw(dx), xr.grad + add, 1e-4, "winograd dgrad")
-        # fused epilogue == direct kernel's fused epilogue
-        act = nhwc(torch.relu(torch.randn(B, 64, H, W, generator=g)))
-        z = nhwc(torch.randn(B, 64, H, W, generator=g))
-        mean, invstd = torch.randn(64, generator=g).to(DEV) * 0.2, (torch.rand(64, generator=g) + 0.5).to(DEV)
-        wf, wd = torch.empty(9, 64, 64, device=DEV), torch.empty(9, 64, 64, device=DEV)
-        call("cova_conv3x3_prep_weights", w.to(DEV), wf, wd)
-        dy_d, part_d = torch.empty(B, H, W, 64, device=DEV), torch.empty(nt, 2, 64, device=DEV)
-        call("cova_conv3x3_dgrad_bnbwd", nhwc(dz), wd, nhwc(add), act, z, mean, invstd, dy_d, part_d, B, H, W)
+        # fused epilogue: dy = (dgrad + addend) * (act > 0), sums (sum dy, sum dy*xhat) -- against torch
+        actc = torch.relu(torch.randn(B, 64, H, W, generator=g))
+        zc = torch.randn(B, 64, H, W, generator=g)
+        act, z = nhwc(actc), nhwc(zc)
+        meanc, invstdc = torch.randn(64, generator=g) * 0.2, torch.rand(64, generator=g) + 0.5
+        mean, invstd = meanc.to(DEV), invstdc.to(DEV)
+        dy_ref = (xr.grad + add) * (actc > 0)
+        xhat = (zc - meanc.view(1, -1, 1, 1)) * invstdc.view(1, -1, 1, 1)
         dy_w, part_w = torch.empty(B, H, W, 64, device=DEV), torch.empty(ntw, 2, 64, device=DEV)
         call("cova_conv3x3_wino", nhwc(dz), ud, nhwc(add), act, z, mean, invstd, dy_w, part_w, B, H, W)
-        close(dy_w, dy_d, 1e-5, "winograd fused dy")
-        close(part_w.sum(0), part_d.sum(0), 1e-4, "winograd fused sums")
+        close(nchw(dy_w), dy_ref, 1e-4, "winograd fused dy")
+        close(part_w[:, 0].sum(0), dy_ref.sum((0, 2, 3)), 1e-4, "winograd fused sum dy")
+        close(part_w[:, 1].sum(0), (dy_ref * xhat).sum((0, 2, 3)), 1e-4, "winograd fused sum dy*xhat")
     finally:
         query("cova_set_option", 2, 0)
         query("cova_set_option", 6, 1)

@@ -6,6 +6,8 @@ import cova_amd  # noqa
 from cova_web_object_detection_amd import _lib
 import probe_lib  # noqa: E402  (tools/probe_lib.py: builds + registers libcova_probe.so)
 probe_lib.load()
+import direct_lib  # noqa: E402  (tools/direct_lib.py: the direct-form 3x3 kernels, out of the product library since round 3)
+direct_lib.load()
 call, query = _lib.call, _lib.query
 dev = "cuda:0"
 B, H, W = int(os.environ.get("B", 16)), 320, 320

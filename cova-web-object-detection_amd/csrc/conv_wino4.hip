@@ -151,20 +151,29 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         asm volatile("" : "+s"(kp));
         return (KArgs)kp;
     };
-    constexpr int NSLOT = 3;
-    constexpr int IN_FLOATS = NSLOT * SLOT_FLOATS;
+    // Granularity of the plane copies.  G16: a copy brings 16 channels = 64 contiguous bytes of every pixel (four adjacent
+    // lanes per pixel, one copy per TWO chunks, two slots); otherwise 8-channel chunks as 2 x 16 bytes per pixel (three slots).
+    // 16 bytes out of a 256-byte pixel per lane make every wave instruction touch 64 different cache lines for 1 KB of data:
+    // measured 0.049 of the plain launch's 0.47 ms against contiguous reads.  (The two-tensor prologue keeps the small
+    // granularity: four 21.8 KB slots do not fit beside the other buffers.)
+    constexpr bool G16 = PRO != 2;
+    constexpr int NSLOT = G16 ? 2 : 3;
+    constexpr int SLOTF = G16 ? NPIX * 16 : SLOT_FLOATS;
+    constexpr int TCI = G16 ? 16 * 36 + 4 : TMP_CI;        // G16 item order: channels of an instruction start 4 banks apart
+    constexpr int TMPF = 8 * TCI;
+    constexpr int IN_FLOATS = NSLOT * SLOTF;
     // tmp[0] and V[1] are adjacent: both are idle at a tile boundary and carry the pair exchange of the output transform
-    __shared__ __attribute__((aligned(16))) float lds[(PRO == 2 ? 2 : 1) * IN_FLOATS + 2 * TMP_FLOATS + 2 * V_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[(PRO == 2 ? 2 : 1) * IN_FLOATS + 2 * TMPF + 2 * V_FLOATS];
     __shared__ float s_pro[PRO ? 192 : 1];        // A | B | C of the affine-on-load prologue
     __shared__ __attribute__((aligned(16))) float s_epi[BN ? 256 : 4];   // mean | invstd | mask scale | mask shift of the epilogue
     __shared__ __attribute__((aligned(16))) float s_red[STATS ? 8 * 32 : 4];   // per wave: 16 channels x (sum | second kind), running totals
     float *s_in = lds;
     float *s_in2 = lds + IN_FLOATS;               // (PRO == 2)
     float *s_tmp1 = lds + (PRO == 2 ? 2 : 1) * IN_FLOATS;
-    float *s_tmp0 = s_tmp1 + TMP_FLOATS;
-    float *s_v1 = s_tmp0 + TMP_FLOATS;
+    float *s_tmp0 = s_tmp1 + TMPF;
+    float *s_v1 = s_tmp0 + TMPF;
     float *s_v0 = s_v1 + V_FLOATS;
-    float *s_x = s_tmp0;                          // exchange area: TMP_FLOATS + V_FLOATS = 41 KB >= 32 KB
+    float *s_x = s_tmp0;                          // exchange area: tmp[0] + V[1] = 41 KB >= 32 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cog = wave & 3, ph = wave >> 2;
@@ -216,6 +225,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const unsigned sb = (unsigned)slot * (SLOT_FLOATS * 4);
         // (the zero page holds 64 floats: the per-chunk offset 8 s + 4 <= 60 stays inside it)
         const float *zA = g_w4_zero_page + 4 * kgA + 8 * s, *zB = g_w4_zero_page + 4 + 8 * s;
+        if (W4_ABL & 4096) {      // (timing experiment: same bytes, but every wave instruction reads 1 KB of contiguous memory
+                                  //  instead of 16 bytes out of 64 different 256-byte pixels; wrong data)
+            const float *fake = tbase + (size_t)(W + 1) * 64 + (size_t)s * 340 * 4 + lane * 4;
+            if (pxA < NPIX) copy16_to_lds(fake + (kgA * 6 + pgA) * 256, in_base + sb + dstA);
+            if (wave < 4 && pxB < NPIX) copy16_to_lds(fake + (6 + pgB) * 256, in_base + sb + dstB);
+            return;
+        }
         if (pxA < NPIX) copy16_to_lds(inA ? tbase + relA + 8 * s : zA, in_base + sb + dstA);
         if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase + relB + 8 * s : zB, in_base + sb + dstB);
         if (PRO == 2) {
@@ -223,11 +239,52 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase2 + relB + 8 * s : zB, in2_base + sb + dstB);
         }
     };
+    // G16: instruction j covers pixels 16 j .. 16 j + 15 (lane = pixel * 4 + 16-byte piece): 22 instructions per 16-channel
+    // group, wave w issues j = w, w + 8, w + 16 (j < 22)
+    int rel16[3] = {0, 0, 0};
+    bool in16[3] = {false, false, false};
+    const int q16 = lane & 3;
+    auto px16 = [&](int i) { return 16 * (wave + 8 * i) + (lane >> 2); };
+    if (G16) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int px = px16(i), r = px / PW, c = px - r * PW;
+            rel16[i] = (r * W + c) * 64 + 4 * q16;
+        }
+    }
+    auto plane_src16 = [&](int k) {
+        const int tile_ = tile_of(k);
+        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
+        const long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
+        tbase = a.in + org;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int px = px16(i), r = px / PW, c = px - r * PW;
+            const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
+            in16[i] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        }
+    };
+    auto copy_group16 = [&](int gi, int slot) {      // 16-channel group gi (0..3) of the tile plane_src16() was called for
+        if (W4_ABL & 8) return;
+        const unsigned sb = in_base + (unsigned)slot * (SLOTF * 4);
+        const float *z = g_w4_zero_page + 4 * q16 + 16 * gi;       // (the zero page holds 64 floats)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 8 * i;
+            if (j < 22 && px16(i) < NPIX) copy16_to_lds(in16[i] ? tbase + rel16[i] + 16 * gi : z, sb + j * 1024);
+        }
+    };
     // Plane copies issued per iteration: P = 2 on waves 0-3, 1 on waves 4-7 (twice that with a second tensor).  At the end
     // of iteration g the copy of planes(g+3), issued at the top of iteration g-1, must have landed: behind it in the queue
     // are the 9 weight loads of iteration g-1, the copies of iteration g and the 9 weight loads of iteration g.
-    auto wait_planes = [&]() {
+    // (G16: copies are issued at even iterations only; the group issued at the top of iteration g-1 must have landed at the
+    //  end of the odd iteration g: behind it are the 9 + 9 weight loads of the two iterations)
+    auto wait_planes = [&](int g) {
         if (W4_ABL & 64) return;
+        if (G16) {
+            if (g & 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (18 & 15) | ((18 >> 4) << 14));
+            return;
+        }
         constexpr int M = PRO == 2 ? 2 : 1;
         if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + 2 * M) & 15) | (((18 + 2 * M) >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + M) & 15) | (((18 + M) >> 4) << 14));
@@ -241,17 +298,23 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     int col_src[2], col_dst[2], col_ch[2], row_src[2], row_dst[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        {
+        if (G16) {      // it = ((tile*6 + c)*2 + kg)*4 + cl: 32 lanes spread over 16 banks of the [px][16] planes
+            const int it = tid + e * THREADS;
+            const int cl = it & 3, kg = (it >> 2) & 1, tc = it >> 3, t = tc / 6, c = tc - t * 6;
+            col_src[e] = ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 16 + kg * 4 + cl;              // + r * PW * 16 + 8 (chunk & 1)
+            col_dst[e] = (kg * 4 + cl) * TCI + t * 36 + c * 6;                                    // + i (6 contiguous)
+            col_ch[e] = kg * 4 + cl;
+        } else {
             const int it = tid + e * THREADS;
             const int cl = it & 3, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15, kg = tt >> 4;
             col_src[e] = kg * SUB_FLOATS + ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + cl;      // + r * PW * 4
-            col_dst[e] = (kg * 4 + cl) * TMP_CI + t * 36 + c * 6;                                 // + i (6 contiguous)
+            col_dst[e] = (kg * 4 + cl) * TCI + t * 36 + c * 6;                                    // + i (6 contiguous)
             col_ch[e] = kg * 4 + cl;
         }
         {
             const int it = tid + e * 256;
             const int i = it % 6, rt = it / 6, t = rt & 15, ci = rt >> 4;
-            row_src[e] = ci * TMP_CI + t * 36 + i;                                                // + c * 6
+            row_src[e] = ci * TCI + t * 36 + i;                                                   // + c * 6
             row_dst[e] = (ci * 16 + t) * VROW + (i < 3 ? 6 * i : 20 + 6 * ((i - 2) % 3));         // + j (6 contiguous); second half in the order i = 5, 3, 4
         }
     }
@@ -263,7 +326,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             // image column / first row of column item e (recomputed from the thread index: once per tile)
-            const int it = tid + e * THREADS, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15;
+            const int it = tid + e * THREADS;
+            const int tc = G16 ? it >> 3 : it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15;
             const int gx = tx_ * TW + 4 * (t & 7) + c - 1, gy = ty_ * TH + 4 * (t >> 3) - 1;
             unsigned m = 0;
 #pragma unroll
@@ -274,14 +338,16 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // One stage item in flight: its six inputs (plus the six of the second tensor), where the result goes, and whether
     // the affine prologue applies (column items).  Reads and transform are separate steps so that MFMAs sit between them.
     struct Item { float d[6], w[6]; float *q; };
-    auto read_col = [&](int e, int slot, float *tmp_w, Item &it) {
-        const float *p = s_in + slot * SLOT_FLOATS + col_src[e];
+    // (slot, coff): where the chunk's planes are -- G16: slot of its 16-channel group, coff = 8 * (chunk & 1)
+    auto read_col = [&](int e, int slot, int coff, float *tmp_w, Item &it) {
+        constexpr int RS = G16 ? PW * 16 : PW * 4;
+        const float *p = s_in + slot * SLOTF + coff + col_src[e];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) it.d[r] = p[r * PW * 4];
+        for (int r = 0; r < 6; ++r) it.d[r] = p[r * RS];
         if (PRO == 2) {
-            const float *p2 = s_in2 + slot * SLOT_FLOATS + col_src[e];
+            const float *p2 = s_in2 + slot * SLOTF + coff + col_src[e];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) it.w[r] = p2[r * PW * 4];
+            for (int r = 0; r < 6; ++r) it.w[r] = p2[r * RS];
         }
         it.q = tmp_w + col_dst[e];
     };
@@ -314,12 +380,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // the three items of an iteration: k = 0 column item 0 | k = 1 column item 1 (waves 0-3) or row item 0 (waves 4-7) |
     // k = 2 row item 0 (waves 0-3) or row item 1.  `lo` is wave-uniform: scalar branches (the empty asm keeps the
     // compiler from turning the arms into per-lane address selects)
-    auto item_read = [&](const int k, Item &it, int slot, float *tmp_w, const float *tmp_r, float *v_w) {
+    auto item_read = [&](const int k, Item &it, int slot, int coff, float *tmp_w, const float *tmp_r, float *v_w) {
         if (W4_ABL & 3) return;
         if (k == 0) {
-            read_col(0, slot, tmp_w, it);
+            read_col(0, slot, coff, tmp_w, it);
         } else if (k == 1) {
-            if (lo) { asm volatile(""); read_col(1, slot, tmp_w, it); }
+            if (lo) { asm volatile(""); read_col(1, slot, coff, tmp_w, it); }
             else { asm volatile(""); read_row(0, tmp_r, v_w, it); }
         } else {
             if (lo) { asm volatile(""); read_row(0, tmp_r, v_w, it); }
@@ -353,11 +419,17 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         }
     };
 
-    // ---- prime the pipeline: planes(0..2) copied, weights(0), weights(1) requested
-    plane_src(0);
-    copy_planes(0, 0);
-    copy_planes(1, 1);
-    copy_planes(2, 2);
+    // ---- prime the pipeline: the planes of chunks 0..2 (G16: groups 0 and 1) copied, the first weights requested
+    if (G16) {
+        plane_src16(0);
+        copy_group16(0, 0);
+        copy_group16(1, 1);
+    } else {
+        plane_src(0);
+        copy_planes(0, 0);
+        copy_planes(1, 1);
+        copy_planes(2, 2);
+    }
     load_quads(Ea, 0, 0, 5, 0);
     if (W4_LEAD2) load_quads(Eb, 1, 0, 5, 0);
     load_quads(L, 0, 5, 9, 20);
@@ -368,11 +440,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         Item it;
         for (int c = 0; c < 2; ++c) {
             float *tw = c ? s_tmp1 : s_tmp0;
-            read_col(0, c, tw, it);
+            const int sl = G16 ? 0 : c, coff = G16 ? 8 * c : 0;
+            read_col(0, sl, coff, tw, it);
             if (PRO) pro_apply(0, c, it);
             transform_store(it);
             if (lo) {
-                read_col(1, c, tw, it);
+                read_col(1, sl, coff, tw, it);
                 if (PRO) pro_apply(1, c, it);
                 transform_store(it);
             }
@@ -382,7 +455,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         transform_store(it);
         if (!lo) { read_row(1, s_tmp0, s_v0, it); transform_store(it); }
     }
-    copy_planes(3, 0);                      // slot 0 has been consumed (barrier above)
+    if (!G16) copy_planes(3, 0);            // slot 0 has been consumed (barrier above)
     __builtin_amdgcn_s_waitcnt(0);          // (one-time: the steady-state wait counts assume two iterations of history)
     __syncthreads();
 
@@ -400,10 +473,23 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const float *tmp_r = PAR ? s_tmp0 : s_tmp1;         // row stage (chunk g+1) reads tmp[(g+1) & 1]
         float *v_w = PAR ? s_v0 : s_v1;                     //   and writes V[(g+1) & 1]
         const float *v_r = (PAR ? s_v1 : s_v0) + v_off;     // MFMAs of chunk g read V[g & 1]
-        const int slot1 = slot == NSLOT - 1 ? 0 : slot + 1, slot2 = slot1 == NSLOT - 1 ? 0 : slot1 + 1;
-        // planes(g+4) -> the slot of planes(g+1), consumed by the previous iteration's column stage
-        if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
-        copy_planes((g + 4) & 7, slot1);
+        int slot2, coff2;                   // where the planes of chunk g + 2 (this iteration's column stage) are
+        if (G16) {
+            // group (g+4) >> 1 (chunks g+4, g+5) -> the slot of group (g >> 1), consumed by the last two column stages
+            if (!(g & 1)) {
+                if (((g + 4) & 7) == 0) plane_src16((g + 4) >> 3);
+                copy_group16(((g + 4) & 7) >> 1, (g >> 1) & 1);
+            }
+            slot2 = ((g + 2) >> 1) & 1;
+            coff2 = 8 * (g & 1);
+        } else {
+            const int slot1 = slot == NSLOT - 1 ? 0 : slot + 1;
+            slot2 = slot1 == NSLOT - 1 ? 0 : slot1 + 1;
+            coff2 = 0;
+            // planes(g+4) -> the slot of planes(g+1), consumed by the previous iteration's column stage
+            if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
+            copy_planes((g + 4) & 7, slot1);
+        }
         if (PRO && ((g + 2) & 7) == 0) row_masks((g + 2) >> 3);
         const int s2 = (g + 2) & 7;
         // wave-uniform weight bases in scalar registers (global_load with an SGPR base + this lane's offset): chunk g + 2
@@ -455,15 +541,15 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         read_v(0);
         W4_SB();
         mfma_range(0, 4);
-        item_read(0, it, slot2, tmp_w, tmp_r, v_w);
+        item_read(0, it, slot2, coff2, tmp_w, tmp_r, v_w);
         W4_SB();
         mfma_range(4, 8);
         item_finish(0, it, s2);
-        item_read(1, it, slot2, tmp_w, tmp_r, v_w);
+        item_read(1, it, slot2, coff2, tmp_w, tmp_r, v_w);
         W4_SB();
         mfma_range(8, 12);
         item_finish(1, it, s2);
-        item_read(2, it, slot2, tmp_w, tmp_r, v_w);
+        item_read(2, it, slot2, coff2, tmp_w, tmp_r, v_w);
         W4_SB();
         mfma_range(12, 16);
         read_v(1);
@@ -473,9 +559,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         mfma_range(16, 36);
         } else {                                    // all three items' reads up front
         Item it0, it1, it2;
-        item_read(0, it0, slot2, tmp_w, tmp_r, v_w);
-        item_read(1, it1, slot2, tmp_w, tmp_r, v_w);
-        item_read(2, it2, slot2, tmp_w, tmp_r, v_w);
+        item_read(0, it0, slot2, coff2, tmp_w, tmp_r, v_w);
+        item_read(1, it1, slot2, coff2, tmp_w, tmp_r, v_w);
+        item_read(2, it2, slot2, coff2, tmp_w, tmp_r, v_w);
         read_v(0);
         W4_SB();
         mfma_range(0, 16);
@@ -487,7 +573,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         W4_SB();
         mfma_range(18, 36);
         }
-        wait_planes();
+        wait_planes(g);
         lds_barrier();
     };
 

@@ -54,12 +54,12 @@ __device__ __forceinline__ void bn_tail_store(float *p, float v)
 }
 
 // Call at the very end of the kernel, by ALL threads of every block, after this block's partial row(s) have been
-// written with bn_tail_store (`partial` = [nparts][2][64]).  `s_dbl` = at least 2048 doubles of shared memory that is
-// free by now.  blockDim.x must be a multiple of 64.
+// written with bn_tail_store (`partial` = [nparts][2][64]).  `s_dbl` = at least 2049 doubles of shared memory that is
+// free by now (2 x 1024 partial sums + the block's ticket flag).  blockDim.x must be a multiple of 64.
 __device__ __forceinline__ void bn_tail_run(const BnTail &t, float *partial, int nparts, double *s_dbl)
 {
     if (t.mode == 0) return;
-    __shared__ int s_last;
+    int &s_last = *reinterpret_cast<int *>(s_dbl + 2048);
     __builtin_amdgcn_s_waitcnt(0);        // this thread's row stores have been acknowledged at device scope ...
     __syncthreads();                      // ... all of the block's have ...
     if (threadIdx.x == 0)                 // ... before its ticket is taken

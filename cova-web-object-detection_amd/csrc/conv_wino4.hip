@@ -54,13 +54,14 @@ namespace {
 namespace w4 {
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;      // 340 halo pixels
 constexpr int THREADS = 512;
-constexpr int SUB_FLOATS = NPIX * 4;           // one 4-channel group of a chunk, pixel-major [px][4]
-constexpr int SLOT_FLOATS = 2 * SUB_FLOATS;    // planes of one 8-channel chunk: 10,880 B
-constexpr int TMP_CI = 16 * 36 + 8;            // column-stage result [ci][tile][c][i]; +8: the channels of an
-constexpr int TMP_FLOATS = 8 * TMP_CI;         // instruction start 8 banks apart; 18,688 B
-constexpr int VROW = 44;                       // V row (ci, tile): [i 0,1,2: 18 floats, 2 pad | i 5,3,4: 18 floats, 6 pad];
-                                               // 11 x 16 B is an odd slot stride: conflict-free ds_read_b128
-constexpr int V_FLOATS = 8 * 16 * VROW;        // 22,528 B
+constexpr int SLOT_FLOATS = NPIX * 16;         // planes of one 16-channel group (two chunks), pixel-major [px][16]: 21,760 B
+constexpr int TMP_CI = 16 * 36 + 4;            // column-stage result [ci][tile][c][i]; +4: the channels of an
+constexpr int TMP_FLOATS = 8 * TMP_CI;         // instruction start 4 banks apart; 18,560 B
+constexpr int VROW = 36;                       // V row (ci, tile): [positions 0-15 of half 0 | 0-15 of half 1 | 16-17 of half 0 |
+                                               // 16-17 of half 1] (half 0 = transform rows i 0,1,2; half 1 = i 5,3,4): both
+                                               // halves read 4 x b128 + 1 x b64 at 16-byte-aligned offsets; 9 x 16 B is an odd
+                                               // slot stride: conflict-free ds_read_b128
+constexpr int V_FLOATS = 8 * 16 * VROW;        // 18,432 B
 constexpr int U_FLOATS = 8 * 8 * 9 * 64 * 4;   // [chunk 8][wave 8][quad 9][lane 64][4]: 147,456 floats
 }  // namespace w4
 
@@ -118,9 +119,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 // the compiler then neither knows the copy (no conservative vmcnt(0) in front of every later LDS read, which the
 // builtin gets unless each buffer is its own __shared__ object) nor waits for it -- every wait on these copies is
 // an explicit s_waitcnt in the kernel.
-__device__ __forceinline__ void copy16_to_lds(const float *gptr, unsigned lds_base_bytes)
+// Address = wave-uniform base (scalar register pair) + this lane's unsigned 32-bit byte offset: no 64-bit per-lane
+// pointers (which the compiler otherwise precomputes per pixel and keeps -- or spills -- across the whole loop).
+__device__ __forceinline__ void copy16_to_lds(const float *base, unsigned off_bytes, unsigned lds_base_bytes)
 {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base_bytes), "v"(gptr) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base_bytes), "v"(off_bytes), "s"(base) : "memory", "m0");
 }
 
 // Barrier that orders LDS accesses only: this wave's ds_writes are complete (lgkmcnt(0)) while global -> LDS copies
@@ -151,27 +154,23 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         asm volatile("" : "+s"(kp));
         return (KArgs)kp;
     };
-    // Granularity of the plane copies.  G16: a copy brings 16 channels = 64 contiguous bytes of every pixel (four adjacent
-    // lanes per pixel, one copy per TWO chunks, two slots); otherwise 8-channel chunks as 2 x 16 bytes per pixel (three slots).
-    // 16 bytes out of a 256-byte pixel per lane make every wave instruction touch 64 different cache lines for 1 KB of data:
-    // measured 0.049 of the plain launch's 0.47 ms against contiguous reads.  (The two-tensor prologue keeps the small
-    // granularity: four 21.8 KB slots do not fit beside the other buffers.)
-    constexpr bool G16 = PRO != 2;
-    constexpr int NSLOT = G16 ? 2 : 3;
-    constexpr int SLOTF = G16 ? NPIX * 16 : SLOT_FLOATS;
-    constexpr int TCI = G16 ? 16 * 36 + 4 : TMP_CI;        // G16 item order: channels of an instruction start 4 banks apart
-    constexpr int TMPF = 8 * TCI;
-    constexpr int IN_FLOATS = NSLOT * SLOTF;
+    // Plane copies bring 16 channels = 64 contiguous bytes of every pixel (four adjacent lanes per pixel), one copy per TWO
+    // chunks, two slots per tensor.  (Round 3's first version copied 8-channel chunks as 2 x 16 bytes per pixel: 16 bytes out
+    // of a 256-byte pixel per lane make every wave instruction touch 64 different cache lines for 1 KB of data -- measured
+    // 0.049 of the plain launch's 0.47 ms against contiguous reads.)
+    constexpr int NSLOT = 2;
+    constexpr int NT = PRO == 2 ? 2 : 1;          // tensors staged
+    constexpr int IN_FLOATS = NSLOT * SLOT_FLOATS;
     // tmp[0] and V[1] are adjacent: both are idle at a tile boundary and carry the pair exchange of the output transform
-    __shared__ __attribute__((aligned(16))) float lds[(PRO == 2 ? 2 : 1) * IN_FLOATS + 2 * TMPF + 2 * V_FLOATS];
-    __shared__ float s_pro[PRO ? 192 : 1];        // A | B | C of the affine-on-load prologue
+    __shared__ __attribute__((aligned(16))) float lds[NT * IN_FLOATS + 2 * TMP_FLOATS + 2 * V_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_epi[BN ? 256 : 4];   // mean | invstd | mask scale | mask shift of the epilogue
+    __shared__ float s_pro[PRO ? 192 : 1];        // A | B | C of the affine-on-load prologue
     __shared__ __attribute__((aligned(16))) float s_red[STATS ? 8 * 32 : 4];   // per wave: 16 channels x (sum | second kind), running totals
     float *s_in = lds;
     float *s_in2 = lds + IN_FLOATS;               // (PRO == 2)
-    float *s_tmp1 = lds + (PRO == 2 ? 2 : 1) * IN_FLOATS;
-    float *s_tmp0 = s_tmp1 + TMPF;
-    float *s_v1 = s_tmp0 + TMPF;
+    float *s_tmp1 = lds + NT * IN_FLOATS;
+    float *s_tmp0 = s_tmp1 + TMP_FLOATS;
+    float *s_v1 = s_tmp0 + TMP_FLOATS;
     float *s_v0 = s_v1 + V_FLOATS;
     float *s_x = s_tmp0;                          // exchange area: tmp[0] + V[1] = 41 KB >= 32 KB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -196,98 +195,62 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const int G = nk * 8;                                                          // chunks of this block
     auto tile_of = [&](int k) { return first + (k < nk ? k : nk - 1) * (int)gridDim.x; };   // past the end: a valid tile
 
-    // ---- plane copies.  A chunk = 2 groups of 4 channels x 340 pixels = 12 wave instructions of 64 pixels x 16 B:
-    // instruction j = (group j / 6, pixel block j % 6); wave w issues j = w and, for w < 4, j = w + 8.
-    const int jA = wave, jB = wave + 8;
-    const int kgA = jA / 6, pgA = jA - 6 * kgA, pgB = jB - 6;                      // (kgB = 1)
-    const int pxA = pgA * 64 + lane, pxB = pgB * 64 + lane;
+    // ---- plane copies.  A group = 16 channels x 340 pixels = 22 wave instructions of 16 pixels x 64 B: instruction j covers
+    // pixels 16 j .. 16 j + 15 (lane = pixel * 4 + 16-byte piece); wave w issues j = w, w + 8, w + 16 (j < 22).
+    // Source of this thread's pixels: (tile base: wave-uniform, scalar registers) + (the pixel's fixed byte offset from
+    // the tile's halo origin: one register per pixel) when the pixel lies inside the image, the zero page otherwise --
+    // two copy instructions under complementary lane masks (the second one is skipped by interior tiles).  The in-image
+    // flags are per tile (lane masks).
     const unsigned in_base = (unsigned)(size_t)(lds_void *)s_in, in2_base = (unsigned)(size_t)(lds_void *)s_in2;
-    const unsigned dstA = kgA * (SUB_FLOATS * 4) + pgA * 1024, dstB = SUB_FLOATS * 4 + pgB * 1024;
-    // Source of this thread's pixels: (tile base: wave-uniform, scalar registers) + (the pixel's fixed element offset from
-    // the tile's halo origin: one register per pixel) when the pixel lies inside the image, the zero page otherwise.  The
-    // in-image flags are per tile (lane masks); no 64-bit per-thread pointers stay live across the loop.
-    const int rA = pxA / PW, cA = pxA - rA * PW, rB = pxB / PW, cB = pxB - rB * PW;
-    const int relA = (rA * W + cA) * 64 + 4 * kgA, relB = (rB * W + cB) * 64 + 4;       // floats
     const float *tbase = a.in, *tbase2 = a.in;         // element (ty*TH - 1, tx*TW - 1, channel 0) of the current tile's image
-    bool inA = false, inB = false;
+    unsigned rel16[3] = {0, 0, 0};
+    bool in16[3] = {false, false, false};
+    const int q16 = lane & 3;
+    auto px16 = [&](int i) { return 16 * (wave + 8 * i) + (lane >> 2); };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int px = px16(i), r = px / PW, c = px - r * PW;
+        rel16[i] = (unsigned)((r * W + c) * 64 + 4 * q16) * 4u;
+    }
     auto plane_src = [&](int k) {
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
         const long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
         tbase = a.in + org;
         if (PRO == 2) tbase2 = a.in2 + org;
-        const int gyA = ty * TH + rA - 1, gxA = tx * TW + cA - 1, gyB = ty * TH + rB - 1, gxB = tx * TW + cB - 1;
-        inA = gyA >= 0 && gyA < H && gxA >= 0 && gxA < W;
-        inB = gyB >= 0 && gyB < H && gxB >= 0 && gxB < W;
-    };
-    auto copy_planes = [&](int s, int slot) {       // chunk s (0..7) of the tile plane_src() was called for
-        if (W4_ABL & 8) return;
-        const unsigned sb = (unsigned)slot * (SLOT_FLOATS * 4);
-        // (the zero page holds 64 floats: the per-chunk offset 8 s + 4 <= 60 stays inside it)
-        const float *zA = g_w4_zero_page + 4 * kgA + 8 * s, *zB = g_w4_zero_page + 4 + 8 * s;
-        if (W4_ABL & 4096) {      // (timing experiment: same bytes, but every wave instruction reads 1 KB of contiguous memory
-                                  //  instead of 16 bytes out of 64 different 256-byte pixels; wrong data)
-            const float *fake = tbase + (size_t)(W + 1) * 64 + (size_t)s * 340 * 4 + lane * 4;
-            if (pxA < NPIX) copy16_to_lds(fake + (kgA * 6 + pgA) * 256, in_base + sb + dstA);
-            if (wave < 4 && pxB < NPIX) copy16_to_lds(fake + (6 + pgB) * 256, in_base + sb + dstB);
-            return;
-        }
-        if (pxA < NPIX) copy16_to_lds(inA ? tbase + relA + 8 * s : zA, in_base + sb + dstA);
-        if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase + relB + 8 * s : zB, in_base + sb + dstB);
-        if (PRO == 2) {
-            if (pxA < NPIX) copy16_to_lds(inA ? tbase2 + relA + 8 * s : zA, in2_base + sb + dstA);
-            if (wave < 4 && pxB < NPIX) copy16_to_lds(inB ? tbase2 + relB + 8 * s : zB, in2_base + sb + dstB);
-        }
-    };
-    // G16: instruction j covers pixels 16 j .. 16 j + 15 (lane = pixel * 4 + 16-byte piece): 22 instructions per 16-channel
-    // group, wave w issues j = w, w + 8, w + 16 (j < 22)
-    int rel16[3] = {0, 0, 0};
-    bool in16[3] = {false, false, false};
-    const int q16 = lane & 3;
-    auto px16 = [&](int i) { return 16 * (wave + 8 * i) + (lane >> 2); };
-    if (G16) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int px = px16(i), r = px / PW, c = px - r * PW;
-            rel16[i] = (r * W + c) * 64 + 4 * q16;
-        }
-    }
-    auto plane_src16 = [&](int k) {
-        const int tile_ = tile_of(k);
-        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
-        const long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
-        tbase = a.in + org;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int px = px16(i), r = px / PW, c = px - r * PW;
+            // (row, column) of the pixel recomputed here, once per tile, behind an opaque move: hoisted out of the loop
+            // they would be six more registers live (or spilled) across it
+            int px = px16(i);
+            asm volatile("" : "+v"(px));
+            const int r = (px * 241) >> 13, c = px - r * PW;          // px / 34 for px < 352
             const int gy = ty * TH + r - 1, gx = tx * TW + c - 1;
             in16[i] = gy >= 0 && gy < H && gx >= 0 && gx < W;
         }
     };
-    auto copy_group16 = [&](int gi, int slot) {      // 16-channel group gi (0..3) of the tile plane_src16() was called for
+    auto copy_group = [&](int gi, int slot) {        // 16-channel group gi (0..3) of the tile plane_src() was called for
         if (W4_ABL & 8) return;
-        const unsigned sb = in_base + (unsigned)slot * (SLOTF * 4);
-        const float *z = g_w4_zero_page + 4 * q16 + 16 * gi;       // (the zero page holds 64 floats)
+        const unsigned sb = (unsigned)slot * (SLOT_FLOATS * 4);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = wave + 8 * i;
-            if (j < 22 && px16(i) < NPIX) copy16_to_lds(in16[i] ? tbase + rel16[i] + 16 * gi : z, sb + j * 1024);
+            if (j < 22 && px16(i) < NPIX) {
+                if (in16[i]) {
+                    copy16_to_lds(tbase + 16 * gi, rel16[i], in_base + sb + j * 1024);
+                    if (PRO == 2) copy16_to_lds(tbase2 + 16 * gi, rel16[i], in2_base + sb + j * 1024);
+                } else {                                            // (the zero page holds 64 floats)
+                    copy16_to_lds(g_w4_zero_page, (unsigned)q16 * 16u, in_base + sb + j * 1024);
+                    if (PRO == 2) copy16_to_lds(g_w4_zero_page, (unsigned)q16 * 16u, in2_base + sb + j * 1024);
+                }
+            }
         }
     };
-    // Plane copies issued per iteration: P = 2 on waves 0-3, 1 on waves 4-7 (twice that with a second tensor).  At the end
-    // of iteration g the copy of planes(g+3), issued at the top of iteration g-1, must have landed: behind it in the queue
-    // are the 9 weight loads of iteration g-1, the copies of iteration g and the 9 weight loads of iteration g.
-    // (G16: copies are issued at even iterations only; the group issued at the top of iteration g-1 must have landed at the
-    //  end of the odd iteration g: behind it are the 9 + 9 weight loads of the two iterations)
+    // Copies are issued at even iterations only; the group issued at the top of iteration g-1 must have landed at the end
+    // of the odd iteration g: behind it in the (in-order) queue are the 9 + 9 weight loads of the two iterations.
     auto wait_planes = [&](int g) {
         if (W4_ABL & 64) return;
-        if (G16) {
-            if (g & 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (18 & 15) | ((18 >> 4) << 14));
-            return;
-        }
-        constexpr int M = PRO == 2 ? 2 : 1;
-        if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + 2 * M) & 15) | (((18 + 2 * M) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((18 + M) & 15) | (((18 + M) >> 4) << 14));
+        if (g & 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (18 & 15) | ((18 >> 4) << 14));
     };
 
     // ---- stage items of this thread: three per iteration, read in one batch (one LDS round trip per iteration).
@@ -295,27 +258,25 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // row stage, 768 items it = ((ci*16 + tile)*6 + i (the channel slowest, as V rows are (ci, tile)).
     // Waves 0-3: column items tid, 512 + tid and row item tid; waves 4-7: column item tid, row items tid, 256 + tid.
     const bool lo = wave < 4;                       // (wave-uniform: scalar branches)
-    int col_src[2], col_dst[2], col_ch[2], row_src[2], row_dst[2];
+    int col_src[2], col_dst[2], col_ch[2], row_src[2], row_dst[2], row_dst2[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        if (G16) {      // it = ((tile*6 + c)*2 + kg)*4 + cl: 32 lanes spread over 16 banks of the [px][16] planes
+        {      // it = ((tile*6 + c)*2 + kg)*4 + cl: 32 lanes spread over 16 banks of the [px][16] planes
             const int it = tid + e * THREADS;
             const int cl = it & 3, kg = (it >> 2) & 1, tc = it >> 3, t = tc / 6, c = tc - t * 6;
             col_src[e] = ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 16 + kg * 4 + cl;              // + r * PW * 16 + 8 (chunk & 1)
-            col_dst[e] = (kg * 4 + cl) * TCI + t * 36 + c * 6;                                    // + i (6 contiguous)
-            col_ch[e] = kg * 4 + cl;
-        } else {
-            const int it = tid + e * THREADS;
-            const int cl = it & 3, tc = it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15, kg = tt >> 4;
-            col_src[e] = kg * SUB_FLOATS + ((4 * (t >> 3)) * PW + 4 * (t & 7) + c) * 4 + cl;      // + r * PW * 4
-            col_dst[e] = (kg * 4 + cl) * TCI + t * 36 + c * 6;                                    // + i (6 contiguous)
+            col_dst[e] = (kg * 4 + cl) * TMP_CI + t * 36 + c * 6;                                 // + i (6 contiguous)
             col_ch[e] = kg * 4 + cl;
         }
         {
             const int it = tid + e * 256;
             const int i = it % 6, rt = it / 6, t = rt & 15, ci = rt >> 4;
-            row_src[e] = ci * TCI + t * 36 + i;                                                   // + c * 6
-            row_dst[e] = (ci * 16 + t) * VROW + (i < 3 ? 6 * i : 20 + 6 * ((i - 2) % 3));         // + j (6 contiguous); second half in the order i = 5, 3, 4
+            row_src[e] = ci * TMP_CI + t * 36 + i;                                                // + c * 6
+            // transform row i -> (half, row within the half): half 1 in the order i = 5, 3, 4; position p = il*6 + j of a
+            // half sits at float 16 half + p (p < 16) or 32 + 2 half + (p - 16): j 0..3 contiguous, j 4..5 possibly apart
+            const int half = i < 3 ? 0 : 1, il = i < 3 ? i : (i - 2) % 3;
+            row_dst[e] = (ci * 16 + t) * VROW + 16 * half + 6 * il;
+            row_dst2[e] = (ci * 16 + t) * VROW + (il < 2 ? 16 * half + 6 * il + 4 : 32 + 2 * half);
         }
     }
     // PRO: rows of an item's column that lie inside the image (bit r), for the tile the planes belong to
@@ -326,8 +287,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             // image column / first row of column item e (recomputed from the thread index: once per tile)
-            const int it = tid + e * THREADS;
-            const int tc = G16 ? it >> 3 : it >> 2, tt = tc / 6, c = tc - tt * 6, t = tt & 15;
+            const int it = tid + e * THREADS, tc = it >> 3, tt = tc / 6, c = tc - tt * 6, t = tt & 15;
             const int gx = tx_ * TW + 4 * (t & 7) + c - 1, gy = ty_ * TH + 4 * (t >> 3) - 1;
             unsigned m = 0;
 #pragma unroll
@@ -337,25 +297,27 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     };
     // One stage item in flight: its six inputs (plus the six of the second tensor), where the result goes, and whether
     // the affine prologue applies (column items).  Reads and transform are separate steps so that MFMAs sit between them.
-    struct Item { float d[6], w[6]; float *q; };
-    // (slot, coff): where the chunk's planes are -- G16: slot of its 16-channel group, coff = 8 * (chunk & 1)
+    struct Item { float d[6], w[6]; float *q, *q2; };       // q: outputs 0..3, q2: outputs 4..5
+    // (slot, coff): where the chunk's planes are -- the slot of its 16-channel group, coff = 8 * (chunk & 1)
     auto read_col = [&](int e, int slot, int coff, float *tmp_w, Item &it) {
-        constexpr int RS = G16 ? PW * 16 : PW * 4;
-        const float *p = s_in + slot * SLOTF + coff + col_src[e];
+        constexpr int RS = PW * 16;
+        const float *p = s_in + slot * SLOT_FLOATS + coff + col_src[e];
 #pragma unroll
         for (int r = 0; r < 6; ++r) it.d[r] = p[r * RS];
         if (PRO == 2) {
-            const float *p2 = s_in2 + slot * SLOTF + coff + col_src[e];
+            const float *p2 = s_in2 + slot * SLOT_FLOATS + coff + col_src[e];
 #pragma unroll
             for (int r = 0; r < 6; ++r) it.w[r] = p2[r * RS];
         }
         it.q = tmp_w + col_dst[e];
+        it.q2 = it.q + 4;
     };
     auto read_row = [&](int e, const float *tmp_r, float *v_w, Item &it) {
         const float *p = tmp_r + row_src[e];
 #pragma unroll
         for (int c = 0; c < 6; ++c) it.d[c] = p[c * 6];
         it.q = v_w + row_dst[e];
+        it.q2 = v_w + row_dst2[e];
     };
     // affine prologue of column item e (chunk s of its tile: channel 8 s + ci); zero padding stays zero
     auto pro_apply = [&](int e, int s, Item &it) {
@@ -375,7 +337,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         bt6(it.d, o);
         *reinterpret_cast<float2 *>(it.q) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2 *>(it.q + 2) = make_float2(o[2], o[3]);
-        *reinterpret_cast<float2 *>(it.q + 4) = make_float2(o[4], o[5]);
+        *reinterpret_cast<float2 *>(it.q2) = make_float2(o[4], o[5]);
     };
     // the three items of an iteration: k = 0 column item 0 | k = 1 column item 1 (waves 0-3) or row item 0 (waves 4-7) |
     // k = 2 row item 0 (waves 0-3) or row item 1.  `lo` is wave-uniform: scalar branches (the empty asm keeps the
@@ -419,17 +381,10 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         }
     };
 
-    // ---- prime the pipeline: the planes of chunks 0..2 (G16: groups 0 and 1) copied, the first weights requested
-    if (G16) {
-        plane_src16(0);
-        copy_group16(0, 0);
-        copy_group16(1, 1);
-    } else {
-        plane_src(0);
-        copy_planes(0, 0);
-        copy_planes(1, 1);
-        copy_planes(2, 2);
-    }
+    // ---- prime the pipeline: the planes of groups 0 and 1 (chunks 0..3) copied, the first weights requested
+    plane_src(0);
+    copy_group(0, 0);
+    copy_group(1, 1);
     load_quads(Ea, 0, 0, 5, 0);
     if (W4_LEAD2) load_quads(Eb, 1, 0, 5, 0);
     load_quads(L, 0, 5, 9, 20);
@@ -440,7 +395,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         Item it;
         for (int c = 0; c < 2; ++c) {
             float *tw = c ? s_tmp1 : s_tmp0;
-            const int sl = G16 ? 0 : c, coff = G16 ? 8 * c : 0;
+            const int sl = 0, coff = 8 * c;
             read_col(0, sl, coff, tw, it);
             if (PRO) pro_apply(0, c, it);
             transform_store(it);
@@ -455,8 +410,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         transform_store(it);
         if (!lo) { read_row(1, s_tmp0, s_v0, it); transform_store(it); }
     }
-    if (!G16) copy_planes(3, 0);            // slot 0 has been consumed (barrier above)
-    __builtin_amdgcn_s_waitcnt(0);          // (one-time: the steady-state wait counts assume two iterations of history)
     __syncthreads();
 
     if (STATS && tid < 256) s_red[tid] = 0.f;       // (ordered before its first use by the barriers of the first tile)
@@ -464,32 +417,21 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
     for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     // V operand rows of this lane: (ci = kg*4 + kq, tile l15), floats ph*20 .. ph*20 + 17
-    const int v_off = (kq * 16 + l15) * VROW + ph * 20;
+    const int v_off = (kq * 16 + l15) * VROW;
 
     // one iteration; PAR = g & 1 (compile time: buffers and weight registers are static)
-    auto iteration = [&](const int g, const int slot, auto par, float (&E)[20]) {
+    auto iteration = [&](const int g, auto par, float (&E)[20]) {
         constexpr int PAR = decltype(par)::value;
         float *tmp_w = PAR ? s_tmp1 : s_tmp0;               // column stage (chunk g+2) writes tmp[g & 1]
         const float *tmp_r = PAR ? s_tmp0 : s_tmp1;         // row stage (chunk g+1) reads tmp[(g+1) & 1]
         float *v_w = PAR ? s_v0 : s_v1;                     //   and writes V[(g+1) & 1]
         const float *v_r = (PAR ? s_v1 : s_v0) + v_off;     // MFMAs of chunk g read V[g & 1]
-        int slot2, coff2;                   // where the planes of chunk g + 2 (this iteration's column stage) are
-        if (G16) {
-            // group (g+4) >> 1 (chunks g+4, g+5) -> the slot of group (g >> 1), consumed by the last two column stages
-            if (!(g & 1)) {
-                if (((g + 4) & 7) == 0) plane_src16((g + 4) >> 3);
-                copy_group16(((g + 4) & 7) >> 1, (g >> 1) & 1);
-            }
-            slot2 = ((g + 2) >> 1) & 1;
-            coff2 = 8 * (g & 1);
-        } else {
-            const int slot1 = slot == NSLOT - 1 ? 0 : slot + 1;
-            slot2 = slot1 == NSLOT - 1 ? 0 : slot1 + 1;
-            coff2 = 0;
-            // planes(g+4) -> the slot of planes(g+1), consumed by the previous iteration's column stage
+        // group (g+4) >> 1 (chunks g+4, g+5) -> the slot of group (g >> 1), consumed by the last two column stages
+        if (!(g & 1)) {
             if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
-            copy_planes((g + 4) & 7, slot1);
+            copy_group(((g + 4) & 7) >> 1, (g >> 1) & 1);
         }
+        const int slot2 = ((g + 2) >> 1) & 1, coff2 = 8 * (g & 1);      // the planes of chunk g + 2 (this iteration's column stage)
         if (PRO && ((g + 2) & 7) == 0) row_masks((g + 2) >> 3);
         const int s2 = (g + 2) & 7;
         // wave-uniform weight bases in scalar registers (global_load with an SGPR base + this lane's offset): chunk g + 2
@@ -506,9 +448,10 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         auto read_v = [&](int kg) {
             if (W4_ABL & 4) return;
             const float *vr = v_r + kg * 64 * VROW;
-            const float4 v0 = *reinterpret_cast<const float4 *>(vr), v1 = *reinterpret_cast<const float4 *>(vr + 4);
-            const float4 v2 = *reinterpret_cast<const float4 *>(vr + 8), v3 = *reinterpret_cast<const float4 *>(vr + 12);
-            const float2 v4 = *reinterpret_cast<const float2 *>(vr + 16);
+            const float *vh = vr + 16 * ph;           // positions 0-15 of this wave's half, then 16-17 behind both halves
+            const float4 v0 = *reinterpret_cast<const float4 *>(vh), v1 = *reinterpret_cast<const float4 *>(vh + 4);
+            const float4 v2 = *reinterpret_cast<const float4 *>(vh + 8), v3 = *reinterpret_cast<const float4 *>(vh + 12);
+            const float2 v4 = *reinterpret_cast<const float2 *>(vr + 32 + 2 * ph);
             const float t[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w,
                                  v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
 #pragma unroll
@@ -582,9 +525,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     // pair (ph 0, ph 1) of a channel group swaps the two output rows the other one owns (ph 0: rows 0-1, ph 1: rows 2-3).
     const int co0 = cog * 16 + kq * 4;
     float *xw = s_x + (cog * 8 * 64 + lane) * 4;                 // this pair's exchange area: [slot 8][lane 64] float4
-    const float cf_s = ph == 0 ? 1.f : 4.f, cf_t0 = ph == 0 ? 1.f : 0.f;       // (wave-uniform scalars)
-    const float cf_d = ph == 0 ? 1.f : 8.f, cf_t1 = ph == 0 ? 0.f : 1.f, cf_h = ph == 0 ? 1.f : 2.f;
     auto tile_epilogue = [&](int k) {
+        // wave-uniform coefficients of the half transform, selected HERE (behind an opaque copy of ph): selected once in
+        // front of the loop they occupy ten vector registers across it
+        int ph_e = ph;
+        asm volatile("" : "+s"(ph_e));
+        const float cf_s = ph_e == 0 ? 1.f : 4.f, cf_t0 = ph_e == 0 ? 1.f : 0.f;
+        const float cf_d = ph_e == 0 ? 1.f : 8.f, cf_t1 = ph_e == 0 ? 0.f : 1.f, cf_h = ph_e == 0 ? 1.f : 2.f;
         if (W4_ABL & 32) {
 #pragma unroll
             for (int p = 0; p < 18; ++p) { asm volatile("" ::"v"(acc[p])); acc[p] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -621,8 +568,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 ys[1][j][r] = cf_h * df;
             }
         }
-#pragma unroll
-        for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         // own output rows 2 ph + io; the operands of one output row (4 pixels x up to 3 tensors) are requested together, the
         // first row's before the exchange so that the exchange hides part of their round trip
         const int t = l15;
@@ -753,15 +698,16 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 *pq = y;
             }
         }
+        // the accumulators restart from zero -- set here, behind the epilogue, whose operands need the 72 registers
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 18; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    int slot = 0;
 #pragma unroll 1
     for (int g = 0; g < G; g += 2) {
-        iteration(g, slot, std::integral_constant<int, 0>{}, Ea);
-        slot = slot == NSLOT - 1 ? 0 : slot + 1;
-        iteration(g + 1, slot, std::integral_constant<int, 1>{}, W4_LEAD2 ? Eb : Ea);
-        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        iteration(g, std::integral_constant<int, 0>{}, Ea);
+        iteration(g + 1, std::integral_constant<int, 1>{}, W4_LEAD2 ? Eb : Ea);
         if ((g & 7) == 6) tile_epilogue(g >> 3);
     }
     if (STATS) {        // one partial row [sum 64 | second kind 64] per block; a channel's two position halves are added

@@ -68,5 +68,15 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// counter-based uniform in [0,1) of the dropout masks (models.py:84,88): element idx of the stream `seed`
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

@@ -1047,10 +1047,13 @@ __global__ __launch_bounds__(wgw::THREADS) void conv3x3_wgrad_wino_kernel(
 //   Q[pos][co][ci] = sum over blocks of part[block][pos][co][ci]                 (fp64, fixed order)
 //   dW[co][ci][r][t] = sum_{a,b} G[a][r] * Q[a*4+b][co][ci] * G[b][t]            (OIHW)
 // block = 16 (co, ci) pairs x 16 slices of partial rows; 256 blocks.
-__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float *__restrict__ part, int nparts,
-                                                                float *__restrict__ dw)
+// blockIdx.y = which of up to four convolutions (one launch finishes all weight gradients of the step's 3x3 stack)
+struct FinishJobs { const float *part[4]; float *dw[4]; };
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const FinishJobs jobs, int nparts)
 {
     __shared__ double s_acc[16][16][16];         // [position][slice][pair]
+    const float *__restrict__ part = jobs.part[blockIdx.y];
+    float *__restrict__ dw = jobs.dw[blockIdx.y];
     const int tx = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + tx;        // (co, ci) pair
     double acc[16];
@@ -1093,7 +1096,7 @@ __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float *__r
 }  // namespace
 
 static int launch_wgrad_wino(const float *act, const float *dz, float *dw, float *ws, int B, int H, int W,
-                             const ProIn proa, const ProIn prod, void *stream)
+                             const ProIn proa, const ProIn prod, void *stream, bool finish = true)
 {
     const int tiles_x = cdiv(W, wgw::TW), tiles_y = cdiv(H, wgw::TH);
     const int ntiles = B * tiles_x * tiles_y;
@@ -1113,7 +1116,11 @@ static int launch_wgrad_wino(const float *act, const float *dz, float *dw, float
         hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<false, false>), g, blk, 0, st, act, dz, ws, H, W,
                            tiles_x, tiles_y, ntiles, proa, prod);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(4096 / 16), dim3(256), 0, st, ws, grid, dw);
+    if (!finish) return COVA_OK;
+    FinishJobs jobs{};
+    jobs.part[0] = ws;
+    jobs.dw[0] = dw;
+    hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(4096 / 16), dim3(256), 0, st, jobs, grid);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -1137,4 +1144,35 @@ COVA_API int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc,
     COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
     return launch_wgrad_wino(act, dz, dw, ws, B, H, W, ProIn{act_abc, nullptr, act_relu},
                              ProIn{dz_abc, dz2, 0}, stream);
+}
+
+// The same in two steps, so that ONE launch can finish the weight gradients of several convolutions: the per-block
+// partial sums only (each convolution needs its own workspace) ...
+COVA_API int cova_conv3x3_wgrad_wino_partial(const float *act, const float *act_abc, int act_relu,
+                                             const float *dz, const float *dz2, const float *dz_abc,
+                                             float *ws, int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(act && dz && ws && B > 0 && H > 0 && W > 0);
+    return launch_wgrad_wino(act, dz, nullptr, ws, B, H, W, ProIn{act_abc, nullptr, act_relu},
+                             ProIn{dz_abc, dz2, 0}, stream, false);
+}
+
+// ... and fold + final transform of up to four of them (pairs 1..3 nullable) into their OIHW gradients
+COVA_API int cova_conv3x3_wgrad_wino_finish(const float *ws0, float *dw0, const float *ws1, float *dw1,
+                                            const float *ws2, float *dw2, const float *ws3, float *dw3, int B, int H,
+                                            int W, void *stream)
+{
+    COVA_REQUIRE(ws0 && dw0 && B > 0 && H > 0 && W > 0);
+    COVA_REQUIRE((ws1 == nullptr) == (dw1 == nullptr) && (ws2 == nullptr) == (dw2 == nullptr) &&
+                 (ws3 == nullptr) == (dw3 == nullptr));
+    const float *ws[4] = {ws0, ws1, ws2, ws3};
+    float *dw[4] = {dw0, dw1, dw2, dw3};
+    FinishJobs jobs{};
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        if (ws[i]) { jobs.part[n] = ws[i]; jobs.dw[n] = dw[i]; ++n; }
+    const int grid = cova_internal_persistent_grid(B * cdiv(W, wgw::TW) * cdiv(H, wgw::TH));
+    hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(4096 / 16, n), dim3(256), 0, (hipStream_t)stream, jobs, grid);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
 }

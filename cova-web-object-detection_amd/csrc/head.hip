@@ -6,15 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx)
-{
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
-}
-
 // out = x * keep / (1-p); keep is generated (and stored) unless given
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, int ldx,
                                                           float *__restrict__ out, int ldo,

@@ -11,7 +11,7 @@
 // -1 pad row), mask -> -9e15, softmax over the K slots, h'_i = sum_k alpha_ik Wh_j[ctx(i,k)].
 // One wavefront per node: the K <= 64 slots live in lanes for the softmax (shuffle
 // reductions), the D hidden channels live in lanes for the gather (256-byte coalesced rows).
-#include "common.h"
+#include "bn_tail.h"
 
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 
@@ -187,6 +187,26 @@ __global__ void roipool_page_range_init_kernel(int B, int *__restrict__ range)
     if (b < B) { range[2 * b] = 0x7fffffff; range[2 * b + 1] = -1; }
 }
 
+// both steps by ONE block (init, block barrier, scan): the form the launches of the step use
+__device__ __forceinline__ void page_ranges_by_block(const float *__restrict__ rois, int n_rois, int B,
+                                                     int *__restrict__ range)
+{
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { range[2 * b] = 0x7fffffff; range[2 * b + 1] = -1; }
+    __syncthreads();
+    for (int n = threadIdx.x; n < n_rois; n += blockDim.x) {
+        const int b = (int)rois[5 * n];
+        if (b < 0 || b >= B) continue;
+        if (n == 0 || (int)rois[5 * (n - 1)] != b) atomicMin(range + 2 * b, n);
+        if (n == n_rois - 1 || (int)rois[5 * (n + 1)] != b) atomicMax(range + 2 * b + 1, n);
+    }
+}
+
+__global__ __launch_bounds__(1024) void roipool_page_range_block_kernel(const float *__restrict__ rois, int n_rois, int B,
+                                                                       int *__restrict__ range)
+{
+    page_ranges_by_block(rois, n_rois, B, range);
+}
+
 // Owner = one wave per (page, feature row, 40-pixel segment), 64 channels (blockIdx.y = channel block); the four
 // waves of a block are independent (own LDS slice, own task stream, no block barrier).
 //   accumulate: lane = channel; boxes touching the row are found 64 at a time (geometry test + ballot), visited
@@ -300,15 +320,21 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
 // producer's BatchNorm-backward sums per pooled entry instead of per map element: both are linear in the routed
 // contributions, and zmax holds the pre-activation at each arg-max:
 //   partial[blk] = (sum g', sum g' * (zmax - mean) * invstd) per channel; boxes -> waves by a fixed rule.
-template <bool STATS>
+// Block (0,0) also builds the per-page box ranges the rows kernel needs (page_range != NULL), and -- TAIL (C = 64) -- the
+// last block to finish turns the partial rows into dgamma / dbeta / the dz coefficients (bn_tail.h): no launch of its own
+// for either.
+template <bool STATS, bool TAIL>
 __global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
     const float *__restrict__ zmax, const int32_t *__restrict__ argmax, int n_rois, int C, int bins,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ gT,
-    int32_t *__restrict__ amT, float *__restrict__ partial)
+    int32_t *__restrict__ amT, float *__restrict__ partial, const float *__restrict__ rois, int B,
+    int *__restrict__ page_range, const BnTail tail)
 {
     __shared__ float s_red[4][2][64];
+    __shared__ double s_tail[TAIL ? 2049 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (page_range != nullptr && blockIdx.x == 0 && blockIdx.y == 0) page_ranges_by_block(rois, n_rois, B, page_range);
     const int c = blockIdx.y * 64 + lane;
     const float mu = STATS ? mean[c] : 0.f, is = STATS ? invstd[c] : 0.f;
     float su = 0.f, sq = 0.f;
@@ -332,9 +358,12 @@ __global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
         __syncthreads();
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6;
-            partial[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * 64 + lane] =
-                (s_red[0][which][lane] + s_red[1][which][lane]) + (s_red[2][which][lane] + s_red[3][which][lane]);
+            const float v = (s_red[0][which][lane] + s_red[1][which][lane]) + (s_red[2][which][lane] + s_red[3][which][lane]);
+            float *dst = partial + ((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * 64 + lane;
+            if (TAIL) bn_tail_store(dst, v);
+            else *dst = v;
         }
+        if (TAIL) bn_tail_run(tail, partial, (int)gridDim.x, s_tail);
     }
 }
 
@@ -705,10 +734,11 @@ __global__ void csr_fill_kernel(const int64_t *__restrict__ ctx, int E, int N, c
 
 // one wave per row: rank every entry among the row's entries (entries are distinct) and store it at its rank
 __global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int *__restrict__ row_ptr, const int *__restrict__ tmp,
-                                                            int N, int *__restrict__ edges)
+                                                            int N, int *__restrict__ edges, int *__restrict__ clean)
 {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
+    if (clean != nullptr && lane < 2) clean[lane * N + j] = 0;      // deg[j], cursor[j]: zero again for the next call
     const int lo = row_ptr[j], deg = row_ptr[j + 1] - lo;
     for (int c0 = 0; c0 < deg; c0 += 64) {
         const int mine = c0 + lane < deg ? tmp[lo + c0 + lane] : 0x7fffffff;
@@ -719,6 +749,46 @@ __global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int *__restric
             for (int t = 0; t < cnt; ++t) rank += __shfl(other, t, 64) < mine ? 1 : 0;
         }
         if (c0 + lane < deg) edges[lo + rank] = mine;
+    }
+}
+
+// Three launches instead of seven for a workspace that is REUSED from call to call (cova_gat_transpose_reuse): its
+// counters are zero on entry and left zero (the row sort clears them), so no memsets; and the exclusive scan is done by
+// the counting kernel's last block (ticket counter; agent-scope atomic loads of the degrees, as bn_tail.h).
+__global__ __launch_bounds__(256) void csr_count_scan_kernel(const int64_t *__restrict__ ctx, int E, int N,
+                                                             int *__restrict__ deg, int *__restrict__ ticket,
+                                                             int *__restrict__ row_ptr)
+{
+    __shared__ int s_part[256];
+    __shared__ int s_last;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const long long j = ctx[e];
+        if (j >= 0 && j < N) atomicAdd(deg + j, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    const int tid = threadIdx.x;
+    const int per = (N + 255) / 256, lo = min(tid * per, N), hi = min(lo + per, N);
+    int t = 0;
+    for (int i = lo; i < hi; ++i) t += __hip_atomic_load(deg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_part[tid] = t;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = s_part[i]; s_part[i] = run; run += v; }
+        row_ptr[N] = run;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int i = lo; i < hi; ++i) {
+        row_ptr[i] = run;
+        run += __hip_atomic_load(deg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -911,12 +981,15 @@ static int roipool_bwd_grid(int B, int H, int W)
 // (no zero-fill, no atomics: every row of the map has one owner wave).  C % 64 == 0.
 static int roipool_page_ranges(const float *rois, int n_rois, int B, int *range, hipStream_t st)
 {
+    if (n_rois <= (1 << 18)) {
+        hipLaunchKernelGGL(roipool_page_range_block_kernel, dim3(1), dim3(1024), 0, st, rois, n_rois, B, range);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     hipLaunchKernelGGL(roipool_page_range_init_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, B, range);
     COVA_LAUNCH_CHECK();
-    if (n_rois > 0) {
-        hipLaunchKernelGGL(roipool_page_range_kernel, dim3(cdiv(n_rois, 256)), dim3(256), 0, st, rois, n_rois, B, range);
-        COVA_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(roipool_page_range_kernel, dim3(cdiv(n_rois, 256)), dim3(256), 0, st, rois, n_rois, B, range);
+    COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
 
@@ -935,21 +1008,27 @@ COVA_API int cova_roipool_bwd_workspace_words(int n_rois, int B, int C, int PH, 
 static int launch_roipool_bwd(const float *gout, int ld_g, const float *pooled, int ld_p, const float *zmax,
                               const float *rois, const int32_t *argmax, int n_rois, int B, int C, int H, int W,
                               int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
-                              float *gfeat, float *partial, void *ws, hipStream_t st)
+                              float *gfeat, float *partial, void *ws, hipStream_t st, const cova_bn_tail *tail = nullptr)
 {
     const size_t ne = (size_t)n_rois * C * PH * PW;
     float *gT = (float *)ws;
     int32_t *amT = (int32_t *)ws + ne;
     int *page_range = (int *)ws + 2 * ne;
-    const int rc = roipool_page_ranges(rois, n_rois, B, page_range, st);
-    if (rc != COVA_OK) return rc;
     const dim3 pgrid(cova_roipool_bwd_bn_num_partials(n_rois), C / 64);
-    if (partial)
-        hipLaunchKernelGGL(roipool_bwd_prep_kernel<true>, pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
-                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial);
+    BnTail t{};
+    if (tail != nullptr && tail->mode != 0) {
+        if (!(partial && C == 64 && tail->mode == 2)) return COVA_ERR_BAD_ARG;
+        t = *tail;
+    }
+    if (t.mode != 0)
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<true, true>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
+    else if (partial)
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<true, false>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
     else
-        hipLaunchKernelGGL(roipool_bwd_prep_kernel<false>, pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
-                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial);
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<false, false>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true> : roipool_bwd_rows_kernel<false>),
                        dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gT, amT, rois, page_range, n_rois,
@@ -981,6 +1060,20 @@ COVA_API int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *poole
     COVA_REQUIRE(B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
     return launch_roipool_bwd(gout, ld_g, pooled, ld_p, zmax, rois, argmax, n_rois, B, C, H, W, PH, PW,
                               spatial_scale, mean, invstd, gfeat, partial, ws, (hipStream_t)stream);
+}
+
+// ... with the BatchNorm-backward finalize of those sums (cova_bn_finalize_bwd_abc) as the tail of the entry pass
+// (tail: host pointer, mode 2, C = 64; NULL or mode 0 = cova_roipool_bwd_bn)
+COVA_API int cova_roipool_bwd_bn_tail(const float *gout, int ld_g, const float *pooled, int ld_p,
+                                      const float *zmax, const float *rois, const int32_t *argmax, int n_rois,
+                                      int B, int C, int H, int W, int PH, int PW, float spatial_scale,
+                                      const float *mean, const float *invstd, float *gfeat, float *partial,
+                                      void *ws, const cova_bn_tail *tail, void *stream)
+{
+    COVA_REQUIRE(gout && pooled && zmax && rois && argmax && mean && invstd && gfeat && partial && ws);
+    COVA_REQUIRE(B > 0 && n_rois >= 0 && C > 0 && C % 64 == 0);
+    return launch_roipool_bwd(gout, ld_g, pooled, ld_p, zmax, rois, argmax, n_rois, B, C, H, W, PH, PW,
+                              spatial_scale, mean, invstd, gfeat, partial, ws, (hipStream_t)stream, tail);
 }
 
 // RoIAlign (extension; see roialign_fwd_kernel): same tensor conventions as cova_roipool_fwd
@@ -1070,7 +1163,25 @@ COVA_API int cova_gat_transpose(const int64_t *ctx, int N, int K, int *csr, void
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, ctx, E, N, row_ptr, cursor, tmp);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, row_ptr, tmp, N, edges);
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, row_ptr, tmp, N, edges, (int *)nullptr);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// The same for a workspace that is kept from call to call: the ints csr[(N+1) + 2NK ..] (2N + 16 of them) must be ZERO on
+// entry (zero the buffer once, when it is allocated) and are zero again when the call's kernels have run -- three
+// launches, no memsets.  One workspace per stream.
+COVA_API int cova_gat_transpose_reuse(const int64_t *ctx, int N, int K, int *csr, void *stream)
+{
+    COVA_REQUIRE(ctx && csr && N > 0 && K > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int E = N * K;
+    int *row_ptr = csr, *edges = csr + N + 1, *tmp = edges + E, *deg = tmp + E, *cursor = deg + N, *ticket = cursor + N;
+    hipLaunchKernelGGL(csr_count_scan_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, ctx, E, N, deg, ticket, row_ptr);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, ctx, E, N, row_ptr, cursor, tmp);
+    COVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, row_ptr, tmp, N, edges, deg);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -239,9 +239,21 @@ def colstats(x, ld, R, C):
 
 
 def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=0, gout=None,
-                prefix=None, unit="boxes"):
-    """Returns (dgamma, dbeta); writes dz (and dres = relu-masked dout)."""
+                prefix=None, unit="boxes", drop=None, colsum=None):
+    """Returns (dgamma, dbeta); writes dz (and dres = relu-masked dout).  ``drop`` = (mask, p): dout is the gradient
+    BEHIND a Dropout of the layer's output (its backward is applied first); ``colsum`` [C]: receives the column sums
+    of dz."""
     C = st.C
+    if (bn1d_fused(not st.frozen) and dres is None and R > 0 and z.dim() == 2 and dz.data_ptr() != dout.data_ptr()):
+        dgamma = _gbuf(gout, (prefix or "") + "weight", (C,), z)
+        dbeta = _gbuf(gout, (prefix or "") + "bias", (C,), z)
+        call("cova_bn1d_bwd", dout, ldd, drop[0] if drop else None, float(drop[1]) if drop else 0.0, act, lda, z, ldz,
+             st.mean, st.invstd, st.scale, R, C, dgamma, dbeta, dz, lddz, colsum)
+        return dgamma, dbeta
+    if drop is not None:
+        dy = _empty((R, C), dout)
+        call("cova_dropout_bwd", dout, ldd, drop[0], dy, C, R, C, float(drop[1]))
+        dout, ldd = dy, C
     n = query("cova_colreduce_num_chunks", R, C)
     part = _empty((n, 2, C), z)
     call("cova_bn_bwd_reduce", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, R, C, part)
@@ -250,6 +262,8 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
     coef = bn_finalize_bwd(part, n, C, R, dgamma, dbeta, unit, frozen=st.frozen)
     call("cova_bn_bwd_apply", dout, ldd, act, lda, z, ldz, st.mean, st.invstd, st.scale, coef, dz,
          lddz, dres, lddres, R, C)
+    if colsum is not None:
+        call("cova_colsum", dz, lddz, R, C, colsum)
     return dgamma, dbeta
 
 
@@ -451,7 +465,7 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     sv["blocks"] = blocks
     # what RoIPool's backward needs of the block that produced the feature map
     last = blocks[1]
-    sv["last"] = dict(out=last["out"], x=last["x"], z=last["z2"], bn=last["bnb"])
+    sv["last"] = dict(out=last["out"], x=last["x"], z=last["z2"], bn=last["bnb"], prefix=BN3_KEYS[3])
     return feat
 
 
@@ -705,12 +719,23 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     Returns the gradient w.r.t. the max-pool output; sv['pool_abc'] = (dgamma, dbeta, abc) of the stem's BatchNorm."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), dfeat)
+    # weight gradients: the four launches leave their per-block partial sums in four workspaces, ONE launch at the end
+    # folds and transforms them (4 x 67 MB at configs[1]; a shared workspace would need a finish launch per convolution)
+    nws = query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2)
+    ws_all = _empty((4, nws), dfeat)
+    jobs = []
+
+    def wgrad(act, act_abc, act_relu, dz, dz2, dz_abc, dw):
+        call("cova_conv3x3_wgrad_wino_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
+        jobs.append(dw)
+
     nt = conv3_num_partials(B, H2, W2, sv["w4"])
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
     # the last bn2 were taken by cova_roipool_bwd_bn
     dA, pend = dfeat, None                  # pend = (dgamma, dbeta, abc) of the bn2 in front of dA, when already known
-    if head_part is not None:
+    if isinstance(head_part, dict):
+        pend = head_part["pend"]
+    elif head_part is not None:
         last = sv["blocks"][1]["bnb"]
         pend = _bn_abc_from_partials(head_part[0], head_part[1], last, R, gout, BN3_KEYS[3], dfeat)
     for blk in (1, 0):
@@ -730,7 +755,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
             g_in, g_in2 = dA, s["z2"]
         grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
-        call("cova_conv3x3_wgrad_wino_pro", s["z1"], bna.abc, 1, g_in, g_in2, g_abc, dw, ws3, B, H2, W2)
+        wgrad(s["z1"], bna.abc, 1, g_in, g_in2, g_abc, dw)
         grads[kb + ".weight"] = dw
         # ---- dgrad of conv2 with bn1's ReLU mask (recomputed from z1) + backward sums in the epilogue
         dy_a = torch.empty_like(dA)
@@ -739,7 +764,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
                                      bna, dy_a, part, nt, R, gout, pa, B, H2, W2)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
-        call("cova_conv3x3_wgrad_wino_pro", s["x"], None, 0, dy_a, s["z1"], abc_a, dw, ws3, B, H2, W2)
+        wgrad(s["x"], None, 0, dy_a, s["z1"], abc_a, dw)
         grads[ka + ".weight"] = dw
         # ---- dgrad of conv1 (+ residual gradient); for block 1 the epilogue prepares block 0's bn2
         dx = torch.empty_like(dA)
@@ -757,6 +782,10 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
             conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, None, None, None, None, None, dx,
                         None, B, H2, W2)
         dA = dx
+    fin = []
+    for i in range(4):
+        fin += [ws_all[i], jobs[i]]
+    call("cova_conv3x3_wgrad_wino_finish", *fin, B, H2, W2)
     return dA
 
 
@@ -882,10 +911,12 @@ def roipool_bwd(sv, gout, ld_g):
     return gfeat
 
 
-def roipool_bwd_bn(sv, gout, ld_g, last):
+def roipool_bwd_bn(sv, gout, ld_g, last, grad_out=None):
     """RoIPool backward for the un-materialised feature map relu(bn(z) + x): the ReLU mask is `pooled > 0`
     (the pooled value is the map's value at the arg-max) and the BatchNorm-backward sums are taken per
-    pooled entry from the z values the forward kept -> (masked gradient map, (partials, count))."""
+    pooled entry from the z values the forward kept -> (masked gradient map, (partials, count)), or -- 64-channel
+    stack, BatchNorm tails on -- (map, {"pend": (dgamma, dbeta, abc)}) with that BatchNorm's finalize done by the
+    entry pass's last block."""
     B, Hf, Wf, C = sv["shape"]
     PH, PW = sv["roi"]
     n = sv["bboxes"].shape[0]
@@ -893,16 +924,49 @@ def roipool_bwd_bn(sv, gout, ld_g, last):
     npart = query("cova_roipool_bwd_bn_num_partials", n)
     part = _empty((npart, 2, C), gout)
     bn = last["bn"]
+    if tails_on(C) and not bn.frozen and last.get("prefix"):
+        dg, db, abc, tail = bn_tail_bwd(bn, B * Hf * Wf, grad_out, last["prefix"], gout)
+        call("cova_roipool_bwd_bn_tail", gout, ld_g, sv["pooled"], sv["ld_pooled"], sv["zmax"], sv["bboxes"],
+             sv["argmax"], n, B, C, Hf, Wf, PH, PW, float(sv["scale"]), bn.mean, bn.invstd, gfeat, part,
+             _roipool_ws(sv, gout), tail.ptr)
+        return gfeat, {"pend": (dg, db, abc)}
     call("cova_roipool_bwd_bn", gout, ld_g, sv["pooled"], sv["ld_pooled"], sv["zmax"], sv["bboxes"], sv["argmax"],
          n, B, C, Hf, Wf, PH, PW, float(sv["scale"]), bn.mean, bn.invstd, gfeat, part, _roipool_ws(sv, gout))
     return gfeat, (part, npart)
 
 
 # ------------------------------------------------------------------------------- BN over [N, C]
-def bn1d_fwd(x, ldx, N, C, prefix, params, buffers, training, out, ldo, relu):
+def bn1d_fused(training):
+    """one launch per BatchNorm1d application (csrc/bn1d.hip): train mode without SyncBN"""
+    return OPTIONS.bn_tail and training and STAT_SYNC is None
+
+
+def bn1d_fwd(x, ldx, N, C, prefix, params, buffers, training, out, ldo, relu, drop=None):
+    """BatchNorm1d (+ReLU) of x [N,C] into out.  ``drop`` = (p, seed, mask or None): also the Dropout of the result
+    -> returns (BNState, dropped, mask)."""
+    if bn1d_fused(training) and N > 0:
+        st = bn_state(C, x, N, True)
+        dropped = mask = None
+        p, seed, given = 0.0, 0, False
+        if drop is not None:
+            p, seed, mask = drop
+            given = mask is not None
+            if given:
+                _check(mask, torch.uint8)
+            else:
+                mask = _empty((N, C), x, torch.uint8)
+            dropped = _empty((N, C), x)
+        call("cova_bn1d_fwd", x, ldx, N, C, params[prefix + "weight"], params[prefix + "bias"],
+             buffers[prefix + "running_mean"], buffers[prefix + "running_var"],
+             buffers.get(prefix + "num_batches_tracked"), BN_MOMENTUM, BN_EPS, 1 if relu else 0, out, ldo, dropped, C,
+             mask, float(p), int(seed), 1 if given else 0, st.scale, st.shift, st.mean, st.invstd)
+        return (st, dropped, mask) if drop is not None else st
     part, n = colstats(x, ldx, N, C) if training else (None, 0)
     st = bn_params(prefix, params, buffers, C, x, training, part, n, N)
     call("cova_bn_act_fwd", x, ldx, st.scale, st.shift, None, 0, out, ldo, N, C, 1 if relu else 0)
+    if drop is not None:
+        dropped, mask = dropout_fwd(out, ldo, N, C, drop[0], drop[1], drop[2])
+        return st, dropped, mask
     return st
 
 
@@ -955,11 +1019,20 @@ def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):
 
 
 # Backward of the neighbour gather: a deterministic gather through the transposed index (no float atomics).
+_CSR_WS = {}
+
+
 def gat_transpose(ctx):
-    """Transposed neighbour index of one batch (shared by every head / layer / backward call of the step)."""
+    """Transposed neighbour index of one batch (shared by every head / layer / backward call of the step).  The
+    workspace is kept per (device, stream, N, K): its counters are zeroed once and left zero by the kernels."""
     N, K = ctx.shape
-    csr = torch.empty((query("cova_gat_transpose_ints", N, K),), dtype=torch.int32, device=ctx.device)
-    call("cova_gat_transpose", ctx, N, K, csr)
+    key = (ctx.device, torch.cuda.current_stream(ctx.device).cuda_stream, N, K)
+    csr = _CSR_WS.get(key)
+    if csr is None:
+        if len(_CSR_WS) >= 8:
+            _CSR_WS.clear()
+        csr = _CSR_WS[key] = torch.zeros((query("cova_gat_transpose_ints", N, K),), dtype=torch.int32, device=ctx.device)
+    call("cova_gat_transpose_reuse", ctx, N, K, csr)
     return csr
 
 
@@ -1052,8 +1125,11 @@ def decoder_fwd(x, N, T, params, buffers, training, p, seeds=(0, 0), masks=None)
     call("cova_sgemm", 0, 1, N, T, T, xd, T, params["decoder.1.weight"], T, z, T,
          params["decoder.1.bias"], 0)
     y = _empty((N, T), x)
-    st = bn1d_fwd(z, T, N, T, "decoder.2.", params, buffers, training, y, T, True)
-    yd, m2 = dropout_fwd(y, T, N, T, p, seeds[1], masks[1] if masks else None) if drop else (y, None)
+    if drop:
+        st, yd, m2 = bn1d_fwd(z, T, N, T, "decoder.2.", params, buffers, training, y, T, True,
+                              drop=(p, seeds[1], masks[1] if masks else None))
+    else:
+        st, yd, m2 = bn1d_fwd(z, T, N, T, "decoder.2.", params, buffers, training, y, T, True), y, None
     logits = _empty((N, NC), x)
     call("cova_linear_small_fwd", yd, T, params["decoder.5.weight"], params["decoder.5.bias"], logits,
          N, T, NC)
@@ -1070,19 +1146,13 @@ def decoder_bwd(sv, dlogits, params, gout=None):
     db2 = _gbuf(gout, "decoder.5.bias", (NC,), dlogits)
     call("cova_linear_small_bwd", dlogits, sv["yd"], T, params["decoder.5.weight"], dyd, T, dW2, db2,
          N, T, NC)
-    if sv["drop"]:
-        dy = _empty((N, T), dlogits)
-        call("cova_dropout_bwd", dyd, T, sv["m2"], dy, T, N, T, float(p))
-    else:
-        dy = dyd
     dz = _empty((N, T), dlogits)
-    dg, db = bn_backward(dy, T, sv["y"], T, sv["z"], T, sv["st"], N, dz, T, None, 0, gout,
-                         "decoder.2.")
     db1 = _gbuf(gout, "decoder.1.bias", (T,), dlogits)
-    call("cova_colsum", dz, T, N, T, db1)
+    dg, db = bn_backward(dyd, T, sv["y"], T, sv["z"], T, sv["st"], N, dz, T, None, 0, gout, "decoder.2.",
+                         drop=(sv["m2"], p) if sv["drop"] else None, colsum=db1)
     dW1 = _gbuf(gout, "decoder.1.weight", (T, T), dlogits)
     call("cova_sgemm", 1, 0, T, T, N, dz, T, sv["xd"], T, dW1, T, None, 0)
-    dxd = dy    # reuse
+    dxd = _empty((N, T), dlogits)
     call("cova_sgemm", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dxd, T, None, 0)
     if sv["drop"]:
         dx = dyd    # reuse
@@ -1153,7 +1223,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
         after_head()
     conv = sv["conv"]
     if N > 0 and sv["roi"]["zmax"] is not None:
-        dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"])
+        dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"], gout)
         grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
     else:
         dfeat = roialign_bwd(sv["roi"], dcomb, T) if sv["roi"].get("kind") == "align" else roipool_bwd(sv["roi"], dcomb, T)

@@ -122,6 +122,14 @@ int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc /*nullabl
                                 const float *dz, const float *dz2 /*nullable*/,
                                 const float *dz_abc /*nullable*/, float *dw, float *ws, int B, int H,
                                 int W, void *stream);
+/* the same in two steps, so that one launch finishes the weight gradients of several convolutions: the per-block
+ * partial sums only (own workspace per convolution) ... */
+int cova_conv3x3_wgrad_wino_partial(const float *act, const float *act_abc, int act_relu, const float *dz,
+                                    const float *dz2, const float *dz_abc, float *ws, int B, int H, int W,
+                                    void *stream);
+/* ... and the fp64 fold + final transform of up to four of them (pairs 1..3 nullable) into OIHW [64,64,3,3] */
+int cova_conv3x3_wgrad_wino_finish(const float *ws0, float *dw0, const float *ws1, float *dw1, const float *ws2,
+                                   float *dw2, const float *ws3, float *dw3, int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 
 /* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
@@ -251,6 +259,23 @@ int cova_bn_bwd_apply(const float *dout, int ldd, const float *act, int lda, con
                       const float *mean, const float *invstd, const float *scale, const float *coef,
                       float *dz, int lddz, float *dres /*nullable*/, int lddres, long long R, int C,
                       void *stream);
+/* nn.BatchNorm1d in train mode over box rows x [R,C] (models.py:68 bbox_feat_encoder.1, :73 bn_additional_feat, :86
+ * decoder.2) as ONE launch: column statistics, running-statistics update, scale/shift/mean/invstd, out = bn(x) (ReLU if
+ * `relu`), and -- dropped != NULL -- nn.Dropout(p) of the result (models.py:88; mask [R,C] generated from `seed` and
+ * stored, or taken as given), i.e. cova_colstats + cova_bn_finalize_fwd + cova_bn_act_fwd (+ cova_dropout_fwd). */
+int cova_bn1d_fwd(const float *x, int ldx, int R, int C, const float *gamma, const float *beta,
+                  float *running_mean /*nullable*/, float *running_var, long long *num_batches_tracked /*nullable*/,
+                  float momentum, float eps, int relu, float *out, int ldo, float *dropped /*nullable*/, int ld_dropped,
+                  uint8_t *mask, float p, unsigned long long seed, int mask_given, float *scale, float *shift,
+                  float *mean, float *invstd, void *stream);
+/* its backward in ONE launch: dy = dout (* drop_mask/(1-p) if drop_mask: the Dropout behind the layer) (* (act > 0) if
+ * act: the ReLU behind it); dgamma, dbeta (nullable); dz [R,C]; dz_colsum (nullable) [C] = column sums of dz (the bias
+ * gradient of the nn.Linear in front, models.py:85) -- i.e. (cova_dropout_bwd +) cova_bn_bwd_reduce +
+ * cova_bn_finalize_bwd + cova_bn_bwd_apply (+ cova_colsum).  dz must not alias dout. */
+int cova_bn1d_bwd(const float *dout, int ldg, const uint8_t *drop_mask /*nullable*/, float p,
+                  const float *act /*nullable*/, int lda, const float *z, int ldz, const float *mean,
+                  const float *invstd, const float *scale, int R, int C, float *dgamma, float *dbeta, float *dz,
+                  int lddz, float *dz_colsum /*nullable*/, void *stream);
 int cova_bn_relu_maxpool_fwd(const float *y /*[B,H1,W1,64]*/, const float *scale, const float *shift,
                              float *out /*[B,H2,W2,64]*/, uint8_t *idx,
                              float *ymax /*nullable [B,H2,W2,64]: raw y at the arg-max*/, int B, int H1,
@@ -291,6 +316,11 @@ int cova_roipool_bwd_bn(const float *gout, int ld_g, const float *pooled, int ld
                         int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
                         float *gfeat, float *partial, void *ws /*cova_roipool_bwd_workspace_words x 4 bytes*/,
                         void *stream);
+/* ... with cova_bn_finalize_bwd_abc of those sums as the tail of the entry pass (tail: host pointer, mode 2; C = 64) */
+int cova_roipool_bwd_bn_tail(const float *gout, int ld_g, const float *pooled, int ld_p, const float *zmax,
+                             const float *rois, const int32_t *argmax, int n_rois, int B, int C, int H, int W,
+                             int PH, int PW, float spatial_scale, const float *mean, const float *invstd,
+                             float *gfeat, float *partial, void *ws, const cova_bn_tail *tail, void *stream);
 /* RoIPool over relu(scale*z + shift + x) formed on the fly (last BasicBlock's bn2+residual+ReLU) */
 int cova_roipool_fwd_bn(const float *z, const float *x, const float *scale, const float *shift,
                         const float *rois, int n_rois, int B, int C, int H, int W, int PH, int PW,
@@ -335,6 +365,9 @@ int cova_gat_fwd(const float *Wh, int ldw, const float *att_w /*[2D]*/, const fl
  * scattering with float atomics (torch's index_select backward): bit-identical reruns for ANY index table. */
 int cova_gat_transpose_ints(int N, int K);
 int cova_gat_transpose(const int64_t *ctx, int N, int K, int *csr /*[cova_gat_transpose_ints]*/, void *stream);
+/* ... into a workspace kept from call to call (one per stream): the last 2N + 16 ints of csr must be zero on entry --
+ * zero the buffer once when allocating it -- and are left zero: three launches, no memsets */
+int cova_gat_transpose_reuse(const int64_t *ctx, int N, int K, int *csr, void *stream);
 /* csr + du [N,K] scratch: deterministic gather form; csr == NULL: scatter form with float atomics */
 int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, const float *s, const float *t,
                  const float *attn, const int64_t *ctx, const float *att_w, int N, int K, int D,

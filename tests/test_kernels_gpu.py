@@ -117,6 +117,68 @@ def test_batchnorm_train_fwd_bwd(R, C, relu, res):
           1e-5, "bn eval")
 
 
+@pytest.mark.parametrize("R,C,relu,drop", [(300, 64, 1, 1), (77, 16, 1, 0), (1440, 976, 1, 1), (50, 6, 0, 0),
+                                           (2100, 33, 1, 1)])
+def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop):
+    """cova_bn1d_fwd / cova_bn1d_bwd (statistics + finalize + apply, with the Dropout behind the layer and the column sums
+    of dz riding along) against torch autograd on the CPU, and against the separate-launch path they replace."""
+    g = torch.Generator().manual_seed(R + 3 * C)
+    x = (torch.randn(R, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    p = 0.3
+    keep = (torch.rand(R, C, generator=g) >= p)
+    y = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if relu:
+        y = F.relu(y)
+    yd = y * keep / (1 - p) if drop else y
+    dout = torch.randn(R, C, generator=g)
+    (yd * dout).sum().backward()
+    params = {"bn.weight": gamma.detach().to(DEV), "bn.bias": beta.detach().to(DEV)}
+    buffers = {"bn.running_mean": rm.to(DEV), "bn.running_var": rv.to(DEV),
+               "bn.num_batches_tracked": torch.zeros((), dtype=torch.long, device=DEV)}
+    xg = x.detach().to(DEV)
+    out = torch.full((R, C + 5), 9.0, device=DEV)            # ld > C: the layer writes into a wider matrix
+    mask = keep.to(torch.uint8).to(DEV)
+    assert engine.bn1d_fused(True)
+    if drop:
+        st, dropped, m = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + 5, relu, drop=(p, 0, mask))
+        close(dropped, yd, 1e-5, "bn1d dropped")
+        assert m is mask
+    else:
+        st = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + 5, relu)
+    close(out[:, :C], y, 1e-5, "bn1d fwd")
+    assert (out[:, C:] == 9.0).all()
+    close(buffers["bn.running_mean"], rm_ref, 1e-5, "running_mean")
+    close(buffers["bn.running_var"], rv_ref, 1e-5, "running_var")
+    assert int(buffers["bn.num_batches_tracked"]) == 1
+    # against the three launches it replaces: same fp64 finalize, statistics summed in another order
+    part, n = engine.colstats(xg, C, R, C)
+    b2 = {k: (rm.to(DEV) if "mean" in k else rv.to(DEV) if "var" in k else torch.zeros((), dtype=torch.long, device=DEV))
+          for k in buffers}
+    st2 = engine.bn_params("bn.", params, b2, C, xg, True, part, n, R)
+    close(st.scale, st2.scale, 2e-6, "scale")
+    close(st.mean, st2.mean, 2e-6, "mean")
+    dz = torch.empty(R, C, device=DEV)
+    colsum = torch.empty(C, device=DEV)
+    dg, db = engine.bn_backward(dout.to(DEV), C, out if relu else None, C + 5, xg, C, st, R, dz, C,
+                                drop=(mask, p) if drop else None, colsum=colsum)
+    close(dz, x.grad, 1e-4, "bn1d dz")
+    close(dg, gamma.grad, 1e-4, "bn1d dgamma")
+    close(db, beta.grad, 1e-4, "bn1d dbeta")
+    assert float((colsum - dz.sum(0)).abs().max()) <= 1e-4 * max(float(dz.abs().max()), 1.0) * (R ** 0.5)
+    # generated mask: the same stream as cova_dropout_fwd
+    if drop:
+        gen = torch.empty(R, C, dtype=torch.uint8, device=DEV)
+        o2, d2 = torch.empty(R, C, device=DEV), torch.empty(R, C, device=DEV)
+        call("cova_bn1d_fwd", xg, C, R, C, params["bn.weight"], params["bn.bias"], None, None, None, 0.1, 1e-5, relu, o2, C,
+             d2, C, gen, p, 1234, 0, st.scale, st.shift, st.mean, st.invstd)
+        ref_o, ref_m = engine.dropout_fwd(o2, C, R, C, p, 1234)
+        assert torch.equal(gen, ref_m) and torch.equal(d2, ref_o)
+
+
 @pytest.mark.parametrize("B,H1,W1", [(1, 8, 8), (2, 13, 21), (1, 32, 32)])
 def test_bn_relu_maxpool(B, H1, W1):
     g = torch.Generator().manual_seed(H1 * 7 + W1)
@@ -211,6 +273,16 @@ def test_roipool_matches_oracle_bit_exact():
     close(gmask, ref_masked, 1e-5, "roipool bwd masked")
     close(part[:, 0].sum(0), ref_masked.sum((0, 1, 2)), 1e-4, "roipool bwd sum dy")
     close(part[:, 1].sum(0), (ref_masked * ((z - mean) * invstd)).sum((0, 1, 2)), 1e-4, "roipool bwd sum dy*xhat")
+    # the BatchNorm-backward finalize as the entry pass's tail: bit-identical to the separate launch
+    st = engine.bn_state(C, z, B * H * W, True)
+    st.mean.copy_(mean), st.invstd.copy_(invstd), st.scale.copy_(scale)
+    dg_r, db_r, abc_r = engine._bn_abc_from_partials(part, npart, st, B * H * W, None, "x.", z)
+    dg_t, db_t, abc_t, tail = engine.bn_tail_bwd(st, B * H * W, None, "x.", z)
+    part_t, gmask_t = torch.empty_like(part), torch.empty_like(gmask)
+    call("cova_roipool_bwd_bn_tail", gout.to(DEV), 576, out_l, 576, zmax, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25,
+         mean, invstd, gmask_t, part_t, scratch, tail.ptr)
+    assert torch.equal(gmask_t, gmask) and torch.equal(part_t, part)
+    assert torch.equal(abc_t, abc_r) and torch.equal(dg_t, dg_r) and torch.equal(db_t, db_r)
     # memory safety: page indices outside [0, B) pool nothing and scatter nothing
     bad = rois.clone()
     bad[::7, 0] = float(B + 3)
@@ -676,6 +748,14 @@ def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
             call("cova_conv3x3_wgrad_wino_pro", x, abc_a if pa else None, 1, dy, z if pd else None,
                  abc_d if pd else None, dw, ws, B, H, W)
             close(dw, ref, 2e-6, "wgrad affine-on-load %s %s" % (pa, pd))
+        # two-step form: partial sums of two convolutions in two workspaces, ONE finish launch -- bit-identical
+        ws2 = torch.empty_like(ws)
+        dwa, dwb, refb = torch.zeros_like(dw), torch.zeros_like(dw), torch.zeros_like(dw)
+        call("cova_conv3x3_wgrad_wino_pro", x, None, 0, dz, None, None, refb, ws, B, H, W)
+        call("cova_conv3x3_wgrad_wino_partial", x, None, 0, dy, None, None, ws, B, H, W)
+        call("cova_conv3x3_wgrad_wino_partial", x, None, 0, dz, None, None, ws2, B, H, W)
+        call("cova_conv3x3_wgrad_wino_finish", ws, dwa, ws2, dwb, None, None, None, None, B, H, W)
+        assert torch.equal(dwa, dw) and torch.equal(dwb, refb)
     finally:
         query("cova_set_option", 2, 0)
 
@@ -769,6 +849,13 @@ def test_gat_backward_gather_is_deterministic_for_arbitrary_graphs(kind):
         lo, hi = csr[j], csr[j + 1]
         assert np.array_equal(csr[N + 1 + lo:N + 1 + hi], np.nonzero(flat == j)[0])
     assert csr[N] == int((flat >= 0).sum())
+    # the reused-workspace form (3 launches, counters left zero) equals the memset form, call after call
+    E, used = N * K, N + 1 + int(csr[N])                    # (slots behind the last edge are never written)
+    one = torch.empty(query("cova_gat_transpose_ints", N, K), dtype=torch.int32, device=DEV)
+    call("cova_gat_transpose", ctx.to(DEV), N, K, one)
+    assert np.array_equal(one.cpu().numpy()[:used], csr[:used])
+    assert np.array_equal(engine.gat_transpose(ctx.to(DEV)).cpu().numpy()[:used], csr[:used])
+    assert int(engine.gat_transpose(ctx.to(DEV))[N + 1 + 2 * E:].abs().sum()) == 0
 
 
 def test_roipool_backward_rows_are_deterministic_and_cover_the_map():

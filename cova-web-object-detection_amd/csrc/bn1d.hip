@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int COLS = 16, SLICES = 64, RUN = 32;      // block = 16 columns x 64 row slices (the launch is latency bound:
-                                                     // rows in flight are what counts); fp32 runs of 32 rows, fp64 across
+                                                     // rows in flight are what counts); RUN: fp32 runs of the dz column sums
 constexpr int THREADS = COLS * SLICES;
 
 // fixed-order fp64 total of the 16 slices' sums (deterministic: no atomics)
@@ -46,20 +46,17 @@ __global__ __launch_bounds__(THREADS) void bn1d_fwd_kernel(
     __shared__ float s_sc[COLS], s_sh[COLS];
     const int tx = threadIdx.x & (COLS - 1), ty = threadIdx.x / COLS;
     const int c = blockIdx.x * COLS + tx;
+    // sums and squares in fp64 from the first add on (the matrices are small and the fp64 rate is not the limit here):
+    // the variance E[x^2] - mean^2 then carries no fp32 summation noise
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r0 = ty; r0 < R; r0 += SLICES * RUN) {
-            float s = 0.f, q = 0.f;
-            const int r1 = min(R, r0 + SLICES * RUN);
+    if (c < C) {
 #pragma unroll 4
-            for (int r = r0; r < r1; r += SLICES) {
-                const float v = x[(size_t)r * ldx + c];
-                s += v;
-                q += v * v;
-            }
-            a += (double)s;
-            b += (double)q;
+        for (int r = ty; r < R; r += SLICES) {
+            const double v = (double)x[(size_t)r * ldx + c];
+            a += v;
+            b = fma(v, v, b);
         }
+    }
     double ta, tb;
     slices_total(s_a, s_b, tx, ty, a, b, ta, tb);
     if (ty == 0 && c < C) {
@@ -109,19 +106,14 @@ __global__ __launch_bounds__(THREADS) void bn1d_bwd_kernel(
         return g;
     };
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r0 = ty; r0 < R; r0 += SLICES * RUN) {
-            float s = 0.f, q = 0.f;
-            const int r1 = min(R, r0 + SLICES * RUN);
+    if (c < C) {
 #pragma unroll 4
-            for (int r = r0; r < r1; r += SLICES) {
-                const float g = dy_at(r);
-                s += g;
-                q += g * ((z[(size_t)r * ldz + c] - mu) * is);
-            }
-            a += (double)s;
-            b += (double)q;
+        for (int r = ty; r < R; r += SLICES) {
+            const float g = dy_at(r);
+            a += (double)g;
+            b = fma((double)g, (double)((z[(size_t)r * ldz + c] - mu) * is), b);    // xhat in fp32, as the apply pass forms it
         }
+    }
     double ta, tb;
     slices_total(s_a, s_b, tx, ty, a, b, ta, tb);
     if (ty == 0 && c < C) {

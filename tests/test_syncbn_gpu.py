@@ -131,16 +131,17 @@ def _check_syncbn(r0, r1, ref, arch):
         g_ref = ref["grads"][i]
         scale = float(g_ref.abs().max())
         d = (r0["grads"][i] - g_ref).double().abs()
-        if arch == "resnet18":
-            assert float(d.max()) <= 2e-4 * scale, (i, float(d.max()) / scale)
-        else:
-            # The deeper stack takes ~4x more ReLU decisions, and the two runs' BatchNorm parameters differ in the last
-            # bit (all-reduced fp32 rows vs one fp64 fold): a pre-activation within 1e-7 of zero may gate differently
-            # and moves a handful of gradient entries by ~1e-3 of the scale.  The bulk (99 % of the
-            # entries) is held to the tight bound, 99.9 % to 1e-3 (measured 2.2e-4), the peak to a loose one.
-            assert float(torch.quantile(d[::7].float(), 0.99)) <= 2e-4 * scale, i
-            assert float(torch.quantile(d[::7].float(), 0.999)) <= 1e-3 * scale, i
-            assert float(d.max()) <= 5e-3 * scale, i
+        # The two runs finalize their BatchNorm statistics in different kernels (the single process in the producing
+        # launches' tails and the one-launch BatchNorm1d, the ranks in stand-alone kernels around the all-reduce of the
+        # fp32 rows): their scale / shift agree to ~1e-5 (E[x^2] - mean^2 in fp64 from fp32 partial sums), so a
+        # pre-activation within ~1e-7 of zero may gate differently and moves a handful of gradient entries by ~1e-3 of
+        # the scale (tools/tail_ab.py shows the case this batch hits: ONE of the decoder's 66,560
+        # ReLU gates, at y = 3e-8, which moves one row of decoder.1.weight's gradient).  The bulk is held to the tight
+        # bound, the peak to a loose one; the deeper stack takes ~4x more ReLU decisions.
+        bulk = 0.999 if arch == "resnet18" else 0.99
+        assert float(torch.quantile(d[::7].float(), bulk)) <= 2e-4 * scale, (i, arch)
+        assert float(torch.quantile(d[::7].float(), 0.999)) <= 1e-3 * scale, i
+        assert float(d.max()) <= 5e-3 * scale, (i, float(d.max()) / scale)
     # state after the last step: each step started from identical parameters, so one Adam step separates the runs
     for k, v in ref["sd"].items():
         if not v.is_floating_point():

@@ -14,6 +14,6 @@ for path in args:
     print("%-50s %-34s %6s %16s %12s" % ("kernel", "counter", "calls", "avg" if raw else "avg/1024", "avg_us"))
     for n, c, k, v, d in rows:
         n = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:50]
-        if raw and ("wino" not in n and "conv" not in n):
+        if raw and ("wino" not in n and "conv" not in n and "roipool" not in n):
             continue
         print("%-50s %-34s %6d %16.1f %12.1f" % (n, c, k, v if raw else v / 1024.0, d / 1e3))

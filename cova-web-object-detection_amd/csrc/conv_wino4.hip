@@ -15,11 +15,13 @@
 //     per tile (8 KB per wave);
 //   * with 72 accumulator registers there is room to keep the transformed WEIGHTS out of LDS altogether: a wave's
 //     operand U[16 co][8 ci][18 positions] is 36 registers per 8-channel chunk, fetched straight from L2
-//     (9 global_load_dwordx4 per wave and chunk, 1 KB contiguous each: the prep kernel writes the register image) with a
-//     lead of TWO chunks (72 registers);
+//     (9 global_load_dwordx4 per wave and chunk, 1 KB contiguous each: the prep kernel writes the register image), each
+//     quad re-requested for the next chunk right after its last MFMA (a two-chunk lead, 72 registers, measured no
+//     faster);
 //   * the transformed input V = B^T d B is formed once per block through LDS in two stages (column stage, row stage:
 //     768 + 768 six-point transforms per 8-channel chunk, three per thread), from planes that arrive as
-//     global -> LDS copies (global_load_lds_dwordx4: no registers);
+//     global -> LDS copies (global_load_lds_dwordx4: no registers), 16 channels = 64 contiguous bytes per pixel and
+//     lane quad (16 bytes per pixel and lane made every wave instruction touch 64 cache lines: -10 % on the launch);
 //   * ONE block barrier per 8-channel chunk: column stage (chunk g+2), row stage (chunk g+1) and the 36 MFMAs of chunk g
 //     run in the same iteration on double-buffered intermediates.
 // LDS traffic per 8-channel chunk and 16 tiles: 74 KB of V operand reads + 73 KB of stage traffic + 11 KB of copies

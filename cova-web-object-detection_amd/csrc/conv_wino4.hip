@@ -36,20 +36,6 @@
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
-#ifndef W4_SCHED
-#define W4_SCHED 0
-#endif
-#ifndef W4_LEAD2
-#define W4_LEAD2 0
-#endif
-#ifndef W4_WEAVE
-#define W4_WEAVE 0
-#endif
-#if W4_SCHED
-#define W4_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define W4_SB() do {} while (0)
-#endif
 
 namespace {
 
@@ -370,10 +356,11 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     const char *ubase = reinterpret_cast<const char *>(a.u) + (size_t)wave * (9 * 1024);
     const unsigned ulane = (unsigned)lane * 16u;
     auto u_ptr = [&](int s) { return ubase + (size_t)((W4_ABL & 128) ? 0 : (s & 7)) * (8 * 9 * 1024); };
-    // Lead of the weights: quads 0-4 (MFMAs 0-19) are requested TWO chunks ahead into Ea / Eb (even / odd chunks), quads
-    // 5-8 one chunk ahead into L: 56 registers instead of 72, and the plane copies -- forced to completion by the first
-    // wait on a younger load, vmcnt being in-order -- still get about one and a half iterations of flight.
-    float Ea[20], Eb[20], L[16];
+    // Lead of the weights: every quad is re-requested for the NEXT chunk right after its last MFMA (36 registers: E =
+    // quads 0-4, L = quads 5-8).  Measured against it: quads 0-4 two chunks ahead (56 registers) and all quads two chunks
+    // ahead (72) -- no faster; the plane copies, forced to completion by the first wait on a younger load (vmcnt is
+    // in-order), have one to two iterations of flight either way.
+    float Ea[20], L[16];
     auto load_quads = [&](float *U, int s, const int q0, const int q1, const int base) {
         const char *p = u_ptr(s);
 #pragma unroll
@@ -388,7 +375,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     copy_group(0, 0);
     copy_group(1, 1);
     load_quads(Ea, 0, 0, 5, 0);
-    if (W4_LEAD2) load_quads(Eb, 1, 0, 5, 0);
     load_quads(L, 0, 5, 9, 20);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -436,13 +422,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const int slot2 = ((g + 2) >> 1) & 1, coff2 = 8 * (g & 1);      // the planes of chunk g + 2 (this iteration's column stage)
         if (PRO && ((g + 2) & 7) == 0) row_masks((g + 2) >> 3);
         const int s2 = (g + 2) & 7;
-        // wave-uniform weight bases in scalar registers (global_load with an SGPR base + this lane's offset): chunk g + 2
-        // for the early quads, chunk g + 1 for the late ones; one base per 4 KB of immediate-offset range
+        // wave-uniform weight bases of chunk g + 1 in scalar registers (global_load with an SGPR base + this lane's offset);
+        // one base per 4 KB of immediate-offset range
         // (the opaque offsets keep the compiler from re-associating the bases into one base + offsets beyond the
         //  immediate range; the pointers themselves stay derived from the kernel argument: global, not flat, loads)
         unsigned o4k = 4096, o8k = 8192;
         asm volatile("" : "+s"(o4k), "+s"(o8k));
-        const char *ue = u_ptr(g + (W4_LEAD2 ? 2 : 1)), *ue1 = ue + o4k, *ul1 = u_ptr(g + 1) + o4k, *ul2 = u_ptr(g + 1) + o8k;
+        const char *ue = u_ptr(g + 1), *ue1 = ue + o4k, *ul1 = u_ptr(g + 1) + o4k, *ul2 = u_ptr(g + 1) + o8k;
         unsigned ul = ulane;
         asm volatile("" : "+v"(ul));         // keeps (uniform base) + (lane offset) apart: LICM would fold the lane offset into
                                              // a 64-bit VGPR base and every load would need vector address arithmetic
@@ -459,9 +445,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
             for (int p = 0; p < 18; ++p) v[kg][p] = t[p];
         };
-        // MFMAs idx0 .. idx1-1 of the chunk (idx = kg*18 + p); a weight quad is re-requested right after its last use.  The
-        // scheduling barriers keep the weight loads SPREAD between the MFMAs: clustered (the compiler's choice) the 72
-        // loads of a CU queue up on its address path and every wave stalls behind them.
+        // MFMAs idx0 .. idx1-1 of the chunk (idx = kg*18 + p); a weight quad is re-requested right after its last use, so
+        // the nine loads of a chunk are spread between the MFMAs.
         auto mfma_range = [&](const int idx0, const int idx1) {
             if (W4_ABL & 4) return;
 #pragma unroll
@@ -474,33 +459,27 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     const float4 t = *reinterpret_cast<const float4 *>(bp + (q & 3) * 1024 + ul);
                     float *U = q < 5 ? &E[4 * q] : &L[4 * q - 20];
                     U[0] = t.x; U[1] = t.y; U[2] = t.z; U[3] = t.w;
-                    W4_SB();
                 }
             }
         };
-        // Order (pinned by the scheduling barriers; register pressure decides it): one stage item in flight at a time, its
-        // reads issued four MFMAs before its transform; the second V group is requested before the last item's transform,
-        // whose vector instructions cover its latency.
-        if constexpr (PRO != 0 || W4_WEAVE) {      // one stage item in flight (prologue variants: register pressure)
+        // Order: the prologue variants keep ONE stage item in flight (register pressure), its reads issued four MFMAs before
+        // its transform, the second V group requested before the last item's transform; the plain variant reads all three
+        // items up front (measured equal or faster there).  The compiler's schedule inside these groups measured equal
+        // to one pinned with scheduling barriers.
+        if constexpr (PRO != 0) {
         Item it;
         read_v(0);
-        W4_SB();
         mfma_range(0, 4);
         item_read(0, it, slot2, coff2, tmp_w, tmp_r, v_w);
-        W4_SB();
         mfma_range(4, 8);
         item_finish(0, it, s2);
         item_read(1, it, slot2, coff2, tmp_w, tmp_r, v_w);
-        W4_SB();
         mfma_range(8, 12);
         item_finish(1, it, s2);
         item_read(2, it, slot2, coff2, tmp_w, tmp_r, v_w);
-        W4_SB();
         mfma_range(12, 16);
         read_v(1);
-        W4_SB();
         item_finish(2, it, s2);
-        W4_SB();
         mfma_range(16, 36);
         } else {                                    // all three items' reads up front
         Item it0, it1, it2;
@@ -508,14 +487,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         item_read(1, it1, slot2, coff2, tmp_w, tmp_r, v_w);
         item_read(2, it2, slot2, coff2, tmp_w, tmp_r, v_w);
         read_v(0);
-        W4_SB();
         mfma_range(0, 16);
         read_v(1);
         mfma_range(16, 18);
         item_finish(0, it0, s2);
         item_finish(1, it1, s2);
         item_finish(2, it2, s2);
-        W4_SB();
         mfma_range(18, 36);
         }
         wait_planes(g);
@@ -709,7 +686,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll 1
     for (int g = 0; g < G; g += 2) {
         iteration(g, std::integral_constant<int, 0>{}, Ea);
-        iteration(g + 1, std::integral_constant<int, 1>{}, W4_LEAD2 ? Eb : Ea);
+        iteration(g + 1, std::integral_constant<int, 1>{}, Ea);
         if ((g & 7) == 6) tile_epilogue(g >> 3);
     }
     if (STATS) {        // one partial row [sum 64 | second kind 64] per block; a channel's two position halves are added

@@ -50,6 +50,10 @@ struct C11Args {
     // SIDE: the prologue's result f(A*in + B*in2 + C) is also written here ([R][Cin]): the consumer of a
     // Bottleneck output materialises it (relu(bn3(z3) + x)) while it reads its operands anyway
     float *side;
+    // ... and its ReLU decisions as one bit per element ([R][Cin/32] words, bit = channel & 31; nullable): the data
+    // gradient that needs this map only as a mask source reads 1/32 of the bytes
+    unsigned *side_bits;
+    const unsigned *act_bits;             // mask source of the EPI 3 epilogue in that form (instead of `act`)
 };
 
 template <int CIN, int COUT, bool EXT = false>
@@ -173,6 +177,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                     make_float4(e[0], e[1], e[2], e[3]);
         }
     };
+    // SIDE: the ReLU decisions of a chunk's 32 values as one word (bit = channel & 31).  x = relu(.) >= +0 here (the
+    // materialising launch always applies the ReLU), so x > 0 <=> its bit pattern != 0: min(bits, 1), no compare
+    auto pack_bits = [&](const float (&x)[32]) {
+        unsigned word = 0u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) word |= min(__float_as_uint(x[i]), 1u) << i;
+        return word;
+    };
 
     // Cross-tile operand prefetch, except in the 256-channel data-gradient variants: those move ~5x more
     // bytes in their epilogue (addend / mask / xhat operands) than through the MFMA operand, are bound by
@@ -209,6 +221,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             for (int c = 0; c < TC; ++c) {
                 if (TC > 1) {
                     prologue(tile, c, nv, nv2, x);
+                    if (SIDE && CIN == 256 && a.side_bits != nullptr && tile * 32 + p < a.R)     // (a lane owns one word per chunk)
+                        a.side_bits[(size_t)(tile * 32 + p) * (CIN / 32) + h * 4 + c] = pack_bits(x);
                     // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
                     if (c + 1 < TC) issue(tile, c + 1, nv, nv2);
                     else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
@@ -246,15 +260,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
 #pragma unroll
                 for (int nn = 0; nn < G::NTP; nn += 2) {       // two accumulators = 8 float4 per tensor in flight
                     float4 ad[2][4], mk[2][4];
+                    const bool bits = a.act_bits != nullptr;          // (wave-uniform)
+                    unsigned mb[2] = {0u, 0u};
                     if (EPI == 3) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
+                        for (int u = 0; u < 2; ++u) {
+                            if (bits) mb[u] = a.act_bits[(size_t)row * (COUT / 32) + ps * G::NTP + nn + u] >> (4 * h);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const size_t o = rbase + (ps * G::NTP + nn + u) * 32 + 8 * j;
                                 if (HAS_ADD) ad[u][j] = *reinterpret_cast<const float4 *>(a.addend + o);
-                                mk[u][j] = *reinterpret_cast<const float4 *>(a.act + o);
+                                if (bits) {            // bit 8j + 4h + k of the word = channel 32n + 8j + 4h + k
+                                    const unsigned q = mb[u] >> (8 * j);
+                                    mk[u][j] = make_float4((float)(q & 1u), (float)((q >> 1) & 1u), (float)((q >> 2) & 1u),
+                                                           (float)((q >> 3) & 1u));
+                                } else {
+                                    mk[u][j] = *reinterpret_cast<const float4 *>(a.act + o);
+                                }
                             }
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -611,21 +635,22 @@ COVA_API int cova_conv1x1_num_partials(long long R, int Cin, int Cout)
 // stat_part2 (with z2/mean2/invstd2): (sum dy, sum dy*xhat2) of a second BatchNorm fed by the same dy.
 COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_abc, int pro_relu,
                           const float *w, int w_trans, const float *addend, const float *act,
-                          const float *mask_scale, const float *mask_shift, const float *z,
+                          const unsigned *act_bits, const float *mask_scale, const float *mask_shift, const float *z,
                           const float *mean, const float *invstd, const float *z2, const float *mean2,
                           const float *invstd2, float *out, float *stat_part, float *stat_part2,
                           long long R, int Cin, int Cout, void *stream)
 {
     COVA_REQUIRE(in && w && out && R > 0);
     COVA_REQUIRE(!in2 || pro_abc);
+    COVA_REQUIRE(!act_bits || !z);           // the bit form only feeds the sum-free data gradient
     const int pro = !pro_abc ? 0 : (in2 ? 2 : 1);
     int epi = 0;
     if (z) {
         COVA_REQUIRE(mean && invstd && stat_part && (act || (mask_scale && mask_shift)));
         COVA_REQUIRE(!z2 || (mean2 && invstd2 && stat_part2));
         epi = 2;
-    } else if (act) {        // masked data gradient whose BatchNorm sums are taken elsewhere (conv1x1_lin.hip)
-        COVA_REQUIRE(!z2 && !stat_part && Cout == 256);
+    } else if (act || act_bits) {        // masked data gradient whose BatchNorm sums are taken elsewhere (conv1x1_lin.hip)
+        COVA_REQUIRE(!z2 && !stat_part && Cout == 256 && !(act && act_bits));
         epi = 3;
     } else {
         COVA_REQUIRE(!addend && !z2);
@@ -633,13 +658,14 @@ COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_ab
     }
     const C11Args a{in, in2, pro_abc, w, addend, act, mask_scale, mask_shift, z, mean, invstd, z2, mean2,
                     invstd2, out, stat_part, stat_part2, R, pro_relu, w_trans,
-                    nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+                    nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, act_bits};
+    const bool masked = act != nullptr || act_bits != nullptr;
     const int grid = c11_grid(R);
     hipStream_t st = (hipStream_t)stream;
     int rc = COVA_ERR_BAD_ARG;
-    if (Cin == 64 && Cout == 64) rc = launch_c11<64, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
-    else if (Cin == 64 && Cout == 256) rc = launch_c11<64, 256>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
-    else if (Cin == 256 && Cout == 64) rc = launch_c11<256, 64>(a, epi, addend != nullptr, act != nullptr, z2 != nullptr, pro, grid, st);
+    if (Cin == 64 && Cout == 64) rc = launch_c11<64, 64>(a, epi, addend != nullptr, masked, z2 != nullptr, pro, grid, st);
+    else if (Cin == 64 && Cout == 256) rc = launch_c11<64, 256>(a, epi, addend != nullptr, masked, z2 != nullptr, pro, grid, st);
+    else if (Cin == 256 && Cout == 64) rc = launch_c11<256, 64>(a, epi, addend != nullptr, masked, z2 != nullptr, pro, grid, st);
     if (rc != COVA_OK) return rc;
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -649,12 +675,16 @@ COVA_API int cova_conv1x1(const float *in, const float *in2, const float *pro_ab
 // relu(A*in + B*in2 + C) = relu(bn3(z3) + identity-or-downsample branch), formed on load AND written to `side`
 // [R,256]: the block output is materialised by its first consumer instead of by an element-wise pass
 // (cova_bn_act_fwd / cova_bn_act2_fwd: one read of the 256-channel map less).
+// side_bits (nullable) [R][8] words: the map's ReLU decisions, bit (c & 31) of word c >> 5 = (side[r][c] > 0) -- what
+// cova_conv1x1's `act_bits` reads.
 COVA_API int cova_conv1x1_materialize(const float *in, const float *in2, const float *pro_abc, const float *w,
-                                      float *side, float *out, float *stat_part, long long R, void *stream)
+                                      float *side, unsigned *side_bits, float *out, float *stat_part, long long R,
+                                      void *stream)
 {
     COVA_REQUIRE(in && in2 && pro_abc && w && side && out && R > 0);
     const C11Args a{in, in2, pro_abc, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                    nullptr, nullptr, out, stat_part, nullptr, R, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, side};
+                    nullptr, nullptr, out, stat_part, nullptr, R, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, side,
+                    side_bits, nullptr};
     const int rc = launch_c11<256, 64>(a, stat_part ? 1 : 0, false, false, false, 2, c11_grid(R), (hipStream_t)stream);
     if (rc != COVA_OK) return rc;
     COVA_LAUNCH_CHECK();
@@ -683,7 +713,8 @@ COVA_API int cova_conv1x1_lin_dgrad(const float *v, const float *avec, const flo
     COVA_REQUIRE(v && avec && w && act && act_abc && m && cvec && out && R > 0);
     COVA_REQUIRE(mask_scale && mask_shift && z && mean && invstd && stat_part);
     const C11Args a{v, nullptr, avec, w, addend, nullptr, mask_scale, mask_shift, z, mean, invstd, nullptr,
-                    nullptr, nullptr, out, stat_part, nullptr, R, 0, 1, act, act_abc, m, cvec, act_relu, nullptr};
+                    nullptr, nullptr, out, stat_part, nullptr, R, 0, 1, act, act_abc, m, cvec, act_relu, nullptr, nullptr,
+                    nullptr};
     const int grid = cova_conv1x1_lin_dgrad_num_partials(R);
     hipStream_t st = (hipStream_t)stream;
     if (addend)

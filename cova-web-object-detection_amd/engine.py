@@ -477,8 +477,8 @@ C256 = 4 * C64
 
 
 def conv1x1(inp, in2, abc, relu, w, w_trans, out, part, R, cin, cout, addend=None, act=None, msc=None,
-            msh=None, z=None, mean=None, invstd=None, z2=None, mean2=None, invstd2=None, part2=None):
-    call("cova_conv1x1", inp, in2, abc, 1 if relu else 0, w, 1 if w_trans else 0, addend, act, msc, msh,
+            msh=None, z=None, mean=None, invstd=None, z2=None, mean2=None, invstd2=None, part2=None, act_bits=None):
+    call("cova_conv1x1", inp, in2, abc, 1 if relu else 0, w, 1 if w_trans else 0, addend, act, act_bits, msc, msh,
          z, mean, invstd, z2, mean2, invstd2, out, part, part2, R, cin, cout)
 
 
@@ -510,8 +510,10 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
             # the block input is materialised by its first consumer (one pass over the 256-channel map less
             # than a separate bn + residual + ReLU kernel)
             x = _empty((B, H2, W2, C256), p1)
+            # ... together with its ReLU decisions, one bit per element: the mask source of this block's input gradient
+            s["x_bits"] = _empty((R, C256 // 32), p1, torch.int32) if training else None
             call("cova_conv1x1_materialize", pending[0], pending[1], pending[2], params[pre + "conv1.weight"], x,
-                 s["z1"], part, R)
+                 s["x_bits"], s["z1"], part, R)
             blocks[-1]["out"] = x
         s["x"] = x
         s["bn1"] = bn(pre + "bn1.", C64, part, n)
@@ -636,7 +638,10 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
             # gradient w.r.t. the previous block's output = conv1's data gradient + the identity branch,
             # masked by that output's ReLU (its BatchNorm sums are taken by the next iteration's v^T a)
             dx = _empty((B, H2, W2, C256), g)
-            conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, None, R, C64, C256, addend=g, act=s["x"])
+            if s.get("x_bits") is not None:
+                conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, None, R, C64, C256, addend=g, act_bits=s["x_bits"])
+            else:
+                conv1x1(dy1, s["z1"], abc1, 0, w1, 1, dx, None, R, C64, C256, addend=g, act=s["x"])
             g = dx
         else:
             # downsample branch (64->256 conv + BatchNorm on the block input p1), linear form as well; then

@@ -171,20 +171,25 @@ int cova_conv3x3_wino4_full_tail(const float *in, const float *in2 /*nullable*/,
  * weight it is).  Prologue / epilogue arguments as cova_conv3x3_wino_pro; stat_part
  * [cova_conv1x1_num_partials][2][Cout] = (sum y, sum y^2) when z == NULL, else (sum dy, sum dy*xhat);
  * z2/mean2/invstd2 + stat_part2: a second BatchNorm (the downsample branch) fed by the same dy.
- * z == NULL with act != NULL (Cout = 256): (acc + addend) * [act > 0] without sums (taken by cova_conv1x1_vprod). */
+ * z == NULL with act != NULL (Cout = 256): (acc + addend) * [act > 0] without sums (taken by cova_conv1x1_vprod);
+ * the same with act_bits [R][8] words instead of act: bit (c & 31) of word c >> 5 = the decision for channel c, as
+ * written by cova_conv1x1_materialize (1/32 of the mask source's bytes). */
 int cova_conv1x1_num_partials(long long R, int Cin, int Cout);
 int cova_conv1x1(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable [3,Cin]*/,
                  int pro_relu, const float *w, int w_trans, const float *addend /*nullable*/,
-                 const float *act /*nullable*/, const float *mask_scale /*nullable*/,
+                 const float *act /*nullable*/, const uint32_t *act_bits /*nullable*/,
+                 const float *mask_scale /*nullable*/,
                  const float *mask_shift /*nullable*/, const float *z /*nullable*/,
                  const float *mean /*nullable*/, const float *invstd /*nullable*/,
                  const float *z2 /*nullable*/, const float *mean2 /*nullable*/,
                  const float *invstd2 /*nullable*/, float *out, float *stat_part /*nullable*/,
                  float *stat_part2 /*nullable*/, long long R, int Cin, int Cout, void *stream);
 /* cova_conv1x1 (256 -> 64, forward; stat_part as there, nullable) on relu(A*in + B*in2 + C), which is also
- * written to side [R,256]: the first consumer of a Bottleneck output materialises it */
+ * written to side [R,256]: the first consumer of a Bottleneck output materialises it -- and (side_bits nullable,
+ * [R][8] words) its ReLU decisions as one bit per element */
 int cova_conv1x1_materialize(const float *in, const float *in2, const float *pro_abc /*[3,256]*/, const float *w,
-                             float *side, float *out, float *stat_part /*nullable*/, long long R, void *stream);
+                             float *side, uint32_t *side_bits, float *out, float *stat_part /*nullable*/, long long R,
+                             void *stream);
 /* dw [Co,Ci] = sum_r (dz_abc[0]*dz + dz_abc[1]*dz2 + dz_abc[2])[r,co] * relu?(act_abc[0]*act + act_abc[2])[r,ci];
  * (Co,Ci) in {(64,64),(256,64),(64,256)}; ws >= cova_conv1x1_wgrad_workspace_floats */
 int cova_conv1x1_wgrad_workspace_floats(long long R, int Co, int Ci);

@@ -231,8 +231,21 @@ def test_conv1x1_materializing_consumer(R):
     for stats in (True, False):
         side, out = torch.full((R, 256), 9.0, device=DEV), torch.empty((R, 64), device=DEV)
         part = torch.empty((n, 2, 64), device=DEV) if stats else None
-        call("cova_conv1x1_materialize", d(z), d(x), d(abc), d(w), side, out, part, R)
+        bits = torch.zeros((R, 8), dtype=torch.int32, device=DEV) if stats else None
+        call("cova_conv1x1_materialize", d(z), d(x), d(abc), d(w), side, bits, out, part, R)
         close(side, a, 1e-6, "materialised input")
+        if bits is not None:      # one bit per element: bit (c & 31) of word c >> 5 = (side[r, c] > 0)
+            sh = torch.arange(32, device=DEV, dtype=torch.int32).view(1, 1, 32)
+            got = ((bits.view(R, 8, 1) >> sh) & 1).view(R, 256).bool()
+            assert torch.equal(got, side > 0)
+            # ... and the data gradient that takes its mask from them equals the one reading the map
+            rs2 = np.random.RandomState(R + 1)
+            dy, zin, add = rnd(rs2, R, 64), rnd(rs2, R, 64), rnd(rs2, R, 256)
+            abc2, w2 = rnd(rs2, 3, 64), rnd(rs2, 64, 256, scale=0.1)
+            o_act, o_bits = torch.empty((R, 256), device=DEV), torch.empty((R, 256), device=DEV)
+            engine.conv1x1(d(dy), d(zin), d(abc2), 0, d(w2), 1, o_act, None, R, 64, 256, addend=d(add), act=side)
+            engine.conv1x1(d(dy), d(zin), d(abc2), 0, d(w2), 1, o_bits, None, R, 64, 256, addend=d(add), act_bits=bits)
+            assert torch.equal(o_act, o_bits)
         # the product is taken on exactly the values that were written
         close(out, side.cpu().double() @ w.double().t(), 2e-5, "conv on the materialised input")
         if stats:

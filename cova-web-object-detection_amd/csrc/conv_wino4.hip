@@ -103,6 +103,17 @@ __device__ __attribute__((aligned(256))) float g_w4_zero_page[64];
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Sum over the 16 lanes of a wave that share (lane & 3); every lane ends up with its class's total.  Two v_add_f32 with
+// DPP operands inside the 16-lane rows (row_ror:4, row_ror:8), two cross-row exchanges.
+__device__ __forceinline__ float quad_class_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // global -> LDS copy of 16 bytes per lane (lane i lands at lds_base + 16 i; lds_base wave-uniform) as inline asm:
 // the compiler then neither knows the copy (no conservative vmcnt(0) in front of every later LDS read, which the
 // builtin gets unless each buffer is its own __shared__ object) nor waits for it -- every wait on these copies is
@@ -499,10 +510,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         lds_barrier();
     };
 
-    // ---- tile epilogue: output transform Y = A^T M A.  This wave holds M[i = 3 ph + il][j] for (channels co0..co0+3,
+    // ---- tile epilogue: output transform Y = A^T M A.  This wave holds M[i = 3 ph + il][j] for (channels cog*16 + kq*4 .. +3,
     // tile l15); A^T over j in registers, then the partial sums over its three rows i for all four output rows; the
     // pair (ph 0, ph 1) of a channel group swaps the two output rows the other one owns (ph 0: rows 0-1, ph 1: rows 2-3).
-    const int co0 = cog * 16 + kq * 4;
     float *xw = s_x + (cog * 8 * 64 + lane) * 4;                 // this pair's exchange area: [slot 8][lane 64] float4
     auto tile_epilogue = [&](int k) {
         // wave-uniform coefficients of the half transform, selected HERE (behind an opaque copy of ph): selected once in
@@ -547,14 +557,19 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 ys[1][j][r] = cf_h * df;
             }
         }
-        // own output rows 2 ph + io; the operands of one output row (4 pixels x up to 3 tensors) are requested together, the
-        // first row's before the exchange so that the exchange hides part of their round trip
-        const int t = l15;
-        const int oy0 = ty * TH + 4 * (t >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t & 7);
+        // own output rows 2 ph + io.  Everything behind the output transform runs in the PIXEL-QUAD layout: lane L' =
+        // (tile t2 = L' >> 2, channel quad L' & 3), i.e. four ADJACENT lanes own one pixel's 64 contiguous bytes of this
+        // wave's 16 channels -- the memory pipeline merges a lane quad's 16-byte pieces into one request, whereas in the
+        // accumulator layout (lane = kq*16 + tile) every piece of every epilogue load and store was a request of its own
+        // (stores alone: -5 % on the launch).  The transformed outputs move there through four ds_bpermute per pixel.
+        // The operands of one output row (4 pixels x up to 3 tensors) are requested together, the first row's before the
+        // exchange so that the exchange hides part of their round trip.
+        const int t2 = lane >> 2, cq = cog * 16 + (lane & 3) * 4;
+        const int oy0 = ty * TH + 4 * (t2 >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t2 & 7);
         const size_t img = (size_t)b * H * W * 64;
         struct Ops { float4 ad[4], z4[4], a4[4]; };
         auto offs = [&](int io, int j) {        // in-image element offset of the pixel's channels (clamped: loads are unconditional)
-            return (unsigned)((min(oy0 + io, H - 1) * W + min(ox0 + j, W - 1)) * 64 + co0);
+            return (unsigned)((min(oy0 + io, H - 1) * W + min(ox0 + j, W - 1)) * 64 + cq);
         };
         auto load_ops = [&](int io, Ops &o) {
 #pragma unroll
@@ -606,11 +621,11 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             const int oy = oy0 + io;
             float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
             if (BN) {           // per-channel constants from LDS, just before their use
-                const float4 m4 = *reinterpret_cast<const float4 *>(s_epi + co0), i4 = *reinterpret_cast<const float4 *>(s_epi + 64 + co0);
+                const float4 m4 = *reinterpret_cast<const float4 *>(s_epi + cq), i4 = *reinterpret_cast<const float4 *>(s_epi + 64 + cq);
                 mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
                 is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
                 if (BN == 1) {
-                    const float4 s4 = *reinterpret_cast<const float4 *>(s_epi + 128 + co0), h4 = *reinterpret_cast<const float4 *>(s_epi + 192 + co0);
+                    const float4 s4 = *reinterpret_cast<const float4 *>(s_epi + 128 + cq), h4 = *reinterpret_cast<const float4 *>(s_epi + 192 + cq);
                     msc[0] = s4.x; msc[1] = s4.y; msc[2] = s4.z; msc[3] = s4.w;
                     msh[0] = h4.x; msh[1] = h4.y; msh[2] = h4.z; msh[3] = h4.w;
                 }
@@ -618,7 +633,12 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = oy < H && ox0 + j < W;
-                const float own[4] = {yo[io][j][0], yo[io][j][1], yo[io][j][2], yo[io][j][3]};
+                // lane L' takes the transformed outputs of (tile L' >> 2, channel quad L' & 3) from lane (L' & 3) * 16 + (L' >> 2)
+                const int src = ((lane & 3) * 16 + (lane >> 2)) * 4;
+                float own[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    own[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, yo[io][j][r])));
                 const float adv[4] = {ops.ad[j].x, ops.ad[j].y, ops.ad[j].z, ops.ad[j].w};
                 const float zv[4] = {ops.z4[j].x, ops.z4[j].y, ops.z4[j].z, ops.z4[j].w};
                 const float av[4] = {ops.a4[j].x, ops.a4[j].y, ops.a4[j].z, ops.a4[j].w};
@@ -639,37 +659,24 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                     }
                     o[r] = v;
                 }
-                // Store through a lane transpose: lane (kq, l15) computed channels kq*4.. of tile l15, but four ADJACENT
-                // lanes should write one pixel's 64 contiguous bytes (the memory pipeline merges a lane quad's 16-byte
-                // pieces into one request; with lane = kq*16 + l15 every piece was a request of its own: measured -5 %
-                // on the whole launch).  Lane L' = (tile L' >> 2, channel quad L' & 3) takes its float4 from lane
-                // (L' & 3) * 16 + (L' >> 2): four ds_bpermute_b32.
-                if (!(W4_ABL & 256)) {
-                    const int src = ((lane & 3) * 16 + (lane >> 2)) * 4;
-                    float4 ov;
-                    ov.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[0])));
-                    ov.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[1])));
-                    ov.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[2])));
-                    ov.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, o[3])));
-                    const int t2 = lane >> 2;
-                    const int oy2 = ty * TH + 4 * (t2 >> 3) + 2 * ph + io, ox2 = tx * TW + 4 * (t2 & 7) + j;
-                    if (oy2 < H && ox2 < W)
-                        *reinterpret_cast<float4 *>(e_out + img + (unsigned)((oy2 * W + ox2) * 64 + cog * 16 + (lane & 3) * 4)) = ov;
-                }
+                if (!(W4_ABL & 256) && ok)
+                    *reinterpret_cast<float4 *>(e_out + img + (unsigned)(((oy0 + io) * W + ox0 + j) * 64 + cq)) =
+                        make_float4(o[0], o[1], o[2], o[3]);
             }
             if ((ADD || BN) && io == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_ops(1, ops);
             }
         }
-        if (STATS) {        // this tile's sums over the wave's 16 tiles -> the wave's running totals (lanes l15 == 0)
+        if (STATS) {        // this tile's sums over the wave's 16 tiles (the lanes of one channel quad: L' & 3) -> the wave's running
+                            // totals (lanes 0..3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ssum[r] = row16_sum(ssum[r]);
-                ssq[r] = row16_sum(ssq[r]);
+                ssum[r] = quad_class_sum(ssum[r]);
+                ssq[r] = quad_class_sum(ssq[r]);
             }
-            if (l15 == 0) {
-                float4 *ps = reinterpret_cast<float4 *>(s_red + wave * 32 + kq * 4), *pq = ps + 4;
+            if (lane < 4) {
+                float4 *ps = reinterpret_cast<float4 *>(s_red + wave * 32 + lane * 4), *pq = ps + 4;
                 float4 x = *ps, y = *pq;
                 x.x += ssum[0]; x.y += ssum[1]; x.z += ssum[2]; x.w += ssum[3];
                 y.x += ssq[0]; y.y += ssq[1]; y.z += ssq[2]; y.w += ssq[3];

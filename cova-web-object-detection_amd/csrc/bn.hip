@@ -269,6 +269,40 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
     }
 }
 
+// bn_act_fwd for the NHWC maps of the 64-channel stack (contiguous [R][64], residual, ReLU) that also leaves the ReLU
+// decisions as one bit per element: bits[r][w] bit k = (out[r][32 w + k] > 0).  The data gradient that needs this map
+// only as its mask source (conv_wino4.hip, `act_bits`) then reads 1/32 of the bytes.  A thread owns 4 channels; the 8
+// lanes of a 32-channel word combine their nibbles with three lane exchanges.
+__global__ __launch_bounds__(256) void bn_act_fwd_bits_kernel(
+    const float *__restrict__ z, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ res, float *__restrict__ out, uint32_t *__restrict__ bits, long long R)
+{
+    const long long total = R * 16;                      // multiple of 16: the 8 lanes of a word are active together
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(z + i * 4);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+        float y[4] = {fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y), fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w)};
+        if (res != nullptr) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(res + i * 4);
+            y[0] += r4.x; y[1] += r4.y; y[2] += r4.z; y[3] += r4.w;
+        }
+        uint32_t word = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = y[j] > 0.f ? y[j] : 0.f;
+            word |= (y[j] > 0.f ? 1u : 0u) << j;
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        word <<= 4 * (threadIdx.x & 7);
+        word |= __shfl_xor(word, 1, 64);
+        word |= __shfl_xor(word, 2, 64);
+        word |= __shfl_xor(word, 4, 64);
+        if ((threadIdx.x & 7) == 0) bits[i >> 3] = word;          // (i >> 3 = row * 2 + word of the row)
+    }
+}
+
 // out = act((z*scale + shift) + (z2*scale2 + shift2)): the join of a Bottleneck whose identity branch has
 // its own conv + BatchNorm (torchvision Bottleneck.forward with `downsample`); contiguous [R, C], C % 4 == 0
 __global__ __launch_bounds__(256) void bn_act2_fwd_kernel(
@@ -744,6 +778,18 @@ COVA_API int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const 
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_grid(R * C)), dim3(256), 0,
                            (hipStream_t)stream, z, ldz, scale, shift, res, ldres, out, ldo, R, C, relu);
+    COVA_LAUNCH_CHECK();
+    return COVA_OK;
+}
+
+// cova_bn_act_fwd (ReLU on) for a contiguous [R][64] map, also writing the ReLU decisions as bits [R][2] words
+COVA_API int cova_bn_act_fwd_bits(const float *z, const float *scale, const float *shift, const float *res, float *out,
+                                  uint32_t *bits, long long R, void *stream)
+{
+    COVA_REQUIRE(z && scale && shift && out && bits && R > 0);
+    COVA_REQUIRE(vec4_ok(z, 64) && vec4_ok(res, 64) && vec4_ok(out, 64) && vec4_ok(scale, 0) && vec4_ok(shift, 0));
+    hipLaunchKernelGGL(bn_act_fwd_bits_kernel, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                       res, out, bits, R);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -86,6 +86,7 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // fma(msc, z, msh) > 0 -- the same expression the affine-on-load prologues evaluate.
 struct W4Epi {
     const float *addend, *act, *z, *mean, *invstd, *msc, *msh;
+    const uint32_t *act_bits;       // BN == 2: the mask as one bit per element ([pixel][2] words) instead of act
 };
 
 struct W4Args {
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const int oy0 = ty * TH + 4 * (t2 >> 3) + 2 * ph, ox0 = tx * TW + 4 * (t2 & 7);
         const size_t img = (size_t)b * H * W * 64;
         struct Ops { float4 ad[4], z4[4], a4[4]; };
+        const bool bits = BN == 2 && la->epi.act_bits != nullptr;       // (wave-uniform)
         auto offs = [&](int io, int j) {        // in-image element offset of the pixel's channels (clamped: loads are unconditional)
             return (unsigned)((min(oy0 + io, H - 1) * W + min(ox0 + j, W - 1)) * 64 + cq);
         };
@@ -578,7 +580,15 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 o.ad[j] = o.z4[j] = o.a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ADD) o.ad[j] = *reinterpret_cast<const float4 *>(e_addend + img + off);
                 if (BN) o.z4[j] = *reinterpret_cast<const float4 *>(e_z + img + off);
-                if (BN == 2) o.a4[j] = *reinterpret_cast<const float4 *>(e_act + img + off);
+                if (BN == 2) {
+                    if (bits) {       // bit (c & 31) of word c >> 5 of the pixel = the decision for channel c
+                        const uint32_t wd = la->epi.act_bits[((size_t)b * H * W * 64 + off) >> 5] >> (cq & 31);
+                        o.a4[j] = make_float4((float)(wd & 1u), (float)((wd >> 1) & 1u), (float)((wd >> 2) & 1u),
+                                              (float)((wd >> 3) & 1u));
+                    } else {
+                        o.a4[j] = *reinterpret_cast<const float4 *>(e_act + img + off);
+                    }
+                }
             }
         };
         Ops ops;
@@ -799,7 +809,7 @@ template <int PRO>
 void launch_w4_pro(const W4Args &a, int grid, hipStream_t st)
 {
     const bool add = a.epi.addend != nullptr;
-    const int bn = a.epi.z == nullptr ? 0 : (a.epi.act == nullptr ? 1 : 2);
+    const int bn = a.epi.z == nullptr ? 0 : (a.epi.act == nullptr && a.epi.act_bits == nullptr ? 1 : 2);
     if (bn == 0) {
         if (a.stat_part) { if (add) launch_w4<true, PRO, true, 0>(a, grid, st); else launch_w4<true, PRO, false, 0>(a, grid, st); }
         else             { if (add) launch_w4<false, PRO, true, 0>(a, grid, st); else launch_w4<false, PRO, false, 0>(a, grid, st); }
@@ -822,7 +832,8 @@ int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu
     }
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));          // 32-bit in-image offsets in the epilogue
-    COVA_REQUIRE(epi.z == nullptr || ((epi.act || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
+    COVA_REQUIRE(epi.z == nullptr || ((epi.act || epi.act_bits || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
+    COVA_REQUIRE(!(epi.act && epi.act_bits));
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
     const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi, t};
     const int grid = cova_internal_persistent_grid2(ntiles, 1);
@@ -867,13 +878,15 @@ COVA_API int cova_conv3x3_wino4_full(const float *in, const float *in2, const fl
                   stat_part, B, H, W, stream);
 }
 
+// act_bits (instead of act): the mask source as one bit per element, [B*H*W][2] words as cova_bn_act_fwd_bits writes them
 COVA_API int cova_conv3x3_wino4_full_tail(const float *in, const float *in2, const float *pro_abc, int pro_relu,
                                           const float *u, const float *addend, const float *act,
-                                          const float *mask_scale, const float *mask_shift, const float *z,
-                                          const float *mean, const float *invstd, float *out, float *stat_part, int B,
-                                          int H, int W, const cova_bn_tail *tail, void *stream)
+                                          const uint32_t *act_bits, const float *mask_scale, const float *mask_shift,
+                                          const float *z, const float *mean, const float *invstd, float *out,
+                                          float *stat_part, int B, int H, int W, const cova_bn_tail *tail, void *stream)
 {
     return run_w4(in, in2, pro_abc, pro_relu, u,
-                  W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr}, out,
-                  stat_part, B, H, W, stream, tail);
+                  W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr,
+                        z ? act_bits : nullptr},
+                  out, stat_part, B, H, W, stream, tail);
 }

@@ -381,14 +381,18 @@ def conv3_num_partials(B, H, W, wino4):
     return query("cova_conv3x3_wino4_num_partials" if wino4 else "cova_conv3x3_wino_num_partials", B, H, W)
 
 
-def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W, tail=None):
+def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W, tail=None,
+                act_bits=None):
     """conv3x3 of f(A*inp + B*in2 + C) (abc / in2 nullable) with the fused epilogue of cova_conv3x3_wino_pro.
-    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3); tail (F(4x4) only): BnTail."""
+    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3); tail (F(4x4) only): BnTail;
+    act_bits (with a tail only): the mask source `act` as one bit per element (cova_bn_act_fwd_bits)."""
     kind, uw = u
     if tail is not None:
         assert kind == "w4"
-        call("cova_conv3x3_wino4_full_tail", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out,
-             part, B, H, W, tail.ptr)
+        if act_bits is not None:
+            act = None
+        call("cova_conv3x3_wino4_full_tail", inp, in2, abc, relu, uw, addend, act, act_bits, msc, msh, z, mean, invstd,
+             out, part, B, H, W, tail.ptr)
     elif kind == "w4":
         call("cova_conv3x3_wino4_full", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
              B, H, W)
@@ -453,14 +457,20 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
         z1, z2 = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
         bna, bnb = conv_bn_pair_fwd(wf[2 * blk], wf[2 * blk + 1], x, z1, z2, BN3_KEYS[2 * blk], BN3_KEYS[2 * blk + 1],
                                     params, buffers, training, part, nt, R, B, H2, W2)
+        out_bits = None
         if blk == 1 and lazy_out:
             out = None
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
         else:
             out = _empty((B, H2, W2, C64), images)
-            call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
+            if blk == 0 and training and sv["w4"] and tails_on():
+                # ... with its ReLU decisions as bits: the mask source of the next block's conv1 data gradient
+                out_bits = _empty((R, 2), images, torch.int32)
+                call("cova_bn_act_fwd_bits", z2, bnb.scale, bnb.shift, x, out, out_bits, R)
+            else:
+                call("cova_bn_act_fwd", z2, C64, bnb.scale, bnb.shift, x, C64, out, C64, R, C64, 1)
             feat = out
-        blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=out, bna=bna, bnb=bnb))
+        blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=out, bna=bna, bnb=bnb, out_bits=out_bits))
         x = out
     sv["blocks"] = blocks
     # what RoIPool's backward needs of the block that produced the feature map
@@ -693,13 +703,15 @@ def bn_bwd_from_partials(part, nparts, dy, z, st, R, dz, gout, prefix):
     return dgamma, dbeta
 
 
-def dgrad_bn_bwd(u, g_in, g_in2, g_abc, addend, act, msc, msh, z, st, out, part, nt, count, gout, prefix, B, H, W):
+def dgrad_bn_bwd(u, g_in, g_in2, g_abc, addend, act, msc, msh, z, st, out, part, nt, count, gout, prefix, B, H, W,
+                 act_bits=None):
     """Data-gradient conv3x3 (input g_abc . (g_in, g_in2) on load, + addend) whose epilogue masks with the ReLU of
     BatchNorm `st` and takes its backward sums; -> (dgamma, dbeta, abc) of that BatchNorm (finalized by the launch's tail
     or by a separate cova_bn_finalize_bwd_abc).  ``count`` = elements per channel of that BatchNorm."""
     if u[0] == "w4" and tails_on() and not st.frozen:
         dg, db, abc, tail = bn_tail_bwd(st, count, gout, prefix, out)
-        conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W, tail)
+        conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W, tail,
+                    act_bits=act_bits)
         return dg, db, abc
     conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W)
     C = st.C
@@ -776,7 +788,8 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
         if blk == 1:
             prev = sv["blocks"][0]
             pend = dgrad_bn_bwd(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, dres, prev["out"], None, None, prev["z2"],
-                                prev["bnb"], dx, _empty((nt, 2, C64), dfeat), nt, R, gout, BN3_KEYS[1], B, H2, W2)
+                                prev["bnb"], dx, _empty((nt, 2, C64), dfeat), nt, R, gout, BN3_KEYS[1], B, H2, W2,
+                                act_bits=prev.get("out_bits"))
         elif sv.get("ymax") is not None:
             # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
             bn1 = sv["bn1"]

@@ -156,10 +156,12 @@ int cova_conv3x3_wino4_full(const float *in, const float *in2 /*nullable*/, cons
                             const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
                             float *stat_part /*nullable*/, int B, int H, int W, void *stream);
 /* ... with the BatchNorm finalize of stat_part as the launch's tail (tail: host pointer; mode 1 for plain statistics,
- * mode 2 for the BatchNorm-backward sums of the z epilogue) */
+ * mode 2 for the BatchNorm-backward sums of the z epilogue).  act_bits (nullable, instead of act): the mask source as
+ * one bit per element, [B*H*W][2] words as cova_bn_act_fwd_bits writes them */
 int cova_conv3x3_wino4_full_tail(const float *in, const float *in2 /*nullable*/, const float *pro_abc /*nullable*/,
                                  int pro_relu, const float *u, const float *addend /*nullable*/,
-                                 const float *act /*nullable*/, const float *mask_scale /*nullable*/,
+                                 const float *act /*nullable*/, const uint32_t *act_bits /*nullable*/,
+                                 const float *mask_scale /*nullable*/,
                                  const float *mask_shift /*nullable*/, const float *z /*nullable*/,
                                  const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
                                  float *stat_part, int B, int H, int W, const cova_bn_tail *tail, void *stream);
@@ -246,6 +248,10 @@ int cova_bn_eval_params(const float *gamma, const float *beta, const float *runn
 int cova_bn_act_fwd(const float *z, int ldz, const float *scale, const float *shift,
                     const float *res /*nullable*/, int ldres, float *out, int ldo, long long R, int C,
                     int relu, void *stream);
+/* cova_bn_act_fwd with ReLU for a contiguous [R,64] map (res nullable), also writing the ReLU decisions as one bit per
+ * element: bits [R][2] words, bit k of word w = (out[r][32 w + k] > 0) */
+int cova_bn_act_fwd_bits(const float *z, const float *scale, const float *shift, const float *res, float *out,
+                         uint32_t *bits, long long R, void *stream);
 /* out = act(bn(z) + bn2(z2)): join of a Bottleneck whose identity branch is conv + BatchNorm */
 int cova_bn_act2_fwd(const float *z, const float *scale, const float *shift, const float *z2,
                      const float *scale2, const float *shift2, float *out, long long R, int C, int relu,

@@ -643,8 +643,8 @@ def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
             tail = engine.BnTail(1, x, R, gamma=gamma, beta=beta, running_mean=rm2, running_var=rv2, num_batches_tracked=nbt2,
                                  scale=got[0], shift=got[1], mean=got[2], invstd=got[3])
             out2, part2 = torch.empty_like(x), torch.empty(n4, 2, 64, device=DEV)
-            call("cova_conv3x3_wino4_full_tail", x, None, None, 0, u4f, None, None, None, None, None, None, None, out2, part2,
-                 B, H, W, tail.ptr)
+            call("cova_conv3x3_wino4_full_tail", x, None, None, 0, u4f, None, None, None, None, None, None, None, None, out2,
+                 part2, B, H, W, tail.ptr)
             assert torch.equal(out, out2) and torch.equal(part, part2)
             for a, b_ in zip(got + [rm2, rv2], ref + [rm, rv]):
                 assert torch.equal(a, b_), "forward tail differs (launch %d)" % rep
@@ -658,10 +658,23 @@ def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
             call("cova_bn_finalize_bwd_abc", part, n4, 64, R, dg, db, mean, invstd, scale, abc_ref)
             dg2, db2, abc2 = torch.empty(64, device=DEV), torch.empty(64, device=DEV), torch.empty(3, 64, device=DEV)
             tail = engine.BnTail(2, x, R, mean=mean, invstd=invstd, scale=scale, dgamma=dg2, dbeta=db2, abc=abc2)
-            call("cova_conv3x3_wino4_full_tail", x, x2, abc, 0, u4d, None, None, msc, msh, z, mean, invstd, out2, part2,
+            call("cova_conv3x3_wino4_full_tail", x, x2, abc, 0, u4d, None, None, None, msc, msh, z, mean, invstd, out2, part2,
                  B, H, W, tail.ptr)
             assert torch.equal(out, out2) and torch.equal(part, part2)
             assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(abc_ref, abc2), "backward tail differs"
+            # ---- mask from a materialised activation, as the map or as the bits cova_bn_act_fwd_bits leaves: identical
+            act, act2, bits = torch.empty_like(x), torch.empty_like(x), torch.empty(B * H * W, 2, dtype=torch.int32, device=DEV)
+            call("cova_bn_act_fwd", z, 64, msc, msh, x2, 64, act, 64, B * H * W, 64, 1)
+            call("cova_bn_act_fwd_bits", z, msc, msh, x2, act2, bits, B * H * W)
+            assert torch.equal(act, act2)
+            sh = torch.arange(32, device=DEV, dtype=torch.int32).view(1, 1, 32)
+            assert torch.equal(((bits.view(-1, 2, 1) >> sh) & 1).view(B, H, W, 64).bool(), act > 0)
+            add = x2 * 0.5
+            call("cova_conv3x3_wino4_full_tail", x, x2, abc, 0, u4d, add, act, None, None, None, z, mean, invstd, out, part,
+                 B, H, W, tail.ptr)
+            call("cova_conv3x3_wino4_full_tail", x, x2, abc, 0, u4d, add, None, bits, None, None, z, mean, invstd, out2, part2,
+                 B, H, W, tail.ptr)
+            assert torch.equal(out, out2) and torch.equal(part, part2)
     finally:
         query("cova_set_option", 2, 0)
 

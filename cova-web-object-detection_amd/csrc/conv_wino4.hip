@@ -32,7 +32,8 @@
 
 // Ablation builds of tools/wino4_bench.py (COVA_EXTRA_FLAGS=-DW4_ABL=<mask>; 0 in the product): 1 no column stage,
 // 2 no row stage, 4 no MFMAs, 8 no plane copies, 16 no weight loads (stale registers), 32 no tile epilogue,
-// 64 no wait for the plane copies, 128 weight loads always from chunk 0, 256 no output stores, 512 no exchange barriers
+// 64 no wait for the plane copies, 128 weight loads always from chunk 0, 256 no output stores, 512 no exchange barriers,
+// 2048 plane copies always from the same rows of the map (L2-resident source)
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     auto plane_src = [&](int k) {
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
-        const long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
+        long long org = ((long long)b * H * W + (long long)(ty * TH - 1) * W + (tx * TW - 1)) * 64;
+        if (W4_ABL & 2048) org = ((long long)(1 + (blockIdx.x & 7)) * 16 * W + 33) * 64;      // copies always from the same few rows (L2 hits)
         tbase = a.in + org;
         if (PRO == 2) tbase2 = a.in2 + org;
 #pragma unroll

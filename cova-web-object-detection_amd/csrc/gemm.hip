@@ -69,16 +69,23 @@ __device__ __forceinline__ void stash_tile(float (*S)[LDT], int tid, const float
     }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A, int lda,
-                                                    const float *__restrict__ Bm, int ldb,
-                                                    float *__restrict__ C, int ldc,
-                                                    const float *__restrict__ bias, int M, int N,
-                                                    int K, int accumulate, int vecA, int vecB)
+// KS = 2: the block is TWO groups of four waves, each with its own LDS tiles, that take alternate k-tiles of the same
+// 64x64 output tile and add their accumulators up at the end (through LDS, fixed order).  These GEMMs leave ~1.4 waves
+// per SIMD and every k-tile is a dependent chain (barrier, LDS round trip, 32 MFMAs on one accumulator): two chains per
+// output tile halve the serial length and give every SIMD a second wave to switch to.
+template <bool TA, bool TB, int KS>
+__global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict__ A, int lda,
+                                                         const float *__restrict__ Bm, int ldb,
+                                                         float *__restrict__ C, int ldc,
+                                                         const float *__restrict__ bias, int M, int N,
+                                                         int K, int accumulate, int vecA, int vecB)
 {
-    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float As_[KS][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs_[KS][BK][LDT];
+    const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;       // k-group of this wave
+    float (*As)[LDT] = As_[grp];
+    float (*Bs)[LDT] = Bs_[grp];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int li = lane & 31, kh2 = lane >> 5;
@@ -88,17 +95,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A,
 
     // A tile: rows = m; stored k-contiguous unless transposed.  B tile: rows = n; stored
     // k-contiguous when transB (B is [N,K]).
+    // (both groups run the same number of iterations -- a past-the-end k-tile fetches zeros -- so the block barriers match)
+    constexpr int KSTEP = BK * KS;
     float va[EPT], vb[EPT];
-    fetch_tile<!TA>(A, lda, m0, M, 0, K, tid, vecA != 0, va);
-    fetch_tile<TB>(Bm, ldb, n0, N, 0, K, tid, vecB != 0, vb);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    fetch_tile<!TA>(A, lda, m0, M, grp * BK, K, tid, vecA != 0, va);
+    fetch_tile<TB>(Bm, ldb, n0, N, grp * BK, K, tid, vecB != 0, vb);
+    for (int k0 = grp * BK; k0 - grp * BK < K; k0 += KSTEP) {
         __syncthreads();                    // previous tile fully consumed
         stash_tile<!TA>(As, tid, va);
         stash_tile<TB>(Bs, tid, vb);
         __syncthreads();
-        if (k0 + BK < K) {                  // next tile in flight while this one computes
-            fetch_tile<!TA>(A, lda, m0, M, k0 + BK, K, tid, vecA != 0, va);
-            fetch_tile<TB>(Bm, ldb, n0, N, k0 + BK, K, tid, vecB != 0, vb);
+        if (k0 + KSTEP - grp * BK < K) {    // this group's next tile in flight while this one computes
+            fetch_tile<!TA>(A, lda, m0, M, k0 + KSTEP, K, tid, vecA != 0, va);
+            fetch_tile<TB>(Bm, ldb, n0, N, k0 + KSTEP, K, tid, vecB != 0, vb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -106,6 +115,18 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *__restrict__ A,
             const float b = Bs[2 * kk + kh2][wn * 32 + li];
             acc = mfma32(a, b, acc);
         }
+    }
+    if (KS == 2) {                          // group 1 hands its accumulator over (its A tile area is free now)
+        __syncthreads();
+        float *red = &As_[0][0][0] + wave * (16 * 64);         // [wave][r][lane]: 4 x 4 KB <= one A tile
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
     }
     const int gn = n0 + wn * 32 + li;
     if (gn < N) {
@@ -133,17 +154,21 @@ COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float
 {
     COVA_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0);
     if (M == 0 || N == 0) return COVA_OK;
-    const dim3 grid(cdiv(N, BN), cdiv(M, BM)), block(256);
+    const dim3 grid(cdiv(N, BN), cdiv(M, BM));
     hipStream_t st = (hipStream_t)stream;
     const int va = vec_ok(A, lda), vb = vec_ok(B, ldb);
-    if (!transA && !transB)
-        hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
-    else if (!transA && transB)
-        hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
-    else if (transA && !transB)
-        hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
-    else
-        hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);
+    // two k-groups per block when there are at least four k-tiles and the grid alone does not fill the chip twice over
+    const bool split = K >= 4 * BK && (long long)grid.x * grid.y < 2 * 4 * 256;
+#define SGEMM_LAUNCH(TA_, TB_)                                                                                              \
+    do {                                                                                                                    \
+        if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
+        else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
+    } while (0)
+    if (!transA && !transB) SGEMM_LAUNCH(false, false);
+    else if (!transA && transB) SGEMM_LAUNCH(false, true);
+    else if (transA && !transB) SGEMM_LAUNCH(true, false);
+    else SGEMM_LAUNCH(true, true);
+#undef SGEMM_LAUNCH
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -54,6 +54,8 @@ struct C11Args {
     // gradient that needs this map only as a mask source reads 1/32 of the bytes
     unsigned *side_bits;
     const unsigned *act_bits;             // mask source of the EPI 3 epilogue in that form (instead of `act`)
+    int part_rows;                        // > gridDim.x: the statistics rows behind the grid are zero-filled (the caller
+                                          // sized them for another launch geometry)
 };
 
 template <int CIN, int COUT, bool EXT = false>
@@ -79,7 +81,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
 {
     using G = C11Geo<CIN, COUT, EXT>;
     constexpr int NTHR = NW * 64;
-    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    // CO: the 256-channel operand is fetched COALESCED -- 8 adjacent lanes on one 128-byte line of a row -- and brought
+    // into the MFMA layout (lane = row) through a wave-private 8 KB LDS transposer.  Row-per-lane loads (8 x 16 bytes
+    // walking the lane's own line, 64 lines per wave instruction) reach 4.2 TB/s on this part, the coalesced pattern
+    // 6.2 TB/s (tools/lane_pattern_probe2.py); the element-wise prologue and the side output run in the coalesced layout
+    // (per-lane channel constants, 128-byte stores).  Needs the 8-wave / one-block-per-CU geometry for the LDS room.
+    constexpr bool CO = CIN == 256 && NW == 8;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + (CO ? NW * 2048 : 0)];
+    float4 *s_tr = reinterpret_cast<float4 *>(lds + G::LDS_FLOATS) + (threadIdx.x >> 6) * 512;      // this wave's transposer
+    const int ca = (threadIdx.x & 63) >> 4, chh = ((threadIdx.x & 63) >> 3) & 1, cq = threadIdx.x & 7;   // CO lane -> (row & 3, K-half, 16-byte piece)
     float *Ws = lds, *s_pro = lds + G::W_FLOATS, *s_pro3 = lds + G::W_FLOATS + 3 * CIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -116,6 +126,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
 
     // operand chunk of (tile, chunk c): 8 float4 = channels h*KH + 32c .. +31 of row tile*32 + p
     auto issue = [&](long long tile, int c, float4 (&v)[8], float4 (&v2)[8]) {
+        if constexpr (CO) {                                     // v[j]: row 4j + ca, K-half chh, piece cq of the chunk
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                long long row = tile * 32 + 4 * j + ca;
+                if (row >= a.R) row = a.R - 1;
+                if (EXT && c == G::CHUNKS) {
+                    v[j] = *reinterpret_cast<const float4 *>(a.in3 + (size_t)row * 64 + chh * 32 + 4 * cq);
+                } else {
+                    const size_t o = (size_t)row * CIN + chh * G::KH + c * 32 + 4 * cq;
+                    v[j] = *reinterpret_cast<const float4 *>(a.in + o);
+                    if (PRO == 2) v2[j] = *reinterpret_cast<const float4 *>(a.in2 + o);
+                }
+            }
+            return;
+        }
         long long row = tile * 32 + p;
         if (row >= a.R) row = a.R - 1;                       // clamped: loads stay unconditional
         if (EXT && c == G::CHUNKS) {                         // the extra 64 channels: half h takes 32h .. 32h+31
@@ -133,6 +158,53 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
         }
     };
     auto prologue = [&](long long tile, int c, float4 (&v)[8], const float4 (&v2)[8], float (&x)[32]) {
+        if constexpr (CO) {
+            const bool ext = EXT && c == G::CHUNKS;
+            int ch = ext ? chh * 32 + 4 * cq : chh * G::KH + c * 32 + 4 * cq;      // this lane's channel quad, all 8 rows
+            asm volatile("" : "+v"(ch));
+            float Aa[4] = {1.f, 1.f, 1.f, 1.f}, Ba[4] = {0.f, 0.f, 0.f, 0.f}, Ca[4] = {0.f, 0.f, 0.f, 0.f};
+            bool relu = false;
+            if (ext) {
+                const float4 A = *reinterpret_cast<const float4 *>(s_pro3 + ch), C = *reinterpret_cast<const float4 *>(s_pro3 + 128 + ch);
+                Aa[0] = A.x; Aa[1] = A.y; Aa[2] = A.z; Aa[3] = A.w; Ca[0] = C.x; Ca[1] = C.y; Ca[2] = C.z; Ca[3] = C.w;
+                relu = a.pro3_relu != 0;
+            } else if (PRO != 0) {
+                const float4 A = *reinterpret_cast<const float4 *>(s_pro + ch), C = *reinterpret_cast<const float4 *>(s_pro + 2 * CIN + ch);
+                Aa[0] = A.x; Aa[1] = A.y; Aa[2] = A.z; Aa[3] = A.w; Ca[0] = C.x; Ca[1] = C.y; Ca[2] = C.z; Ca[3] = C.w;
+                if (PRO == 2) {
+                    const float4 B = *reinterpret_cast<const float4 *>(s_pro + CIN + ch);
+                    Ba[0] = B.x; Ba[1] = B.y; Ba[2] = B.z; Ba[3] = B.w;
+                }
+                relu = a.pro_relu != 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                if (ext || PRO != 0) {
+                    const float e2[4] = {v2[j].x, v2[j].y, v2[j].z, v2[j].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)         // (the same expressions as the row-per-lane path)
+                        e[k] = (PRO == 2 && !ext) ? fmaf(Aa[k], e[k], fmaf(Ba[k], e2[k], Ca[k])) : fmaf(Aa[k], e[k], Ca[k]);
+                    if (relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) e[k] = e[k] > 0.f ? e[k] : 0.f;
+                    }
+                }
+                const float4 e4 = make_float4(e[0], e[1], e[2], e[3]);
+                const long long rj = tile * 32 + 4 * j + ca;
+                if (SIDE && !ext && rj < a.R) *reinterpret_cast<float4 *>(a.side + (size_t)rj * CIN + ch) = e4;
+                // transposer slot of (row r, half, piece q): (2 r + half) * 8 + (q ^ (r & 7)) -- the eight lanes of a line
+                // write one 128-byte row, the eight readers of consecutive rows hit eight different 16-byte bank groups
+                const int rl = 4 * j + ca;
+                s_tr[(2 * rl + chh) * 8 + (cq ^ (rl & 7))] = e4;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 t = s_tr[(2 * p + h) * 8 + (q ^ (p & 7))];
+                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+            }
+            return;
+        }
         const long long srow = tile * 32 + p;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -375,6 +447,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             float t = 0.f;
             for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + which) * COUT + c];
             a.part[(size_t)blockIdx.x * 2 * COUT + i] = t;
+            for (int r = blockIdx.x + gridDim.x; r < a.part_rows; r += gridDim.x) a.part[(size_t)r * 2 * COUT + i] = 0.f;
         }
         if (HAS_X2)
             for (int i = tid; i < 2 * COUT; i += NTHR) {
@@ -567,12 +640,18 @@ int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_
     if (a.side) {           // materialising consumer: 256 -> 64 forward with the two-tensor prologue
         if constexpr (CIN == 256) {
             if (pro != 2 || epi > 1) return COVA_ERR_BAD_ARG;
+            // eight waves, one block per CU: room for the coalesced-operand transposer (the statistics rows the caller
+            // sized with cova_conv1x1_num_partials beyond this grid are zero-filled by the kernel)
+            C11Args b = a;
+            b.part_rows = grid;
+            const long long nb8 = ((a.R + 31) / 32 + 7) / 8;
+            const int grid8 = cova_internal_persistent_grid2(nb8 > (1 << 30) ? (1 << 30) : (int)nb8, 1);
             if (epi == 1)
-                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 1, false, false, false, false, 4, true>), dim3(grid),
-                                   dim3(256), 0, st, a);
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 1, false, false, false, false, 8, true>), dim3(grid8),
+                                   dim3(512), 0, st, b);
             else
-                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 0, false, false, false, false, 4, true>), dim3(grid),
-                                   dim3(256), 0, st, a);
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 0, false, false, false, false, 8, true>), dim3(grid8),
+                                   dim3(512), 0, st, b);
             return COVA_OK;
         }
         return COVA_ERR_BAD_ARG;

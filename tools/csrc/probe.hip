@@ -239,6 +239,29 @@ __global__ __launch_bounds__(512) void lane_pattern_probe_kernel(const float *__
     extern __shared__ float dyn_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 3 || mode == 4) {
+        // the 1x1-convolution operand of a [R,256] map: a wave takes 32 rows of 1 KB, four chunks of 8 float4 per lane.
+        // mode 3: row per lane (lane = row p | K-half h: 8 x 16 B walk one 128-byte line of the lane's own row);
+        // mode 4: the same bytes with 8 adjacent lanes on one 128-byte line
+        for (long long run = (long long)blockIdx.x * 8 + wave; run < nruns / 4; run += (long long)gridDim.x * 8) {
+            const float *src = in + run * 32 * 256;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int off;
+                    if (mode == 3) off = (lane & 31) * 256 + (lane >> 5) * 128 + c * 32 + 4 * j;
+                    else off = (4 * j + (lane >> 4)) * 256 + ((lane >> 3) & 1) * 128 + c * 32 + 4 * (lane & 7);
+                    v[j] = *reinterpret_cast<const float4 *>(src + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+            }
+        }
+        if (acc.x == 12345.678f) *reinterpret_cast<float4 *>(out + threadIdx.x * 4) = acc;
+        return;
+    }
     for (long long run = (long long)blockIdx.x * 8 + wave; run < nruns; run += (long long)gridDim.x * 8) {
         const float *src = in + run * 32 * 64;
         float *dst = out + run * 32 * 64;
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(512) void lane_pattern_probe_kernel(const float *__
 COVA_API int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
                                      int blocks, int lds_bytes, void *stream)
 {
-    COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 2 && blocks > 0 && lds_bytes >= 0);
+    COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 4 && blocks > 0 && lds_bytes >= 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lane_pattern_probe_kernel),

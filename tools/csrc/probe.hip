@@ -239,6 +239,28 @@ __global__ __launch_bounds__(512) void lane_pattern_probe_kernel(const float *__
     extern __shared__ float dyn_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 5 || mode == 6) {
+        // the 64->256 forward convolution's OUTPUT pattern on a [R,256] map: a wave owns 32 rows x 256 channels.
+        // mode 5: channel per lane (lane = channel n*32 + p of rows (r&3) + 8 (r>>2) + 4 h): 4-byte stores, two 128-byte
+        //         runs per instruction; mode 6: the same bytes as float4 stores, 16 lanes per 256-byte run
+        for (long long run = (long long)blockIdx.x * 8 + wave; run < nruns / 4; run += (long long)gridDim.x * 8) {
+            float *dst = out + run * 32 * 256;
+            if (mode == 5) {
+#pragma unroll 1
+                for (int n = 0; n < 8; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 256 + n * 32 + (lane & 31)] = (float)(lane + r);
+            } else {
+#pragma unroll 1
+                for (int n = 0; n < 8; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<float4 *>(dst + (4 * n + r) * 256 + lane * 4) = make_float4(1.f, 2.f, 3.f, (float)lane);
+            }
+        }
+        return;
+    }
     if (mode == 3 || mode == 4) {
         // the 1x1-convolution operand of a [R,256] map: a wave takes 32 rows of 1 KB, four chunks of 8 float4 per lane.
         // mode 3: row per lane (lane = row p | K-half h: 8 x 16 B walk one 128-byte line of the lane's own row);
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(512) void lane_pattern_probe_kernel(const float *__
 COVA_API int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
                                      int blocks, int lds_bytes, void *stream)
 {
-    COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 4 && blocks > 0 && lds_bytes >= 0);
+    COVA_REQUIRE(in && out && npix > 0 && npix % 32 == 0 && mode >= 0 && mode <= 6 && blocks > 0 && lds_bytes >= 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lane_pattern_probe_kernel),

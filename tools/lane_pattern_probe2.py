@@ -11,6 +11,7 @@ dev = "cuda:0"
 npix = 32 * 320 * 320 * 4            # in 64-float units: a [3,276,800 x 256] map
 x = torch.randn(npix, 64, device=dev)
 y = torch.empty(4096, device=dev)
+yo = torch.empty_like(x)
 
 
 def timeit(fn, n=10):
@@ -29,4 +30,7 @@ def timeit(fn, n=10):
 for lds, blocks, what in ((100 * 1024, 256, "1 block/CU (2 waves/SIMD)"), (0, 2048, "full occupancy")):
     for mode, name in ((3, "row per lane"), (4, "8 lanes per 128-byte line")):
         t = timeit(lambda: _lib.call("cova_probe_lane_pattern", x, y, npix, mode, 1, blocks, lds))
+        print("%-28s %-28s %.3f ms  %.2f TB/s" % (what, name, t, x.numel() * 4 / 1e9 / t))
+    for mode, name in ((5, "store: channel per lane, 4 B"), (6, "store: float4, contiguous")):
+        t = timeit(lambda: _lib.call("cova_probe_lane_pattern", x, yo, npix, mode, 1, blocks, lds))
         print("%-28s %-28s %.3f ms  %.2f TB/s" % (what, name, t, x.numel() * 4 / 1e9 / t))

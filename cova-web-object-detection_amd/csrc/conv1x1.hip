@@ -16,7 +16,9 @@
 // Implicit GEMM M = pixels, N = Cout, K = Cin on v_mfma_f32_32x32x2_f32 (exact f32).  A wave owns
 // 32 pixel rows: lane (p = lane&31, h = lane>>5) supplies row p's channels of K-half h, so its
 // operand is 128 contiguous bytes per 32-channel chunk -- loaded straight from HBM into registers
-// (8 float4), no LDS staging of activations.  K is permuted (step s of half h = channel h*Cin/2+s)
+// (8 float4).  For the 64-channel operand that is done row per lane; the 256-channel operand (round 3) is fetched
+// coalesced, 8 adjacent lanes per 128-byte line, and turned into the row-per-lane MFMA layout by a wave-private LDS
+// transposer (see CO in the kernel: 4.2 vs 6.2 TB/s of load bandwidth between the two patterns).  K is permuted (step s of half h = channel h*Cin/2+s)
 // identically for both operands, which leaves every dot product an exact f32 FMA chain.  The
 // weight [Cout][Cin+4] stays resident in LDS for the whole persistent launch; a lane's four
 // consecutive k are one ds_read_b128 (row stride Cin+4 floats: the 16 lanes of a b128 group hit

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
     // walking the lane's own line, 64 lines per wave instruction) reach 4.2 TB/s on this part, the coalesced pattern
     // 6.2 TB/s (tools/lane_pattern_probe2.py); the element-wise prologue and the side output run in the coalesced layout
     // (per-lane channel constants, 128-byte stores).  Needs the 8-wave / one-block-per-CU geometry for the LDS room.
-    constexpr bool CO = CIN == 256 && NW == 8;
+    constexpr bool CO = NW == 8;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + (CO ? NW * 2048 : 0)];
     float4 *s_tr = reinterpret_cast<float4 *>(lds + G::LDS_FLOATS) + (threadIdx.x >> 6) * 512;      // this wave's transposer
     const int ca = (threadIdx.x & 63) >> 4, chh = ((threadIdx.x & 63) >> 3) & 1, cq = threadIdx.x & 7;   // CO lane -> (row & 3, K-half, 16-byte piece)
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                 float t = 0.f;
                 for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + (which ? 2 : 0)) * COUT + c];
                 a.part2[(size_t)blockIdx.x * 2 * COUT + i] = t;
+                for (int r = blockIdx.x + gridDim.x; r < a.part_rows; r += gridDim.x) a.part2[(size_t)r * 2 * COUT + i] = 0.f;
             }
     }
 }
@@ -633,10 +634,16 @@ template <int CIN, int COUT>
 int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_x2, int pro, int grid,
                hipStream_t st)
 {
+    // eight waves, one block per CU (room for the coalesced-operand transposer); the statistics rows the caller sized
+    // with cova_conv1x1_num_partials beyond this grid are zero-filled by the kernel
+    C11Args b8 = a;
+    b8.part_rows = grid;
+    const long long nb8_ = ((a.R + 31) / 32 + 7) / 8;
+    const int grid8_ = cova_internal_persistent_grid2(nb8_ > (1 << 30) ? (1 << 30) : (int)nb8_, 1);
 #define C11_LAUNCH(PRO, EPI, ADD, MA, X2)                                                            \
     do {                                                                                             \
-        hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, PRO, EPI, ADD, MA, X2>), dim3(grid), dim3(256), \
-                           0, st, a);                                                                \
+        hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, PRO, EPI, ADD, MA, X2, false, 8>), dim3(grid8_), dim3(512), \
+                           0, st, b8);                                                               \
         return COVA_OK;                                                                              \
     } while (0)
     if (a.side) {           // materialising consumer: 256 -> 64 forward with the two-tensor prologue

@@ -56,8 +56,6 @@ struct C11Args {
     // gradient that needs this map only as a mask source reads 1/32 of the bytes
     unsigned *side_bits;
     const unsigned *act_bits;             // mask source of the EPI 3 epilogue in that form (instead of `act`)
-    int part_rows;                        // > gridDim.x: the statistics rows behind the grid are zero-filled (the caller
-                                          // sized them for another launch geometry)
 };
 
 template <int CIN, int COUT, bool EXT = false>
@@ -449,7 +447,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             float t = 0.f;
             for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + which) * COUT + c];
             a.part[(size_t)blockIdx.x * 2 * COUT + i] = t;
-            for (int r = blockIdx.x + gridDim.x; r < a.part_rows; r += gridDim.x) a.part[(size_t)r * 2 * COUT + i] = 0.f;
         }
         if (HAS_X2)
             for (int i = tid; i < 2 * COUT; i += NTHR) {
@@ -457,7 +454,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                 float t = 0.f;
                 for (int w = 0; w < NW; ++w) t += s_red[(w * 3 + (which ? 2 : 0)) * COUT + c];
                 a.part2[(size_t)blockIdx.x * 2 * COUT + i] = t;
-                for (int r = blockIdx.x + gridDim.x; r < a.part_rows; r += gridDim.x) a.part2[(size_t)r * 2 * COUT + i] = 0.f;
             }
     }
 }
@@ -634,33 +630,23 @@ template <int CIN, int COUT>
 int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_x2, int pro, int grid,
                hipStream_t st)
 {
-    // eight waves, one block per CU (room for the coalesced-operand transposer); the statistics rows the caller sized
-    // with cova_conv1x1_num_partials beyond this grid are zero-filled by the kernel
-    C11Args b8 = a;
-    b8.part_rows = grid;
-    const long long nb8_ = ((a.R + 31) / 32 + 7) / 8;
-    const int grid8_ = cova_internal_persistent_grid2(nb8_ > (1 << 30) ? (1 << 30) : (int)nb8_, 1);
+    // eight waves, one block per CU (room for the coalesced-operand transposer): grid = c11_grid(R), which is also the
+    // number of statistics rows (cova_conv1x1_num_partials)
 #define C11_LAUNCH(PRO, EPI, ADD, MA, X2)                                                            \
     do {                                                                                             \
-        hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, PRO, EPI, ADD, MA, X2, false, 8>), dim3(grid8_), dim3(512), \
-                           0, st, b8);                                                               \
+        hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, PRO, EPI, ADD, MA, X2, false, 8>), dim3(grid), dim3(512), \
+                           0, st, a);                                                                \
         return COVA_OK;                                                                              \
     } while (0)
     if (a.side) {           // materialising consumer: 256 -> 64 forward with the two-tensor prologue
         if constexpr (CIN == 256) {
             if (pro != 2 || epi > 1) return COVA_ERR_BAD_ARG;
-            // eight waves, one block per CU: room for the coalesced-operand transposer (the statistics rows the caller
-            // sized with cova_conv1x1_num_partials beyond this grid are zero-filled by the kernel)
-            C11Args b = a;
-            b.part_rows = grid;
-            const long long nb8 = ((a.R + 31) / 32 + 7) / 8;
-            const int grid8 = cova_internal_persistent_grid2(nb8 > (1 << 30) ? (1 << 30) : (int)nb8, 1);
             if (epi == 1)
-                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 1, false, false, false, false, 8, true>), dim3(grid8),
-                                   dim3(512), 0, st, b);
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 1, false, false, false, false, 8, true>), dim3(grid),
+                                   dim3(512), 0, st, a);
             else
-                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 0, false, false, false, false, 8, true>), dim3(grid8),
-                                   dim3(512), 0, st, b);
+                hipLaunchKernelGGL((conv1x1_kernel<CIN, COUT, 2, 0, false, false, false, false, 8, true>), dim3(grid),
+                                   dim3(512), 0, st, a);
             return COVA_OK;
         }
         return COVA_ERR_BAD_ARG;
@@ -699,10 +685,10 @@ int launch_c11(const C11Args &a, int epi, bool has_add, bool mask_act, bool has_
 #undef C11_LAUNCH
 }
 
-inline int c11_grid(long long R)
+inline int c11_grid(long long R)            // 32-row tiles, eight waves per block, one block per CU
 {
-    const long long ntiles = (R + 31) / 32, nb = (ntiles + 3) / 4;
-    return cova_internal_persistent_grid2(nb > (1 << 30) ? (1 << 30) : (int)nb, 2);
+    const long long ntiles = (R + 31) / 32, nb = (ntiles + 7) / 8;
+    return cova_internal_persistent_grid2(nb > (1 << 30) ? (1 << 30) : (int)nb, 1);
 }
 
 }  // namespace

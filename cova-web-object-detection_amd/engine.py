@@ -1050,7 +1050,11 @@ def gat_transpose(ctx):
         if len(_CSR_WS) >= 8:
             _CSR_WS.clear()
         csr = _CSR_WS[key] = torch.zeros((query("cova_gat_transpose_ints", N, K),), dtype=torch.int32, device=ctx.device)
-    call("cova_gat_transpose_reuse", ctx, N, K, csr)
+    try:
+        call("cova_gat_transpose_reuse", ctx, N, K, csr)
+    except Exception:
+        _CSR_WS.pop(key, None)          # its counters may be half-updated: never reuse it
+        raise
     return csr
 
 

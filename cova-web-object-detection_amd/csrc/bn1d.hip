@@ -1,9 +1,9 @@
 // BatchNorm1d over the box rows ([R, C] matrices: the positional encoder's `bbox_feat_encoder.1`, models.py:68,
 // CoVA++'s `bn_additional_feat`, :73, and the decoder's `decoder.2`, :86) -- train mode, ONE launch per application.
 // The columns of a BatchNorm1d are independent, and the matrices are small (1 440 x 976 at configs[1]): a block owns
-// 16 columns for ALL rows, so statistics, finalize and apply need no grid-wide step -- reduce (pass 1), per-column
+// 8 columns for ALL rows, so statistics, finalize and apply need no grid-wide step -- reduce (pass 1), per-column
 // parameters (one thread per column, fp64, bn_tail.h's channel functions = what cova_bn_finalize_* compute), apply
-// (pass 2; the block's 16 columns x R rows come back from L2).  The neighbouring element-wise ops ride along:
+// (pass 2; the block's columns x R rows come back from L2).  The neighbouring element-wise ops ride along:
 //   forward : + ReLU (models.py:69,87) + the decoder's second Dropout (models.py:88) on the result;
 //   backward: the Dropout backward of the incoming gradient, the ReLU mask, (sum dy, sum dy*xhat), dgamma / dbeta, dz,
 //             and the column sums of dz (= the bias gradient of the Linear in front, models.py:85).
@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int COLS = 16, SLICES = 64, RUN = 32;      // block = 16 columns x 64 row slices (the launch is latency bound:
+constexpr int COLS = 8, SLICES = 128, RUN = 32;      // block = 8 columns x 128 row slices (the launch is latency bound:
                                                      // rows in flight are what counts); RUN: fp32 runs of the dz column sums
 constexpr int THREADS = COLS * SLICES;
 

@@ -996,7 +996,7 @@ static int roipool_page_ranges(const float *rois, int n_rois, int B, int *range,
 COVA_API int cova_roipool_bwd_bn_num_partials(int n_rois)
 {
     const int g = cdiv(n_rois > 0 ? n_rois : 1, 4);
-    return g < 64 ? g : 64;
+    return g < 256 ? g : 256;          // (64 blocks left the entry pass latency bound: 40 us for 1 440 boxes)
 }
 
 // 4-byte words of workspace of cova_roipool_bwd / cova_roipool_bwd_bn: transposed contributions + positions, page ranges

@@ -134,12 +134,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // Software pipeline, one iteration = one 8-channel chunk g of the block's chunk stream (8 chunks per tile, the stream
 // runs across tiles):
-//   request planes(g+4) as global -> LDS copies (ring of 3 slots) | column stage(g+2): planes -> tmp[g & 1] |
-//   row stage(g+1): tmp[(g+1) & 1] -> V[(g+1) & 1] | 36 MFMAs of chunk g from V[g & 1] and the weight registers of
-//   chunk g, each weight quad re-requested for chunk g+2 right after its last use | wait for planes(g+3) | barrier.
-// vmcnt retires in order, so waiting for a weight load also waits for every older plane copy: the copies' time of
-// flight equals the weights' lead -- two iterations.  Waves 0-3 (position half 0) run stages then MFMAs, waves 4-7 MFMAs
-// then stages, so that on every SIMD one wave is in its MFMAs while the other does transform work.
+//   even g: request the planes of the 16-channel group of chunks g+4, g+5 as global -> LDS copies (two slots per tensor) |
+//   column stage(g+2): planes -> tmp[g & 1] | row stage(g+1): tmp[(g+1) & 1] -> V[(g+1) & 1] | 36 MFMAs of chunk g from
+//   V[g & 1] and the weight registers of chunk g, each weight quad re-requested for chunk g+1 right after its last use |
+//   odd g: wait for the copies issued at g-1 | barrier.
+// Every wave interleaves its three stage items with its MFMAs (reads, 16 MFMAs, transforms, 20 MFMAs; the prologue
+// variants one item at a time).  vmcnt retires in order, so the wait in front of a weight quad's first use also waits
+// for older plane copies (measured: giving the copies two full iterations through exact wait counts changes nothing).
 // BN: 0 plain (+ statistics if STATS), 1 = ReLU mask from z + BatchNorm-backward sums, 2 = mask from act + sums.
 template <bool STATS, int PRO, bool ADD, int BN>
 __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const W4Args a)

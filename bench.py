@@ -27,13 +27,17 @@ Prints ONE JSON line on rank 0.  Extra objects:
                   timed on this host: 2-page and 16-page batches, forward and forward+backward+Adam, medians.
 """
 import argparse
+import datetime
 import json
 import os
+import signal
 import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
+import traceback
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL: before the HIP runtime starts
 
@@ -44,7 +48,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-in
 PEAK_HBM_TBS = 8.0
 WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3): the weight gradients
 WINO4_RATIO = 4.0                                  # ... / Winograd F(4x4,3x3): forward and data-gradient launches
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILES = [os.path.join("profiles", "r04_hbm_traffic.json"), os.path.join("profiles", "r03_hbm_traffic.json")]
 
 WORKLOADS = {
     2: dict(name="configs[1]", H=1280, W=1280, pages=16, boxes=90, cs=12, backbone="resnet18", n_heads=1,
@@ -116,15 +120,19 @@ def flop_model(wl):
 def read_traffic(kernel_key, pages):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/hbm_traffic.py writes the file)."""
-    path = os.path.join(ROOT, TRAFFIC_FILE)
-    if not os.path.exists(path):
-        return None, None
-    try:
-        d = json.load(open(path))
-        e = d["kernels"][kernel_key]
-        return e["traffic_bytes_per_launch"] * pages / d["pages"], TRAFFIC_FILE
-    except Exception:
-        return None, None
+    for rel in TRAFFIC_FILES:          # the newest PMC pass that has the kernel (an older round's file is a stale number:
+        path = os.path.join(ROOT, rel)  # the source is named in the line)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+            e = d["kernels"][kernel_key]
+            step = d.get("step_traffic_bytes")
+            return (e["traffic_bytes_per_launch"] * pages / d["pages"], rel,
+                    step * pages / d["pages"] if step else None)
+        except Exception:
+            continue
+    return None, None, None
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -219,14 +227,59 @@ def free_port():
 
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
-    import torch
-    env = dict(os.environ)
-    if torch.cuda.device_count() < args.gpus:
-        # code-path check on a box with fewer GPUs: ranks share devices, collectives through gloo
-        env.setdefault("COVA_BENCH_BACKEND", "gloo")
+    env = dict(os.environ)      # (fewer GPUs than ranks: the preflight of every rank reports it; COVA_BENCH_BACKEND=gloo
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    raise SystemExit(subprocess.call(cmd, env=env))     #  opts into the shared-device code-path check)
+
+
+# ------------------------------------------------------------------------------------ N > 1 first-contact hardening
+class Guard:
+    """Makes sure a multi-rank run ends with ONE JSON line on rank 0 instead of a hang: every phase has a deadline
+    (`--collective-timeout`, also the process group's timeout); when it passes, when another rank dies (the launcher
+    then SIGTERMs this one) or when this rank raises, rank 0 prints {"error": ...} in the bench line's shape and the
+    process exits non-zero."""
+
+    def __init__(self, args, rank, world):
+        self.args, self.rank, self.world = args, rank, world
+        self.done = False
+        self.phase = "start"
+        self.deadline = None
+        self.lock = threading.Lock()
+        if rank == 0:
+            signal.signal(signal.SIGTERM, lambda *_: self.fail("terminated by the launcher (another rank failed or was killed) "
+                                                               "during phase '%s'" % self.phase, 4))
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def enter(self, phase, seconds=None):
+        """Name the phase; multi-rank runs also arm its deadline (a single rank has no collective to hang in, and its
+        CPU-baseline leg legitimately takes minutes)."""
+        self.phase = phase
+        self.deadline = time.monotonic() + (seconds or self.args.collective_timeout) if self.world > 1 else None
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.monotonic() > d and not self.done:
+                self.fail("phase '%s' exceeded --collective-timeout %.0f s on rank %d (a collective that never completed?)"
+                          % (self.phase, self.args.collective_timeout, self.rank), 3)
+
+    def fail(self, msg, code):
+        with self.lock:
+            if not self.done:
+                self.done = True
+                if self.rank == 0:
+                    print(json.dumps({"metric": "webpages/sec fwd+bwd (90 bboxes, K=24)", "value": None, "unit": "webpages/s",
+                                      "n_gpus": self.world, "steps": self.args.steps, "warmup": self.args.warmup,
+                                      "higher_is_better": True, "error": msg}), flush=True)
+                else:
+                    print("bench.py rank %d: %s" % (self.rank, msg), file=sys.stderr, flush=True)
+        os._exit(code)
+
+    def finish(self):
+        self.done = True
 
 
 def main():
@@ -248,6 +301,9 @@ def main():
                     help="length of the `sustained` leg after the headline measurement (0 = skip)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm statistics over the whole data-parallel batch (default: per rank, as DDP)")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="deadline (s) of every phase of a multi-rank run and of the process group's collectives: past it "
+                         "rank 0 prints a JSON line with \"error\" instead of hanging")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,28 +312,57 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    guard = Guard(args, rank, world)
+    try:
+        run(args, guard, rank, local_rank, world)
+    except SystemExit:
+        raise
+    except BaseException as e:          # noqa: BLE001 -- whatever it is, the line goes out and the other ranks get torn down
+        traceback.print_exc()
+        guard.fail("rank %d, phase '%s': %s: %s" % (rank, guard.phase, type(e).__name__, e), 2)
+
+
+def run(args, guard, rank, local_rank, world):
     import torch
     import cova_amd  # noqa: F401
     from cova_web_object_detection_amd import _lib, synthetic, weights
     from cova_web_object_detection_amd.trainer import HotPathTrainer, shard_pages
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- preflight: one GPU per rank (COVA_BENCH_BACKEND=gloo opts into the shared-device DIAGNOSTIC run of the code path)
+    guard.enter("preflight")
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise RuntimeError("no GPU visible (torch.cuda.device_count() == 0)")
     backend = os.environ.get("COVA_BENCH_BACKEND", "nccl")
-    if backend == "nccl" and world > torch.cuda.device_count():
-        backend = "gloo"            # more ranks than GPUs (code-path check on a small box): shared devices, DIAGNOSTIC
+    if backend == "nccl" and world > n_dev:
+        raise RuntimeError("--gpus %d needs %d visible GPUs, torch.cuda.device_count() = %d (set COVA_BENCH_BACKEND=gloo "
+                           "for a shared-device code-path check; its throughput is meaningless)" % (world, world, n_dev))
     if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
+        guard.enter("init_process_group")
+        tmo = datetime.timedelta(seconds=args.collective_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        # first contact: one all-reduce of ones over the data-path backend; every rank must see the world size
+        guard.enter("checksum all-reduce")
+        ones = torch.ones((1,), device=device, dtype=torch.float32)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != world:
+            raise RuntimeError("checksum all-reduce of ones returned %d, expected the world size %d" % (ranks_seen, world))
 
+    guard.enter("model + batch + warm-up")
     wl = dict(WORKLOADS[args.config])
     if args.scaling == "strong":
         lo, hi = shard_pages(args.global_pages, rank, world)
@@ -313,11 +398,15 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    timed = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv1_fwd_tail", "cova_conv3x3_wino", "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro",
-             "cova_conv3x3_wgrad_wino",
-             "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad", "cova_bn_relu_maxpool_fwd",
-             "cova_conv1x1", "cova_conv1x1_wgrad", "cova_bn_act_fwd", "cova_bn_act2_fwd", "cova_roipool_fwd_bn",
-             "cova_roipool_bwd_bn", "cova_sgemm", "cova_gat_fwd", "cova_gat_bwd"]
+    guard.enter("timed steps")
+    timed = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv1_fwd_tail", "cova_conv3x3_wino",
+             "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
+             "cova_conv3x3_wgrad_wino_partial", "cova_conv3x3_wgrad_wino_finish", "cova_conv3x3_wgrad4_partial",
+             "cova_conv3x3_wgrad4_finish", "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad",
+             "cova_bn_relu_maxpool_fwd", "cova_conv1x1", "cova_conv1x1_wgrad", "cova_bn_act_fwd", "cova_bn_act_fwd_bits",
+             "cova_bn_act2_fwd", "cova_roipool_fwd_bn", "cova_roipool_bwd_bn", "cova_roipool_bwd_bn_tail", "cova_bn1d_fwd",
+             "cova_bn1d_bwd", "cova_sgemm", "cova_gat_fwd", "cova_gat_bwd"]
+    timed = [n for n in timed if n in _lib.lib().protos]
     _lib.PROFILE = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else timed)}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -348,7 +437,10 @@ def main():
     # sustained leg: >= N seconds of back-to-back train steps (reported separately from the headline)
     sustained = None
     if args.sustained_seconds > 0:
-        n_s = max(args.steps, int(args.sustained_seconds / max(dt / args.steps, 1e-4)) + 1)
+        guard.enter("sustained leg", args.collective_timeout + 2 * args.sustained_seconds)
+        # step count fixed up front from the headline rate (+5 %: every rank runs the same number of steps and the leg
+        # must last AT LEAST the stated time)
+        n_s = max(args.steps, int(1.05 * args.sustained_seconds / max(dt / args.steps, 1e-4)) + 2)
         barrier()
         t_s = time.perf_counter()
         for _ in range(n_s):
@@ -359,6 +451,7 @@ def main():
                      "seconds": round(dt_s, 2), "ms_per_step": round(1e3 * dt_s / n_s, 3)}
 
     # forward only (eval mode, running statistics): the second number SURVEY.md section 8d asks for
+    guard.enter("forward-only leg")
     for _ in range(2):
         trainer.predict(batch)
     barrier()
@@ -371,6 +464,7 @@ def main():
     # the drop-in nn.Module route with the reference's loop cadence (train.py:45-60: zero_grad, forward,
     # argmax + .item(), CE-sum + .item(), backward, torch.optim.Adam.step) -- two host reads per step
     dropin = None
+    guard.enter("report")
     if world == 1 and args.config in (2, 3) and args.roi_op == "pool":
         import contextlib
         import warnings
@@ -427,7 +521,12 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches_timed": conv_n}
         if conv_n:
             ach = executed / conv_ms / 1e9
-            traffic, src = read_traffic(kname, px_pages)
+            traffic, src, step_traffic = read_traffic(kname, px_pages)
+            if traffic:
+                roof.update(hbm_achieved_tb_per_s=round(traffic / conv_ms / 1e9, 3),
+                            hbm_frac=round(traffic / conv_ms / 1e9 / PEAK_HBM_TBS, 4))
+            if step_traffic:
+                roof.update(step_traffic_bytes=int(step_traffic))
             roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio, avg_launch_ms=round(conv_ms, 4),
                         executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
@@ -455,8 +554,15 @@ def main():
         f_conv1 = 2 * 64 * 147 * pages * (wl["H"] // 2) * (wl["W"] // 2)
         specs = [("conv1_7x7_fwd", ["cova_conv1_fwd", "cova_conv1_fwd_tail"], None, f_conv1, 0),
                  ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0),
-                 ("conv3x3_wgrad_winograd", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino"], None,
+                 ("conv3x3_wgrad_winograd_f2x2", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
+                                                  "cova_conv3x3_wgrad_wino_partial"], None,
                   fm["conv3_launch_per_page"] * pages / WINO_RATIO, 0),
+                 ("conv3x3_wgrad_winograd_f4x4", ["cova_conv3x3_wgrad4_partial"], None,
+                  fm["conv3_launch_per_page"] * pages / WINO4_RATIO, 0),
+                 ("conv3x3_wgrad_finish_all_convs", ["cova_conv3x3_wgrad_wino_finish", "cova_conv3x3_wgrad4_finish"], None, 0, 0),
+                 ("bn_act_fwd_bits", ["cova_bn_act_fwd_bits"], None, 0, pages * 64 * 4 * 3 * hw),
+                 ("roipool_fwd_lazy_feature", ["cova_roipool_fwd_bn"], None, 0, 0),
+                 ("roipool_bwd_with_bn_tail", ["cova_roipool_bwd_bn", "cova_roipool_bwd_bn_tail"], None, 0, 0),
                  ("bn_relu_maxpool_fwd", ["cova_bn_relu_maxpool_fwd"], None, 0,
                   pages * 64 * (4 * 4 * hw + (4 + 4 + 1) * hw))]
         if wl["backbone"] == "resnet50":
@@ -486,6 +592,7 @@ def main():
                                    % (wl["name"], wl["H"], wl["W"], pages, wl["boxes"], 2 * wl["cs"], wl["desc"]),
                        "baseline_config": args.config, "pages_per_gpu": pages, "global_pages": global_pages,
                        "boxes_per_gpu": n_boxes, "world_size": world, "collective_backend": "rccl" if backend == "nccl" else backend,
+                       "rccl_ranks_seen": ranks_seen, "gpus_visible": n_dev,
                        "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") + diag,
                        "loss": round(loss_val, 3)},
             "roofline": roof, "step": step, "other_kernels": others,
@@ -503,6 +610,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.roi_op == "pool":
             out["cpu_baseline"] = cpu_baseline(wl, not args.cpu_baseline_quick)
         print(json.dumps(out), flush=True)
+    guard.finish()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -44,6 +44,13 @@ __device__ __forceinline__ void bn_bwd_abc_channel(double s1, double s2, double 
     abc[2 * C + c] = (float)(sc * (mu * is * c2 - c1));
 }
 
+// The publish protocol below (relaxed agent-scope stores, s_waitcnt(0), relaxed ticket) is ordered only where stores
+// and non-returning atomics are counted in vmcnt and sc1 stores write through: gfx9 / CDNA.  An architecture with a
+// separate store counter (gfx10+) would race silently -- refuse to build for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "bn_tail.h: the fence-free partial-row hand-off is written for gfx90a / gfx942 / gfx950 (stores in vmcnt); use release / acquire at agent scope on the ticket for other targets"
+#endif
+
 // A block's partial row is written with device-scope (agent) relaxed atomic stores and read back by the last block with
 // device-scope atomic loads: per-access coherence across the eight XCDs' L2s.  A __threadfence() instead would write
 // back and invalidate the whole L2 of the XCD at the end of every block -- measured: +0.6 ms per train step, because

@@ -32,6 +32,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define COVA_API extern "C" __attribute__((visibility("default")))
 
+// neighbour slots per node the wave-per-node GAT kernels hold in registers: four 64-lane passes (-cs <= 128)
+#define COVA_GAT_MAX_K 256
+
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 FMA chain.
 // lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].

@@ -88,6 +88,7 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 struct W4Epi {
     const float *addend, *act, *z, *mean, *invstd, *msc, *msh;
     const uint32_t *act_bits;       // BN == 2: the mask as one bit per element ([pixel][2] words) instead of act
+    int inf_relu;                   // BN == 3 (inference epilogue  out = f(msc*y + msh + addend)): f = ReLU
 };
 
 struct W4Args {
@@ -141,7 +142,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Every wave interleaves its three stage items with its MFMAs (reads, 16 MFMAs, transforms, 20 MFMAs; the prologue
 // variants one item at a time).  vmcnt retires in order, so the wait in front of a weight quad's first use also waits
 // for older plane copies (measured: giving the copies two full iterations through exact wait counts changes nothing).
-// BN: 0 plain (+ statistics if STATS), 1 = ReLU mask from z + BatchNorm-backward sums, 2 = mask from act + sums.
+// BN: 0 plain (+ statistics if STATS), 1 = ReLU mask from z + BatchNorm-backward sums, 2 = mask from act + sums,
+//     3 = inference: out = f(msc*y + msh (+ addend)), the BatchNorm (running statistics) + residual + ReLU that follow
+//         the conv in a BasicBlock (same expression and order as cova_bn_act_fwd), no statistics.
 template <bool STATS, int PRO, bool ADD, int BN>
 __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const W4Args a)
 {
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         const int c = tid & 63, kind = (tid >> 6) & 3;
         const KArgs la = late_args();
         const float *src = kind == 0 ? la->epi.mean : kind == 1 ? la->epi.invstd : kind == 2 ? la->epi.msc : la->epi.msh;
-        s_epi[kind * 64 + c] = (kind < 2 || BN == 1) ? src[c] : 0.f;
+        const bool used = BN == 3 ? kind >= 2 : (kind < 2 || BN == 1);       // (unused pointers may be NULL)
+        s_epi[kind * 64 + c] = used ? src[c] : 0.f;
     }
     if (PRO || BN) __syncthreads();
 
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 const unsigned off = offs(io, j);
                 o.ad[j] = o.z4[j] = o.a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ADD) o.ad[j] = *reinterpret_cast<const float4 *>(e_addend + img + off);
-                if (BN) o.z4[j] = *reinterpret_cast<const float4 *>(e_z + img + off);
+                if (BN == 1 || BN == 2) o.z4[j] = *reinterpret_cast<const float4 *>(e_z + img + off);
                 if (BN == 2) {
                     if (bits) {       // bit (c & 31) of word c >> 5 of the pixel = the decision for channel c
                         const uint32_t wd = la->epi.act_bits[((size_t)b * H * W * 64 + off) >> 5] >> (cq & 31);
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 const float4 m4 = *reinterpret_cast<const float4 *>(s_epi + cq), i4 = *reinterpret_cast<const float4 *>(s_epi + 64 + cq);
                 mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
                 is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
-                if (BN == 1) {
+                if (BN == 1 || BN == 3) {
                     const float4 s4 = *reinterpret_cast<const float4 *>(s_epi + 128 + cq), h4 = *reinterpret_cast<const float4 *>(s_epi + 192 + cq);
                     msc[0] = s4.x; msc[1] = s4.y; msc[2] = s4.z; msc[3] = s4.w;
                     msh[0] = h4.x; msh[1] = h4.y; msh[2] = h4.z; msh[3] = h4.w;
@@ -659,6 +663,13 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = own[r];
+                    if (BN == 3) {                  // inference: BatchNorm (running statistics) + residual + ReLU
+                        v = fmaf(msc[r], v, msh[r]);
+                        if (ADD) v += adv[r];
+                        if (la->epi.inf_relu) v = v > 0.f ? v : 0.f;
+                        o[r] = v;
+                        continue;
+                    }
                     if (ADD) v += adv[r];
                     if (BN) {
                         const float gate = BN == 2 ? av[r] : fmaf(msc[r], zv[r], msh[r]);
@@ -813,7 +824,9 @@ void launch_w4_pro(const W4Args &a, int grid, hipStream_t st)
 {
     const bool add = a.epi.addend != nullptr;
     const int bn = a.epi.z == nullptr ? 0 : (a.epi.act == nullptr && a.epi.act_bits == nullptr ? 1 : 2);
-    if (bn == 0) {
+    if (a.epi.z == nullptr && a.epi.msc != nullptr) {          // inference epilogue (no statistics)
+        if (add) launch_w4<false, PRO, true, 3>(a, grid, st); else launch_w4<false, PRO, false, 3>(a, grid, st);
+    } else if (bn == 0) {
         if (a.stat_part) { if (add) launch_w4<true, PRO, true, 0>(a, grid, st); else launch_w4<true, PRO, false, 0>(a, grid, st); }
         else             { if (add) launch_w4<false, PRO, true, 0>(a, grid, st); else launch_w4<false, PRO, false, 0>(a, grid, st); }
     } else if (bn == 1) {
@@ -836,6 +849,7 @@ int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));          // 32-bit in-image offsets in the epilogue
     COVA_REQUIRE(epi.z == nullptr || ((epi.act || epi.act_bits || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
+    COVA_REQUIRE(epi.z != nullptr || epi.msc == nullptr || (epi.msh != nullptr && stat_part == nullptr));     // inference epilogue
     COVA_REQUIRE(!(epi.act && epi.act_bits));
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
     const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi, t};
@@ -879,6 +893,19 @@ COVA_API int cova_conv3x3_wino4_full(const float *in, const float *in2, const fl
     return run_w4(in, in2, pro_abc, pro_relu, u,
                   W4Epi{addend, z ? act : nullptr, z, mean, invstd, z ? mask_scale : nullptr, z ? mask_shift : nullptr}, out,
                   stat_part, B, H, W, stream);
+}
+
+// Inference form (eval-mode forward, train.py:99-129): out = f(scale[c]*conv(g(in)) + shift[c] + addend), f = ReLU if relu;
+// g = relu?(A[c]*in + C[c]) on load when pro_abc is given (the producer's BatchNorm + ReLU), identity otherwise.
+// The BatchNorm (running statistics), residual add and ReLU that follow the conv in a BasicBlock (torchvision resnet.py
+// BasicBlock.forward; models.py:49-51) sit in the epilogue: same expression and operation order as cova_bn_act_fwd.
+COVA_API int cova_conv3x3_wino4_bnact(const float *in, const float *pro_abc, int pro_relu, const float *u,
+                                      const float *addend, const float *scale, const float *shift, int relu, float *out,
+                                      int B, int H, int W, void *stream)
+{
+    COVA_REQUIRE(scale && shift);
+    return run_w4(in, nullptr, pro_abc, pro_relu, u,
+                  W4Epi{addend, nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, relu}, out, nullptr, B, H, W, stream);
 }
 
 // act_bits (instead of act): the mask source as one bit per element, [B*H*W][2] words as cova_bn_act_fwd_bits writes them

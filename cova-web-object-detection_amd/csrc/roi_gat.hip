@@ -9,7 +9,7 @@
 // dense projections Wh = h [W_i;W_j]^T are one GEMM per node (gemm.hip) and this file does the
 // O(N*K) part: e_ik = LeakyReLU(s_i + t_ctx(i,k)), s = a_i.Wh_i + b, t = a_j.Wh_j (t = 0 for the
 // -1 pad row), mask -> -9e15, softmax over the K slots, h'_i = sum_k alpha_ik Wh_j[ctx(i,k)].
-// One wavefront per node: the K <= 64 slots live in lanes for the softmax (shuffle
+// One wavefront per node: the K neighbour slots live in lanes (ceil(K / 64) passes, K <= 256) for the softmax (shuffle
 // reductions), the D hidden channels live in lanes for the gather (256-byte coalesced rows).
 #include "bn_tail.h"
 
@@ -596,6 +596,9 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float *__restrict
     if (lane == 0) { s[n] = a + att_b[0]; t[n] = b; }
 }
 
+// KP = number of 64-slot passes a wave makes over the K neighbour slots (K <= 64 KP; KP = 1 is the reference's usual
+// range, -cs <= 32); slot k lives in lane k & 63 of pass k >> 6.  models.py:171-177 accepts any n_context.
+template <int KP>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(
     const float *__restrict__ Wh, int ldw, const float *__restrict__ s, const float *__restrict__ t,
     const int64_t *__restrict__ ctx, int N, int K, int D, float slope, float *__restrict__ attn,
@@ -603,36 +606,57 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
 {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
-    long long j = -1;
-    float e = -INFINITY;
-    if (lane < K) {
-        j = ctx[(size_t)n * K + lane];
-        if (j >= N) j = -1;                                 // out-of-range id: memory-safe, acts as a pad
-        const float u = s[n] + (j >= 0 ? t[j] : 0.f);
-        const float lr = u > 0.f ? u : slope * u;
-        e = j >= 0 ? lr : -9e15f;                          // models.py:202-203
+    int jj[KP];
+    float e[KP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int k = 64 * p + lane;
+        long long j = -1;
+        e[p] = -INFINITY;
+        if (k < K) {
+            j = ctx[(size_t)n * K + k];
+            if (j >= N) j = -1;                                 // out-of-range id: memory-safe, acts as a pad
+            const float u = s[n] + (j >= 0 ? t[j] : 0.f);
+            const float lr = u > 0.f ? u : slope * u;
+            e[p] = j >= 0 ? lr : -9e15f;                       // models.py:202-203
+        }
+        jj[p] = (int)j;
+        m = fmaxf(m, e[p]);
     }
-    const float m = wave_max(e);
-    const float p = lane < K ? expf(e - m) : 0.f;
-    const float denom = wave_sum(p);
-    const float alpha = p / denom;
-    if (lane < K) attn[(size_t)n * K + lane] = alpha;
-    const int jj = (int)j;
-    const float aw = jj >= 0 ? alpha : 0.f;                 // pads: weight 0 on a valid (clamped) row
+    m = wave_max(m);
+    float pr[KP], psum = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        pr[p] = 64 * p + lane < K ? expf(e[p] - m) : 0.f;
+        psum += pr[p];
+    }
+    const float denom = wave_sum(psum);
+    float aw[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const float alpha = pr[p] / denom;
+        if (64 * p + lane < K) attn[(size_t)n * K + 64 * p + lane] = alpha;
+        aw[p] = jj[p] >= 0 ? alpha : 0.f;                      // pads: weight 0 on a valid (clamped) row
+    }
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int d = d0 + lane, dd = d < D ? d : 0;
         float acc = 0.f;
-        for (int k0 = 0; k0 < K; k0 += 8) {                  // 8 neighbour rows in flight, added in slot order
-            float v[8], a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = min(k0 + u, K - 1);
-                const int jk = __shfl(jj, kk, 64);
-                a[u] = k0 + u < K ? __shfl(aw, kk, 64) : 0.f;
-                v[u] = Wh[(size_t)(jk >= 0 ? jk : 0) * ldw + D + dd];
+        for (int p = 0; p < KP; ++p) {
+            const int Kp = min(64, K - 64 * p);                 // slots of this pass
+            for (int k0 = 0; k0 < Kp; k0 += 8) {                // 8 neighbour rows in flight, added in slot order
+                float v[8], a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = min(k0 + u, Kp - 1);
+                    const int jk = __shfl(jj[p], kk, 64);
+                    a[u] = k0 + u < Kp ? __shfl(aw[p], kk, 64) : 0.f;
+                    v[u] = Wh[(size_t)(jk >= 0 ? jk : 0) * ldw + D + dd];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = a[u] != 0.f ? fmaf(a[u], v[u], acc) : acc;
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = a[u] != 0.f ? fmaf(a[u], v[u], acc) : acc;
         }
         if (d < D) hprime[(size_t)n * ldh + d] = acc;
     }
@@ -643,6 +667,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
 //   du = de * LeakyReLU'(u);  ds_i = sum_k du_k;  dt[ctx_k] += du_k;
 //   dWh_i[i] = ds_i * a_i;  dWh_j[ctx_k] += alpha_k*g_i (+ dt_j*a_j added by gat_bwd_finish)
 // dWh [N, 2D] must be zeroed in its second half (and dt zeroed) before the launch.
+template <int KP>
 __global__ __launch_bounds__(256) void gat_bwd_kernel(
     const float *__restrict__ g, int ldg, const float *__restrict__ Wh, int ldw,
     const float *__restrict__ s, const float *__restrict__ t, const float *__restrict__ attn,
@@ -651,43 +676,61 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel(
 {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
-    long long j = -1;
-    float alpha = 0.f;
-    if (lane < K) {
-        j = ctx[(size_t)n * K + lane];
-        if (j >= N) j = -1;
-        alpha = attn[(size_t)n * K + lane];
+    int jj[KP];
+    float alpha[KP], dalpha[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int k = 64 * p + lane;
+        long long j = -1;
+        alpha[p] = 0.f;
+        dalpha[p] = 0.f;
+        if (k < K) {
+            j = ctx[(size_t)n * K + k];
+            if (j >= N) j = -1;
+            alpha[p] = attn[(size_t)n * K + k];
+        }
+        jj[p] = (int)j;
     }
-    const int jj = (int)j;
     // dalpha for every slot: lanes over channels, one wave reduction per slot
-    float dalpha = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const int jk = __shfl(jj, k, 64);
-        float part = 0.f;
-        if (jk >= 0)
-            for (int d = lane; d < D; d += 64)
-                part += g[(size_t)n * ldg + d] * Wh[(size_t)jk * ldw + D + d];
-        part = wave_sum(part);
-        if (lane == k) dalpha = part;
+#pragma unroll
+    for (int p = 0; p < KP; ++p)
+        for (int k = 0; k < min(64, K - 64 * p); ++k) {
+            const int jk = __shfl(jj[p], k, 64);
+            float part = 0.f;
+            if (jk >= 0)
+                for (int d = lane; d < D; d += 64)
+                    part += g[(size_t)n * ldg + d] * Wh[(size_t)jk * ldw + D + d];
+            part = wave_sum(part);
+            if (lane == k) dalpha[p] = part;
+        }
+    float ad = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) ad += alpha[p] * dalpha[p];
+    const float dot = wave_sum(ad);
+    float dus = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        float du = 0.f;
+        if (64 * p + lane < K && jj[p] >= 0) {
+            const float de = alpha[p] * (dalpha[p] - dot);
+            const float u = s[n] + t[jj[p]];
+            du = de * (u > 0.f ? 1.f : slope);
+            atomicAdd(dt + jj[p], du);
+        }
+        dus += du;
     }
-    const float dot = wave_sum(alpha * dalpha);
-    float du = 0.f;
-    if (lane < K && jj >= 0) {
-        const float de = alpha * (dalpha - dot);
-        const float u = s[n] + t[jj];
-        du = de * (u > 0.f ? 1.f : slope);
-        atomicAdd(dt + jj, du);
-    }
-    const float dsn = wave_sum(du);
+    const float dsn = wave_sum(dus);
     if (lane == 0) ds[n] = dsn;
     for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
-    for (int k = 0; k < K; ++k) {
-        const int jk = __shfl(jj, k, 64);
-        const float ak = __shfl(alpha, k, 64);
-        if (jk < 0) continue;
-        for (int d = lane; d < D; d += 64)
-            atomicAdd(dWh + (size_t)jk * lddw + D + d, ak * g[(size_t)n * ldg + d]);
-    }
+#pragma unroll
+    for (int p = 0; p < KP; ++p)
+        for (int k = 0; k < min(64, K - 64 * p); ++k) {
+            const int jk = __shfl(jj[p], k, 64);
+            const float ak = __shfl(alpha[p], k, 64);
+            if (jk < 0) continue;
+            for (int d = lane; d < D; d += 64)
+                atomicAdd(dWh + (size_t)jk * lddw + D + d, ak * g[(size_t)n * ldg + d]);
+        }
 }
 
 // ---- transposed neighbour index (CSR over destination nodes): lets the backward GATHER what the
@@ -795,6 +838,7 @@ __global__ __launch_bounds__(256) void csr_count_scan_kernel(const int64_t *__re
 // backward, source side (one wave per node i): everything that stays with node i -- du [N,K] (0 on pads),
 // ds, dWh_i = ds * a_i.  The contributions to OTHER nodes (dt[ctx], dWh_j[ctx]) are gathered by
 // gat_bwd_dst_kernel from du / attn / g through the transposed index.
+template <int KP>
 __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
     const float *__restrict__ g, int ldg, const float *__restrict__ Wh, int ldw,
     const float *__restrict__ s, const float *__restrict__ t, const float *__restrict__ attn,
@@ -803,43 +847,61 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
 {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
-    long long j = -1;
-    float alpha = 0.f;
-    if (lane < K) {
-        j = ctx[(size_t)n * K + lane];
-        if (j >= N) j = -1;
-        alpha = attn[(size_t)n * K + lane];
-    }
-    const int jj = (int)j;
-    float dalpha = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 4) {                     // four neighbour rows in flight per channel slice
-        int jk[4];
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
+    int jj[KP];
+    float alpha[KP], dalpha[KP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) jk[u] = __shfl(jj, min(k0 + u, K - 1), 64);
-        for (int d = lane; d < D; d += 64) {
-            const float gv = g[(size_t)n * ldg + d];
-            float w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = Wh[(size_t)(jk[u] >= 0 ? jk[u] : 0) * ldw + D + d];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) part[u] = fmaf(gv, w[u], part[u]);
+    for (int p = 0; p < KP; ++p) {
+        const int k = 64 * p + lane;
+        long long j = -1;
+        alpha[p] = 0.f;
+        dalpha[p] = 0.f;
+        if (k < K) {
+            j = ctx[(size_t)n * K + k];
+            if (j >= N) j = -1;
+            alpha[p] = attn[(size_t)n * K + k];
         }
+        jj[p] = (int)j;
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float tot = wave_sum(part[u]);
-            if (lane == k0 + u && jk[u] >= 0) dalpha = tot;
+    for (int p = 0; p < KP; ++p) {
+        const int Kp = min(64, K - 64 * p);
+        for (int k0 = 0; k0 < Kp; k0 += 4) {                   // four neighbour rows in flight per channel slice
+            int jk[4];
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jk[u] = __shfl(jj[p], min(k0 + u, Kp - 1), 64);
+            for (int d = lane; d < D; d += 64) {
+                const float gv = g[(size_t)n * ldg + d];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = Wh[(size_t)(jk[u] >= 0 ? jk[u] : 0) * ldw + D + d];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) part[u] = fmaf(gv, w[u], part[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float tot = wave_sum(part[u]);
+                if (lane == k0 + u && jk[u] >= 0) dalpha[p] = tot;
+            }
         }
     }
-    const float dot = wave_sum(alpha * dalpha);
-    float du = 0.f;
-    if (lane < K && jj >= 0) {
-        const float de = alpha * (dalpha - dot);
-        const float u = s[n] + t[jj];
-        du = de * (u > 0.f ? 1.f : slope);
+    float ad = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) ad += alpha[p] * dalpha[p];
+    const float dot = wave_sum(ad);
+    float dus = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        float du = 0.f;
+        if (64 * p + lane < K && jj[p] >= 0) {
+            const float de = alpha[p] * (dalpha[p] - dot);
+            const float u = s[n] + t[jj[p]];
+            du = de * (u > 0.f ? 1.f : slope);
+        }
+        if (64 * p + lane < K) du_out[(size_t)n * K + 64 * p + lane] = du;
+        dus += du;
     }
-    if (lane < K) du_out[(size_t)n * K + lane] = du;
-    const float dsn = wave_sum(du);
+    const float dsn = wave_sum(dus);
     if (lane == 0) ds[n] = dsn;
     for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
 }
@@ -1133,13 +1195,21 @@ COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const fl
                           const int64_t *ctx, int N, int K, int D, float slope, float *s, float *t,
                           float *attn, float *hprime, int ldh, void *stream)
 {
-    COVA_REQUIRE(Wh && att_w && att_b && ctx && s && t && attn && hprime && K > 0 && K <= 64 && D > 0);
+    COVA_REQUIRE(Wh && att_w && att_b && ctx && s && t && attn && hprime && K > 0 && K <= COVA_GAT_MAX_K && D > 0);
     if (N == 0) return COVA_OK;
     hipLaunchKernelGGL(gat_scores_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh,
                        ldw, att_w, att_b, s, t, N, D);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gat_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, Wh, ldw,
-                       s, t, ctx, N, K, D, slope, attn, hprime, ldh);
+    const dim3 grid(cdiv(N, 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define COVA_GAT_FWD(KP) hipLaunchKernelGGL(gat_fwd_kernel<KP>, grid, blk, 0, st, Wh, ldw, s, t, ctx, N, K, D, slope, attn, hprime, ldh)
+    switch ((K + 63) / 64) {        // one wave per node, K slots in ceil(K / 64) passes over the lanes
+    case 1: COVA_GAT_FWD(1); break;
+    case 2: COVA_GAT_FWD(2); break;
+    case 3: COVA_GAT_FWD(3); break;
+    default: COVA_GAT_FWD(4); break;
+    }
+#undef COVA_GAT_FWD
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -1195,12 +1265,20 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
                           float *d_att_w, float *d_att_b, const int *csr, float *du, void *stream)
 {
     COVA_REQUIRE(g && Wh && s && t && attn && ctx && att_w && dWh && ds && dt && d_att_w && d_att_b);
-    COVA_REQUIRE(K > 0 && K <= 64 && D > 0 && N > 0);
+    COVA_REQUIRE(K > 0 && K <= COVA_GAT_MAX_K && D > 0 && N > 0);
     COVA_REQUIRE(!csr || du);
     hipStream_t st = (hipStream_t)stream;
+    const int kp = (K + 63) / 64;
     if (csr != nullptr) {
-        hipLaunchKernelGGL(gat_bwd_src_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
-                           ctx, att_w, N, K, D, slope, dWh, lddw, ds, du);
+#define COVA_GAT_SRC(KP) hipLaunchKernelGGL(gat_bwd_src_kernel<KP>, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, \
+                                            attn, ctx, att_w, N, K, D, slope, dWh, lddw, ds, du)
+        switch (kp) {
+        case 1: COVA_GAT_SRC(1); break;
+        case 2: COVA_GAT_SRC(2); break;
+        case 3: COVA_GAT_SRC(3); break;
+        default: COVA_GAT_SRC(4); break;
+        }
+#undef COVA_GAT_SRC
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(gat_bwd_dst_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, attn, du, csr,
                            csr + N + 1, att_w, N, K, D, dWh, lddw, dt);
@@ -1210,8 +1288,15 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
         if (e != hipSuccess) return (int)e;
         e = hipMemset2DAsync(dWh + D, sizeof(float) * (size_t)lddw, 0, sizeof(float) * (size_t)D, (size_t)N, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(gat_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn,
-                           ctx, att_w, N, K, D, slope, dWh, lddw, ds, dt);
+#define COVA_GAT_BWD(KP) hipLaunchKernelGGL(gat_bwd_kernel<KP>, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, attn, \
+                                            ctx, att_w, N, K, D, slope, dWh, lddw, ds, dt)
+        switch (kp) {
+        case 1: COVA_GAT_BWD(1); break;
+        case 2: COVA_GAT_BWD(2); break;
+        case 3: COVA_GAT_BWD(3); break;
+        default: COVA_GAT_BWD(4); break;
+        }
+#undef COVA_GAT_BWD
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(gat_bwd_addt_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, st, dWh, lddw, dt,
                            att_w, N, D);

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from .weights import BACKBONE_CHANNELS as C64
 
+GAT_MAX_K = 256        # COVA_GAT_MAX_K of csrc/common.h: neighbour slots per node (four 64-lane passes of a wavefront)
+
 call, query = _lib.call, _lib.query
 BN_MOMENTUM, BN_EPS, LEAKY_SLOPE = 0.1, 1e-5, 0.2   # nn.BatchNorm defaults; models.py:156
 
@@ -78,8 +80,9 @@ def check_batch(cfg, images, bboxes, additional_feats, context_indices, training
                                % (N, tuple(context_indices.shape)))
         if context_indices.is_floating_point() or context_indices.dtype == torch.bool:
             raise IndexError("context_indices must be an integer tensor (models.py:186 indexes with it)")
-        if context_indices.shape[1] > 64:
-            raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
+        if context_indices.shape[1] > GAT_MAX_K:
+            raise ValueError("n_context > %d (-cs > %d) is not supported by the wave-per-node kernel"
+                             % (GAT_MAX_K, GAT_MAX_K // 2))
     if training and N == 1:
         # torch.nn.functional.batch_norm's _verify_batch_size, hit by the first BatchNorm1d of the forward
         width = cfg["bbox_hidden_dim"] or A or None
@@ -434,7 +437,8 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     """layer1 of ResNet-18: two BasicBlocks (the reference's backbone, models.py:49-51)"""
     images = p1
     B, H, W, H1, W1, H2, W2 = sv["dims"]
-    w4 = OPTIONS.wino4 and training       # (inference keeps the BatchNorm-in-epilogue F(2x2) form)
+    infer = not training and not save
+    w4 = OPTIONS.wino4 and (training or infer)        # (an eval-mode forward that keeps its graph runs F(2x2,3x3))
     wf, wd = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4)
     sv["wd"], sv["w4"] = wd, w4
     R = B * H2 * W2
@@ -442,15 +446,31 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     x = p1
     blocks = []
     for blk in (0, 1):
-        if not training and not save:
-            # inference: running statistics are known up front, so BatchNorm (+ residual) + ReLU sit in
-            # the conv epilogues -- two launches per BasicBlock, nothing else touches the maps
+        if infer:
+            # inference: running statistics are known up front, so BatchNorm (+ residual) + ReLU sit in the conv
+            # prologues / epilogues -- two launches per BasicBlock, nothing else touches the maps
             bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, False)
             bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, False)
-            a1, out = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
-            call("cova_conv3x3_wino_bnact", x, wf[2 * blk][1], None, bna.scale, bna.shift, 1, a1, B, H2, W2)
-            call("cova_conv3x3_wino_bnact", a1, wf[2 * blk + 1][1], x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
-            blocks.append(dict(x=x, z1=None, a1=a1, z2=None, out=out, bna=bna, bnb=bnb))
+            ua, ub = wf[2 * blk][1], wf[2 * blk + 1][1]
+            if w4:
+                # F(4x4,3x3): conv1 plain; conv2 reads relu(bn1(z1)) formed on load and either carries bn2 + identity +
+                # ReLU in its epilogue, or (last block, lazy feature map) leaves them to RoIPool
+                z1 = _empty((B, H2, W2, C64), images)
+                call("cova_conv3x3_wino4", x, ua, z1, None, B, H2, W2)
+                if blk == 1 and lazy_out:
+                    z2 = _empty((B, H2, W2, C64), images)
+                    call("cova_conv3x3_wino4_pro", z1, bna.abc, 1, ub, z2, None, B, H2, W2)
+                    feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
+                    blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=None, bna=bna, bnb=bnb))
+                    continue
+                out = _empty((B, H2, W2, C64), images)
+                call("cova_conv3x3_wino4_bnact", z1, bna.abc, 1, ub, x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
+                blocks.append(dict(x=x, z1=z1, a1=None, z2=None, out=out, bna=bna, bnb=bnb))
+            else:
+                a1, out = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
+                call("cova_conv3x3_wino_bnact", x, ua, None, bna.scale, bna.shift, 1, a1, B, H2, W2)
+                call("cova_conv3x3_wino_bnact", a1, ub, x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
+                blocks.append(dict(x=x, z1=None, a1=a1, z2=None, out=out, bna=bna, bnb=bnb))
             x = feat = out
             continue
         part = _empty((nt, 2, C64), images) if training else None
@@ -1042,7 +1062,9 @@ _CSR_WS = {}
 
 def gat_transpose(ctx):
     """Transposed neighbour index of one batch (shared by every head / layer / backward call of the step).  The
-    workspace is kept per (device, stream, N, K): its counters are zeroed once and left zero by the kernels."""
+    workspace is kept per (device, stream, N, K): its counters are zeroed once and left zero by the kernels.
+    The returned tensor IS that cached workspace: it is valid until the next gat_transpose call with the same
+    (device, stream, N, K) -- use it within the step that built it (clone it to keep it longer)."""
     N, K = ctx.shape
     key = (ctx.device, torch.cuda.current_stream(ctx.device).cuda_stream, N, K)
     csr = _CSR_WS.get(key)
@@ -1052,7 +1074,7 @@ def gat_transpose(ctx):
         csr = _CSR_WS[key] = torch.zeros((query("cova_gat_transpose_ints", N, K),), dtype=torch.int32, device=ctx.device)
     try:
         call("cova_gat_transpose_reuse", ctx, N, K, csr)
-    except Exception:
+    except BaseException:               # (KeyboardInterrupt between the three launches included)
         _CSR_WS.pop(key, None)          # its counters may be half-updated: never reuse it
         raise
     return csr

@@ -23,6 +23,8 @@ import torch.nn as nn
 from . import engine
 from .weights import backbone_channels
 
+GAT_MAX_K = engine.GAT_MAX_K
+
 _FIELDS = ("roi_output_size", "n_classes", "use_context", "hidden_dim", "bbox_hidden_dim",
            "n_additional_feat", "drop_prob")
 
@@ -248,8 +250,9 @@ def _check_gat_inputs(h_i, context_indices, in_features):
                            % (h_i.shape[0], tuple(context_indices.shape)))
     if context_indices.is_floating_point() or context_indices.dtype == torch.bool:
         raise IndexError("context_indices must be an integer tensor (models.py:186 indexes with it)")
-    if context_indices.shape[1] > 64:
-        raise ValueError("n_context > 64 is not supported by the wave-per-node kernel")
+    if context_indices.shape[1] > GAT_MAX_K:
+        raise ValueError("n_context > %d (-cs > %d) is not supported by the wave-per-node kernel"
+                             % (GAT_MAX_K, GAT_MAX_K // 2))
 
 
 class GraphAttentionLayer(nn.Module):

@@ -109,6 +109,7 @@ class HotPathTrainer:
         self.step_count, self.dropout_seed = 0, int(dropout_seed)
         self.sync_bn = bool(sync_bn) and world_size > 1
         self._ar_events = []              # (start, end) HIP events around the collective waits of optimizer_step
+        self.measure_allreduce = True     # record them (up to 4096 steps; exposed_allreduce_ms() drains the list)
         if world_size > 1:
             self.broadcast_state(src=0)
 
@@ -149,6 +150,8 @@ class HotPathTrainer:
             p.copy_(state_dict[k].to(p.device).view_as(p))
         for k in self.buffers:
             self.buffers[k].copy_(state_dict[k].to(self.device))
+        if self.world_size > 1:             # every rank calls it (a collective): replicas continue from rank 0's copy
+            self.broadcast_state(src=0)
 
     def optimizer_state_dict(self):
         """Adam moments + step count (the reference keeps no optimizer state in its checkpoints, train.py:84;
@@ -161,6 +164,8 @@ class HotPathTrainer:
         self.exp_avg.copy_(state["exp_avg"].to(self.device))
         self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device))
         self.hp.update(state.get("hp", {}))
+        if self.world_size > 1:             # (collective, as load_state_dict)
+            self.broadcast_state(src=0)
 
     def forward_backward(self, batch, masks=None):
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""
@@ -191,12 +196,11 @@ class HotPathTrainer:
         """SyncBN bookkeeping of one step: whole-batch / local element-count ratios for the page-shaped
         (conv stack) and box-shaped (BatchNorm1d) statistics; one tiny all-reduce + host read."""
         import torch.distributed as dist
-        local = torch.tensor([batch["images"].shape[0], batch["bboxes"].shape[0]], dtype=torch.float64,
-                             device=self.device)
-        total = local.clone()
+        n_pages, n_boxes = int(batch["images"].shape[0]), int(batch["bboxes"].shape[0])      # host ints: no device read
+        total = torch.tensor([n_pages, n_boxes], dtype=torch.float64, device=self.device)
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
-        tot = total.tolist()
-        r = [tot[0] / max(float(local[0].item()), 1.0), tot[1] / max(float(local[1].item()), 1.0)]
+        tot = total.tolist()                                                                   # the step's one host read
+        r = [tot[0] / max(float(n_pages), 1.0), tot[1] / max(float(n_boxes), 1.0)]
         if tot[1] == 1.0:
             raise ValueError("Expected more than 1 value per channel when training (1 box in the whole batch)")
         return engine.StatSync(self.group, r[0], r[1])
@@ -220,16 +224,19 @@ class HotPathTrainer:
 
     def optimizer_step(self):
         if self.world_size > 1:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            timing = self.measure_allreduce and len(self._ar_events) < 4096
+            if timing:                      # events on THIS trainer's device / stream (not the process' current device)
+                st = torch.cuda.current_stream(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
             if getattr(self, "_head_work", None) is not None:
                 self.gbucket.all_reduce_range(0, self._head_offset(), self.group)
                 self._head_work.wait()
                 self._head_work = None
             else:
                 self.gbucket.all_reduce_sum(self.group)
-            e1.record()
-            if len(self._ar_events) < 4096:
+            if timing:
+                e1.record(st)
                 self._ar_events.append((e0, e1))
         b1, b2 = self.hp["betas"]
         engine.call("cova_adam_step", self.pbucket.flat, self.gbucket.flat, self.exp_avg,

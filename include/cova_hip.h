@@ -165,6 +165,13 @@ int cova_conv3x3_wino4_full_tail(const float *in, const float *in2 /*nullable*/,
                                  const float *mask_shift /*nullable*/, const float *z /*nullable*/,
                                  const float *mean /*nullable*/, const float *invstd /*nullable*/, float *out,
                                  float *stat_part, int B, int H, int W, const cova_bn_tail *tail, void *stream);
+/* ... inference form (replaces conv -> eval-mode BatchNorm -> (+ identity) -> ReLU of torchvision's BasicBlock.forward in
+ * train.evaluate_model's no-grad forward, train.py:99-129; models.py:49-51):
+ * out = f(scale[c]*conv(g(in)) + shift[c] + addend), f = ReLU if relu; g = relu?(A[c]*in + C[c]) on load when pro_abc
+ * ([3][64] = A | unused | C) is given.  Same expression and operation order as cova_bn_act_fwd; no statistics */
+int cova_conv3x3_wino4_bnact(const float *in, const float *pro_abc /*nullable*/, int pro_relu, const float *u,
+                             const float *addend /*nullable*/, const float *scale, const float *shift, int relu,
+                             float *out, int B, int H, int W, void *stream);
 
 /* ---- ResNet-50-stem extension (BASELINE.json configs[2], [4]; the reference wires resnet18 only,
  * models.py:49): 1x1 convolutions of torchvision's Bottleneck (conv1, conv3, downsample[0]) on NHWC rows.
@@ -366,7 +373,8 @@ int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int 
 
 /* ------------------------------------------------------------------ graph attention (models.py:171-212)
  * replaces: GraphAttentionLayer.forward after the projections: gather, score, LeakyReLU, mask,
- * softmax, weighted sum.  Wh [N,2D] = h [W_i;W_j]^T.  K <= 64.  Neighbour ids >= N are treated like the
+ * softmax, weighted sum.  Wh [N,2D] = h [W_i;W_j]^T.  K <= 256 (the K slots of a node are held by one wavefront in
+ * ceil(K/64) passes over its lanes; models.py:171-177 takes any n_context).  Neighbour ids >= N are treated like the
  * -1 pad (the reference's h_i_padded[context_indices] raises an index error for them). */
 int cova_gat_fwd(const float *Wh, int ldw, const float *att_w /*[2D]*/, const float *att_b /*[1]*/,
                  const int64_t *ctx /*[N,K]*/, int N, int K, int D, float slope, float *s /*[N]*/,

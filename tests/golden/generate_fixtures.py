@@ -115,10 +115,9 @@ def case_full_model(name, n_pages, img_h, boxes, cs, seed, hidden_dim=384, bbox_
     print(name, "loss", loss.item(), "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
-def case_gat():
+def case_gat(name="gat_layer", seed=7, N=13, K=6, Fd=40, D=16):
     """models.GraphAttentionLayer on hand-made graphs, incl. an all -1 row."""
-    rs = np.random.RandomState(7)
-    N, K, Fd, D = 13, 6, 40, 16
+    rs = np.random.RandomState(seed)
     layer = ref_models.GraphAttentionLayer(Fd, D)
     sd = {"W_i.weight": torch.from_numpy(rs.uniform(-0.3, 0.3, (D, Fd)).astype(np.float32)),
           "W_j.weight": torch.from_numpy(rs.uniform(-0.3, 0.3, (D, Fd)).astype(np.float32)),
@@ -140,8 +139,13 @@ def case_gat():
         out["w/" + k] = v.numpy()
     for k, p in layer.named_parameters():
         out["grad/" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "gat_layer.npz"), **out)
-    print("gat_layer ok")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
+def case_gat_k100():
+    """n_context = 100 (`-cs 50`): more neighbour slots than a wavefront has lanes (models.py:171-177 takes any K)"""
+    case_gat("gat_layer_k100", seed=11, N=150, K=100, Fd=24, D=8)
 
 
 def case_collate():
@@ -276,6 +280,7 @@ if __name__ == "__main__":
             globals()[name]()
         sys.exit(0)
     case_gat()
+    case_gat_k100()
     case_collate()
     case_collate_raw()
     case_attn_export()

@@ -5,7 +5,7 @@ non-square pages (configs[4]: 1280 x 4096) and N = 300 boxes / K = 48 neighbours
 
 The oracle for the new pieces is the build's own torch-CPU restatement (oracle/cova_oracle.py: SELF-ORACLE,
 parity unpinned by the reference); geometry cases on the reference's own model use the reference-pinned oracle.
-Tolerances as in test_model_gpu.py: forward 1e-4 of the tensor scale, loss 2e-4, gradients 2e-4 of each
+Tolerances as in test_model_gpu.py (about 5x the measured round-off): forward 5e-5 of the tensor scale, loss 2e-5, gradients 1e-4 of each
 tensor's scale under forced routing.
 """
 import numpy as np
@@ -266,7 +266,7 @@ def test_bn_act2():
 
 
 # ------------------------------------------------------------------------------------ whole model
-def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4, bbox_hidden=32):
+def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=1e-4, bbox_hidden=32):
     cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=hidden, bbox_hidden_dim=bbox_hidden,
                n_additional_feat=0, drop_prob=0.0)
     sd = weights.seeded_state_dict(seed, logit_gain=4.0, **{k: v for k, v in cfg.items() if k != "drop_prob"},
@@ -285,7 +285,7 @@ def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4, bbox_
     ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"], batch["additional_feats"],
                     batch["context_indices"], ocfg, False)
     err = float((logits.cpu() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-4, err
+    assert err < 5e-5, err                  # (gates at ~5x the measured errors, as tests/test_model_gpu.py)
     ok = margins_ok(ref, 10 * max(err, 1e-6) * float(ref.abs().max()))
     assert torch.equal(logits.argmax(1).cpu()[ok], ref.argmax(1)[ok])
     # ---- train: loss, gradients under forced routing, running statistics
@@ -297,8 +297,8 @@ def run_case(cfg_kw, img_h, img_w, boxes, cs, seed, hidden=96, tight=2e-4, bbox_
     loss_ref, logits_ref, grads_ref, after, _ = O.loss_and_grads(
         sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
         batch["labels"], ocfg, None, routing)
-    assert float((logits.detach().cpu() - logits_ref).abs().max() / logits_ref.abs().max()) < 2e-4
-    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    assert float((logits.detach().cpu() - logits_ref).abs().max() / logits_ref.abs().max()) < 5e-5
+    assert abs(loss.item() - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))
     grads = {k: p.grad for k, p in m.named_parameters()}
     assert set(grads) == set(grads_ref)
     compare_grads(grads, grads_ref, rtol=tight, outlier_frac=0.0)
@@ -346,9 +346,24 @@ def test_without_positional_encoder_bbox_hidden_dim_zero():
 
 
 def test_context_size_32_fills_the_wave_wide_neighbour_table():
-    """`-cs 32` => K = 64 neighbour slots, the most one wavefront-per-node GAT kernel takes (64 lanes = 64 slots):
+    """`-cs 32` => K = 64 neighbour slots, exactly one wavefront (64 lanes = 64 slots):
     pages of 70 / 9 boxes, so rows mix full windows, -1 padding and (second page) rows that are mostly padding."""
     run_case(dict(), 64, 64, [70, 9], 32, 52, hidden=384)
+
+
+@pytest.mark.parametrize("cs,boxes", [(50, [130, 9]), (100, [230, 40])])
+def test_context_size_beyond_one_wavefront(cs, boxes):
+    """`-cs 50` / `-cs 100` => K = 100 / 200 neighbour slots (/root/reference models.py:171-177 and utils.py:19 take any
+    value): two / four 64-lane passes per node in the GAT kernels, against the reference-pinned oracle at model level
+    (eval logits + decisions, train loss, every gradient)."""
+    run_case(dict(), 64, 64, boxes, cs, 53, hidden=96)
+
+
+def test_context_size_beyond_the_kernel_limit_is_refused():
+    m = CoVA((3, 3), 64, 4, True, 32, 16, 0, 0.0, None).to(DEV)
+    batch = synthetic.make_batch(1, img_h=64, boxes_per_page=[12], context_size=129, seed=5)
+    with pytest.raises(ValueError, match="n_context > 256"):
+        m(*[batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")])
 
 
 def test_eval_mode_backward_uses_frozen_batchnorm():

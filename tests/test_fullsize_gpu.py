@@ -184,15 +184,15 @@ def test_single_page_train_step_full_resolution_matches_oracle():
         sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
         batch["labels"], cfg, None, routing)
     err = rel(logits, logits_ref)
-    assert err < 2e-4, err
-    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    assert err < 5e-5, err                                                # ~5x the measured round-off (3.6e-6 / 5e-7 / 2.5e-5:
+    assert abs(loss.item() - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))     # profiles/r03_wino4_margin.txt, r02_grad_parity_1280*.txt)
     tol = 10 * max(err, 1e-6) * float(logits_ref.abs().max())
     top2 = torch.topk(logits_ref, 2, dim=1).values
     ok = (top2[:, 0] - top2[:, 1]) > tol
     assert torch.equal(pred.cpu()[ok], logits_ref.argmax(1)[ok])          # integer predictions, exact
     # all discrete decisions (max-pool / RoIPool argmax, 3e7 ReLU gates) forced to the HIP forward's:
     # the remaining difference is fp32 round-off
-    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    compare_grads(grads, grads_ref, rtol=1e-4, outlier_frac=0.0)
     assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
     for k in buffers:
         if not k.endswith("num_batches_tracked"):
@@ -224,14 +224,14 @@ def test_single_page_train_step_full_resolution_extension_matches_self_oracle(kw
         sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
         batch["labels"], ocfg, None, routing)
     err = rel(logits, logits_ref)
-    assert err < 2e-4, err
-    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    assert err < 5e-5, err                                                # ~5x the measured round-off (3.6e-6 / 5e-7 / 2.5e-5:
+    assert abs(loss.item() - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))     # profiles/r03_wino4_margin.txt, r02_grad_parity_1280*.txt)
     tol = 10 * max(err, 1e-6) * float(logits_ref.abs().max())
     top2 = torch.topk(logits_ref, 2, dim=1).values
     ok = (top2[:, 0] - top2[:, 1]) > tol
     assert torch.equal(pred.cpu()[ok], logits_ref.argmax(1)[ok])          # integer predictions, exact
     assert set(grads) == set(grads_ref)
-    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    compare_grads(grads, grads_ref, rtol=1e-4, outlier_frac=0.0)
     assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
     for k in buffers:
         if not k.endswith("num_batches_tracked"):

@@ -218,5 +218,6 @@ def test_check_batch_host_contract():
         engine.check_batch(cfg, img, bb[:1], af[:1], ctx[:1], True)
     with pytest.raises(ValueError, match=r"torch.Size\(\[1, 960\]\)"):     # no positional encoder: decoder BN
         engine.check_batch(dict(cfg, bbox_hidden_dim=0), img, bb[:1], af[:1], ctx[:1], True)
+    engine.check_batch(cfg, img, bb, af, torch.zeros(6, 100, dtype=torch.long), True)      # -cs 50: beyond one wavefront
     with pytest.raises(ValueError):
-        engine.check_batch(cfg, img, bb, af, torch.zeros(6, 65, dtype=torch.long), True)
+        engine.check_batch(cfg, img, bb, af, torch.zeros(6, engine.GAT_MAX_K + 1, dtype=torch.long), True)

@@ -742,6 +742,37 @@ def test_conv3x3_winograd_inference_epilogue(B, H, W, cap, geo):
         query("cova_set_option", 6, 1)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 8, 32), (2, 19, 45), (3, 100, 200)])
+def test_conv3x3_winograd_f4x4_inference_epilogue(B, H, W):
+    """cova_conv3x3_wino4_bnact (the eval-mode forward's launches, train.py:99-129) == the F(4x4,3x3) convolution (with
+    or without the BatchNorm+ReLU-on-load prologue) followed by cova_bn_act_fwd (scale/shift, optional residual,
+    optional ReLU), bit-exact; and against torch-CPU."""
+    g = torch.Generator().manual_seed(13 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    xc, rc = rnd(B, 64, H, W), rnd(B, 64, H, W)
+    x, res = nhwc(xc), nhwc(rc)
+    w = rnd(64, 64, 3, 3) * 0.05
+    sc, sh = (rnd(64) * 0.5 + 1.0).to(DEV), (rnd(64) * 0.3).to(DEV)
+    abc = rnd(3, 64).to(DEV)
+    uf, ud = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
+    R = B * H * W
+    for pro in (None, abc):
+        conv = torch.empty_like(x)
+        if pro is None:
+            call("cova_conv3x3_wino4", x, uf, conv, None, B, H, W)
+        else:
+            call("cova_conv3x3_wino4_pro", x, pro, 1, uf, conv, None, B, H, W)
+        for addend, relu in ((None, 1), (res, 1), (None, 0), (res, 0)):
+            ref, out = torch.empty_like(x), torch.empty_like(x)
+            call("cova_bn_act_fwd", conv, 64, sc, sh, addend, 64 if addend is not None else 0, ref, 64, R, 64, relu)
+            call("cova_conv3x3_wino4_bnact", x, pro, 1, uf, addend, sc, sh, relu, out, B, H, W)
+            assert torch.equal(out, ref), (pro is not None, addend is not None, relu)
+    a1 = torch.relu(xc * abc[0].cpu().view(1, -1, 1, 1) + abc[2].cpu().view(1, -1, 1, 1))
+    t = F.conv2d(a1.double(), w.double(), padding=1) * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1) + rc
+    close(out.permute(0, 3, 1, 2), t, 2e-5, "F(4x4) inference epilogue vs torch (prologue, +res, no relu)")
+
+
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
 def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
     g = torch.Generator().manual_seed(3 * H + W + B)

@@ -1,10 +1,15 @@
 """GPU parity tests, model level: the drop-in CoVA / GraphAttentionLayer modules against the golden
 vectors captured from the reference (tests/golden/*.npz) and against the CPU oracle.
 
-Tolerances (fp32 path): forward logits atol=rtol=1e-4 of the logit scale;
-gradients 1e-3 of each tensor's scale (floored at 1% of the largest gradient: several parameters
-have analytically zero gradient); integer outputs exact on rows whose top-2 logit margin exceeds
-10x the observed fp error.
+Tolerances (fp32 path; the gates sit at about 5x the errors measured on MI355X, profiles/r03_wino4_margin.txt and
+profiles/r04_parity_margin.txt -- SURVEY.md section 8c's starting point was 1e-4 / 1e-3):
+  forward logits (eval and train) 5e-5 of the logit scale (measured 3e-6 .. 9e-6), CE-sum loss 2e-5 (measured <= 1.4e-6);
+  gradients, every discrete decision forced to the HIP forward's: 1e-4 of each tensor's scale (measured 1.1e-5 .. 4e-5;
+  scale floored at 1 % of the largest gradient: several parameters have analytically zero gradient);
+  gradients against the reference's own fixtures with NOTHING forced: head 2e-3 / conv stack 5e-2 as hard bounds (one
+  near-tie flip moves a few conv-stack entries by ~1e-3) AND the fraction of fixture entries beyond 2e-4 is printed and
+  bounded (<= 0.5 %);
+  integer outputs exact on rows whose top-2 logit margin exceeds 10x the observed fp error.
 """
 import os
 
@@ -17,7 +22,9 @@ pytestmark = pytest.mark.gpu
 from cova_web_object_detection_amd import engine, synthetic, weights  # noqa: E402
 from cova_web_object_detection_amd.models import CoVA, GraphAttentionLayer  # noqa: E402
 from helpers import (FULL_CASES, GOLDEN, assert_gate_flips_near_zero, assert_routing_near_ties,  # noqa: E402
-                     check_grads, compare_grads, load_case, margins_ok, routing_from_saved)
+                     check_grads, compare_grads, load_case, margins_ok, routing_from_saved, unforced_fraction_above)
+
+LOGIT_TOL, LOSS_TOL, GRAD_TOL = 5e-5, 2e-5, 1e-4
 from oracle import cova_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
@@ -40,8 +47,9 @@ def relerr(got, ref):
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
 
 
-def test_gat_layer_matches_reference_fixture():
-    fx = np.load(GOLDEN + "/gat_layer.npz")
+@pytest.mark.parametrize("fixture", ["gat_layer", "gat_layer_k100"])     # K = 6; K = 100: two 64-lane passes per node
+def test_gat_layer_matches_reference_fixture(fixture):
+    fx = np.load(GOLDEN + "/%s.npz" % fixture)
     N, Fd = fx["h"].shape
     D = fx["w/W_i.weight"].shape[0]
     layer = GraphAttentionLayer(Fd, D)
@@ -76,11 +84,11 @@ def test_full_model_matches_reference_fixture(name):
         own = torch.cat((visual, bbf, m.bn_additional_feat(args[2])), dim=1)
         hp, attn = m.gat(own, args[3], return_attn_wts=True)
     err = relerr(logits.cpu(), fx["eval/logits"])
-    assert err < 1e-4, err
-    assert relerr(visual.cpu().numpy().reshape(-1)[::7], fx["eval/visual_sample"]) < 1e-4
-    assert relerr(bbf.cpu(), fx["eval/bbox_feats"]) < 1e-4
-    assert relerr(attn.cpu(), fx["eval/attn"]) < 1e-4
-    assert relerr(hp.cpu().numpy().reshape(-1)[::5], fx["eval/context_sample"]) < 1e-4
+    assert err < LOGIT_TOL, err
+    assert relerr(visual.cpu().numpy().reshape(-1)[::7], fx["eval/visual_sample"]) < LOGIT_TOL
+    assert relerr(bbf.cpu(), fx["eval/bbox_feats"]) < LOGIT_TOL
+    assert relerr(attn.cpu(), fx["eval/attn"]) < LOGIT_TOL
+    assert relerr(hp.cpu().numpy().reshape(-1)[::5], fx["eval/context_sample"]) < LOGIT_TOL
     ref_logits = torch.from_numpy(fx["eval/logits"])
     tol = 10 * max(err, 1e-6) * float(ref_logits.abs().max())
     ok = margins_ok(ref_logits, tol)
@@ -101,8 +109,8 @@ def test_full_model_matches_reference_fixture(name):
     routing = routing_from_saved(logits.grad_fn.sv)      # the HIP forward's max-pool / RoIPool routing
     loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
     loss.backward()
-    assert relerr(logits.detach().cpu(), fx["train/logits"]) < 2e-4
-    assert abs(loss.item() - float(fx["train/loss"])) <= 2e-4 * abs(float(fx["train/loss"]))
+    assert relerr(logits.detach().cpu(), fx["train/logits"]) < LOGIT_TOL
+    assert abs(loss.item() - float(fx["train/loss"])) <= LOSS_TOL * abs(float(fx["train/loss"]))
     grads = {k: p.grad for k, p in m.named_parameters()}
     # (1) heads do not depend on the routing: compare with the reference's gradients directly;
     #     conv-stack gradients get a loose bound here (a single near-tie flip moves them by ~1e-3)
@@ -112,14 +120,19 @@ def test_full_model_matches_reference_fixture(name):
     conv_only = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample"))
                  and "/convnet." in k}
     check_grads(conv_only, grads, rtol=5e-2)
+    # ... and, in one hop, how many of the reference's gradient entries (all tensors, nothing forced) are beyond 2e-4
+    frac, total, worst, per = unforced_fraction_above(fx, grads, rtol=2e-4)
+    print("%s: %d of %d unforced fixture gradient entries beyond 2e-4 (%.4f %%), worst %s %.2e"
+          % (name, round(frac * total), total, 100 * frac, worst, per[worst][2]))
+    assert frac <= 5e-3, (frac, worst, per[worst])
     # (2) tight check of everything against the oracle forced to the same routing; the oracle
     #     itself is pinned to the reference's gradients by tests/test_oracle_cpu.py
     b = batch
     _, _, grads_ref, after, inter = O.loss_and_grads(sd, b["images"], b["bboxes"], b["additional_feats"],
                                                      b["context_indices"], b["labels"], cfg, None, routing)
     # every discrete decision of the HIP forward (max-pool / RoIPool argmax, ReLU gates) is forced
-    # in the oracle's backward, so what remains is fp32 round-off: 2e-4 of each tensor's scale
-    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    # in the oracle's backward, so what remains is fp32 round-off: 1e-4 of each tensor's scale
+    compare_grads(grads, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
     assert_routing_near_ties(routing, inter, b["bboxes"], (3, 3), m.roi_pool.spatial_scale)
     # ... and the decisions that were forced are the oracle's own, up to pre-activations within round-off of
     # zero / exact ties: counted and bounded against the UNFORCED oracle
@@ -157,9 +170,9 @@ def test_fused_loss_and_engine_step_match_oracle():
         sd, batch["images"], batch["bboxes"], batch["additional_feats"], batch["context_indices"],
         batch["labels"], cfg, [m.float() for m in masks], routing)
     assert_routing_near_ties(routing, inter, batch["bboxes"], (3, 3), 0.25)
-    assert relerr(logits.cpu(), logits_ref) < 2e-4
-    assert abs(loss.item() - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
-    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    assert relerr(logits.cpu(), logits_ref) < LOGIT_TOL
+    assert abs(loss.item() - float(loss_ref)) <= LOSS_TOL * abs(float(loss_ref))
+    compare_grads(grads, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
     for k in buffers:
         if not k.endswith("num_batches_tracked"):
             assert relerr(buffers[k].cpu(), after[k]) < 1e-4, k
@@ -184,7 +197,7 @@ def test_module_surface_and_no_cpu_fallback():
             b.zero_()
     b2 = m(*args)
     assert a.shape == (11, 4) and torch.isfinite(a).all()
-    assert torch.equal(a, b2) or True      # running stats moved between the calls; shape/finite is the contract
+    assert torch.equal(a, b2)              # train mode: batch statistics + the same dropout stream -> bit-identical logits
     m2 = CoVA((3, 3), 64, 4, False, 384, 32, 0, 0.0, None).to(DEV)   # use_context=False branch
     out = m2(args[0], args[1], args[2], torch.empty((0, 0), dtype=torch.long, device=DEV))
     assert out.shape == (11, 4)
@@ -237,7 +250,7 @@ def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
     loss_ref, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"],
                                                     batch["additional_feats"], batch["context_indices"],
                                                     batch["labels"], cfg, None)
-    assert abs(losses[0] - float(loss_ref)) <= 2e-4 * abs(float(loss_ref))
+    assert abs(losses[0] - float(loss_ref)) <= LOSS_TOL * abs(float(loss_ref))
     logits, pred = tr.predict(dbatch)
     assert logits.shape == (39, 4) and torch.equal(pred, logits.argmax(1))
 
@@ -289,7 +302,7 @@ def test_training_trajectory_follows_the_cpu_oracle():
             for it, a, r in curve:
                 f.write("%3d %12.5f %12.5f %9.2e\n" % (it, a, r, abs(a - r) / max(abs(r), 1e-9)))
     first, last = curve[0], curve[-1]
-    assert abs(first[1] - first[2]) <= 2e-4 * abs(first[2])                    # same start
+    assert abs(first[1] - first[2]) <= LOSS_TOL * abs(first[2])                    # same start
     assert last[2] < 0.5 * first[2], "the oracle run did not learn: not a meaningful trajectory"
     # band: 5 % of the current loss + 0.2 % of the initial one.  The two runs are chaotic once the weights have separated
     # by Adam's +-lr steps on noise-level gradients (and the multi-threaded CPU side is not bit-reproducible itself):
@@ -442,7 +455,7 @@ def test_small_and_ragged_batches_match_oracle_forward(use_context, boxes):
             got = m(*args)
         ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"], batch["additional_feats"],
                         batch["context_indices"], cfg, training, None)
-        assert relerr(got.cpu(), ref) < 2e-4, (training, relerr(got.cpu(), ref))
+        assert relerr(got.cpu(), ref) < LOGIT_TOL, (training, relerr(got.cpu(), ref))
     empty = m(args[0], args[1][:0], args[2][:0], args[3][:0] if use_context else args[3])
     assert empty.shape == (0, 4)
 
@@ -626,7 +639,7 @@ def test_malformed_input_raises_like_the_reference_forward():
     m.eval()
     ref = O.forward(O.clone_state_dict(sd), batch["images"], batch["bboxes"][:1], batch["additional_feats"][:1],
                     one[3].cpu(), cfg, False, None)
-    assert relerr(m(*one).detach().cpu(), ref) < 2e-4          # a single box is fine with running statistics
+    assert relerr(m(*one).detach().cpu(), ref) < LOGIT_TOL          # a single box is fine with running statistics
     m.train()
     for bad in ((img[:, :1], bb, af, ctx), (img, bb[:, :4], af, ctx), (img, bb, af, ctx[:5]),
                 (img, bb, torch.rand(bb.shape[0], 3, device=DEV), ctx), (img[0], bb, af, ctx)):
@@ -673,7 +686,7 @@ def test_input_layout_and_index_dtype_do_not_change_the_result():
         got = m(img, lone.to(DEV), af, ctx)
     ref = O.forward(O.clone_state_dict(sd), batch["images"], lone, batch["additional_feats"],
                     batch["context_indices"], cfg, False, None)
-    assert relerr(got.cpu(), ref) < 2e-4
+    assert relerr(got.cpu(), ref) < LOGIT_TOL
 
 
 @pytest.mark.gpu
@@ -692,12 +705,12 @@ def test_f2x2_conv_path_keeps_reference_parity(name, monkeypatch):
     routing = routing_from_saved(logits.grad_fn.sv)
     loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
     loss.backward()
-    assert relerr(logits.detach().cpu(), fx["train/logits"]) < 2e-4
-    assert abs(loss.item() - float(fx["train/loss"])) <= 2e-4 * abs(float(fx["train/loss"]))
+    assert relerr(logits.detach().cpu(), fx["train/logits"]) < LOGIT_TOL
+    assert abs(loss.item() - float(fx["train/loss"])) <= LOSS_TOL * abs(float(fx["train/loss"]))
     grads = {k: p.grad for k, p in m.named_parameters()}
     _, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
                                              batch["context_indices"], batch["labels"], cfg, None, routing)
-    compare_grads(grads, grads_ref, rtol=2e-4, outlier_frac=0.0)
+    compare_grads(grads, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
     for k, buf in m.named_buffers():
         if "buf/" + k in fx:
             assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k

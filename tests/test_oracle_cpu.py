@@ -37,8 +37,9 @@ def test_eval_decision_rule_matches_reference():
         assert np.array_equal(acc, fx["img_acc_k%d" % k][:, 1:])
 
 
-def test_gat_layer_matches_reference():
-    fx = np.load(GOLDEN + "/gat_layer.npz")
+@pytest.mark.parametrize("fixture", ["gat_layer", "gat_layer_k100"])
+def test_gat_layer_matches_reference(fixture):
+    fx = np.load(GOLDEN + "/%s.npz" % fixture)
     sd = {"gat." + k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w/")}
     h = torch.from_numpy(fx["h"]).requires_grad_(True)
     for k in sd:
@@ -286,3 +287,70 @@ def test_roialign_self_oracle_properties():
     o = O.roi_align(f, torch.tensor([[0, 0.5, 0.5, 5.0, 4.0]]), (2, 3), 1.0, 2, False)
     o.sum().backward()
     assert abs(float(f.grad.sum()) - 6.0) < 1e-5          # 6 bins, each a unit of weight, all samples inside
+
+
+def _roialign_dense(feat, rois, PH, PW, scale, sampling_ratio, aligned):
+    """A second, independent RoIAlign formulation (float64, no per-neighbour case analysis): bilinear interpolation is
+    the tensor-product hat-function interpolant of the pixel grid, so a sample at (y, x) is  hat_y @ feat @ hat_x  with
+    hat_y[i] = max(0, 1 - |clip(y, 0, H-1) - i|); a bin is the mean of its samples' DENSE weight maps; samples more
+    than one pixel outside contribute nothing (Mask R-CNN, section 3 / torchvision ops.RoIAlign contract).  Returns
+    (out [N,C,PH,PW], weight maps [N,PH,PW,H,W]) -- the transposed maps are the backward."""
+    B, C, H, W = feat.shape
+    N = rois.shape[0]
+    wmap = np.zeros((N, PH, PW, H, W))
+    off = 0.5 if aligned else 0.0
+    for n in range(N):
+        b, x1, y1, x2, y2 = [float(v) for v in rois[n]]
+        sw, sh = x1 * scale - off, y1 * scale - off
+        rw, rh = x2 * scale - off - sw, y2 * scale - off - sh
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / PH))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / PW))
+        if gh <= 0 or gw <= 0:
+            continue
+        ys = sh + (rh / PH) * (np.arange(PH)[:, None] + (np.arange(gh)[None, :] + 0.5) / gh)      # [PH, gh]
+        xs = sw + (rw / PW) * (np.arange(PW)[:, None] + (np.arange(gw)[None, :] + 0.5) / gw)      # [PW, gw]
+        hat_y = np.maximum(0.0, 1.0 - np.abs(np.clip(ys, 0, H - 1)[..., None] - np.arange(H)))   # [PH, gh, H]
+        hat_x = np.maximum(0.0, 1.0 - np.abs(np.clip(xs, 0, W - 1)[..., None] - np.arange(W)))   # [PW, gw, W]
+        hat_y *= ((ys >= -1.0) & (ys <= H))[..., None]
+        hat_x *= ((xs >= -1.0) & (xs <= W))[..., None]
+        wmap[n] = np.einsum("pih,qjw->pqhw", hat_y, hat_x) / (gh * gw)
+    page = rois[:, 0].astype(int)
+    out = np.einsum("npqhw,nchw->ncpq", wmap, feat.astype(np.float64)[page])
+    return out, wmap
+
+
+@pytest.mark.parametrize("sr,aligned", [(2, False), (0, False), (3, True), (0, True)])
+def test_roialign_against_independent_dense_formulation(sr, aligned):
+    """oracle.roi_align (the checker of the RoIAlign kernels; torchvision is not installed, so it is a restatement
+    of the published algorithm) against the dense hat-function formulation above: values AND the backward, on boxes
+    that cross every border, lie partly or wholly more than a pixel outside, are smaller than one feature pixel
+    (clamped to 1 unless `aligned`), inverted, and on two pages."""
+    rs = np.random.RandomState(21)
+    B, C, H, W = 2, 3, 11, 14
+    s = 0.25
+    feat = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    rois = [[0, -9.3, -7.1, 20.7, 18.2], [1, 30.2, 21.9, 90.4, 77.7], [0, 50.1, 40.3, 54.2, 41.1],
+            [1, 10.3, 10.2, 10.9, 10.6], [0, 3.3, 2.2, 51.7, 40.4], [1, -60.5, -50.5, -12.2, -11.1],
+            [0, 44.4, 30.3, 70.7, 60.6], [1, 20.6, 30.1, 8.3, 12.2], [0, 0.7, 0.3, 55.1, 43.2]]
+    for _ in range(40):
+        x1, y1 = rs.uniform(-12, 4 * W + 6), rs.uniform(-12, 4 * H + 6)
+        rois.append([rs.randint(0, B), x1, y1, x1 + rs.uniform(-3, 40), y1 + rs.uniform(-3, 40)])
+    rois = np.asarray(rois, np.float32)
+    PH, PW = 3, 2
+    f = torch.from_numpy(feat).requires_grad_(True)
+    out = O.roi_align(f, torch.from_numpy(rois), (PH, PW), s, sr, aligned)
+    ref, wmap = _roialign_dense(feat, rois, PH, PW, s, sr, aligned)
+    scale = np.abs(ref).max()
+    assert np.abs(out.detach().numpy() - ref).max() <= 2e-5 * scale, np.abs(out.detach().numpy() - ref).max() / scale
+    assert (np.abs(ref).reshape(len(rois), -1).max(1) == 0).any()           # a box wholly outside pools to exactly 0
+    assert float(out[5].detach().abs().max()) == 0.0
+    g = rs.standard_normal(out.shape).astype(np.float32)
+    (out * torch.from_numpy(g)).sum().backward()
+    gref = np.zeros((B, C, H, W))
+    page = rois[:, 0].astype(int)
+    contrib = np.einsum("npqhw,ncpq->nchw", wmap, g.astype(np.float64))
+    for n in range(len(rois)):
+        gref[page[n]] += contrib[n]
+    assert np.abs(f.grad.numpy() - gref).max() <= 2e-5 * np.abs(gref).max()

@@ -315,6 +315,8 @@ class Options:
     overlap_allreduce = os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
     # BatchNorm finalize as the tail of the producing convolution launch (no separate finalize launches)
     bn_tail = os.environ.get("COVA_BN_TAIL", "1") != "0"
+    # weight gradients of the 3x3 convolutions as F(4x4,3x3) (csrc/conv_wgrad4.hip) instead of F(2x2,3x3)
+    wgrad4 = os.environ.get("COVA_WGRAD4", "1") != "0"
 
 
 OPTIONS = Options()
@@ -633,7 +635,8 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     nt = conv3_num_partials(B, H2, W2, sv["w4"])
-    ws3 = _empty((query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
+    ws3 = _empty((query("cova_conv3x3_wgrad4_workspace_floats" if OPTIONS.wgrad4 else
+                        "cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
     ws1 = _empty((max(query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),
                       query("cova_conv1x1_vprod_workspace_floats", R)),), g)
     nd = query("cova_conv1x1_lin_dgrad_num_partials", R)
@@ -653,7 +656,11 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
         # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
         dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
-        call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
+        if OPTIONS.wgrad4:
+            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, ws3, B, H2, W2)
+            call("cova_conv3x3_wgrad4_finish", ws3, dw, None, None, None, None, None, None, B, H2, W2)
+        else:
+            call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
         grads[pre + "conv2.weight"] = dw
         dy1 = _empty((B, H2, W2, C64), g)
         part = _empty((nt, 2, C64), g)
@@ -758,12 +765,14 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     R = B * H2 * W2
     # weight gradients: the four launches leave their per-block partial sums in four workspaces, ONE launch at the end
     # folds and transforms them (4 x 67 MB at configs[1]; a shared workspace would need a finish launch per convolution)
-    nws = query("cova_conv3x3_wgrad_workspace_floats", B, H2, W2)
+    wg = "cova_conv3x3_wgrad4" if OPTIONS.wgrad4 else "cova_conv3x3_wgrad_wino"
+    nws = query("cova_conv3x3_wgrad4_workspace_floats" if OPTIONS.wgrad4 else "cova_conv3x3_wgrad_workspace_floats",
+                B, H2, W2)
     ws_all = _empty((4, nws), dfeat)
     jobs = []
 
     def wgrad(act, act_abc, act_relu, dz, dz2, dz_abc, dw):
-        call("cova_conv3x3_wgrad_wino_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
+        call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
         jobs.append(dw)
 
     nt = conv3_num_partials(B, H2, W2, sv["w4"])
@@ -823,7 +832,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     fin = []
     for i in range(4):
         fin += [ws_all[i], jobs[i]]
-    call("cova_conv3x3_wgrad_wino_finish", *fin, B, H2, W2)
+    call(wg + "_finish", *fin, B, H2, W2)
     return dA
 
 

@@ -131,6 +131,21 @@ int cova_conv3x3_wgrad_wino_partial(const float *act, const float *act_abc, int 
 int cova_conv3x3_wgrad_wino_finish(const float *ws0, float *dw0, const float *ws1, float *dw1, const float *ws2,
                                    float *dw2, const float *ws3, float *dw3, int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
+/* Weight gradient in Winograd F(4x4,3x3) form (csrc/conv_wgrad4.hip; 1.78x fewer MFMAs than the F(2x2,3x3) form above,
+ * fp32 error 3.7e-6 of the gradient's scale): replaces autograd's conv2d weight gradient of the four layer1 3x3
+ * convolutions (torchvision BasicBlock conv1 / conv2, models.py:49-51; loss.backward() at train.py:59).  Same two-step
+ * contract as cova_conv3x3_wgrad_wino_partial / _finish: activation = relu?(A*act + C) on load (act_abc nullable),
+ * gradient = A*dz + B*dz2 + C on load (dz_abc, dz2 nullable), per-block partials into ws
+ * (cova_conv3x3_wgrad4_workspace_floats), then the fp64 fold + G^T Q G of up to four convolutions in one launch. */
+int cova_conv3x3_wgrad4_num_partials(int B, int H, int W);
+int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W);
+int cova_conv3x3_wgrad4_partial(const float *act, const float *act_abc /*nullable*/, int act_relu, const float *dz,
+                                const float *dz2 /*nullable*/, const float *dz_abc /*nullable*/, float *ws, int B, int H,
+                                int W, void *stream);
+int cova_conv3x3_wgrad4_finish(const float *ws0, float *dw0, const float *ws1, float *dw1, const float *ws2,
+                               float *dw2, const float *ws3, float *dw3, int B, int H, int W, void *stream);
+int cova_conv3x3_wgrad4(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B, int H, int W,
+                        void *stream);
 
 /* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
  * the output scale): u_fwd / u_dgrad 147,456 floats each (the per-wave register image written by the prep kernel);

@@ -197,6 +197,31 @@ class _ReluFn(torch.autograd.Function):
         return g * gate.to(g.dtype), None
 
 
+class _LeakyFn(torch.autograd.Function):
+    """LeakyReLU (models.py:156,200) whose BACKWARD slope choice can be forced, as _ReluFn: the sign of an attention
+    score e = a . [Wh_i || Wh_j] + b within round-off of zero is a discrete decision too."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, forced_gate=None):
+        gate = (x > 0) if forced_gate is None else forced_gate.to(torch.bool)
+        ctx.save_for_backward(gate)
+        ctx.alpha = alpha
+        return F.leaky_relu(x, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        return torch.where(gate, g, ctx.alpha * g), None, None
+
+
+def _leaky(x, alpha, routing, key):
+    if not routing:
+        return F.leaky_relu(x, alpha)
+    if "_tap" in routing:
+        routing["_tap"][key] = x.detach()
+    return _LeakyFn.apply(x, alpha, routing.get(key))
+
+
 def _relu(x, routing, key):
     if routing and "_tap" in routing:             # tests: keep the pre-activation of every gate
         routing["_tap"][key] = x.detach()
@@ -314,7 +339,7 @@ def gat_prefixes(sd):
     return layers
 
 
-def gat_stack(h_i, context_indices, sd, alpha=0.2):
+def gat_stack(h_i, context_indices, sd, alpha=0.2, routing=None):
     """Extension: every layer concatenates its heads' outputs (each head = the reference's
     GraphAttentionLayer on the same neighbour table), layers are chained without a nonlinearity in
     between (the reference layer has none after the aggregation either, models.py:206-208).
@@ -323,7 +348,7 @@ def gat_stack(h_i, context_indices, sd, alpha=0.2):
     for heads in gat_prefixes(sd):
         outs = []
         for p in heads:
-            o, a = gat(h, context_indices, sd, alpha, True, prefix=p)
+            o, a = gat(h, context_indices, sd, alpha, True, prefix=p, routing=routing)
             outs.append(o)
             if p == heads[0]:
                 attn0 = a
@@ -331,8 +356,9 @@ def gat_stack(h_i, context_indices, sd, alpha=0.2):
     return h, attn0
 
 
-def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False, prefix="gat."):
-    """models.py:171-212, same operation order as the reference."""
+def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False, prefix="gat.", routing=None):
+    """models.py:171-212, same operation order as the reference.  ``routing`` (tests): forced LeakyReLU slope
+    decisions / pre-activation tap under the key "gate_" + prefix + "leaky" ([N, K])."""
     N, K = context_indices.shape
     W_i, W_j = sd[prefix + "W_i.weight"], sd[prefix + "W_j.weight"]
     D = W_i.shape[0]
@@ -343,7 +369,7 @@ def gat(h_i, context_indices, sd, alpha=0.2, return_attn_wts=False, prefix="gat.
     Wh_j = F.linear(h_j, W_j)
     e = F.linear(torch.cat((Wh_i_rep, Wh_j), dim=2), sd[prefix + "attention_layer.weight"],
                  sd[prefix + "attention_layer.bias"]).squeeze(2)
-    e = F.leaky_relu(e, alpha)
+    e = _leaky(e, alpha, routing, "gate_" + prefix + "leaky")
     e = torch.where(context_indices >= 0, e, -9e15 * torch.ones_like(e))
     attn = torch.softmax(e, dim=1)
     h_prime = (attn.unsqueeze(-1) * Wh_j).sum(1)
@@ -388,7 +414,7 @@ def forward(sd, images, bboxes, additional_feats, context_indices, cfg, training
     own = torch.cat(parts, dim=1)                           # models.py:110
     inter = {"feat": feat, "visual": visual, "own": own}
     if cfg.get("use_context", True):
-        ctx_repr, attn = gat_stack(own, context_indices, sd)
+        ctx_repr, attn = gat_stack(own, context_indices, sd, routing=routing)
         inter["attn"] = attn
         inter["context"] = ctx_repr
     else:

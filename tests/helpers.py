@@ -113,6 +113,13 @@ def routing_from_saved(sv):
     if hd > 0:
         r["gate_bbox"] = (sv["comb"][:, n_vis:n_vis + hd] > 0).cpu()
     r["gate_dec"] = (sv["dec"]["y"] > 0).cpu()
+    # LeakyReLU slope decisions of every GAT head: the sign of u = s_i + t_j (pad slots: t = 0; they are masked anyway)
+    for layer in sv.get("gat") or []:
+        for head in layer["heads"]:
+            ctx = head["ctx"]
+            t = torch.cat((head["t"], head["t"].new_zeros(1)))
+            u = head["s"].view(-1, 1) + t[ctx.clamp(min=-1)]
+            r["gate_" + head["prefix"] + "leaky"] = (u > 0).cpu()
     return r
 
 

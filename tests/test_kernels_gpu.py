@@ -773,6 +773,54 @@ def test_conv3x3_winograd_f4x4_inference_epilogue(B, H, W):
     close(out.permute(0, 3, 1, 2), t, 2e-5, "F(4x4) inference epilogue vs torch (prologue, +res, no relu)")
 
 
+@pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (1, 4, 4, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 6),
+                                       (2, 163, 37, 2)])
+def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
+    """F(4x4,3x3) weight gradient (csrc/conv_wgrad4.hip) against torch-CPU in fp64: sizes that are not multiples of the
+    4 x 16-pixel K-step (ragged right / bottom tiles, a map smaller than one tile), few blocks walking many segments
+    (grid cap) and the usual one; affine-on-load operands against the same launch on pre-transformed tensors; two
+    launches bit-identical (fixed summation order)."""
+    g = torch.Generator().manual_seed(5 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    xc, dzc = rnd(B, 64, H, W), rnd(B, 64, H, W)
+    wr = (rnd(64, 64, 3, 3) * 0.05).double().requires_grad_(True)
+    (F.conv2d(xc.double(), wr, padding=1) * dzc.double()).sum().backward()
+    x, dy, z = nhwc(xc), nhwc(dzc), nhwc(rnd(B, 64, H, W))
+    abc_a, abc_d = rnd(3, 64).to(DEV), rnd(3, 64).to(DEV)
+    R = B * H * W
+    query("cova_set_option", 2, cap)
+    try:
+        ws = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", B, H, W), device=DEV)
+        assert ws.numel() == query("cova_conv3x3_wgrad4_num_partials", B, H, W) * 18 * 4096
+        dw = torch.zeros(64, 64, 3, 3, device=DEV)
+        call("cova_conv3x3_wgrad4", x, dy, dw, ws, B, H, W)
+        close(dw, wr.grad, 5e-5, "F(4x4) wgrad vs fp64")      # (random data: no coherent signal; the F(2x2) test allows 2e-4)
+        dw2 = torch.zeros_like(dw)
+        call("cova_conv3x3_wgrad4", x, dy, dw2, ws, B, H, W)
+        assert torch.equal(dw, dw2)
+        # operands transformed on load == the plain launch on materialised operands (same fma, same order: bit-exact)
+        a1 = torch.empty_like(x)
+        call("cova_bn_act_fwd", x, 64, abc_a[0], abc_a[2], None, 0, a1, 64, R, 64, 1)
+        dz2 = torch.addcmul(torch.addcmul(abc_d[2].expand_as(dy), z, abc_d[1]), dy, abc_d[0])     # A*dy + (B*z + C)
+        dz1 = torch.addcmul(abc_d[2].expand_as(dy), dy, abc_d[0])                                 # A*dy + C
+        ws2 = torch.empty_like(ws)
+        for pa, pd in ((True, 2), (True, 0), (False, 2), (False, 1), (True, 1)):
+            ref, got = torch.zeros_like(dw), torch.zeros_like(dw)
+            call("cova_conv3x3_wgrad4", a1 if pa else x, {0: dy, 1: dz1, 2: dz2}[pd], ref, ws, B, H, W)
+            call("cova_conv3x3_wgrad4_partial", x, abc_a if pa else None, 1, dy, z if pd == 2 else None,
+                 abc_d if pd else None, ws2, B, H, W)
+            call("cova_conv3x3_wgrad4_finish", ws2, got, None, None, None, None, None, None, B, H, W)
+            # (pd != 0: torch.addcmul rounds the products, the kernel's fma does not -- an ulp on the operand)
+            close(got, ref, 2e-6 if pd == 0 else 1e-5, "F(4x4) wgrad affine-on-load %s %s" % (pa, pd))
+        # one finish launch for two convolutions
+        dwa, dwb = torch.zeros_like(dw), torch.zeros_like(dw)
+        call("cova_conv3x3_wgrad4_partial", x, None, 0, dy, None, None, ws, B, H, W)
+        call("cova_conv3x3_wgrad4_finish", ws, dwa, ws2, dwb, None, None, None, None, B, H, W)
+        assert torch.equal(dwa, dw) and torch.equal(dwb, got)
+    finally:
+        query("cova_set_option", 2, 0)
+
+
 @pytest.mark.parametrize("B,H,W,cap", [(1, 8, 32, 0), (2, 19, 45, 0), (3, 100, 200, 0), (3, 100, 200, 5)])
 def test_conv3x3_winograd_wgrad_affine_on_load(B, H, W, cap):
     g = torch.Generator().manual_seed(3 * H + W + B)

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r4b
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r4b/tests.log
+tail -4 gpurun_out/r4b/tests.log
+python bench.py --no-cpu-baseline --sustained-seconds 0 > gpurun_out/r4b/bench_wg4.json 2> gpurun_out/r4b/bench_wg4.err
+COVA_WGRAD4=0 python bench.py --no-cpu-baseline --sustained-seconds 0 > gpurun_out/r4b/bench_wg2.json 2> gpurun_out/r4b/bench_wg2.err
+python - <<'PY'
+import json
+for n in ("wg4", "wg2"):
+    try:
+        d = json.load(open("gpurun_out/r4b/bench_%s.json" % n))
+        print(n, d["value"], d["ms_per_step"], d["forward_only"]["value"], {k: v["avg_launch_ms"] for k, v in d["other_kernels"].items() if "wgrad" in k})
+    except Exception as e:
+        print(n, "failed", e)
+PY

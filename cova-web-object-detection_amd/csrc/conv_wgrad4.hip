@@ -26,26 +26,39 @@
 //     wave's PRIVATE 9 KB of LDS as [pixel][64 channels] -- the copy is also the transposition to lane = channel, and a
 //     wave-private buffer needs no barrier, only the issuing wave's own vmcnt;
 //   * a block walks DOWN a 16-pixel-wide strip of the map: the two bottom rows of a patch are the two top rows of the
-//     next one, re-read from L2 one K-step later (the vertical halo never goes back to HBM);
-//   * the next patch is requested as soon as the first transform stage has read the current one (about 0.7 K-step of
-//     flight; every copy is unconditional: edge patches clamp the address, the consumer zeroes padding) and the patch
-//     after it is touched into L2 by one extra load per tensor, so that the copy does not see an HBM round trip;
+//     next one and stay in the wave's buffer (a ring of three row pairs): 24 of a patch's 36 pixels are requested;
+//   * the next patch is requested once the first transform stage has read the current one (every copy is unconditional:
+//     edge patches clamp the address, the consumer zeroes padding);
 //   * the two waves of a SIMD (input role / gradient role) run an iteration in opposite order (transform then MFMAs /
 //     MFMAs then transform); operands are double buffered, one block barrier per K-step (LDS-only).
+// Side output: the gradient operand A*dz + B*dz2 + C written once (gradient-role waves of the half-0 blocks), for the data-
+// gradient launch of the same convolution.
 // Operand prologues as the F(2x2) kernel's: activation = relu?(A*act + C) on load, gradient = A*dz + B*dz2 + C on load
 // (the BatchNorm+ReLU of the producer / the BatchNorm-backward apply, never materialised); zero padding stays zero.
 #include "common.h"
 #include <type_traits>
 
 // Ablation builds of tools/wgrad4_bench.py (tools/wg4_abl_build.sh, -DWG4_ABL=<mask>; 0 in the product): 1 no MFMAs,
-// 2 no pixel copies, 4 no L2 touches, 8 no transform (reads + arithmetic + operand writes), 16 no operand reads of the
+// 2 no pixel copies, 8 no transform (reads + arithmetic + operand writes), 16 no operand reads of the
 // MFMA phase (stale registers), 32 copies always from the walker's first patch (L2-resident source), 64 both roles
-// in the same order (MFMAs first)
+// in the same order (MFMAs first), 128 no row-pair ring (every patch requested whole)
 #ifndef WG4_ABL
 #define WG4_ABL 0
 #endif
 
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
+
+// -DWG4_TRACE (tools only): s_memtime stamps of waves 0 and 4 of block 0 at the phase boundaries of iterations 100..103
+#ifdef WG4_TRACE
+__device__ unsigned long long g_wg4_trace[2 * 4 * 8];
+#define WG4_STAMP(slot)                                                                                         \
+    do {                                                                                                        \
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && wg4_k >= 100 && wg4_k < 104 && lane == 0)           \
+            g_wg4_trace[((wave >> 2) * 4 + (wg4_k - 100)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();         \
+    } while (0)
+#else
+#define WG4_STAMP(slot) do { } while (0)
+#endif
 
 namespace {
 
@@ -63,6 +76,7 @@ struct Wg4Args {
     const float *act, *dz, *dz2;     // NHWC [B,H,W,64]; dz2 nullable
     float *part;                     // [grid][18][64][64]
     const float *act_abc, *dz_abc;   // [3][64] = A | B | C, or nullptr (plain operand)
+    float *dz_out;                   // nullable: the gradient operand as formed on load (A*dz + B*dz2 + C), NHWC [B,H,W,64]
     int act_relu;
     int H, W, tiles_y, strips, nseg_y, seg_rows, nsegs;
 };
@@ -155,7 +169,6 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
     using namespace wg4;
     __shared__ __attribute__((aligned(16))) float s_op[2 * BUF_FLOATS];
     __shared__ __attribute__((aligned(1024))) float s_raw[8 * RAW_FLOATS];      // wave-private pixel buffers
-    __shared__ __attribute__((aligned(256))) float s_sink[8 * 64];             // where the L2 touches land (never read)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W;
@@ -274,62 +287,68 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         constexpr unsigned FULL = (1u << NR) - 1u;
         // every pixel of the patch of `it` requested (unconditionally: an edge patch clamps its addresses, the consumer
         // zeroes what lies outside the image; the K-steps past the end re-request a valid patch)
-        auto fetch = [&](const Wg4It &it_, bool edge) __attribute__((always_inline)) {
+        // Input role: the buffer is a RING of the patch's three row pairs -- walking down a strip, the bottom pair of a patch
+        // is the top pair of the next one and stays where it is; only the two new pairs are requested (24 of 36 pixels).
+        // Row pair p of a patch with ring phase phi lives in pair slot (p + phi) % 3 (12 pixel slots each).
+        // one copy: block (br, bc) of the patch of `it` (and of the second gradient tensor)
+        auto piece = [&](const Wg4It &it_, bool edge, int phi, int br, int bc) __attribute__((always_inline)) {
             if (WG4_ABL & 2) return;
             Wg4It it = it_;
             if (WG4_ABL & 32) { it.seg = walker; seg_setup(it); }
             const int gy0 = 4 * it.ty - (VROLE ? 1 : 0), gx0 = 16 * it.strip + 4 * tcol - (VROLE ? 1 : 0);
             const float *src = VROLE ? a.act : a.dz;
-            if (!edge) {
-#pragma unroll
-                for (int br = 0; br < NB; ++br) {            // one scalar base per row pair and block column
-                    const unsigned off = (unsigned)(((it.b * H + gy0 + 2 * br) * W + gx0) * 256);       // (< 4 GB: host check)
-#pragma unroll
-                    for (int bc = 0; bc < NB; ++bc) {
-                        const int j = br * NB + bc;
-                        wg4_copy16(reinterpret_cast<const char *>(src) + off + 512 * bc, laneoff, raw_lds + 1024 * j);
-                        if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2) + off + 512 * bc, laneoff, raw_lds + 1024 * (4 + j));
-                    }
-                }
+            int ps = br + phi;                                   // pair slot (the gradient role has no ring: phi = 0)
+            if (VROLE && ps >= 3) ps -= 3;
+            const unsigned dst = raw_lds + (VROLE ? 3072u * (unsigned)ps : 2048u * (unsigned)br) + 1024u * (unsigned)bc;
+            if (!edge) {                                         // scalar base of the row pair + the block column
+                const unsigned off = (unsigned)(((it.b * H + gy0 + 2 * br) * W + gx0) * 256 + 512 * bc);     // (< 4 GB: host check)
+                wg4_copy16(reinterpret_cast<const char *>(src) + off, laneoff, dst);
+                if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2) + off, laneoff, dst + 4096);
             } else {
-#pragma unroll
-                for (int j = 0; j < NB * NB; ++j) {
-                    const int r = 2 * (j / NB) + (sub >> 1), c = 2 * (j % NB) + (sub & 1);
-                    const int gy = min(max(gy0 + r, 0), H - 1), gx = min(max(gx0 + c, 0), W - 1);
-                    const unsigned eo = (unsigned)(((it.b * H + gy) * W + gx) * 256 + c4 * 16);
-                    wg4_copy16(reinterpret_cast<const char *>(src), eo, raw_lds + 1024 * j);
-                    if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2), eo, raw_lds + 1024 * (4 + j));
-                }
+                const int r = 2 * br + (sub >> 1), c = 2 * bc + (sub & 1);
+                const int gy = min(max(gy0 + r, 0), H - 1), gx = min(max(gx0 + c, 0), W - 1);
+                const unsigned eo = (unsigned)(((it.b * H + gy) * W + gx) * 256 + c4 * 16);
+                wg4_copy16(reinterpret_cast<const char *>(src), eo, dst);
+                if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2), eo, dst + 4096);
             }
         };
-        // L2 warm-up of the patch AFTER nxt (same strip, one tile row further down: what the walk requests next except at a
-        // segment's end, where the touch is merely useless): ONE load instruction per tensor, lane = a 128-byte line of
-        // the patch's four new pixel rows, destination never read.  The copies themselves have only about 0.7 K-step of
-        // flight (their buffer is single: LDS is full) -- less than a loaded HBM round trip; with the lines already on
-        // their way to L2 the copy finds them there.  Loads retire in order, so the consumer's wait is vmcnt(#touches):
-        // the copies (older) have landed, the touches may still fly.
-        constexpr int PF_PX = VROLE ? 6 : 4;                 // pixels per row of the patch
-        constexpr int NPF = TWO ? 2 : 1;                     // touches per K-step
-        const unsigned sink_lds = (unsigned)(size_t)(wg4_lds_void *)(s_sink + wave * 64);
-        const int pl = min(lane, 8 * PF_PX - 1);             // 4 rows x PF_PX pixels x 2 lines
-        const int pf_r = pl / (2 * PF_PX), pf_c = (pl % (2 * PF_PX)) >> 1, pf_h = pl & 1;
-        auto touch = [&](const Wg4It &it) __attribute__((always_inline)) {
-            if (WG4_ABL & (4 | 2)) return;
-            const int gyb = 4 * (it.ty + 1) + (VROLE ? 1 : 0), gxb = 16 * it.strip + 4 * tcol - (VROLE ? 1 : 0);
-            const int gy = min(gyb + pf_r, H - 1), gx = min(max(gxb + pf_c, 0), W - 1);
-            const unsigned po = (unsigned)(((it.b * H + gy) * W + gx) * 256 + pf_h * 128);
-            // (a global -> LDS copy of 4 bytes per lane into the wave's sink: a register destination written by a load the
-            //  compiler does not know about could be handed to another value while the load is in flight)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(sink_lds), "v"(po), "s"(VROLE ? a.act : a.dz) : "memory", "m0");
-            if (TWO) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(sink_lds), "v"(po), "s"(a.dz2) : "memory", "m0");
+        // a continued walk of the input role keeps row pair 0 (wave-uniform)
+        auto first_pair = [&](const Wg4It &it) __attribute__((always_inline)) {
+            return (VROLE && it.rr != 0 && !(WG4_ABL & 128)) ? 1 : 0;
         };
-        // transform of the patch in the pixel buffer (validity masks crm / ccm) into `buf`; the patch of `nxt` is requested
-        // as soon as the first stage has read the buffer
+        auto fetch = [&](const Wg4It &it, bool edge, int phi) __attribute__((always_inline)) {
+            const int br0 = first_pair(it);
+#pragma unroll
+            for (int br = 0; br < NB; ++br) {
+                if (br < br0) continue;
+#pragma unroll
+                for (int bc = 0; bc < NB; ++bc) piece(it, edge, phi, br, bc);
+            }
+        };
+        // side output (gradient role, position half 0): the operand as formed on load, written once -- the data-gradient
+        // launch of the same convolution then reads ONE tensor with no prologue instead of forming it again per tap
+        const bool emit = !VROLE && PROD != 0 && HALF == 0 && a.dz_out != nullptr;
+        unsigned cur_org = 0;                                // element offset of the current tile's pixel (0, 0)
+        auto origin = [&](const Wg4It &it) __attribute__((always_inline)) {
+            return (unsigned)(((it.b * H + 4 * it.ty) * W + 16 * it.strip + 4 * tcol) * 64);
+        };
+        int phi = 0;                                         // ring phase of the patch in the buffer
+        int wg4_k = -1;                                      // (trace builds)
+        (void)wg4_k;
         auto transform = [&](float *buf, const Wg4It &nxt, unsigned crm, unsigned ccm, unsigned nrm, unsigned ncm) __attribute__((always_inline)) {
-            if (WG4_ABL & (4 | 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (NPF == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // this wave's copies of the patch have landed
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                 // (behind them only the L2 touches)
-            if (WG4_ABL & 8) { fetch(nxt, nrm != FULL || ncm != FULL); touch(nxt); return; }
+            // this lane's channel of pair slot (p + phi) % 3, p = 0..2 (input role; gradient role: two fixed pairs)
+            const float *pair_r[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                int ps = p + phi;
+                if (ps >= 3) ps -= 3;
+                pair_r[p] = raw_r + (VROLE ? 768 * ps : 512 * p);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's copies of the patch have landed
+            const int nphi = (!VROLE || (WG4_ABL & 128)) ? 0 : (nxt.rr == 0 ? phi : (phi == 0 ? 2 : phi - 1));      // (phi + 2) % 3 down the strip
+            const bool nedge = nrm != FULL || ncm != FULL;
+            if (WG4_ABL & 8) { fetch(nxt, nedge, nphi); phi = nphi; return; }
+            WG4_STAMP(1);
             float t[3][NR];
             auto stage1 = [&](auto cedge_t) __attribute__((always_inline)) {
             constexpr bool cedge = decltype(cedge_t)::value;
@@ -338,16 +357,20 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                 float d[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const int slot = 4 * ((r >> 1) * NB + (c >> 1)) + 2 * (r & 1) + (c & 1);
-                    float v = raw_r[64 * slot];
+                    const int slot = 4 * (c >> 1) + 2 * (r & 1) + (c & 1);          // within the row pair's slots
+                    float v = pair_r[r >> 1][64 * slot];
                     if (VROLE && PROA) {
                         v = fmaf(pA, v, pC);                        // same expression as the forward prologue
                         if (a.act_relu) v = fmaxf(v, 0.f);
                     }
-                    if (TWO) v = fmaf(pA, v, fmaf(pB, raw_r[64 * (16 + slot)], pC));            // dz = A*dy + B*z + C
+                    if (TWO) v = fmaf(pA, v, fmaf(pB, pair_r[r >> 1][64 * (16 + slot)], pC));   // dz = A*dy + B*z + C
                     if (!VROLE && PROD == 1) v = fmaf(pA, v, pC);
                     if (cedge && !(((crm >> r) & (ccm >> c) & 1u) != 0u)) v = 0.f;              // zero padding stays zero
                     d[r] = v;
+                    if (!VROLE && PROD != 0 && HALF == 0) {
+                        if (emit && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u)))
+                            a.dz_out[cur_org + (unsigned)((r * W + c) * 64) + lane] = v;
+                    }
                 }
                 float o[3];
                 if constexpr (VROLE) wg4_bt_half<HALF>(d[0], d[1], d[2], d[3], d[4], d[5], o);
@@ -358,8 +381,10 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
             if (crm != FULL || ccm != FULL) stage1(std::true_type{});      // (wave-uniform: nothing but registers lives across)
             else stage1(std::false_type{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer has been read: it may be overwritten
-            fetch(nxt, nrm != FULL || ncm != FULL);
-            touch(nxt);
+            WG4_STAMP(2);
+            fetch(nxt, nedge, nphi);          // the buffer is free: the next patch is requested
+            phi = nphi;
+            WG4_STAMP(3);
             // second stage row by row, stored as soon as a row is complete: position p = 6 al + b sits at float p of the
             // group-0 row (p < 9), at float p - 9 of the group-1 row otherwise
             float *r0 = buf + tcol * TILE_FLOATS + ((VROLE ? 64 : 0) + lane) * ROW;
@@ -392,13 +417,14 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         seg_setup(nxt);
         unsigned crm, ccm, nrm, ncm;
         masks(nxt, nrm, ncm);
-        fetch(nxt, true);                                     // patch 0 (through the clamping path: once per block)
-        touch(nxt);
+        fetch(nxt, true, 0);                                  // patch 0 (through the clamping path: once per block)
         crm = nrm; ccm = ncm;
+        cur_org = origin(nxt);
         advance(nxt);
         masks(nxt, nrm, ncm);
         transform(s_op, nxt, crm, ccm, nrm, ncm);             // patch 0 -> buffer 0; requests patch 1
         crm = nrm; ccm = ncm;
+        cur_org = origin(nxt);
         advance(nxt);
         wg4_lds_barrier();
         // The two waves of a SIMD (wave w: input role, wave w + 4: gradient role) run the iteration in OPPOSITE order --
@@ -407,15 +433,23 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         // only reads buffer k & 1 and only writes the other one: the order inside it is free.)
 #pragma unroll 1
         for (int k = 0; k < n_k; ++k) {
-            if (!VROLE || (WG4_ABL & 64)) mfma_phase(s_op + (k & 1) * BUF_FLOATS);
-            if (k + 1 < n_k) {
+            wg4_k = k;
+            WG4_STAMP(0);
+            if (!VROLE || (WG4_ABL & 64)) { mfma_phase(s_op + (k & 1) * BUF_FLOATS); WG4_STAMP(5); }
+            const bool more = k + 1 < n_k;
+            if (more) {
                 masks(nxt, nrm, ncm);
-                transform(s_op + ((k + 1) & 1) * BUF_FLOATS, nxt, crm, ccm, nrm, ncm);      // patch k + 1; requests k + 2
+                transform(s_op + ((k + 1) & 1) * BUF_FLOATS, nxt, crm, ccm, nrm, ncm);      // patch k + 1
+            }
+            WG4_STAMP(4);
+            if (VROLE && !(WG4_ABL & 64)) { mfma_phase(s_op + (k & 1) * BUF_FLOATS); WG4_STAMP(5); }
+            if (more) {
                 crm = nrm; ccm = ncm;
+                cur_org = origin(nxt);
                 advance(nxt);
             }
-            if (VROLE && !(WG4_ABL & 64)) mfma_phase(s_op + (k & 1) * BUF_FLOATS);
             wg4_lds_barrier();
+            WG4_STAMP(6);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last request, never consumed, has landed before the LDS is released)
     };
@@ -529,11 +563,11 @@ Wg4Geo wg4_geometry(int B, int H, int W)
 }
 
 int launch_wgrad4(const float *act, const float *act_abc, int act_relu, const float *dz, const float *dz2,
-                  const float *dz_abc, float *ws, int B, int H, int W, hipStream_t st)
+                  const float *dz_abc, float *dz_out, float *ws, int B, int H, int W, hipStream_t st)
 {
     const Wg4Geo g = wg4_geometry(B, H, W);
-    const Wg4Args a{act, dz, dz_abc ? dz2 : nullptr, ws, act_abc, dz_abc, act_relu, H, W, g.tiles_y, g.strips, g.nseg_y,
-                    g.seg_rows, g.nsegs};
+    const Wg4Args a{act, dz, dz_abc ? dz2 : nullptr, ws, act_abc, dz_abc, dz_abc ? dz_out : nullptr, act_relu, H, W,
+                    g.tiles_y, g.strips, g.nseg_y, g.seg_rows, g.nsegs};
     const dim3 grid(g.grid), blk(wg4::THREADS);
     const int prod = !dz_abc ? 0 : (dz2 ? 2 : 1);
 #define COVA_WG4(PA, PD) hipLaunchKernelGGL((conv3x3_wgrad4_kernel<PA, PD>), grid, blk, 0, st, a)
@@ -559,13 +593,15 @@ COVA_API int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W)
 // Per-block partial sums of the weight gradient in the F(4x4,3x3) domain; operands transformed on load as
 // cova_conv3x3_wgrad_wino_partial: activation = relu?(A*act + C) (act_abc [3,64], B row ignored; NULL = plain),
 // gradient = A*dz + B*dz2 + C (dz_abc [3,64], dz2 nullable; NULL = plain).  ws: cova_conv3x3_wgrad4_workspace_floats.
+// dz_out (nullable, needs dz_abc): also writes the gradient operand as formed on load, NHWC [B,H,W,64] -- every pixel once.
 COVA_API int cova_conv3x3_wgrad4_partial(const float *act, const float *act_abc, int act_relu, const float *dz,
-                                         const float *dz2, const float *dz_abc, float *ws, int B, int H, int W,
-                                         void *stream)
+                                         const float *dz2, const float *dz_abc, float *dz_out, float *ws, int B, int H,
+                                         int W, void *stream)
 {
     COVA_REQUIRE(act && dz && ws && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)B * H * W * 256 < (1ll << 32));          // 32-bit byte offsets of the pixel rows
-    return launch_wgrad4(act, act_abc, act_relu, dz, dz2, dz_abc, ws, B, H, W, (hipStream_t)stream);
+    COVA_REQUIRE(dz_out == nullptr || dz_abc != nullptr);
+    return launch_wgrad4(act, act_abc, act_relu, dz, dz2, dz_abc, dz_out, ws, B, H, W, (hipStream_t)stream);
 }
 
 // Fold + final transform of up to four convolutions' partials (pairs 1..3 nullable) into their OIHW gradients
@@ -587,11 +623,18 @@ COVA_API int cova_conv3x3_wgrad4_finish(const float *ws0, float *dw0, const floa
     return COVA_OK;
 }
 
+#ifdef WG4_TRACE
+COVA_API int cova_wg4_trace_read(unsigned long long *host64)
+{
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_wg4_trace), sizeof(unsigned long long) * 64);
+}
+#endif
+
 // act, dz NHWC [B,H,W,64] -> dw OIHW [64,64,3,3] (plain operands, both steps)
 COVA_API int cova_conv3x3_wgrad4(const float *act, const float *dz, float *dw, float *ws, int B, int H, int W, void *stream)
 {
     COVA_REQUIRE(act && dz && dw && ws && B > 0 && H > 0 && W > 0);
-    const int rc = launch_wgrad4(act, nullptr, 0, dz, nullptr, nullptr, ws, B, H, W, (hipStream_t)stream);
+    const int rc = launch_wgrad4(act, nullptr, 0, dz, nullptr, nullptr, nullptr, ws, B, H, W, (hipStream_t)stream);
     if (rc != COVA_OK) return rc;
     return cova_conv3x3_wgrad4_finish(ws, dw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, stream);
 }

@@ -657,7 +657,7 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
         dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
         if OPTIONS.wgrad4:
-            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, ws3, B, H2, W2)
+            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, None, ws3, B, H2, W2)
             call("cova_conv3x3_wgrad4_finish", ws3, dw, None, None, None, None, None, None, B, H2, W2)
         else:
             call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
@@ -772,8 +772,16 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     jobs = []
 
     def wgrad(act, act_abc, act_relu, dz, dz2, dz_abc, dw):
-        call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
+        """-> the gradient operand dz_abc . (dz, dz2) as a materialised map (F(4x4) kernel's side output) or None"""
+        out = None
+        if OPTIONS.wgrad4:
+            if dz_abc is not None and sv["w4"]:
+                out = torch.empty_like(dz)
+            call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, out, ws_all[len(jobs)], B, H2, W2)
+        else:
+            call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
         jobs.append(dw)
+        return out
 
     nt = conv3_num_partials(B, H2, W2, sv["w4"])
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
@@ -801,8 +809,10 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
             g_in, g_in2 = dA, s["z2"]
         grads[pb + "weight"], grads[pb + "bias"] = dg, db
         dw = _gbuf(gout, kb + ".weight", (64, 64, 3, 3), dfeat)
-        wgrad(s["z1"], bna.abc, 1, g_in, g_in2, g_abc, dw)
+        dzm = wgrad(s["z1"], bna.abc, 1, g_in, g_in2, g_abc, dw)
         grads[kb + ".weight"] = dw
+        if dzm is not None:             # the data gradient below reads the materialised operand: one tensor, no prologue
+            g_in, g_in2, g_abc = dzm, None, None
         # ---- dgrad of conv2 with bn1's ReLU mask (recomputed from z1) + backward sums in the epilogue
         dy_a = torch.empty_like(dA)
         part = _empty((nt, 2, C64), dfeat)
@@ -810,23 +820,24 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
                                      bna, dy_a, part, nt, R, gout, pa, B, H2, W2)
         grads[pa + "weight"], grads[pa + "bias"] = dg, db
         dw = _gbuf(gout, ka + ".weight", (64, 64, 3, 3), dfeat)
-        wgrad(s["x"], None, 0, dy_a, s["z1"], abc_a, dw)
+        dzm = wgrad(s["x"], None, 0, dy_a, s["z1"], abc_a, dw)
         grads[ka + ".weight"] = dw
+        d_in, d_in2, d_abc = (dy_a, s["z1"], abc_a) if dzm is None else (dzm, None, None)
         # ---- dgrad of conv1 (+ residual gradient); for block 1 the epilogue prepares block 0's bn2
         dx = torch.empty_like(dA)
         if blk == 1:
             prev = sv["blocks"][0]
-            pend = dgrad_bn_bwd(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, dres, prev["out"], None, None, prev["z2"],
+            pend = dgrad_bn_bwd(sv["wd"][2 * blk], d_in, d_in2, d_abc, dres, prev["out"], None, None, prev["z2"],
                                 prev["bnb"], dx, _empty((nt, 2, C64), dfeat), nt, R, gout, BN3_KEYS[1], B, H2, W2,
                                 act_bits=prev.get("out_bits"))
         elif sv.get("ymax") is not None:
             # stem: ReLU mask of bn1 (from the pooled arg-max value) + its backward sums in the epilogue
             bn1 = sv["bn1"]
-            sv["pool_abc"] = dgrad_bn_bwd(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, dres, None, bn1.scale, bn1.shift,
+            sv["pool_abc"] = dgrad_bn_bwd(sv["wd"][2 * blk], d_in, d_in2, d_abc, dres, None, bn1.scale, bn1.shift,
                                           sv["ymax"], bn1, dx, _empty((nt, 2, C64), dfeat), nt, B * H1 * W1, gout,
                                           "convnet.1.", B, H2, W2)
         else:
-            conv3x3_pro(sv["wd"][2 * blk], dy_a, s["z1"], abc_a, 0, dres, None, None, None, None, None, None, dx,
+            conv3x3_pro(sv["wd"][2 * blk], d_in, d_in2, d_abc, 0, dres, None, None, None, None, None, None, dx,
                         None, B, H2, W2)
         dA = dx
     fin = []

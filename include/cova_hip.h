@@ -140,8 +140,9 @@ int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad4_num_partials(int B, int H, int W);
 int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad4_partial(const float *act, const float *act_abc /*nullable*/, int act_relu, const float *dz,
-                                const float *dz2 /*nullable*/, const float *dz_abc /*nullable*/, float *ws, int B, int H,
-                                int W, void *stream);
+                                const float *dz2 /*nullable*/, const float *dz_abc /*nullable*/,
+                                float *dz_out /*nullable: also writes A*dz + B*dz2 + C, NHWC [B,H,W,64]*/, float *ws, int B,
+                                int H, int W, void *stream);
 int cova_conv3x3_wgrad4_finish(const float *ws0, float *dw0, const float *ws1, float *dw1, const float *ws2,
                                float *dw2, const float *ws3, float *dw3, int B, int H, int W, void *stream);
 int cova_conv3x3_wgrad4(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B, int H, int W,

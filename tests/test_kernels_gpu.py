@@ -807,14 +807,18 @@ def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
         for pa, pd in ((True, 2), (True, 0), (False, 2), (False, 1), (True, 1)):
             ref, got = torch.zeros_like(dw), torch.zeros_like(dw)
             call("cova_conv3x3_wgrad4", a1 if pa else x, {0: dy, 1: dz1, 2: dz2}[pd], ref, ws, B, H, W)
+            dzo = torch.full_like(dy, float("nan")) if pd else None
             call("cova_conv3x3_wgrad4_partial", x, abc_a if pa else None, 1, dy, z if pd == 2 else None,
-                 abc_d if pd else None, ws2, B, H, W)
+                 abc_d if pd else None, dzo, ws2, B, H, W)
             call("cova_conv3x3_wgrad4_finish", ws2, got, None, None, None, None, None, None, B, H, W)
+            if pd == 2:     # the side output = the operand the data-gradient kernel's prologue would form: same fma, every pixel once
+                assert torch.isfinite(dzo).all()
+                close(dzo, dz2, 1e-6, "materialised gradient operand")
             # (pd != 0: torch.addcmul rounds the products, the kernel's fma does not -- an ulp on the operand)
             close(got, ref, 2e-6 if pd == 0 else 1e-5, "F(4x4) wgrad affine-on-load %s %s" % (pa, pd))
         # one finish launch for two convolutions
         dwa, dwb = torch.zeros_like(dw), torch.zeros_like(dw)
-        call("cova_conv3x3_wgrad4_partial", x, None, 0, dy, None, None, ws, B, H, W)
+        call("cova_conv3x3_wgrad4_partial", x, None, 0, dy, None, None, None, ws, B, H, W)
         call("cova_conv3x3_wgrad4_finish", ws, dwa, ws2, dwb, None, None, None, None, B, H, W)
         assert torch.equal(dwa, dw) and torch.equal(dwb, got)
     finally:

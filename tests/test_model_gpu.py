@@ -256,7 +256,7 @@ def test_reference_style_train_loop_matches_fused_trainer_and_oracle():
     assert logits.shape == (39, 4) and torch.equal(pred, logits.argmax(1))
 
 
-def test_training_trajectory_follows_the_cpu_oracle():
+def test_training_trajectory_follows_the_cpu_oracle(request):
     """Stand-in for the reference's accuracy claim (README.md:41-42; the CoVA dataset is not available offline):
     80 Adam steps (lr 5e-4, weight_decay 1e-3: /root/reference main.py:133-139) of the HIP trainer against the CPU oracle
     (oracle.loss_and_grads + torch.optim.Adam) on a memorisable synthetic task -- three batches of two 96-pixel pages
@@ -275,6 +275,12 @@ def test_training_trajectory_follows_the_cpu_oracle():
     steps = 80
     gen = torch.Generator().manual_seed(5)
     keys = O.param_keys(sd)
+    # one CPU thread: the oracle side is then run-to-run reproducible (multi-threaded reductions are not, and an earlier test
+    # of the session may have changed the thread count) -- with a chaotic trajectory the band below would otherwise
+    # depend on what ran before
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    request.addfinalizer(lambda: torch.set_num_threads(n_threads))
     tr = HotPathTrainer(cfg, sd, DEV)
     ref_sd, state = O.clone_state_dict(sd), None
     curve = []

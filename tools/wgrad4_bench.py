@@ -23,12 +23,13 @@ def t(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
-only = sys.argv[1:]          # e.g. "12" = PROA + two-tensor gradient prologue
+only = [a for a in sys.argv[1:] if not a.startswith("--")]          # e.g. "12" = PROA + two-tensor gradient prologue
 for name, pa, pd in (("00", False, 0), ("10", True, 0), ("02", False, 2), ("12", True, 2)):
     if only and name not in only:
         continue
     args = (x, abc_a if pa else None, 1, dy, z if pd == 2 else None, abc_d if pd else None)
-    t4 = t(lambda: call("cova_conv3x3_wgrad4_partial", *args, ws4, B, H, W))
+    dzo = torch.empty_like(dy) if (pd and "--emit" in sys.argv) else None
+    t4 = t(lambda: call("cova_conv3x3_wgrad4_partial", *args, dzo, ws4, B, H, W))
     t2 = t(lambda: call("cova_conv3x3_wgrad_wino_partial", *args, ws2, B, H, W))
     print("prologue act=%d grad=%d   F(4x4) %.3f ms   F(2x2) %.3f ms" % (pa, pd, t4, t2), flush=True)
 f4 = t(lambda: call("cova_conv3x3_wgrad4_finish", ws4, dw, ws4, dw, ws4, dw, ws4, dw, B, H, W))

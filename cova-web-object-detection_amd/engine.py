@@ -656,15 +656,20 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
         # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
         dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
+        d_in, d_in2, d_abc = dy2, s["z2"], abc2
         if OPTIONS.wgrad4:
-            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, None, ws3, B, H2, W2)
+            # ... with dz2 = abc2 . (dy2, z2) as its side output: the data gradient below reads one tensor, no prologue
+            dzm = _empty((B, H2, W2, C64), g) if sv["w4"] else None
+            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dzm, ws3, B, H2, W2)
             call("cova_conv3x3_wgrad4_finish", ws3, dw, None, None, None, None, None, None, B, H2, W2)
+            if dzm is not None:
+                d_in, d_in2, d_abc = dzm, None, None
         else:
             call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
         grads[pre + "conv2.weight"] = dw
         dy1 = _empty((B, H2, W2, C64), g)
         part = _empty((nt, 2, C64), g)
-        dg, db, abc1 = dgrad_bn_bwd(s["ud"], dy2, s["z2"], abc2, None, None, bn1.scale, bn1.shift, s["z1"], bn1, dy1, part,
+        dg, db, abc1 = dgrad_bn_bwd(s["ud"], d_in, d_in2, d_abc, None, None, bn1.scale, bn1.shift, s["z1"], bn1, dy1, part,
                                     nt, R, gout, pre + "bn1.", B, H2, W2)
         grads[pre + "bn1.weight"], grads[pre + "bn1.bias"] = dg, db
         # conv1 (Cin->64): dz1 = abc1 . (dy1, z1) on load

@@ -38,6 +38,20 @@
 #define W4_ABL 0
 #endif
 
+// -DW4_TRACE (tools only): s_memtime stamps of waves 0 and 4 (the two position halves on one SIMD) of block 0 over the
+// sixteen iterations + two tile epilogues that start at chunk 32 of its stream
+#ifdef W4_TRACE
+__device__ unsigned long long g_w4_trace[2 * 20 * 8];
+#define W4_STAMP(row, slot)                                                                                  \
+    do {                                                                                                     \
+        const int r__ = (row);                                                                               \
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && r__ >= 0 && r__ < 20 && lane == 0)                \
+            g_w4_trace[((wave >> 2) * 20 + r__) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                \
+    } while (0)
+#else
+#define W4_STAMP(row, slot) do { } while (0)
+#endif
+
 namespace {
 
 namespace w4 {
@@ -434,6 +448,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         float *v_w = PAR ? s_v0 : s_v1;                     //   and writes V[(g+1) & 1]
         const float *v_r = (PAR ? s_v1 : s_v0) + v_off;     // MFMAs of chunk g read V[g & 1]
         // group (g+4) >> 1 (chunks g+4, g+5) -> the slot of group (g >> 1), consumed by the last two column stages
+        // (issued behind the first 16 MFMAs instead -- three LDS-DMA instructions stall the wave ~450 cycles, tools/w4_trace.py --
+        //  the launch takes exactly as long: 0.492 vs 0.493 ms; the stall moves, the iteration does not shrink)
         if (!(g & 1)) {
             if (((g + 4) & 7) == 0) plane_src((g + 4) >> 3);
             copy_group(((g + 4) & 7) >> 1, (g >> 1) & 1);
@@ -485,6 +501,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         // its transform, the second V group requested before the last item's transform; the plain variant reads all three
         // items up front (measured equal or faster there).  The compiler's schedule inside these groups measured equal
         // to one pinned with scheduling barriers.
+        W4_STAMP(g - 32, 0);
         if constexpr (PRO != 0) {
         Item it;
         read_v(0);
@@ -506,16 +523,22 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         item_read(1, it1, slot2, coff2, tmp_w, tmp_r, v_w);
         item_read(2, it2, slot2, coff2, tmp_w, tmp_r, v_w);
         read_v(0);
+        W4_STAMP(g - 32, 1);
         mfma_range(0, 16);
+        W4_STAMP(g - 32, 2);
         read_v(1);
         mfma_range(16, 18);
         item_finish(0, it0, s2);
         item_finish(1, it1, s2);
         item_finish(2, it2, s2);
+        W4_STAMP(g - 32, 3);
         mfma_range(18, 36);
         }
+        W4_STAMP(g - 32, 4);
         wait_planes(g);
+        W4_STAMP(g - 32, 5);
         lds_barrier();
+        W4_STAMP(g - 32, 6);
     };
 
     // ---- tile epilogue: output transform Y = A^T M A.  This wave holds M[i = 3 ph + il][j] for (channels cog*16 + kq*4 .. +3,
@@ -599,6 +622,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
             }
         };
         Ops ops;
+        W4_STAMP(16 + 2 * (k - 4), 0);
         if (ADD || BN) load_ops(0, ops);
         // exchange (three barriers; the area is idle between two iterations): ph 1 writes, ph 0 reads and writes into the
         // same slots, ph 1 reads
@@ -616,12 +640,14 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rx[io][j] = *reinterpret_cast<const float4 *>(xw + (io * 4 + j) * 256);
         };
+        W4_STAMP(16 + 2 * (k - 4), 1);
         if (ph == 1) put();
         if (!(W4_ABL & 512)) lds_barrier();
         if (ph == 0) { get(); put(); }
         if (!(W4_ABL & 512)) lds_barrier();
         if (ph == 1) get();
         if (!(W4_ABL & 512)) lds_barrier();
+        W4_STAMP(16 + 2 * (k - 4), 2);
         // complete the own rows right away (the received values die here): rows are summed in the order i = 0..5 on both
         // waves, (rows 0-2) + (rows 3-5)
 #pragma unroll
@@ -692,6 +718,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
                 load_ops(1, ops);
             }
         }
+        W4_STAMP(16 + 2 * (k - 4), 3);
         if (STATS) {        // this tile's sums over the wave's 16 tiles (the lanes of one channel quad: L' & 3) -> the wave's running
                             // totals (lanes 0..3)
 #pragma unroll
@@ -783,6 +810,13 @@ int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 // ====================================================================================
 // C ABI
 // ====================================================================================
+#ifdef W4_TRACE
+COVA_API int cova_w4_trace_read(unsigned long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_trace), sizeof(unsigned long long) * 320);
+}
+#endif
+
 COVA_API int cova_conv3x3_wino4_num_tiles(int B, int H, int W)
 {
     return B * cdiv(W, w4::TW) * cdiv(H, w4::TH);

@@ -27,6 +27,22 @@ def family(name):
     return name.split("<")[0]
 
 
+def step_total(path, counter, which=2):
+    """Sum of `counter` over the launches of ONE training step (delimited by the Adam launches, as tools/rocpd_step.py),
+    or None when the database has no usable launch order."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    order = next((c for c in ("dispatch_id", "start", "id") if c in cols), None)
+    if order is None:
+        return None
+    rows = db.execute("select kernel_name, value from counters_collection where counter_name = ? order by %s" % order,
+                      (counter,)).fetchall()
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+    if len(adam) <= which:
+        return None
+    return sum(v for _, v in rows[adam[which - 1] + 1:adam[which] + 1])
+
+
 def main():
     fetch_db, write_db, pages, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     txt = sys.argv[sys.argv.index("--txt") + 1] if "--txt" in sys.argv else None
@@ -47,8 +63,14 @@ def main():
     for k, (calls, fk, wk, us) in fam.items():
         kernels[k] = {"launches": calls, "fetch_size_kib_raw": round(fk / calls, 1), "write_size_kib": round(wk / calls, 1),
                       "traffic_bytes_per_launch": round((2.0 * fk + wk) / calls * 1024.0), "avg_us": round(us / calls, 1)}
-    json.dump({"pages": pages, "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 half-count of 16-B/lane reads)",
-               "kernels": kernels}, open(out_path, "w"), indent=1, sort_keys=True)
+    doc = {"pages": pages, "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 half-count of 16-B/lane reads)",
+           "kernels": kernels}
+    sf, sw = step_total(fetch_db, "FETCH_SIZE"), step_total(write_db, "WRITE_SIZE")
+    if sf is not None and sw is not None:         # every launch of one training step (Adam to Adam), the same correction
+        doc["step_traffic_bytes"] = round((2.0 * sf + sw) * 1024.0)
+        doc["step_traffic_note"] = "sum over the launches of one training step of the trace (second one), KiB counters * 1024"
+        lines.append("# one training step (Adam to Adam): 2*FETCH + WRITE = %.2f GB" % (doc["step_traffic_bytes"] / 1e9))
+    json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
     if txt:
         open(txt, "w").write("\n".join(lines) + "\n")
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the F(4x4,3x3) kernel (tools/wino4_bench.py): output in gpurun_out/r3b/pmc_wino4.txt
+# PMC passes over the F(4x4,3x3) kernel (tools/wino4_bench.py): output in gpurun_out/${PMC_OUT:-r3b}/pmc_wino4.txt
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -11,4 +11,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
   rocprofv3 --pmc $set -d /tmp/pmc_w4_$i -- python $root/tools/wino4_bench.py > /tmp/pmc_w4_$i.log 2>&1 || tail -3 /tmp/pmc_w4_$i.log
   db=$(find /tmp/pmc_w4_$i -name "*.db" | head -1)
   [ -n "$db" ] && python $root/tools/rocpd_pmc.py --raw $db | grep -E "wino4_kernel|c64_wino_kernel"
-done > $root/gpurun_out/r3b/pmc_wino4.txt 2>&1
+done > $root/gpurun_out/${PMC_OUT:-r3b}/pmc_wino4.txt 2>&1

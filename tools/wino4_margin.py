@@ -94,7 +94,7 @@ def show(title, res):
 
 
 emit("# Parity margins of the 3x3 convolution kernels: F(2x2,3x3) (csrc/conv_wino.hip) vs F(4x4,3x3) (csrc/conv_wino4.hip),")
-emit("# tools/wino4_margin.py on one MI355X.  Test gates: logits 1e-4 (eval) / 2e-4 (train), loss 2e-4, gradients 2e-4 of")
+emit("# tools/wino4_margin.py on one MI355X.  Test gates (round 4): logits 5e-5, loss 2e-5, gradients 1e-4 of")
 emit("# each tensor's scale against the forced-routing oracle; flipped gates must sit within 2e-5 of zero and be fewer than")
 emit("# 1e-4 of a layer's decisions (tests/helpers.py).  'ref' = the fixture captured from the imported reference.")
 emit()

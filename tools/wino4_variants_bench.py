@@ -34,8 +34,10 @@ full = lambda *a: call("cova_conv3x3_wino4_full", *a, out, part, B, H, W)
 cases = [
     ("<1,0,0,0> forward, statistics", lambda: full(x, N, N, 0, uf, N, N, N, N, N, N, N)),
     ("<1,1,0,0> forward, BN+ReLU on load", lambda: full(x, N, abc, 1, uf, N, N, N, N, N, N, N)),
+    ("<1,0,0,1> dgrad (materialised operand), mask from z", lambda: full(x, N, N, 0, ud, N, N, abc[0], abc[2], z, mean, invstd)),
+    ("<1,0,1,1> ... + addend", lambda: full(x, N, N, 0, ud, add, N, abc[0], abc[2], z, mean, invstd)),
+    ("<1,0,1,2> ... + addend, mask from act", lambda: full(x, N, N, 0, ud, add, act, N, N, z, mean, invstd)),
     ("<1,2,0,1> dgrad, two tensors on load, mask from z", lambda: full(x, x2, abc, 0, ud, N, N, abc[0], abc[2], z, mean, invstd)),
-    ("<1,2,1,1> ... + addend", lambda: full(x, x2, abc, 0, ud, add, N, abc[0], abc[2], z, mean, invstd)),
     ("<1,2,1,2> ... + addend, mask from act", lambda: full(x, x2, abc, 0, ud, add, act, N, N, z, mean, invstd)),
 ]
 print(" ".join("%.3f" % timeit(fn) for _, fn in cases), " ms :", " | ".join(n.split(">")[0] + ">" for n, _ in cases))

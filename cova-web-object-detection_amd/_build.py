@@ -18,7 +18,9 @@ def needs_build():
 
 # per-file extra flags.  conv_wino: no SLP vectorisation -- on gfx950 packed f32 VALU ops cannot issue
 # in the shadow of an MFMA (LLVM unpacks them again and leaves the shuffle moves behind).
-FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"],
+              # conv_wgrad4: the same (packed transform arithmetic cost 210 register moves per K-step of the input role)
+              "conv_wgrad4.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force=False, verbose=False):

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         constexpr int NR = VROLE ? 6 : 4;                    // patch rows = columns
         constexpr int NB = NR / 2;                           // 2 x 2 pixel blocks per patch row / column
         constexpr bool TWO = !VROLE && PROD == 2;
-        // per-channel prologue constants (lane = channel)
+        // per-channel prologue constants (lane = channel); ReLU as max(., 0) or max(., -inf): one instruction either way
+        const float relu_floor = a.act_relu ? 0.f : -INFINITY;
         float pA = 1.f, pB = 0.f, pC = 0.f;
         if (VROLE) {
             if (PROA) { pA = a.act_abc[lane]; pC = a.act_abc[128 + lane]; }
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         // side output (gradient role, position half 0): the operand as formed on load, written once -- the data-gradient
         // launch of the same convolution then reads ONE tensor with no prologue instead of forming it again per tap
         const bool emit = !VROLE && PROD != 0 && HALF == 0 && a.dz_out != nullptr;
+        unsigned emit_lane = (unsigned)lane * 4u;
+        asm volatile("" : "+v"(emit_lane));
         unsigned cur_org = 0;                                // element offset of the current tile's pixel (0, 0)
         auto origin = [&](const Wg4It &it) __attribute__((always_inline)) {
             return (unsigned)(((it.b * H + 4 * it.ty) * W + 16 * it.strip + 4 * tcol) * 64);
@@ -359,17 +362,18 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                 for (int r = 0; r < NR; ++r) {
                     const int slot = 4 * (c >> 1) + 2 * (r & 1) + (c & 1);          // within the row pair's slots
                     float v = pair_r[r >> 1][64 * slot];
-                    if (VROLE && PROA) {
-                        v = fmaf(pA, v, pC);                        // same expression as the forward prologue
-                        if (a.act_relu) v = fmaxf(v, 0.f);
-                    }
+                    if (VROLE && PROA) v = fmaxf(fmaf(pA, v, pC), relu_floor);     // same expression as the forward prologue
                     if (TWO) v = fmaf(pA, v, fmaf(pB, pair_r[r >> 1][64 * (16 + slot)], pC));   // dz = A*dy + B*z + C
                     if (!VROLE && PROD == 1) v = fmaf(pA, v, pC);
                     if (cedge && !(((crm >> r) & (ccm >> c) & 1u) != 0u)) v = 0.f;              // zero padding stays zero
                     d[r] = v;
                     if (!VROLE && PROD != 0 && HALF == 0) {
-                        if (emit && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u)))
-                            a.dz_out[cur_org + (unsigned)((r * W + c) * 64) + lane] = v;
+                        // (scalar base of the pixel + ONE lane offset: global_store with an SGPR pair, no per-lane pointers)
+                        if (emit && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u))) {
+                            unsigned ob = (cur_org + (unsigned)((r * W + c) * 64)) * 4u;
+                            asm volatile("" : "+s"(ob));
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dz_out) + ob + emit_lane) = v;
+                        }
                     }
                 }
                 float o[3];

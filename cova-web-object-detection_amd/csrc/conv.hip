@@ -291,6 +291,306 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// conv1 v3: the same implicit GEMM on the bf16 matrix pipe with f32-class error.  gfx950 has no reduced-precision
+// fast path for f32 operands (no xf32), and v_mfma_f32_32x32x2_f32 runs at the VECTOR rate (1/16 of the bf16 MFMA rate)
+// on the lanes the VALU uses: the v2 kernel above is bound by it (0.69 of that peak).  Here every f32 operand x is
+// split EXACTLY into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significand bits, by truncation: each residual is
+// exact in f32 and the third piece is exact in bf16), and a*b is accumulated in f32 as the six products of order
+// <= 2:  a2 b0 + a0 b2 + a1 b1 + a1 b0 + a0 b1 + a0 b0  (the three dropped ones are <= 2^-24 |a b|: below the rounding
+// of the f32 product itself).  Products of bf16 pieces are exact in f32, so the only roundings are the accumulator's
+// -- 6 v_mfma_f32_32x32x16_bf16 (16 k-slots each, 32 cycles) replace 8 v_mfma_f32_32x32x2_f32 (2 taps each, 64 cycles),
+// and the bf16 MFMAs leave the vector lanes to the other waves of the SIMD.  Measured against fp64 the error is that
+// of the f32 kernel (tools/conv1_bench.py; tests/test_kernels_gpu.py::test_conv1_bf16_split_error_class).
+//   * the image patch is split ONCE per element, when the prefetched registers are written to LDS, and stored as three
+//     planes of packed bf16 PAIRS of horizontally adjacent columns (2m, 2m+1) of the patch: the stride-2 window of
+//     output pixel x starts at patch column 2x, so its 7 taps of one kernel row are the four consecutive dwords
+//     m = x .. x+3 of that row (the eighth half-dword meets a zero weight) -- the A operand of a K-step is 2
+//     ds_read2_b32 per piece and NO vector arithmetic (a first version that split the taps per output pixel, 44
+//     operations per K-step, had more vector instructions than the MFMAs can cover);
+//   * K = 21 kernel rows (c, kh) of 8 slots, two per K-step (lane half g = l >> 5 takes row 2s + g): 11 K-steps;
+//   * the WEIGHTS live in registers: wave = (channel block cb = w & 1, output rows 2q, 2q+1 of the tile, q = w >> 1)
+//     holds the 11 x 3 B operands of its 32 channels (132 registers) for the whole launch, split once per block from
+//     the OIHW weight.  LDS then holds the patch only (double-buffered, 34 KB): block = 256 threads = 4 rows x 32 px,
+//     TWO blocks per CU whose phases (MFMA loop / LDS refill / output stores) drift apart -- a first 1024-thread
+//     version with a 66 KB weight image in LDS and all 16 waves of the CU behind the same two barriers per tile ran
+//     its phases back to back (0.83 ms: ablation 0.19 LDS reads + 0.33 MFMAs + 0.10 refill + 0.20 stores);
+//   * one barrier per tile, over LDS traffic only: the next patch is written to the other buffer BEFORE this tile's
+//     output stores are issued, so the stores drain beside the next tile's MFMAs.
+// ------------------------------------------------------------------------------------
+// Ablation builds of tools/c1b_abl_build.sh (0 in the product): 1 no output stores, 2 no MFMAs, 4 no patch prefetch / LDS refill
+#ifndef C1B_ABL
+#define C1B_ABL 0
+#endif
+
+namespace c1b {
+constexpr int TH = 4, TW = 32;
+constexpr int PR = 2 * TH + 5;                 // 13 input rows
+constexpr int NSEG = 3 * PR;                   // 39 (channel, row) segments
+constexpr int SEGW = 36;                       // dwords per segment: pairs m = 0 .. 34 (+1)
+constexpr int PLANE = NSEG * SEGW;             // 1404 dwords per piece plane
+constexpr int BUF = 3 * PLANE;                 // one patch buffer: 16,848 B
+constexpr int KSTEPS = 11;
+constexpr int KREG = 8;                        // K-steps whose B operands stay in registers (96); the other 3 are read from LDS
+constexpr int THREADS = 256;
+constexpr int NPRE = (PLANE + THREADS - 1) / THREADS;        // 6 pair slots per thread
+__host__ __device__ constexpr int row_off(int t) { return t < 21 ? ((t / 7) * PR + t % 7) * SEGW : 0; }
+}  // namespace c1b
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// (xe, xo) -> three dwords of packed bf16 pieces (even element in the low half): 11 operations
+__device__ __forceinline__ void bf3_split_pair(float xe, float xo, uint32_t &q0, uint32_t &q1, uint32_t &q2)
+{
+    const uint32_t ue = __builtin_bit_cast(uint32_t, xe), uo = __builtin_bit_cast(uint32_t, xo);
+    q0 = __builtin_amdgcn_perm(uo, ue, 0x07060302u);
+    const float re = xe - __builtin_bit_cast(float, ue & 0xFFFF0000u);
+    const float ro = xo - __builtin_bit_cast(float, uo & 0xFFFF0000u);
+    const uint32_t ve = __builtin_bit_cast(uint32_t, re), vo = __builtin_bit_cast(uint32_t, ro);
+    q1 = __builtin_amdgcn_perm(vo, ve, 0x07060302u);
+    const float se = re - __builtin_bit_cast(float, ve & 0xFFFF0000u);
+    const float so = ro - __builtin_bit_cast(float, vo & 0xFFFF0000u);
+    q2 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, so), __builtin_bit_cast(uint32_t, se), 0x07060302u);
+}
+
+__device__ __forceinline__ void bf3_split8(const float (&x)[8], u32x4 &p0, u32x4 &p1, u32x4 &p2)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t a, b, c;
+        bf3_split_pair(x[2 * i], x[2 * i + 1], a, b, c);
+        p0[i] = a; p1[i] = b; p2[i] = c;
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma32bf(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Patch prefetch load as inline asm (wave-uniform base + 32-bit byte offset): the compiler neither waits for it nor
+// moves it -- left to itself it sinks these loads (twelve live registers beside 132 of weights) to just in front of
+// their use, i.e. behind the MFMA loop they are meant to hide under.  The one wait is in write_lds.
+__device__ __forceinline__ float c1b_load(const float *base, unsigned off_bytes)
+{
+    float v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off_bytes), "s"(base) : "memory");
+    return v;
+}
+
+// barrier over LDS traffic only (global stores and loads stay in flight across it)
+__device__ __forceinline__ void c1b_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool STATS>
+__global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
+    const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
+    float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
+    int w_oihw, const BnTail tail)
+{
+    using namespace c1b;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF + 4 * 128];     // (>= the 2049 doubles of bn_tail_run)
+    __shared__ u32x4 s_wl[KSTEPS - KREG][2][3][64];   // B operands of the last K-steps, per channel block (registers: 12 per K-step)
+    uint32_t *s_pp = lds;                                        // [buffer][piece][segment][pair]
+    float *s_red = reinterpret_cast<float *>(lds + 2 * BUF);     // [wave][sum 64 | sum of squares 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (STATS) { s_red[tid] = 0.f; s_red[tid + 256] = 0.f; }
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int cb = wave & 1, q = wave >> 1;
+    int tile = blockIdx.x;
+
+    // The next tile's patch is prefetched into registers during the MFMAs: slot it of thread tid = pair
+    // (it * 256 + tid) of the [segment][36] grid, two loads.  Every load is UNCONDITIONAL at a clamped address (a
+    // branch around a load makes the compiler wait for all outstanding loads at the join); whether a value is inside the
+    // image is kept as one bit and applied when the slot is written to LDS.
+    static_assert(NPRE == 6, "write_lds lists the twelve prefetch registers");
+    float pre[2 * NPRE];
+    unsigned premask = 0u;
+    auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));          // the slot's index math stays here (hoisted out of the tile loop it costs
+        const int item = it * THREADS + t_;   // six registers per slot: the weights already take 132)
+        const int itc = item < PLANE ? item : PLANE - 1;
+        const int seg = itc / SEGW, m = itc - seg * SEGW;
+        const int c = seg / PR, r = seg - c * PR;
+        const int gy = 2 * ty * TH - 3 + r, gx = 2 * tx * TW - 3 + 2 * m;
+        const bool oky = item < PLANE && gy >= 0 && gy < H;
+        const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+        const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+        const int cx0 = gx < 0 ? 0 : (gx >= W ? W - 1 : gx), cx1 = gx + 1 < 0 ? 0 : (gx + 1 >= W ? W - 1 : gx + 1);
+        const unsigned rowo = (unsigned)((c * H + cy) * W);              // 32-bit in-image offset (checked at launch)
+        pre[2 * it] = c1b_load(img_b, (rowo + cx0) * 4u);
+        pre[2 * it + 1] = c1b_load(img_b, (rowo + cx1) * 4u);
+        premask = (premask & ~(3u << (2 * it))) | ((ok0 ? 1u : 0u) << (2 * it)) | ((ok1 ? 2u : 0u) << (2 * it));
+    };
+    auto write_lds = [&](uint32_t *dst) {
+        // the one wait for the prefetched patch (the values pass through the statement: no use can move above it)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]),
+                       "+v"(pre[7]), "+v"(pre[8]), "+v"(pre[9]), "+v"(pre[10]), "+v"(pre[11])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int item = it * THREADS + t_;
+            if (item < PLANE) {
+                const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
+                const float xo = ((premask >> (2 * it + 1)) & 1u) ? pre[2 * it + 1] : 0.f;
+                uint32_t q0, q1, q2;
+                bf3_split_pair(xe, xo, q0, q1, q2);
+                dst[item] = q0;
+                dst[PLANE + item] = q1;
+                dst[2 * PLANE + item] = q2;
+            }
+        }
+    };
+    if (tile < ntiles) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) issue_slot(it, img + (size_t)b * 3 * H * W, ty, tx);
+    }
+    // B operands of this wave's 32 channels: K-step s, lane (n, g) = the 7 weights of channel cb*32+n in kernel row
+    // t = 2s + g = (c, kh) and a zero, as three packed-bf16 pieces.  wk is the OIHW weight, or (w_oihw == 0) the
+    // [154][64] K-pair layout of cova_conv1_prep_weights.
+    u32x4 wb[KREG][3];
+    {
+        const int co = cb * 32 + li;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int t = 2 * s + kh2;
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = 0.f;
+                if (j < 7) {
+                    const int tc = t < 21 ? t : 20;
+                    const int tap = tc * 7 + j;                  // c*49 + kh*7 + kw
+                    int idx;
+                    if (w_oihw) {
+                        idx = co * 147 + tap;
+                    } else {                                     // inverse of c1::pair_tap
+                        int row;
+                        if (tap < 98) row = 2 * (tap % 49) + tap / 49;
+                        else {
+                            const int kh = (tap - 98) / 7, kw = (tap - 98) % 7;
+                            row = kh < 3 ? 2 * (49 + kh * 7 + kw) : kh == 3 ? 2 * (70 + kw) : 2 * (49 + (kh - 4) * 7 + kw) + 1;
+                        }
+                        idx = row * 64 + co;
+                    }
+                    v = wk[idx];
+                    if (t >= 21) v = 0.f;
+                }
+                wv[j] = v;
+            }
+            if (s < KREG) {
+                bf3_split8(wv, wb[s < KREG ? s : 0][0], wb[s < KREG ? s : 0][1], wb[s < KREG ? s : 0][2]);
+            } else {                                             // (both waves of a channel block write the same values)
+                u32x4 w0, w1, w2;
+                bf3_split8(wv, w0, w1, w2);
+                s_wl[s < KREG ? 0 : s - KREG][cb][0][lane] = w0;
+                s_wl[s < KREG ? 0 : s - KREG][cb][1][lane] = w1;
+                s_wl[s < KREG ? 0 : s - KREG][cb][2][lane] = w2;
+            }
+        }
+    }
+    if (tile < ntiles) write_lds(s_pp);
+    __syncthreads();
+
+    int cur = 0;
+    float tot_s = 0.f, tot_q = 0.f;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const int next = has_next ? tile + (int)gridDim.x : tile;       // (last tile: re-reads its own patch, unused)
+        const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
+        const float *nimg = img + (size_t)(next / (tiles_x * tiles_y)) * 3 * H * W;
+        const uint32_t *a_org = s_pp + cur * BUF + (4 * q) * SEGW + li;  // output row 2q (+ 2*SEGW: row 2q+1), dwords li..li+3
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s < NPRE && !(C1B_ABL & 4)) issue_slot(s, nimg, nty, ntx);   // the next tile's patch
+            const uint32_t *ap = a_org + (kh2 ? row_off(2 * s + 1) : row_off(2 * s));
+            u32x4 a00, a01, a02, a10, a11, a12;                  // [row][piece]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a00[i] = ap[i];
+                a01[i] = ap[PLANE + i];
+                a02[i] = ap[2 * PLANE + i];
+                a10[i] = ap[2 * SEGW + i];
+                a11[i] = ap[2 * SEGW + PLANE + i];
+                a12[i] = ap[2 * SEGW + 2 * PLANE + i];
+            }
+            if (C1B_ABL & 2) {
+                asm volatile("" ::"v"(a00), "v"(a01), "v"(a02), "v"(a10), "v"(a11), "v"(a12));
+                continue;
+            }
+            u32x4 b0, b1, b2;
+            if (s < KREG) {
+                b0 = wb[s < KREG ? s : 0][0]; b1 = wb[s < KREG ? s : 0][1]; b2 = wb[s < KREG ? s : 0][2];
+            } else {
+                b0 = s_wl[s < KREG ? 0 : s - KREG][cb][0][lane];
+                b1 = s_wl[s < KREG ? 0 : s - KREG][cb][1][lane];
+                b2 = s_wl[s < KREG ? 0 : s - KREG][cb][2][lane];
+            }
+            acc0 = mfma32bf(a02, b0, acc0); acc1 = mfma32bf(a12, b0, acc1);
+            acc0 = mfma32bf(a00, b2, acc0); acc1 = mfma32bf(a10, b2, acc1);
+            acc0 = mfma32bf(a01, b1, acc0); acc1 = mfma32bf(a11, b1, acc1);
+            acc0 = mfma32bf(a01, b0, acc0); acc1 = mfma32bf(a11, b0, acc1);
+            acc0 = mfma32bf(a00, b1, acc0); acc1 = mfma32bf(a10, b1, acc1);
+            acc0 = mfma32bf(a00, b0, acc0); acc1 = mfma32bf(a10, b0, acc1);
+        }
+        if (has_next && !(C1B_ABL & 4)) write_lds(s_pp + (cur ^ 1) * BUF);
+        c1b_lds_barrier();               // the next patch is complete; every wave is done reading this one
+        cur ^= 1;
+        // output rows y0 + 2q, + 1: D register r of lane l = pixel mfma32_row(r, l), channel cb*32 + (l & 31)
+        float sm = 0.f, sq = 0.f;
+        if (C1B_ABL & 1) {
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int oy = y0 + 2 * q + rr;
+                const size_t rowb = ((size_t)b * H1 + oy) * W1 + x0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = mfma32_row(r, lane);
+                    if (oy < H1 && x0 + px < W1) {
+                        const float v = rr == 0 ? acc0[r] : acc1[r];
+                        out[(rowb + (size_t)px) * 64 + cb * 32 + li] = v;
+                        sm += v;
+                        sq += v * v;
+                    }
+                }
+            }
+        }
+        tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
+        tot_q += sq;
+    }
+    if (STATS) {
+        tot_s += __shfl_xor(tot_s, 32, 64);
+        tot_q += __shfl_xor(tot_q, 32, 64);
+        if (lane < 32) {
+            s_red[wave * 128 + cb * 32 + li] = tot_s;
+            s_red[wave * 128 + 64 + cb * 32 + li] = tot_q;
+        }
+    }
+    __syncthreads();
+    if (STATS && tid < 128) {
+        float t = 0.f;
+        for (int w = 0; w < 4; ++w) t += s_red[w * 128 + tid];
+        bn_tail_store(stat_part + (size_t)blockIdx.x * 128 + tid, t);
+    }
+    if (STATS) bn_tail_run(tail, stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
+}
+
+// ------------------------------------------------------------------------------------
 // weight layout transforms (tiny; run once per step because the weights change every step)
 // ------------------------------------------------------------------------------------
 __global__ void prep_w7x7_kernel(const float *__restrict__ w, float *__restrict__ wk)
@@ -646,6 +946,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
+int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) instead of the bf16-split one (A/B, tests)
 
 }  // namespace
 
@@ -665,6 +966,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
     if (key == 5) { g_ablate = value; return COVA_OK; }
     if (key == 6) return cova_internal_set_wino_geometry(value);
+    if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -674,9 +976,15 @@ COVA_API int cova_conv_out_size(int in_size, int kernel, int stride, int pad)
 }
 
 COVA_API int cova_conv1_num_tiles(int B, int H, int W);
+static int conv1_fwd_tiles(int B, int H, int W)
+{
+    const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    return g_conv1_f32 ? B * cdiv(H1, c1::TH) * cdiv(W1, c1::TW) : B * cdiv(H1, c1b::TH) * cdiv(W1, c1b::TW);
+}
+
 COVA_API int cova_conv1_num_partials(int B, int H, int W)
 {
-    return persistent_grid(cova_conv1_num_tiles(B, H, W), 2);
+    return persistent_grid(conv1_fwd_tiles(B, H, W), 2);
 }
 
 COVA_API int cova_conv1_num_tiles(int B, int H, int W)
@@ -705,6 +1013,19 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
                      t.mean && t.invstd);
     }
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
+    if (!g_conv1_f32) {
+        const int tiles_x = cdiv(W1, c1b::TW), tiles_y = cdiv(H1, c1b::TH);
+        const int ntiles = B * tiles_x * tiles_y;
+        const dim3 pgrid(persistent_grid(ntiles, 2)), block(c1b::THREADS);
+        if (stat_part)
+            hipLaunchKernelGGL(conv1_7x7_bf3_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out, stat_part,
+                               H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+        else
+            hipLaunchKernelGGL(conv1_7x7_bf3_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out,
+                               stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     const int tiles_x = cdiv(W1, c1::TW), tiles_y = cdiv(H1, c1::TH);
     const dim3 block(c1::THREADS);
     const int ntiles = B * tiles_x * tiles_y;

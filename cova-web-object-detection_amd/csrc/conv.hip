@@ -13,6 +13,8 @@
 // for conv3x3 (fwd, dgrad and wgrad each), 2*64*147 = 18,816 FLOP per output pixel for conv1.
 #include "common.h"
 #include "bn_tail.h"
+#include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -321,18 +323,35 @@ __global__ __launch_bounds__(c1::THREADS, 4) void conv1_7x7_v2_kernel(
 #ifndef C1B_ABL
 #define C1B_ABL 0
 #endif
+#ifndef C1B_SB
+#define C1B_SB 0             // what may cross the pipeline's scheduling fences (0: nothing; 6: VALU + SALU)
+#endif
+
+// -DC1B_TRACE (tools only): s_memtime stamps of all four waves of blocks 0 and gridDim.x/2 (the latter shares block 0's
+// CU when the grid is 2 x CUs in dispatch order -- checked by the hardware id stamped in slot 7) over tiles 8..27
+#ifdef C1B_TRACE
+__device__ unsigned long long g_c1b_trace[2 * 4 * 20 * 8];
+#define C1B_STAMP(slot)                                                                                       \
+    do {                                                                                                      \
+        if (tr_blk >= 0 && tr_it >= 0 && tr_it < 20 && lane == 0 && wave < 4)                                 \
+            g_c1b_trace[((tr_blk * 4 + wave) * 20 + tr_it) * 8 + (slot)] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+#else
+#define C1B_STAMP(slot) do { } while (0)
+#endif
 
 namespace c1b {
-constexpr int TH = 4, TW = 32;
-constexpr int PR = 2 * TH + 5;                 // 13 input rows
-constexpr int NSEG = 3 * PR;                   // 39 (channel, row) segments
+constexpr int TH = 8, TW = 32;
+constexpr int PR = 2 * TH + 5;                 // 21 input rows
+constexpr int NSEG = 3 * PR;                   // 63 (channel, row) segments
 constexpr int SEGW = 36;                       // dwords per segment: pairs m = 0 .. 34 (+1)
-constexpr int PLANE = NSEG * SEGW;             // 1404 dwords per piece plane
-constexpr int BUF = 3 * PLANE;                 // one patch buffer: 16,848 B
+constexpr int PLANE = NSEG * SEGW;             // 2268 dwords per piece plane
+constexpr int BUF = 3 * PLANE;                 // one patch buffer: 27,216 B
 constexpr int KSTEPS = 11;
-constexpr int KREG = 8;                        // K-steps whose B operands stay in registers (96); the other 3 are read from LDS
-constexpr int THREADS = 256;
-constexpr int NPRE = (PLANE + THREADS - 1) / THREADS;        // 6 pair slots per thread
+constexpr int WB_VEC = KSTEPS * 2 * 3 * 64;    // uint4 entries of the weight image [K-step][channel block][piece][lane]: 67,584 B
+constexpr int THREADS = 512;
+constexpr int NPRE = (PLANE + THREADS - 1) / THREADS;        // 5 pair slots per thread
+constexpr int RF0 = 7;                         // K-step at which the prefetched patch starts going to LDS
 __host__ __device__ constexpr int row_off(int t) { return t < 21 ? ((t / 7) * PR + t % 7) * SEGW : 0; }
 }  // namespace c1b
 
@@ -381,34 +400,54 @@ __device__ __forceinline__ float c1b_load(const float *base, unsigned off_bytes)
 // barrier over LDS traffic only (global stores and loads stay in flight across it)
 __device__ __forceinline__ void c1b_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void c1b_static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void c1b_static_for(F &&f)
+{
+    c1b_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// output store with a wave-uniform base, a 32-bit per-lane byte offset and an immediate: no address arithmetic
+template <int IMM>
+__device__ __forceinline__ void c1b_store(const float *base, unsigned off_bytes, float v)
+{
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off_bytes), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
 template <bool STATS>
-__global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
+__global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
     float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
     int w_oihw, const BnTail tail)
 {
     using namespace c1b;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF + 4 * 128];     // (>= the 2049 doubles of bn_tail_run)
-    __shared__ u32x4 s_wl[KSTEPS - KREG][2][3][64];   // B operands of the last K-steps, per channel block (registers: 12 per K-step)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF + 4 * WB_VEC + 8 * 128];
     uint32_t *s_pp = lds;                                        // [buffer][piece][segment][pair]
-    float *s_red = reinterpret_cast<float *>(lds + 2 * BUF);     // [wave][sum 64 | sum of squares 64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (STATS) { s_red[tid] = 0.f; s_red[tid + 256] = 0.f; }
+    u32x4 *s_wb = reinterpret_cast<u32x4 *>(lds + 2 * BUF);      // B operands [K-step][channel block][piece][lane]
+    float *s_red = reinterpret_cast<float *>(lds + 2 * BUF + 4 * WB_VEC);     // [wave][sum 64 | sum of squares 64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (STATS) { s_red[tid] = 0.f; s_red[tid + 512] = 0.f; }
     const int li = lane & 31, kh2 = lane >> 5;
     const int cb = wave & 1, q = wave >> 1;
     int tile = blockIdx.x;
 
     // The next tile's patch is prefetched into registers during the MFMAs: slot it of thread tid = pair
-    // (it * 256 + tid) of the [segment][36] grid, two loads.  Every load is UNCONDITIONAL at a clamped address (a
+    // (it * 512 + tid) of the [segment][36] grid, two loads.  Every load is UNCONDITIONAL at a clamped address (a
     // branch around a load makes the compiler wait for all outstanding loads at the join); whether a value is inside the
     // image is kept as one bit and applied when the slot is written to LDS.
-    static_assert(NPRE == 6, "write_lds lists the twelve prefetch registers");
+    static_assert(NPRE == 5, "write_lds lists the ten prefetch registers");
     float pre[2 * NPRE];
     unsigned premask = 0u;
     auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
         int t_ = tid;
-        asm volatile("" : "+v"(t_));          // the slot's index math stays here (hoisted out of the tile loop it costs
-        const int item = it * THREADS + t_;   // six registers per slot: the weights already take 132)
+        asm volatile("" : "+v"(t_));          // the slot's index math stays here (not hoisted out of the tile loop)
+        const int item = it * THREADS + t_;
         const int itc = item < PLANE ? item : PLANE - 1;
         const int seg = itc / SEGW, m = itc - seg * SEGW;
         const int c = seg / PR, r = seg - c * PR;
@@ -422,84 +461,105 @@ __global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
         pre[2 * it + 1] = c1b_load(img_b, (rowo + cx1) * 4u);
         premask = (premask & ~(3u << (2 * it))) | ((ok0 ? 1u : 0u) << (2 * it)) | ((ok1 ? 2u : 0u) << (2 * it));
     };
-    auto write_lds = [&](uint32_t *dst) {
-        // the one wait for the prefetched patch (the values pass through the statement: no use can move above it)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]),
-                       "+v"(pre[7]), "+v"(pre[8]), "+v"(pre[9]), "+v"(pre[10]), "+v"(pre[11])
-                     :
-                     : "memory");
-#pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int item = it * THREADS + t_;
-            if (item < PLANE) {
-                const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
-                const float xo = ((premask >> (2 * it + 1)) & 1u) ? pre[2 * it + 1] : 0.f;
-                uint32_t q0, q1, q2;
-                bf3_split_pair(xe, xo, q0, q1, q2);
-                dst[item] = q0;
-                dst[PLANE + item] = q1;
-                dst[2 * PLANE + item] = q2;
-            }
+    // The one wait for the prefetched patch (the values pass through the statement: no use can move above it).
+    // NEWER = the vector-memory instructions issued after the last prefetch load that need not have completed: the
+    // output stores of the pending tile that sit between that load and this wait in program order (stores and loads
+    // retire in order on gfx9: waiting for "all but the NEWER youngest" is waiting for the loads).
+#define C1B_REFILL_WAIT(NEWER)                                                                                          \
+    asm volatile("s_waitcnt vmcnt(%10)"                                                                                \
+                 : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]),   \
+                   "+v"(pre[7]), "+v"(pre[8]), "+v"(pre[9])                                                            \
+                 : "n"(NEWER)                                                                                          \
+                 : "memory")
+    auto refill_slot = [&](int it, uint32_t *dst) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int item = it * THREADS + t_;
+        if (item < PLANE) {
+            const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
+            const float xo = ((premask >> (2 * it + 1)) & 1u) ? pre[2 * it + 1] : 0.f;
+            uint32_t q0, q1, q2;
+            bf3_split_pair(xe, xo, q0, q1, q2);
+            dst[item] = q0;
+            dst[PLANE + item] = q1;
+            dst[2 * PLANE + item] = q2;
         }
+    };
+    auto write_lds = [&](uint32_t *dst) {
+        C1B_REFILL_WAIT(0);
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) refill_slot(it, dst);
     };
     if (tile < ntiles) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) issue_slot(it, img + (size_t)b * 3 * H * W, ty, tx);
     }
-    // B operands of this wave's 32 channels: K-step s, lane (n, g) = the 7 weights of channel cb*32+n in kernel row
-    // t = 2s + g = (c, kh) and a zero, as three packed-bf16 pieces.  wk is the OIHW weight, or (w_oihw == 0) the
+    // B-operand image: entry (K-step s, channel block cb, lane (n, g)) = the 7 weights of channel cb*32+n in kernel
+    // row t = 2s + g = (c, kh) and a zero, as three packed-bf16 pieces.  wk is the OIHW weight, or (w_oihw == 0) the
     // [154][64] K-pair layout of cova_conv1_prep_weights.
-    u32x4 wb[KREG][3];
-    {
-        const int co = cb * 32 + li;
+    for (int e = tid; e < KSTEPS * 2 * 64; e += THREADS) {
+        const int l = e & 63, cbe = (e >> 6) & 1, s = e >> 7;
+        const int co = cbe * 32 + (l & 31), t = 2 * s + (l >> 5);
+        float wv[8];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int t = 2 * s + kh2;
-            float wv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = 0.f;
-                if (j < 7) {
-                    const int tc = t < 21 ? t : 20;
-                    const int tap = tc * 7 + j;                  // c*49 + kh*7 + kw
-                    int idx;
-                    if (w_oihw) {
-                        idx = co * 147 + tap;
-                    } else {                                     // inverse of c1::pair_tap
-                        int row;
-                        if (tap < 98) row = 2 * (tap % 49) + tap / 49;
-                        else {
-                            const int kh = (tap - 98) / 7, kw = (tap - 98) % 7;
-                            row = kh < 3 ? 2 * (49 + kh * 7 + kw) : kh == 3 ? 2 * (70 + kw) : 2 * (49 + (kh - 4) * 7 + kw) + 1;
-                        }
-                        idx = row * 64 + co;
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (t < 21 && j < 7) {
+                const int tap = t * 7 + j;                       // c*49 + kh*7 + kw
+                if (w_oihw) {
+                    v = wk[co * 147 + tap];
+                } else {                                         // inverse of c1::pair_tap
+                    int row;
+                    if (tap < 98) row = 2 * (tap % 49) + tap / 49;
+                    else {
+                        const int kh = (tap - 98) / 7, kw = (tap - 98) % 7;
+                        row = kh < 3 ? 2 * (49 + kh * 7 + kw) : kh == 3 ? 2 * (70 + kw) : 2 * (49 + (kh - 4) * 7 + kw) + 1;
                     }
-                    v = wk[idx];
-                    if (t >= 21) v = 0.f;
+                    v = wk[row * 64 + co];
                 }
-                wv[j] = v;
             }
-            if (s < KREG) {
-                bf3_split8(wv, wb[s < KREG ? s : 0][0], wb[s < KREG ? s : 0][1], wb[s < KREG ? s : 0][2]);
-            } else {                                             // (both waves of a channel block write the same values)
-                u32x4 w0, w1, w2;
-                bf3_split8(wv, w0, w1, w2);
-                s_wl[s < KREG ? 0 : s - KREG][cb][0][lane] = w0;
-                s_wl[s < KREG ? 0 : s - KREG][cb][1][lane] = w1;
-                s_wl[s < KREG ? 0 : s - KREG][cb][2][lane] = w2;
-            }
+            wv[j] = v;
         }
+        u32x4 q0, q1, q2;
+        bf3_split8(wv, q0, q1, q2);
+        s_wb[((s * 2 + cbe) * 3 + 0) * 64 + l] = q0;
+        s_wb[((s * 2 + cbe) * 3 + 1) * 64 + l] = q1;
+        s_wb[((s * 2 + cbe) * 3 + 2) * 64 + l] = q2;
     }
     if (tile < ntiles) write_lds(s_pp);
     __syncthreads();
 
+    // Output of an INTERIOR tile (all 8 x 32 pixels inside the map) is not stored after its MFMAs but during the NEXT
+    // tile's: the accumulators move to p0 / p1 and their 32 stores are issued three per K-step between the MFMA
+    // groups.  The phase trace of a version that stored right away showed why: 7,700 of a tile's 17,200 cycles were the
+    // 32 store instructions (the launch writes 1.68 GB: the write path runs at its rate while every wave of the chip is in
+    // its store phase and idles through the MFMA phases) -- the matrix pipe was 49 % busy.
+    f32x16 p0, p1;
+    bool pend = false;
+    const float *pb00 = out, *pb01 = out, *pb10 = out, *pb11 = out;      // [row][pixels 0-15 | 16-31] bases of the pending tile
+    const unsigned st_off = (unsigned)((4 * kh2) * 64 + li) * 4u;       // lane: pixel 4*(l >> 5), channel l & 31
+    float tot_s = 0.f, tot_q = 0.f, sm = 0.f, sq = 0.f;
+    auto pend_store = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 32) {
+            constexpr int rr = k >> 4, r = k & 15;
+            constexpr int imm = ((r & 3) + 8 * ((r >> 2) & 1)) * 256;
+            const float v = rr == 0 ? p0[r] : p1[r];
+            c1b_store<imm>(rr == 0 ? ((r >> 3) ? pb01 : pb00) : ((r >> 3) ? pb11 : pb10), st_off, v);
+            sm += v;
+            sq = fmaf(v, v, sq);
+        }
+    };
+    const u32x4 *b_base = s_wb + cb * 3 * 64 + lane;
+
     int cur = 0;
-    float tot_s = 0.f, tot_q = 0.f;
+#ifdef C1B_TRACE
+    const int tr_blk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
+    int tr_it = -8;
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
+        C1B_STAMP(0);
         const int tx = tile % tiles_x;
         const int ty = (tile / tiles_x) % tiles_y;
         const int b = tile / (tiles_x * tiles_y);
@@ -513,45 +573,88 @@ __global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        // Software pipeline over half K-steps: the LDS reads of a group of operands are issued one group (6 MFMAs,
+        // ~190 cycles) ahead of the MFMAs that take them -- G1 = first pieces of both rows (products a0 b2, a0 b1,
+        // a0 b0), G2 = second and third pieces (a2 b0, a1 b1, a1 b0); the B operands of K-step s+1 in the middle of
+        // K-step s.  Left to the compiler every read sat directly in front of its MFMA with a wait in between.
+        u32x4 g1[2], g2a[2], g2b[2];                             // [row]: piece 0 | piece 1 | piece 2
+        u32x4 bl[2][3];                                          // [K-step parity][piece]
+        auto a_ptr = [&](int s_) { return a_org + (kh2 ? row_off(2 * s_ + 1) : row_off(2 * s_)); };
+        auto load_g1 = [&](int s_) {
+            const uint32_t *ap = a_ptr(s_);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            if (s < NPRE && !(C1B_ABL & 4)) issue_slot(s, nimg, nty, ntx);   // the next tile's patch
-            const uint32_t *ap = a_org + (kh2 ? row_off(2 * s + 1) : row_off(2 * s));
-            u32x4 a00, a01, a02, a10, a11, a12;                  // [row][piece]
+            for (int i = 0; i < 4; ++i) { g1[0][i] = ap[i]; g1[1][i] = ap[2 * SEGW + i]; }
+        };
+        auto load_g2 = [&](int s_) {
+            const uint32_t *ap = a_ptr(s_);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a00[i] = ap[i];
-                a01[i] = ap[PLANE + i];
-                a02[i] = ap[2 * PLANE + i];
-                a10[i] = ap[2 * SEGW + i];
-                a11[i] = ap[2 * SEGW + PLANE + i];
-                a12[i] = ap[2 * SEGW + 2 * PLANE + i];
+                g2a[0][i] = ap[PLANE + i];     g2a[1][i] = ap[2 * SEGW + PLANE + i];
+                g2b[0][i] = ap[2 * PLANE + i]; g2b[1][i] = ap[2 * SEGW + 2 * PLANE + i];
             }
-            if (C1B_ABL & 2) {
-                asm volatile("" ::"v"(a00), "v"(a01), "v"(a02), "v"(a10), "v"(a11), "v"(a12));
-                continue;
+        };
+        auto load_b = [&](int s_) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bl[s_ & 1][pc] = b_base[(s_ * 2 * 3 + pc) * 64];
+        };
+        load_g1(0);
+        load_b(0);
+        c1b_static_for<KSTEPS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const u32x4 b0 = bl[s & 1][0], b1 = bl[s & 1][1], b2 = bl[s & 1][2];
+            load_g2(s);
+            if (s < NPRE && !(C1B_ABL & 4)) issue_slot(s, nimg, nty, ntx);   // the next tile's patch
+            // ... and goes to the other LDS buffer during K-steps 7-9, one slot per half step: the loads are then 3 K-steps
+            // (~1,200 cycles + the partner wave's) old.  Stores 14 .. 20 of a pending tile were issued after the last load.
+            if (s == RF0 && !(C1B_ABL & 4)) {
+                if (pend && !(C1B_ABL & 1)) C1B_REFILL_WAIT(3 * RF0 - 3 * (NPRE - 1));
+                else C1B_REFILL_WAIT(0);
             }
-            u32x4 b0, b1, b2;
-            if (s < KREG) {
-                b0 = wb[s < KREG ? s : 0][0]; b1 = wb[s < KREG ? s : 0][1]; b2 = wb[s < KREG ? s : 0][2];
+            if (s >= RF0 && 2 * (s - RF0) < NPRE && !(C1B_ABL & 4)) refill_slot(2 * (s - RF0), s_pp + (cur ^ 1) * BUF);
+            if (pend && !(C1B_ABL & 1)) {
+                pend_store(std::integral_constant<int, 3 * s>{});
+                pend_store(std::integral_constant<int, 3 * s + 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(C1B_SB);
+            if (!(C1B_ABL & 2)) {
+                acc0 = mfma32bf(g1[0], b2, acc0); acc1 = mfma32bf(g1[1], b2, acc1);
+                acc0 = mfma32bf(g1[0], b1, acc0); acc1 = mfma32bf(g1[1], b1, acc1);
+                acc0 = mfma32bf(g1[0], b0, acc0); acc1 = mfma32bf(g1[1], b0, acc1);
             } else {
-                b0 = s_wl[s < KREG ? 0 : s - KREG][cb][0][lane];
-                b1 = s_wl[s < KREG ? 0 : s - KREG][cb][1][lane];
-                b2 = s_wl[s < KREG ? 0 : s - KREG][cb][2][lane];
+                asm volatile("" ::"v"(g1[0]), "v"(g1[1]), "v"(b0), "v"(b1), "v"(b2));
             }
-            acc0 = mfma32bf(a02, b0, acc0); acc1 = mfma32bf(a12, b0, acc1);
-            acc0 = mfma32bf(a00, b2, acc0); acc1 = mfma32bf(a10, b2, acc1);
-            acc0 = mfma32bf(a01, b1, acc0); acc1 = mfma32bf(a11, b1, acc1);
-            acc0 = mfma32bf(a01, b0, acc0); acc1 = mfma32bf(a11, b0, acc1);
-            acc0 = mfma32bf(a00, b1, acc0); acc1 = mfma32bf(a10, b1, acc1);
-            acc0 = mfma32bf(a00, b0, acc0); acc1 = mfma32bf(a10, b0, acc1);
-        }
-        if (has_next && !(C1B_ABL & 4)) write_lds(s_pp + (cur ^ 1) * BUF);
+            __builtin_amdgcn_sched_barrier(C1B_SB);
+            if (s + 1 < KSTEPS) { load_g1(s + 1); load_b(s + 1); }
+            if (s >= RF0 && 2 * (s - RF0) + 1 < NPRE && !(C1B_ABL & 4)) refill_slot(2 * (s - RF0) + 1, s_pp + (cur ^ 1) * BUF);
+            if (pend && !(C1B_ABL & 1)) pend_store(std::integral_constant<int, 3 * s + 2>{});
+            __builtin_amdgcn_sched_barrier(C1B_SB);
+            if (!(C1B_ABL & 2)) {
+                acc0 = mfma32bf(g2b[0], b0, acc0); acc1 = mfma32bf(g2b[1], b0, acc1);
+                acc0 = mfma32bf(g2a[0], b1, acc0); acc1 = mfma32bf(g2a[1], b1, acc1);
+                acc0 = mfma32bf(g2a[0], b0, acc0); acc1 = mfma32bf(g2a[1], b0, acc1);
+            } else {
+                asm volatile("" ::"v"(g2a[0]), "v"(g2a[1]), "v"(g2b[0]), "v"(g2b[1]));
+            }
+            __builtin_amdgcn_sched_barrier(C1B_SB);
+        });
+        tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
+        tot_q += sq;
+        sm = 0.f; sq = 0.f;
+        pend = false;
+        C1B_STAMP(1);
+        C1B_STAMP(2);
         c1b_lds_barrier();               // the next patch is complete; every wave is done reading this one
+        C1B_STAMP(3);
         cur ^= 1;
         // output rows y0 + 2q, + 1: D register r of lane l = pixel mfma32_row(r, l), channel cb*32 + (l & 31)
-        float sm = 0.f, sq = 0.f;
-        if (C1B_ABL & 1) {
+        if (y0 + TH <= H1 && x0 + TW <= W1) {                    // interior: stored during the next tile (or after the loop)
+            p0 = acc0; p1 = acc1;
+            pend = true;
+            pb00 = out + (((size_t)b * H1 + y0 + 2 * q) * W1 + x0) * 64 + cb * 32;
+            pb01 = pb00 + 16 * 64;
+            pb10 = pb00 + (size_t)W1 * 64;
+            pb11 = pb10 + 16 * 64;
+        } else if (C1B_ABL & 1) {
             asm volatile("" ::"v"(acc0), "v"(acc1));
         } else {
 #pragma unroll
@@ -565,14 +668,26 @@ __global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
                         const float v = rr == 0 ? acc0[r] : acc1[r];
                         out[(rowb + (size_t)px) * 64 + cb * 32 + li] = v;
                         sm += v;
-                        sq += v * v;
+                        sq = fmaf(v, v, sq);
                     }
                 }
             }
         }
-        tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
-        tot_q += sq;
+        C1B_STAMP(4);
+#ifdef C1B_TRACE
+        if (tr_blk >= 0 && tr_it >= 0 && tr_it < 20 && lane == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_c1b_trace[((tr_blk * 4 + (wave & 3)) * 20 + tr_it) * 8 + 7] = hw;
+        }
+        ++tr_it;
+#endif
     }
+    if (pend && !(C1B_ABL & 1)) {        // the block's last tile
+        c1b_static_for<32>(pend_store);
+    }
+    tot_s += sm;
+    tot_q += sq;
     if (STATS) {
         tot_s += __shfl_xor(tot_s, 32, 64);
         tot_q += __shfl_xor(tot_q, 32, 64);
@@ -584,7 +699,7 @@ __global__ __launch_bounds__(c1b::THREADS, 2) void conv1_7x7_bf3_kernel(
     __syncthreads();
     if (STATS && tid < 128) {
         float t = 0.f;
-        for (int w = 0; w < 4; ++w) t += s_red[w * 128 + tid];
+        for (int w = 0; w < 8; ++w) t += s_red[w * 128 + tid];
         bn_tail_store(stat_part + (size_t)blockIdx.x * 128 + tid, t);
     }
     if (STATS) bn_tail_run(tail, stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
@@ -970,6 +1085,13 @@ COVA_API int cova_set_option(int key, int value)
     return COVA_ERR_BAD_ARG;
 }
 
+#ifdef C1B_TRACE
+COVA_API int cova_c1b_trace_read(unsigned long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c1b_trace), sizeof(unsigned long long) * 2 * 4 * 20 * 8);
+}
+#endif
+
 COVA_API int cova_conv_out_size(int in_size, int kernel, int stride, int pad)
 {
     return (in_size + 2 * pad - kernel) / stride + 1;
@@ -984,7 +1106,7 @@ static int conv1_fwd_tiles(int B, int H, int W)
 
 COVA_API int cova_conv1_num_partials(int B, int H, int W)
 {
-    return persistent_grid(conv1_fwd_tiles(B, H, W), 2);
+    return persistent_grid(conv1_fwd_tiles(B, H, W), g_conv1_f32 ? 2 : 1);
 }
 
 COVA_API int cova_conv1_num_tiles(int B, int H, int W)
@@ -1016,7 +1138,7 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
     if (!g_conv1_f32) {
         const int tiles_x = cdiv(W1, c1b::TW), tiles_y = cdiv(H1, c1b::TH);
         const int ntiles = B * tiles_x * tiles_y;
-        const dim3 pgrid(persistent_grid(ntiles, 2)), block(c1b::THREADS);
+        const dim3 pgrid(persistent_grid(ntiles, 1)), block(c1b::THREADS);
         if (stat_part)
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out, stat_part,
                                H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);

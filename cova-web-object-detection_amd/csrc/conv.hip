@@ -444,7 +444,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     static_assert(NPRE == 5, "write_lds lists the ten prefetch registers");
     float pre[2 * NPRE];
     unsigned premask = 0u;
-    auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
+    unsigned po0 = 0u, po1 = 0u, pm = 0u;     // a slot's byte offsets and in-image bits between its two halves
+    auto slot_addr = [&](int it, int ty, int tx) {
         int t_ = tid;
         asm volatile("" : "+v"(t_));          // the slot's index math stays here (not hoisted out of the tile loop)
         const int item = it * THREADS + t_;
@@ -457,33 +458,44 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
         const int cx0 = gx < 0 ? 0 : (gx >= W ? W - 1 : gx), cx1 = gx + 1 < 0 ? 0 : (gx + 1 >= W ? W - 1 : gx + 1);
         const unsigned rowo = (unsigned)((c * H + cy) * W);              // 32-bit in-image offset (checked at launch)
-        pre[2 * it] = c1b_load(img_b, (rowo + cx0) * 4u);
-        pre[2 * it + 1] = c1b_load(img_b, (rowo + cx1) * 4u);
-        premask = (premask & ~(3u << (2 * it))) | ((ok0 ? 1u : 0u) << (2 * it)) | ((ok1 ? 2u : 0u) << (2 * it));
+        po0 = (rowo + cx0) * 4u;
+        po1 = (rowo + cx1) * 4u;
+        pm = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
     };
-    // The one wait for the prefetched patch (the values pass through the statement: no use can move above it).
-    // NEWER = the vector-memory instructions issued after the last prefetch load that need not have completed: the
-    // output stores of the pending tile that sit between that load and this wait in program order (stores and loads
-    // retire in order on gfx9: waiting for "all but the NEWER youngest" is waiting for the loads).
+    auto slot_load = [&](int it, const float *img_b) {
+        pre[2 * it] = c1b_load(img_b, po0);
+        pre[2 * it + 1] = c1b_load(img_b, po1);
+        premask = (premask & ~(3u << (2 * it))) | (pm << (2 * it));
+    };
+    auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
+        slot_addr(it, ty, tx);
+        slot_load(it, img_b);
+    };
 #define C1B_REFILL_WAIT(NEWER)                                                                                          \
     asm volatile("s_waitcnt vmcnt(%10)"                                                                                \
                  : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]),   \
                    "+v"(pre[7]), "+v"(pre[8]), "+v"(pre[9])                                                            \
                  : "n"(NEWER)                                                                                          \
                  : "memory")
-    auto refill_slot = [&](int it, uint32_t *dst) {
+    uint32_t rq0 = 0u, rq1 = 0u, rq2 = 0u;     // a slot's three packed dwords between its two halves
+    auto refill_split = [&](int it) {
+        const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
+        const float xo = ((premask >> (2 * it + 1)) & 1u) ? pre[2 * it + 1] : 0.f;
+        bf3_split_pair(xe, xo, rq0, rq1, rq2);
+    };
+    auto refill_write = [&](int it, uint32_t *dst) {
         int t_ = tid;
         asm volatile("" : "+v"(t_));
         const int item = it * THREADS + t_;
         if (item < PLANE) {
-            const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
-            const float xo = ((premask >> (2 * it + 1)) & 1u) ? pre[2 * it + 1] : 0.f;
-            uint32_t q0, q1, q2;
-            bf3_split_pair(xe, xo, q0, q1, q2);
-            dst[item] = q0;
-            dst[PLANE + item] = q1;
-            dst[2 * PLANE + item] = q2;
+            dst[item] = rq0;
+            dst[PLANE + item] = rq1;
+            dst[2 * PLANE + item] = rq2;
         }
+    };
+    auto refill_slot = [&](int it, uint32_t *dst) {
+        refill_split(it);
+        refill_write(it, dst);
     };
     auto write_lds = [&](uint32_t *dst) {
         C1B_REFILL_WAIT(0);
@@ -573,69 +585,83 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        // Software pipeline over half K-steps: the LDS reads of a group of operands are issued one group (6 MFMAs,
-        // ~190 cycles) ahead of the MFMAs that take them -- G1 = first pieces of both rows (products a0 b2, a0 b1,
-        // a0 b0), G2 = second and third pieces (a2 b0, a1 b1, a1 b0); the B operands of K-step s+1 in the middle of
-        // K-step s.  Left to the compiler every read sat directly in front of its MFMA with a wait in between.
-        u32x4 g1[2], g2a[2], g2b[2];                             // [row]: piece 0 | piece 1 | piece 2
-        u32x4 bl[2][3];                                          // [K-step parity][piece]
+        // One stream per wave in which EVERY MFMA is followed by a few of the other instructions (a scheduling fence
+        // after each chunk keeps the order): a wave that issues six MFMAs back to back and then its ~30 other
+        // instructions leaves the matrix pipe idle for most of that lump, and the partner wave of the SIMD -- which has
+        // the same shape -- does not fill it (phase trace of that version: the older wave of a SIMD finished its
+        // K loop in 9,400 cycles, the younger 3,000 later, 8,450 of them MFMA time of the pair).
+        // Operands are double-buffered in registers and fetched one K-step ahead: during the six MFMAs on the first
+        // pieces (G1: a0 b2, a0 b1, a0 b0 of both rows) the next K-step's first pieces and B operands, during the six on
+        // the second and third pieces (G2: a2 b0, a1 b1, a1 b0) the next K-step's second and third pieces.  The other
+        // chunks carry the next tile's patch prefetch (K-steps 0-4), its split and LDS writes (K-steps 7-9), and the
+        // pending tile's 32 output stores (three per K-step).
+        u32x4 g1[2][2], g2a[2][2], g2b[2][2], bl[2][3];          // [K-step parity][row] / [K-step parity][piece]
         auto a_ptr = [&](int s_) { return a_org + (kh2 ? row_off(2 * s_ + 1) : row_off(2 * s_)); };
-        auto load_g1 = [&](int s_) {
-            const uint32_t *ap = a_ptr(s_);
+        auto load4 = [&](u32x4 &d, const uint32_t *p_) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { g1[0][i] = ap[i]; g1[1][i] = ap[2 * SEGW + i]; }
+            for (int i = 0; i < 4; ++i) d[i] = p_[i];
         };
-        auto load_g2 = [&](int s_) {
-            const uint32_t *ap = a_ptr(s_);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                g2a[0][i] = ap[PLANE + i];     g2a[1][i] = ap[2 * SEGW + PLANE + i];
-                g2b[0][i] = ap[2 * PLANE + i]; g2b[1][i] = ap[2 * SEGW + 2 * PLANE + i];
-            }
-        };
-        auto load_b = [&](int s_) {
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bl[s_ & 1][pc] = b_base[(s_ * 2 * 3 + pc) * 64];
-        };
-        load_g1(0);
-        load_b(0);
+        auto load_b = [&](int s_, int pc) { bl[s_ & 1][pc] = b_base[(s_ * 2 * 3 + pc) * 64]; };
+        load4(g1[0][0], a_ptr(0)); load4(g1[0][1], a_ptr(0) + 2 * SEGW);
+        load_b(0, 0); load_b(0, 1); load_b(0, 2);
+        load4(g2a[0][0], a_ptr(0) + PLANE); load4(g2a[0][1], a_ptr(0) + 2 * SEGW + PLANE);
+        load4(g2b[0][0], a_ptr(0) + 2 * PLANE); load4(g2b[0][1], a_ptr(0) + 2 * SEGW + 2 * PLANE);
+        uint32_t *rdst = s_pp + (cur ^ 1) * BUF;
+        const bool st = pend && !(C1B_ABL & 1);
         c1b_static_for<KSTEPS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            const u32x4 b0 = bl[s & 1][0], b1 = bl[s & 1][1], b2 = bl[s & 1][2];
-            load_g2(s);
-            if (s < NPRE && !(C1B_ABL & 4)) issue_slot(s, nimg, nty, ntx);   // the next tile's patch
-            // ... and goes to the other LDS buffer during K-steps 7-9, one slot per half step: the loads are then 3 K-steps
-            // (~1,200 cycles + the partner wave's) old.  Stores 14 .. 20 of a pending tile were issued after the last load.
-            if (s == RF0 && !(C1B_ABL & 4)) {
-                if (pend && !(C1B_ABL & 1)) C1B_REFILL_WAIT(3 * RF0 - 3 * (NPRE - 1));
-                else C1B_REFILL_WAIT(0);
-            }
-            if (s >= RF0 && 2 * (s - RF0) < NPRE && !(C1B_ABL & 4)) refill_slot(2 * (s - RF0), s_pp + (cur ^ 1) * BUF);
-            if (pend && !(C1B_ABL & 1)) {
-                pend_store(std::integral_constant<int, 3 * s>{});
-                pend_store(std::integral_constant<int, 3 * s + 1>{});
-            }
-            __builtin_amdgcn_sched_barrier(C1B_SB);
-            if (!(C1B_ABL & 2)) {
-                acc0 = mfma32bf(g1[0], b2, acc0); acc1 = mfma32bf(g1[1], b2, acc1);
-                acc0 = mfma32bf(g1[0], b1, acc0); acc1 = mfma32bf(g1[1], b1, acc1);
-                acc0 = mfma32bf(g1[0], b0, acc0); acc1 = mfma32bf(g1[1], b0, acc1);
-            } else {
-                asm volatile("" ::"v"(g1[0]), "v"(g1[1]), "v"(b0), "v"(b1), "v"(b2));
-            }
-            __builtin_amdgcn_sched_barrier(C1B_SB);
-            if (s + 1 < KSTEPS) { load_g1(s + 1); load_b(s + 1); }
-            if (s >= RF0 && 2 * (s - RF0) + 1 < NPRE && !(C1B_ABL & 4)) refill_slot(2 * (s - RF0) + 1, s_pp + (cur ^ 1) * BUF);
-            if (pend && !(C1B_ABL & 1)) pend_store(std::integral_constant<int, 3 * s + 2>{});
-            __builtin_amdgcn_sched_barrier(C1B_SB);
-            if (!(C1B_ABL & 2)) {
-                acc0 = mfma32bf(g2b[0], b0, acc0); acc1 = mfma32bf(g2b[1], b0, acc1);
-                acc0 = mfma32bf(g2a[0], b1, acc0); acc1 = mfma32bf(g2a[1], b1, acc1);
-                acc0 = mfma32bf(g2a[0], b0, acc0); acc1 = mfma32bf(g2a[1], b0, acc1);
-            } else {
-                asm volatile("" ::"v"(g2a[0]), "v"(g2a[1]), "v"(g2b[0]), "v"(g2b[1]));
-            }
-            __builtin_amdgcn_sched_barrier(C1B_SB);
+            constexpr int s = decltype(sc)::value, P = s & 1, N = P ^ 1;
+            constexpr bool more = s + 1 < KSTEPS;
+            const u32x4 b0 = bl[P][0], b1 = bl[P][1], b2 = bl[P][2];
+            // slot of the patch refill handled in this K-step's G1 / G2 chunks 4, 5 (-1: none)
+            constexpr int rs1 = (s >= RF0 && 2 * (s - RF0) < NPRE) ? 2 * (s - RF0) : -1;
+            constexpr int rs2 = (s >= RF0 && 2 * (s - RF0) + 1 < NPRE) ? 2 * (s - RF0) + 1 : -1;
+            // ---- G1: first pieces
+            c1b_static_for<6>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, row = i & 1;
+                if (!(C1B_ABL & 2)) {
+                    const u32x4 bb = i < 2 ? b2 : (i < 4 ? b1 : b0);
+                    if (row == 0) acc0 = mfma32bf(g1[P][0], bb, acc0); else acc1 = mfma32bf(g1[P][1], bb, acc1);
+                } else {
+                    asm volatile("" ::"v"(g1[P][row]), "v"(b0), "v"(b1), "v"(b2));
+                }
+                if constexpr (i == 0) { if (more) load4(g1[N][0], a_ptr(s + 1)); if (st) pend_store(std::integral_constant<int, 3 * s>{}); }
+                if constexpr (i == 1) { if (more) load4(g1[N][1], a_ptr(s + 1) + 2 * SEGW); }
+                if constexpr (i == 2) { if (more) { load_b(s + 1, 0); load_b(s + 1, 1); } if (st) pend_store(std::integral_constant<int, 3 * s + 1>{}); }
+                if constexpr (i == 3) { if (more) load_b(s + 1, 2); }
+                if constexpr (i == 4) {
+                    if (s < NPRE && !(C1B_ABL & 4)) slot_addr(s, nty, ntx);          // the next tile's patch
+                    if (rs1 >= 0 && !(C1B_ABL & 4)) {
+                        if (rs1 == 0) {       // stores 14 .. 22 of a pending tile were issued after the last prefetch load
+                            if (st) C1B_REFILL_WAIT(3 * RF0 + 2 - 3 * (NPRE - 1) - 2);
+                            else C1B_REFILL_WAIT(0);
+                        }
+                        refill_split(rs1);
+                    }
+                }
+                if constexpr (i == 5) {
+                    if (s < NPRE && !(C1B_ABL & 4)) slot_load(s, nimg);
+                    if (rs1 >= 0 && !(C1B_ABL & 4)) refill_write(rs1, rdst);
+                }
+                __builtin_amdgcn_sched_barrier(C1B_SB);
+            });
+            // ---- G2: second and third pieces
+            c1b_static_for<6>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, row = i & 1;
+                if (!(C1B_ABL & 2)) {
+                    if (i < 2) { if (row == 0) acc0 = mfma32bf(g2b[P][0], b0, acc0); else acc1 = mfma32bf(g2b[P][1], b0, acc1); }
+                    else { const u32x4 bb = i < 4 ? b1 : b0;
+                           if (row == 0) acc0 = mfma32bf(g2a[P][0], bb, acc0); else acc1 = mfma32bf(g2a[P][1], bb, acc1); }
+                } else {
+                    asm volatile("" ::"v"(g2a[P][row]), "v"(g2b[P][row]));
+                }
+                if constexpr (i == 0) { if (more) load4(g2a[N][0], a_ptr(s + 1) + PLANE); }
+                if constexpr (i == 1) { if (more) load4(g2a[N][1], a_ptr(s + 1) + 2 * SEGW + PLANE); if (st) pend_store(std::integral_constant<int, 3 * s + 2>{}); }
+                if constexpr (i == 2) { if (more) load4(g2b[N][0], a_ptr(s + 1) + 2 * PLANE); }
+                if constexpr (i == 3) { if (more) load4(g2b[N][1], a_ptr(s + 1) + 2 * SEGW + 2 * PLANE); }
+                if constexpr (i == 4) { if (rs2 >= 0 && !(C1B_ABL & 4)) refill_split(rs2); }
+                if constexpr (i == 5) { if (rs2 >= 0 && !(C1B_ABL & 4)) refill_write(rs2, rdst); }
+                __builtin_amdgcn_sched_barrier(C1B_SB);
+            });
         });
         tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
         tot_q += sq;

@@ -387,16 +387,6 @@ __device__ __forceinline__ f32x16 mfma32bf(u32x4 a, u32x4 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Patch prefetch load as inline asm (wave-uniform base + 32-bit byte offset): the compiler neither waits for it nor
-// moves it -- left to itself it sinks these loads (twelve live registers beside 132 of weights) to just in front of
-// their use, i.e. behind the MFMA loop they are meant to hide under.  The one wait is in write_lds.
-__device__ __forceinline__ float c1b_load(const float *base, unsigned off_bytes)
-{
-    float v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off_bytes), "s"(base) : "memory");
-    return v;
-}
-
 // barrier over LDS traffic only (global stores and loads stay in flight across it)
 __device__ __forceinline__ void c1b_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -410,13 +400,6 @@ template <int N, class F>
 __device__ __forceinline__ void c1b_static_for(F &&f)
 {
     c1b_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// output store with a wave-uniform base, a 32-bit per-lane byte offset and an immediate: no address arithmetic
-template <int IMM>
-__device__ __forceinline__ void c1b_store(const float *base, unsigned off_bytes, float v)
-{
-    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off_bytes), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
 
 template <bool STATS>
@@ -444,7 +427,7 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     static_assert(NPRE == 5, "write_lds lists the ten prefetch registers");
     float pre[2 * NPRE];
     unsigned premask = 0u;
-    unsigned po0 = 0u, po1 = 0u, pm = 0u;     // a slot's byte offsets and in-image bits between its two halves
+    unsigned po0 = 0u, po1 = 0u, pm = 0u;     // a slot's element offsets and in-image bits between its two halves
     auto slot_addr = [&](int it, int ty, int tx) {
         int t_ = tid;
         asm volatile("" : "+v"(t_));          // the slot's index math stays here (not hoisted out of the tile loop)
@@ -458,25 +441,19 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
         const int cx0 = gx < 0 ? 0 : (gx >= W ? W - 1 : gx), cx1 = gx + 1 < 0 ? 0 : (gx + 1 >= W ? W - 1 : gx + 1);
         const unsigned rowo = (unsigned)((c * H + cy) * W);              // 32-bit in-image offset (checked at launch)
-        po0 = (rowo + cx0) * 4u;
-        po1 = (rowo + cx1) * 4u;
+        po0 = rowo + cx0;
+        po1 = rowo + cx1;
         pm = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
     };
     auto slot_load = [&](int it, const float *img_b) {
-        pre[2 * it] = c1b_load(img_b, po0);
-        pre[2 * it + 1] = c1b_load(img_b, po1);
+        pre[2 * it] = img_b[po0];
+        pre[2 * it + 1] = img_b[po1];
         premask = (premask & ~(3u << (2 * it))) | (pm << (2 * it));
     };
     auto issue_slot = [&](int it, const float *img_b, int ty, int tx) {
         slot_addr(it, ty, tx);
         slot_load(it, img_b);
     };
-#define C1B_REFILL_WAIT(NEWER)                                                                                          \
-    asm volatile("s_waitcnt vmcnt(%10)"                                                                                \
-                 : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]),   \
-                   "+v"(pre[7]), "+v"(pre[8]), "+v"(pre[9])                                                            \
-                 : "n"(NEWER)                                                                                          \
-                 : "memory")
     uint32_t rq0 = 0u, rq1 = 0u, rq2 = 0u;     // a slot's three packed dwords between its two halves
     auto refill_split = [&](int it) {
         const float xe = ((premask >> (2 * it)) & 1u) ? pre[2 * it] : 0.f;
@@ -498,7 +475,6 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         refill_write(it, dst);
     };
     auto write_lds = [&](uint32_t *dst) {
-        C1B_REFILL_WAIT(0);
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) refill_slot(it, dst);
     };
@@ -549,16 +525,16 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     // its store phase and idles through the MFMA phases) -- the matrix pipe was 49 % busy.
     f32x16 p0, p1;
     bool pend = false;
-    const float *pb00 = out, *pb01 = out, *pb10 = out, *pb11 = out;      // [row][pixels 0-15 | 16-31] bases of the pending tile
-    const unsigned st_off = (unsigned)((4 * kh2) * 64 + li) * 4u;       // lane: pixel 4*(l >> 5), channel l & 31
+    float *pb00 = out, *pb01 = out, *pb10 = out, *pb11 = out;            // [row][pixels 0-15 | 16-31] bases of the pending tile
+    const unsigned st_off = (unsigned)((4 * kh2) * 64 + li);            // lane: pixel 4*(l >> 5), channel l & 31
     float tot_s = 0.f, tot_q = 0.f, sm = 0.f, sq = 0.f;
     auto pend_store = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 32) {
             constexpr int rr = k >> 4, r = k & 15;
-            constexpr int imm = ((r & 3) + 8 * ((r >> 2) & 1)) * 256;
+            constexpr int imm = ((r & 3) + 8 * ((r >> 2) & 1)) * 64;
             const float v = rr == 0 ? p0[r] : p1[r];
-            c1b_store<imm>(rr == 0 ? ((r >> 3) ? pb01 : pb00) : ((r >> 3) ? pb11 : pb10), st_off, v);
+            (rr == 0 ? ((r >> 3) ? pb01 : pb00) : ((r >> 3) ? pb11 : pb10))[st_off + imm] = v;
             sm += v;
             sq = fmaf(v, v, sq);
         }
@@ -607,7 +583,10 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         load4(g2a[0][0], a_ptr(0) + PLANE); load4(g2a[0][1], a_ptr(0) + 2 * SEGW + PLANE);
         load4(g2b[0][0], a_ptr(0) + 2 * PLANE); load4(g2b[0][1], a_ptr(0) + 2 * SEGW + 2 * PLANE);
         uint32_t *rdst = s_pp + (cur ^ 1) * BUF;
-        const bool st = pend && !(C1B_ABL & 1);
+        // (two instantiations -- with and without a pending tile's stores: straight-line code either way, so the
+        // compiler's wait for a prefetched value counts exactly the loads and stores issued after it)
+        auto kloop = [&](auto stc) {
+        constexpr bool st = decltype(stc)::value && !(C1B_ABL & 1);
         c1b_static_for<KSTEPS>([&](auto sc) {
             constexpr int s = decltype(sc)::value, P = s & 1, N = P ^ 1;
             constexpr bool more = s + 1 < KSTEPS;
@@ -630,13 +609,7 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
                 if constexpr (i == 3) { if (more) load_b(s + 1, 2); }
                 if constexpr (i == 4) {
                     if (s < NPRE && !(C1B_ABL & 4)) slot_addr(s, nty, ntx);          // the next tile's patch
-                    if (rs1 >= 0 && !(C1B_ABL & 4)) {
-                        if (rs1 == 0) {       // stores 14 .. 22 of a pending tile were issued after the last prefetch load
-                            if (st) C1B_REFILL_WAIT(3 * RF0 + 2 - 3 * (NPRE - 1) - 2);
-                            else C1B_REFILL_WAIT(0);
-                        }
-                        refill_split(rs1);
-                    }
+                    if (rs1 >= 0 && !(C1B_ABL & 4)) refill_split(rs1);
                 }
                 if constexpr (i == 5) {
                     if (s < NPRE && !(C1B_ABL & 4)) slot_load(s, nimg);
@@ -663,6 +636,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
                 __builtin_amdgcn_sched_barrier(C1B_SB);
             });
         });
+        };
+        if (pend) kloop(std::true_type{}); else kloop(std::false_type{});
         tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
         tot_q += sq;
         sm = 0.f; sq = 0.f;
@@ -1047,6 +1022,305 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
         }
 }
 
+// ------------------------------------------------------------------------------------
+// conv1 weight gradient on the bf16 matrix pipe (operands split exactly into three bf16 pieces, six products, f32
+// accumulation: see conv1_7x7_bf3_kernel).  M = output channel (2 blocks), N = tap (5 blocks of 32), K = pixel:
+// 30 v_mfma_f32_32x32x16_bf16 (960 cycles) per 16 pixels replace 40 v_mfma_f32_32x32x2_f32 (2,560 cycles).
+//   * K-slot PAIRS are vertically adjacent output pixels (rows 2q, 2q+1 of the tile, same column): the thread that
+//     finishes dy1 of a column (BatchNorm + ReLU + MaxPool backward, below) holds both, splits them and writes packed
+//     dwords [pair][piece][channel] -- the A operand of a lane (channel, 8 pixels) is 4 dwords at a constant stride;
+//   * the image patch is stored as packed pairs of rows (r, r+2) -- the two input rows a tap reads for such a pair --
+//     [c][r][piece][column parity][36]: the B operand of a lane (tap, 8 pixels = 4 consecutive columns x 2 rows) is 4
+//     consecutive dwords; every element is split once, by the thread that prefetched it;
+//   * wave = (channel block, row pair q): 5 accumulators over the 64 pixels of its rows = 4 K-steps of 30 MFMAs,
+//     every MFMA followed by one LDS operand read for the next group or one slot of the next tile's prefetch
+//     (operands double-buffered in registers);
+//   * LDS: 96 KB of packed dy1 + 48 KB shared in time by the pooled-gradient windows (while dy1 is finished) and the
+//     patch planes (during the MFMAs): four barriers per tile.
+// ------------------------------------------------------------------------------------
+namespace wg1b {
+constexpr int TH = 8, TW = 32, THREADS = 512;
+constexpr int DYP_DW = 128 * 3 * 64;             // [pair 4 x 32][piece][channel]: 24,576 dwords
+constexpr int PROW = 3 * 72;                     // dwords per (c, r) row of the patch planes: [piece][parity][36]
+constexpr int PPV_DW = 3 * 19 * PROW;            // 12,312 dwords
+constexpr int WIN_W = TW / 2 + 1, NWIN = (TH / 2 + 1) * WIN_W, WIN_ITEMS = NWIN * 16;   // 17, 85, 1360
+constexpr int PATCH_ITEMS = 3 * 19 * 69;         // 3933 (c, r, column) pairs of rows (r, r+2)
+constexpr int NPRE_P = (PATCH_ITEMS + THREADS - 1) / THREADS;     // 8
+constexpr int NSLOT = NPRE_P + 8 + 3;            // prefetch slots per tile: patch | 8 rows of the y1 / dy column | pool windows
+}  // namespace wg1b
+
+template <bool POOL>
+__global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
+    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
+{
+    using namespace wg1b;
+    constexpr int NPOOL = POOL ? 3 : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DYP_DW + PPV_DW];
+    uint32_t *s_dyp = lds;
+    uint32_t *s_x = lds + DYP_DW;                                    // patch planes | pooled-gradient windows
+    float *s_dpw = reinterpret_cast<float *>(s_x);                   // POOL: [window][64]
+    uint32_t *s_ixw = s_x + NWIN * 64;                               // POOL: [window][16] arg-max codes x4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh2 = lane >> 5;
+    const int cob = wave & 1, q = wave >> 1;
+
+    int toff[5];
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb) {
+        const int k = tb * 32 + li;
+        const int kk = k < 147 ? k : 0;                              // (columns 147..159 of the result are never read)
+        toff[tb] = ((kk / 49) * 19 + 4 * q + (kk % 49) / 7) * PROW + ((kk % 7) & 1) * 36 + ((kk % 7) >> 1) + 4 * kh2;
+    }
+    const int a_base = ((q * 32 + 4 * kh2) * 3) * 64 + cob * 32 + li;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- prefetch registers of the NEXT tile (all loads unconditional at clamped addresses, validity as bits)
+    float pre[2 * NPRE_P];
+    unsigned premask = 0u;
+    f32x4 pd[8];
+    unsigned pd_in = 0u;
+    f32x4 pdp[POOL ? 3 : 1];
+    float pixf[POOL ? 3 : 1];
+    unsigned pool_in = 0u;
+    const int qx = tid >> 4, c4 = tid & 15;
+    const int cc = (((qx & 3) << 1) | ((qx >> 2) & 1)) + 8 * (qx >> 3);   // this thread's column of the tile
+    auto issue_slot = [&](int n, int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));          // the slot's index math stays here
+        if (n < NPRE_P) {                     // rows (r, r+2) of patch column j, channel c
+            const int item = n * THREADS + t_;
+            const int itc = item < PATCH_ITEMS ? item : PATCH_ITEMS - 1;
+            const int seg = itc / 69, j = itc - seg * 69;
+            const int c = seg / 19, r = seg - c * 19;
+            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
+            const bool okx = item < PATCH_ITEMS && gx >= 0 && gx < W;
+            const bool ok0 = okx && gy >= 0 && gy < H, ok1 = okx && gy + 2 >= 0 && gy + 2 < H;
+            const int cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const int cy0 = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cy1 = gy + 2 < 0 ? 0 : (gy + 2 >= H ? H - 1 : gy + 2);
+            const float *img_b = img + (size_t)b * 3 * H * W;
+            pre[2 * n] = img_b[(unsigned)((c * H + cy0) * W + cx)];
+            pre[2 * n + 1] = img_b[(unsigned)((c * H + cy1) * W + cx)];
+            premask = (premask & ~(3u << (2 * n))) | ((ok0 ? 1u : 0u) << (2 * n)) | ((ok1 ? 2u : 0u) << (2 * n));
+        } else if (n < NPRE_P + 8) {          // row it of this thread's column: 4 channels of dy (POOL: y1)
+            const int it = n - NPRE_P;
+            const int gy = y0 + it, gx = x0 + cc;
+            const bool in = gy < H1 && gx < W1;
+            const int cy = gy < H1 ? gy : H1 - 1, cx = gx < W1 ? gx : W1 - 1;
+            pd[it] = *reinterpret_cast<const f32x4 *>(dy + (size_t)b * H1 * W1 * 64 + (unsigned)(((cy * W1 + cx) << 6) + c4 * 4));
+            pd_in = (pd_in & ~(1u << it)) | ((in ? 1u : 0u) << it);
+        } else if (POOL) {                    // (window, channel group) item of the pooled gradient
+            const int k = n - NPRE_P - 8;
+            const int item = t_ + k * THREADS;
+            const int itc = item < WIN_ITEMS ? item : WIN_ITEMS - 1;
+            const int wr = itc / (WIN_W * 16), wc = (itc >> 4) % WIN_W;
+            const int ph = (y0 >> 1) + wr, pw = (x0 >> 1) + wc;
+            const bool in = item < WIN_ITEMS && ph < pool.H2 && pw < pool.W2;
+            const int cph = ph < pool.H2 ? ph : pool.H2 - 1, cpw = pw < pool.W2 ? pw : pool.W2 - 1;
+            const unsigned o = (unsigned)((cph * pool.W2 + cpw) * 64 + (itc & 15) * 4);
+            pdp[POOL ? k : 0] = *reinterpret_cast<const f32x4 *>(pool.dp + (size_t)b * pool.H2 * pool.W2 * 64 + o);
+            pixf[POOL ? k : 0] = *reinterpret_cast<const float *>(pool.idx + (size_t)b * pool.H2 * pool.W2 * 64 + o);
+            pool_in = (pool_in & ~(1u << k)) | ((in ? 1u : 0u) << k);
+        }
+    };
+    // this thread's 4 channels of A | B | C; fetched where used (kept out of the MFMA loop's registers)
+    auto coef = [&](int which) {
+        int o = which * 64 + (tid & 15) * 4;
+        asm volatile("" : "+v"(o));
+        return *reinterpret_cast<const float4 *>(pool.abc + o);
+    };
+    auto write_windows = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPOOL; ++k) {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int item = t_ + k * THREADS;                             // = window * 16 + channel group
+            if (item < WIN_ITEMS) {
+                const bool in = (pool_in >> k) & 1u;
+                f32x4 v = pdp[POOL ? k : 0];
+                if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};                    // (no gradient from windows outside the map)
+                *reinterpret_cast<f32x4 *>(s_dpw + item * 4) = v;
+                s_ixw[item] = __builtin_bit_cast(uint32_t, pixf[POOL ? k : 0]);
+            }
+        }
+    };
+    // dy1 of this thread's column (POOL:  A * route(dp) + B * y1 + C, as conv1_wgrad_v2_kernel finishes it in LDS), split
+    // and packed by row pairs (2b, 2b+1) into s_dyp.  The column permutation gives every wave four columns of one parity,
+    // so the set of pooling windows that can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform.
+    auto finish_dy = [&]() {
+        float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA, cC = cA;
+        if (POOL) { cA = coef(0); cB = coef(1); cC = coef(2); }
+        const bool codd = (wave & 1) != 0;                                  // == cc & 1
+        const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
+        const int kx0 = codd ? 2 : 1;                                      // its kx; the second (odd only): wc0+1, kx 0
+        auto batch = [&](const int bq, const int ne) {
+            float4 cur[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const bool in = (pd_in >> (2 * bq + rr)) & 1u;
+                const f32x4 pv = pd[2 * bq + rr];
+                float4 v = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (POOL) {
+                    v.x = fmaf(cB.x, v.x, cC.x); v.y = fmaf(cB.y, v.y, cC.y);
+                    v.z = fmaf(cB.z, v.z, cC.z); v.w = fmaf(cB.w, v.w, cC.w);
+                }
+                cur[rr] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (POOL) {
+                uint32_t word[3][2];
+                float4 dval[3][2];
+                // candidates of rows 2b, 2b+1: (row, window row - b, ky)
+                constexpr int crow[3] = {0, 1, 1}, cwr[3] = {0, 0, 1}, cky[3] = {1, 2, 0};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e >= ne) continue;
+                        const int win = (bq + cwr[k]) * WIN_W + wc0 + e;
+                        word[k][e] = s_ixw[win * 16 + c4];
+                        dval[k][e] = *reinterpret_cast<const float4 *>(s_dpw + win * 64 + c4 * 4);
+                    }
+                float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e >= ne) continue;
+                        const uint32_t code = (uint32_t)(cky[k] * 3 + (e == 0 ? kx0 : 0));
+                        const float dv[4] = {dval[k][e].x, dval[k][e].y, dval[k][e].z, dval[k][e].w};
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx)
+                            g[crow[k]][jx] += (((word[k][e] >> (8 * jx)) & 255u) == code) ? dv[jx] : 0.f;
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    cur[rr].x = fmaf(cA.x, g[rr][0], cur[rr].x);
+                    cur[rr].y = fmaf(cA.y, g[rr][1], cur[rr].y);
+                    cur[rr].z = fmaf(cA.z, g[rr][2], cur[rr].z);
+                    cur[rr].w = fmaf(cA.w, g[rr][3], cur[rr].w);
+                }
+            }
+            u32x4 w0, w1, w2;
+            {
+                const float lo[4] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w}, hi[4] = {cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    uint32_t u0, u1, u2;
+                    bf3_split_pair(lo[jx], hi[jx], u0, u1, u2);
+                    w0[jx] = u0; w1[jx] = u1; w2[jx] = u2;
+                }
+            }
+            u32x4 *dst = reinterpret_cast<u32x4 *>(s_dyp + ((bq * 32 + cc) * 3) * 64 + c4 * 4);
+            dst[0] = w0;
+            dst[16] = w1;
+            dst[32] = w2;
+            __builtin_amdgcn_sched_barrier(0);       // one batch in flight at a time (registers)
+        };
+        if (codd) {
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) batch(bq, 2);
+        } else {
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) batch(bq, 1);
+        }
+    };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int n = 0; n < NPRE_P; ++n) {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int item = n * THREADS + t_;
+            if (item < PATCH_ITEMS) {
+                const int seg = item / 69, j = item - seg * 69;          // seg = c * 19 + r
+                const float x0v = ((premask >> (2 * n)) & 1u) ? pre[2 * n] : 0.f;
+                const float x1v = ((premask >> (2 * n + 1)) & 1u) ? pre[2 * n + 1] : 0.f;
+                uint32_t q0, q1, q2;
+                bf3_split_pair(x0v, x1v, q0, q1, q2);
+                uint32_t *d = s_x + seg * PROW + (j & 1) * 36 + (j >> 1);
+                d[0] = q0;
+                d[72] = q1;
+                d[144] = q2;
+            }
+        }
+    };
+    // the prefetched tile -> LDS: windows | barrier | dy1 | barrier | patch | barrier
+    auto stage_tile = [&]() {
+        if (POOL) {
+            write_windows();
+            __syncthreads();
+        }
+        finish_dy();
+        __syncthreads();
+        write_patch();
+        __syncthreads();
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int n = 0; n < NSLOT; ++n)
+            if (n < NPRE_P + 8 + NPOOL) issue_slot(n, tile);
+        stage_tile();
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const int next = has_next ? tile + (int)gridDim.x : tile;       // (last tile: re-reads itself, unused)
+        // Operands double-buffered in registers; every MFMA is followed by ONE of: a 4-dword operand read for the next
+        // group (A of the next K-step | B of the next group of tap blocks) or one prefetch slot of the next tile.
+        u32x4 A[2][3], Bq[2][3];                                     // [K-step parity][piece] | [group parity][piece]
+        auto load_a = [&](int ks, int pc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[ks & 1][pc][i] = s_dyp[a_base + ((8 * ks + i) * 3 + pc) * 64];
+        };
+        auto load_bu = [&](int buf, int tb, int ks, int pc) {
+            const uint32_t *p_ = s_x + toff[tb] + pc * 72 + 8 * ks;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bq[buf][pc][i] = p_[i];
+        };
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) { load_a(0, pc); load_bu(0, 0, 0, pc); }
+        // group gi = 5 ks + tb: the six products of one tap block (a chain on one accumulator: the partner wave's MFMAs sit
+        // between its links); operands of a group in 12 registers, the next group's arriving in the other 12
+        c1b_static_for<20>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value, ks = gi / 5, tb = gi % 5, buf = gi & 1, nb = buf ^ 1;
+            constexpr int ngi = gi + 1, nks = ngi / 5, ntb = ngi % 5;
+            constexpr bool more = ngi < 20;
+            c1b_static_for<6>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int pa = m < 3 ? 0 : (m == 3 ? 2 : 1), pb = m == 0 ? 2 : (m == 1 || m == 4 ? 1 : 0);
+                acc[tb] = mfma32bf(A[ks & 1][pa], Bq[buf][pb], acc[tb]);
+                if constexpr (m < 3) {
+                    if (more) load_bu(nb, ntb, nks, m);
+                } else if constexpr (tb == 3) {
+                    if (ks + 1 < 4) load_a(ks + 1, m - 3);
+                } else {
+                    constexpr int n = ks * 12 + (tb == 4 ? 3 : tb) * 3 + (m - 3);
+                    if (n < NPRE_P + 8 + NPOOL) issue_slot(n, next);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        __syncthreads();                 // every wave is done with this tile's operands
+        if (has_next) stage_tile();
+    }
+    // partial layout: part[(block*4 + q)][co 64][k 160]
+    float *dst = part + ((size_t)(blockIdx.x * 4 + q)) * (64 * 160);
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob * 32 + mfma32_row(r, lane);
+            dst[co * 160 + tb * 32 + li] = acc[tb][r];
+        }
+}
+
 __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *__restrict__ part,
                                                                   int nparts, float *__restrict__ dw)
 {
@@ -1227,9 +1501,14 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
     const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
-    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
-                       (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
-                       B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
+    if (g_conv1_f32)
+        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
+                           (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
+                           B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
+    else
+        hipLaunchKernelGGL(conv1_wgrad_bf3_kernel<true>, dim3(grid), dim3(wg1b::THREADS), 0,
+                           (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
+                           B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 4, dw);
@@ -1246,9 +1525,14 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
-    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
-                       (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
-                       B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+    if (g_conv1_f32)
+        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
+                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+    else
+        hipLaunchKernelGGL(conv1_wgrad_bf3_kernel<false>, dim3(grid), dim3(wg1b::THREADS), 0,
+                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 4, dw);

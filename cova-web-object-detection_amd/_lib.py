@@ -58,6 +58,8 @@ class _Lib:
             f.argtypes = types
             f.restype = ctypes.c_int
             self.fn[name] = f
+        if os.environ.get("COVA_CONV1_F32") == "1":      # A/B: conv1 on the f32-MFMA kernels instead of the bf16-split ones
+            self.cdll.cova_set_option(7, 1)
 
 
     def load_extra(self, header, lib_path):

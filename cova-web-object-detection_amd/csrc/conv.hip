@@ -358,18 +358,25 @@ __host__ __device__ constexpr int row_off(int t) { return t < 21 ? ((t / 7) * PR
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// (xe, xo) -> three dwords of packed bf16 pieces (even element in the low half): 11 operations
+// (xe, xo) -> three dwords of packed bf16 pieces (even element in the low half): 11 operations.  Each piece is the
+// round-to-nearest-even bf16 of what is left (v_cvt_pk_bf16_f32), each residual is exact in f32; after three pieces
+// at most 2^-26 |x| is left.  (Pieces by truncation represent x exactly but are all of x's sign: the three dropped
+// cross products then add up coherently -- measured as a 10x larger error of the per-channel sums of the convolution.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf3_pack_rne(float xe, float xo)
+{
+    const f32x2 v = {xe, xo};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void bf3_split_pair(float xe, float xo, uint32_t &q0, uint32_t &q1, uint32_t &q2)
 {
-    const uint32_t ue = __builtin_bit_cast(uint32_t, xe), uo = __builtin_bit_cast(uint32_t, xo);
-    q0 = __builtin_amdgcn_perm(uo, ue, 0x07060302u);
-    const float re = xe - __builtin_bit_cast(float, ue & 0xFFFF0000u);
-    const float ro = xo - __builtin_bit_cast(float, uo & 0xFFFF0000u);
-    const uint32_t ve = __builtin_bit_cast(uint32_t, re), vo = __builtin_bit_cast(uint32_t, ro);
-    q1 = __builtin_amdgcn_perm(vo, ve, 0x07060302u);
-    const float se = re - __builtin_bit_cast(float, ve & 0xFFFF0000u);
-    const float so = ro - __builtin_bit_cast(float, vo & 0xFFFF0000u);
-    q2 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, so), __builtin_bit_cast(uint32_t, se), 0x07060302u);
+    q0 = bf3_pack_rne(xe, xo);
+    const float re = xe - __builtin_bit_cast(float, q0 << 16);
+    const float ro = xo - __builtin_bit_cast(float, q0 & 0xFFFF0000u);
+    q1 = bf3_pack_rne(re, ro);
+    const float se = re - __builtin_bit_cast(float, q1 << 16);
+    const float so = ro - __builtin_bit_cast(float, q1 & 0xFFFF0000u);
+    q2 = bf3_pack_rne(se, so);
 }
 
 __device__ __forceinline__ void bf3_split8(const float (&x)[8], u32x4 &p0, u32x4 &p1, u32x4 &p2)
@@ -527,7 +534,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     bool pend = false;
     float *pb00 = out, *pb01 = out, *pb10 = out, *pb11 = out;            // [row][pixels 0-15 | 16-31] bases of the pending tile
     const unsigned st_off = (unsigned)((4 * kh2) * 64 + li);            // lane: pixel 4*(l >> 5), channel l & 31
-    float tot_s = 0.f, tot_q = 0.f, sm = 0.f, sq = 0.f;
+    double tot_s = 0.0, tot_q = 0.0;          // per-lane totals over the block's tiles: tile sums in f32, their sum in f64
+    float sm = 0.f, sq = 0.f;
     auto pend_store = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 32) {
@@ -638,8 +646,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         });
         };
         if (pend) kloop(std::true_type{}); else kloop(std::false_type{});
-        tot_s += sm;                     // per-lane running totals over the block's tiles (two levels: tile, launch)
-        tot_q += sq;
+        tot_s += (double)sm;             // (two v_add_f64 per tile)
+        tot_q += (double)sq;
         sm = 0.f; sq = 0.f;
         pend = false;
         C1B_STAMP(1);
@@ -687,14 +695,14 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     if (pend && !(C1B_ABL & 1)) {        // the block's last tile
         c1b_static_for<32>(pend_store);
     }
-    tot_s += sm;
-    tot_q += sq;
+    tot_s += (double)sm;
+    tot_q += (double)sq;
     if (STATS) {
         tot_s += __shfl_xor(tot_s, 32, 64);
         tot_q += __shfl_xor(tot_q, 32, 64);
         if (lane < 32) {
-            s_red[wave * 128 + cb * 32 + li] = tot_s;
-            s_red[wave * 128 + 64 + cb * 32 + li] = tot_q;
+            s_red[wave * 128 + cb * 32 + li] = (float)tot_s;
+            s_red[wave * 128 + 64 + cb * 32 + li] = (float)tot_q;
         }
     }
     __syncthreads();
@@ -1038,6 +1046,10 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 //   * LDS: 96 KB of packed dy1 + 48 KB shared in time by the pooled-gradient windows (while dy1 is finished) and the
 //     patch planes (during the MFMAs): four barriers per tile.
 // ------------------------------------------------------------------------------------
+#ifndef WG1B_PRIO
+#define WG1B_PRIO 0            // tools: 1 static priority for waves 4-7 in the MFMA loop, 2 alternating per pair of units
+#endif
+
 namespace wg1b {
 constexpr int TH = 8, TW = 32, THREADS = 512;
 constexpr int DYP_DW = 128 * 3 * 64;             // [pair 4 x 32][piece][channel]: 24,576 dwords
@@ -1048,6 +1060,19 @@ constexpr int PATCH_ITEMS = 3 * 19 * 69;         // 3933 (c, r, column) pairs of
 constexpr int NPRE_P = (PATCH_ITEMS + THREADS - 1) / THREADS;     // 8
 constexpr int NSLOT = NPRE_P + 8 + 3;            // prefetch slots per tile: patch | 8 rows of the y1 / dy column | pool windows
 }  // namespace wg1b
+
+// -DC1B_TRACE: stamps of the eight waves of block 0, tiles 8..27: 0 end of the MFMA loop, 1 after its barrier, 2 windows written,
+// 3 dy1 finished, 4 after its barrier, 5 patch written (+ barrier) = start of the next MFMA loop
+#ifdef C1B_TRACE
+__device__ unsigned long long g_wg1b_trace[8 * 20 * 8];
+#define WG1B_STAMP(slot)                                                                                      \
+    do {                                                                                                      \
+        if (blockIdx.x == 0 && tr_it >= 0 && tr_it < 20 && lane == 0)                                         \
+            g_wg1b_trace[(wave * 20 + tr_it) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#else
+#define WG1B_STAMP(slot) do { } while (0)
+#endif
 
 template <bool POOL>
 __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
@@ -1089,7 +1114,11 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
     float pixf[POOL ? 3 : 1];
     unsigned pool_in = 0u;
     const int qx = tid >> 4, c4 = tid & 15;
-    const int cc = (((qx & 3) << 1) | ((qx >> 2) & 1)) + 8 * (qx >> 3);   // this thread's column of the tile
+    // this thread's column of the tile: every wave gets four columns of one parity (wave-uniform candidate windows below),
+    // waves 0-3 odd and 4-7 even ones: the two waves of a SIMD (w, w + 4) are one of each (odd columns gather from twice
+    // as many windows: with the parity in bit 0 of the wave index two SIMDs carried both heavy waves), and the heavy one
+    // is the older wave, which the SIMD's arbitration favours (the other way round the phase was 1,000 cycles longer)
+    const int cc = (((qx & 3) << 1) | (((qx >> 4) & 1) ^ 1)) + 8 * ((qx >> 2) & 3);
     auto issue_slot = [&](int n, int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int y0 = ty * TH, x0 = tx * TW;
@@ -1152,12 +1181,12 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
         }
     };
     // dy1 of this thread's column (POOL:  A * route(dp) + B * y1 + C, as conv1_wgrad_v2_kernel finishes it in LDS), split
-    // and packed by row pairs (2b, 2b+1) into s_dyp.  The column permutation gives every wave four columns of one parity,
-    // so the set of pooling windows that can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform.
+    // and packed by row pairs (2b, 2b+1) into s_dyp.  With four columns of one parity per wave the set of pooling windows
+    // that can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform.
     auto finish_dy = [&]() {
         float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA, cC = cA;
         if (POOL) { cA = coef(0); cB = coef(1); cC = coef(2); }
-        const bool codd = (wave & 1) != 0;                                  // == cc & 1
+        const bool codd = (wave >> 2) == 0;                                 // == cc & 1
         const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
         const int kx0 = codd ? 2 : 1;                                      // its kx; the second (odd only): wc0+1, kx 0
         auto batch = [&](const int bq, const int ne) {
@@ -1250,16 +1279,24 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
             }
         }
     };
+#ifdef C1B_TRACE
+    int tr_it = -8;
+#endif
     // the prefetched tile -> LDS: windows | barrier | dy1 | barrier | patch | barrier
     auto stage_tile = [&]() {
+        WG1B_STAMP(1);
         if (POOL) {
             write_windows();
             __syncthreads();
         }
+        WG1B_STAMP(2);
         finish_dy();
+        WG1B_STAMP(3);
         __syncthreads();
+        WG1B_STAMP(4);
         write_patch();
         __syncthreads();
+        WG1B_STAMP(5);
     };
 
     int tile = blockIdx.x;
@@ -1274,41 +1311,71 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
         const int next = has_next ? tile + (int)gridDim.x : tile;       // (last tile: re-reads itself, unused)
         // Operands double-buffered in registers; every MFMA is followed by ONE of: a 4-dword operand read for the next
         // group (A of the next K-step | B of the next group of tap blocks) or one prefetch slot of the next tile.
-        u32x4 A[2][3], Bq[2][3];                                     // [K-step parity][piece] | [group parity][piece]
+        // The 20 (K-step, tap block) units of a tile are taken in PAIRS whose MFMAs alternate (two accumulators: a chain
+        // of MFMAs on ONE accumulator issues every ~64 cycles, and the partner wave does not get the gaps -- phase trace
+        // of that version: the older wave of a SIMD took 7,600 cycles for its 120 MFMAs, the younger finished 3,700
+        // later).  Product order  a0 b1, a1 b1, a0 b2, a0 b0, a1 b0, a2 b0:  a unit's B pieces 1 / 2 / 0 are dead after
+        // MFMAs 3 / 5 / 11 of its pair and the next pair's pieces are read into the same registers right there (24
+        // operand registers, no second set); the other slots carry the next K-step's A operand (double-buffered) and the
+        // next tile's prefetch.
+        u32x4 A[2][3], Bq[2][3];                                     // [K-step parity][piece] | [unit of the pair][piece]
         auto load_a = [&](int ks, int pc) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) A[ks & 1][pc][i] = s_dyp[a_base + ((8 * ks + i) * 3 + pc) * 64];
         };
-        auto load_bu = [&](int buf, int tb, int ks, int pc) {
-            const uint32_t *p_ = s_x + toff[tb] + pc * 72 + 8 * ks;
+        auto load_bu = [&](int u, int unit, int pc) {                // unit = 5 ks + tb
+            const uint32_t *p_ = s_x + toff[unit % 5] + pc * 72 + 8 * (unit / 5);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Bq[buf][pc][i] = p_[i];
+            for (int i = 0; i < 4; ++i) Bq[u][pc][i] = p_[i];
         };
+#if WG1B_PRIO == 1
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) { load_a(0, pc); load_bu(0, 0, 0, pc); }
-        // group gi = 5 ks + tb: the six products of one tap block (a chain on one accumulator: the partner wave's MFMAs sit
-        // between its links); operands of a group in 12 registers, the next group's arriving in the other 12
-        c1b_static_for<20>([&](auto gc) {
-            constexpr int gi = decltype(gc)::value, ks = gi / 5, tb = gi % 5, buf = gi & 1, nb = buf ^ 1;
-            constexpr int ngi = gi + 1, nks = ngi / 5, ntb = ngi % 5;
-            constexpr bool more = ngi < 20;
-            c1b_static_for<6>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                constexpr int pa = m < 3 ? 0 : (m == 3 ? 2 : 1), pb = m == 0 ? 2 : (m == 1 || m == 4 ? 1 : 0);
-                acc[tb] = mfma32bf(A[ks & 1][pa], Bq[buf][pb], acc[tb]);
-                if constexpr (m < 3) {
-                    if (more) load_bu(nb, ntb, nks, m);
-                } else if constexpr (tb == 3) {
-                    if (ks + 1 < 4) load_a(ks + 1, m - 3);
-                } else {
-                    constexpr int n = ks * 12 + (tb == 4 ? 3 : tb) * 3 + (m - 3);
-                    if (n < NPRE_P + 8 + NPOOL) issue_slot(n, next);
+        for (int pc = 0; pc < 3; ++pc) { load_a(0, pc); load_bu(0, 0, pc); load_bu(1, 1, pc); }
+        c1b_static_for<10>([&](auto gc) {
+            constexpr int gp = decltype(gc)::value;                  // pair gp = units 2 gp, 2 gp + 1
+#if WG1B_PRIO == 2
+            if ((wave >> 2) == (gp & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+            constexpr bool more = gp + 1 < 10;
+            c1b_static_for<12>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, pr = m >> 1, u = m & 1, unit = 2 * gp + u;
+                constexpr int ks = unit / 5, tb = unit % 5;
+                constexpr int pa = (pr == 1 || pr == 4) ? 1 : (pr == 5 ? 2 : 0), pb = pr < 2 ? 1 : (pr == 2 ? 2 : 0);
+                acc[tb] = mfma32bf(A[ks & 1][pa], Bq[u][pb], acc[tb]);
+                // what follows this MFMA
+                constexpr int nunit = 2 * (gp + 1) + u;              // the unit that takes this one's operand registers
+                if constexpr (m == 2 || m == 3) { if (more) load_bu(u, nunit, 1); }
+                else if constexpr (m == 4 || m == 5) { if (more) load_bu(u, nunit, 2); }
+                else if constexpr (m == 10 || m == 11) { if (more) load_bu(u, nunit, 0); }
+                else {
+                    // six free slots per pair (m = 0, 1, 6, 7, 8, 9): the next K-step's A operand in the pair that
+                    // starts K-step ks' = (2 gp) / 5 (its last unit is >= 3 units away), then prefetch slots
+                    constexpr int f = gp * 6 + (m < 2 ? m : m - 4);  // 0 .. 59
+                    constexpr int ks0 = (2 * gp) / 5;
+                    constexpr bool first_of_ks = (2 * gp) % 5 < 2;   // the pair holding unit 5 ks0 or 5 ks0 + 1
+                    if constexpr (first_of_ks && (m < 2 || m == 6)) {
+                        if (ks0 + 1 < 4) load_a(ks0 + 1, m < 2 ? m : 2);
+                    } else {
+                        // slots in order over the remaining free positions
+                        constexpr int used_a = 3 * ((2 * gp) / 5 + (first_of_ks ? 0 : 1));      // A positions before this pair
+                        constexpr int n = f - used_a - (first_of_ks ? 3 : 0);
+                        if constexpr (n >= 0) { if (n < NPRE_P + 8 + NPOOL) issue_slot(n, next); }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+#if WG1B_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        WG1B_STAMP(0);
         __syncthreads();                 // every wave is done with this tile's operands
         if (has_next) stage_tile();
+#ifdef C1B_TRACE
+        ++tr_it;
+#endif
     }
     // partial layout: part[(block*4 + q)][co 64][k 160]
     float *dst = part + ((size_t)(blockIdx.x * 4 + q)) * (64 * 160);
@@ -1386,6 +1453,10 @@ COVA_API int cova_set_option(int key, int value)
 }
 
 #ifdef C1B_TRACE
+COVA_API int cova_wg1b_trace_read(unsigned long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg1b_trace), sizeof(unsigned long long) * 8 * 20 * 8);
+}
 COVA_API int cova_c1b_trace_read(unsigned long long *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c1b_trace), sizeof(unsigned long long) * 2 * 4 * 20 * 8);

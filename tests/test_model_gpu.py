@@ -112,27 +112,12 @@ def test_full_model_matches_reference_fixture(name):
     assert relerr(logits.detach().cpu(), fx["train/logits"]) < LOGIT_TOL
     assert abs(loss.item() - float(fx["train/loss"])) <= LOSS_TOL * abs(float(fx["train/loss"]))
     grads = {k: p.grad for k, p in m.named_parameters()}
-    # (1) heads do not depend on the routing: compare with the reference's gradients directly;
-    #     conv-stack gradients get a loose bound here (a single near-tie flip moves them by ~1e-3)
-    head = {k: v for k, v in fx.items() if not (k.startswith(("grad", "gradnorm", "gradsample"))
-                                                  and "/convnet." in k)}
-    check_grads(head, grads, rtol=2e-3)
-    conv_only = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample"))
-                 and "/convnet." in k}
-    check_grads(conv_only, grads, rtol=5e-2)
-    # ... and, in one hop, how many of the reference's gradient entries (all tensors, nothing forced) are beyond 2e-4
-    frac, total, worst, per = unforced_fraction_above(fx, grads, rtol=2e-4)
-    print("%s: %d of %d unforced fixture gradient entries beyond 2e-4 (%.4f %%), worst %s %.2e"
-          % (name, round(frac * total), total, 100 * frac, worst, per[worst][2]))
-    assert frac <= 2e-2, (frac, worst, per[worst])      # measured 0 .. 0.6 % (ONE near-tie gate flip moves ~450 entries of a
-                                                        # 36,864-entry conv weight by ~1e-3; the forced-routing check below is the tight one)
-    # (2) tight check of everything against the oracle forced to the same routing; the oracle
-    #     itself is pinned to the reference's gradients by tests/test_oracle_cpu.py
+    # (1) the tight check: everything against the oracle forced to the HIP forward's discrete decisions (max-pool /
+    #     RoIPool argmax, ReLU gates, LeakyReLU slopes of the attention scores); the oracle itself is pinned to the
+    #     reference's gradients by tests/test_oracle_cpu.py.  What remains is fp32 round-off: 1e-4 of each tensor's scale
     b = batch
     _, _, grads_ref, after, inter = O.loss_and_grads(sd, b["images"], b["bboxes"], b["additional_feats"],
                                                      b["context_indices"], b["labels"], cfg, None, routing)
-    # every discrete decision of the HIP forward (max-pool / RoIPool argmax, ReLU gates) is forced
-    # in the oracle's backward, so what remains is fp32 round-off: 1e-4 of each tensor's scale
     compare_grads(grads, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
     assert_routing_near_ties(routing, inter, b["bboxes"], (3, 3), m.roi_pool.spatial_scale)
     # ... and the decisions that were forced are the oracle's own, up to pre-activations within round-off of
@@ -140,7 +125,29 @@ def test_full_model_matches_reference_fixture(name):
     tap = {}
     O.loss_and_grads(sd, b["images"], b["bboxes"], b["additional_feats"], b["context_indices"], b["labels"],
                      cfg, None, {"_tap": tap})
-    assert_gate_flips_near_zero(routing, tap)
+    flips = assert_gate_flips_near_zero(routing, tap)
+    # (2) the reference's OWN gradients, nothing forced.  When every discrete decision of the HIP forward is the unforced
+    #     oracle's, this one-hop comparison is as tight as (1).  A decision that sits within round-off of its threshold and
+    #     falls the other way is not an error of either side, but it moves whatever lies upstream of it: measured, ONE
+    #     decoder ReLU gate at a pre-activation of -4.7e-6 (scale 7.8) moved 22 % of all entries by more than 2e-4 (worst
+    #     4e-3, the decoder row of that unit); one gate in the conv stack ~450 entries of a 36,864-entry weight by ~1e-3.
+    #     So: no flips -> tight bound; flips (counted and placed by assert_gate_flips_near_zero above) -> loose bounds.
+    nflip = sum(flips.values())
+    head = {k: v for k, v in fx.items() if not (k.startswith(("grad", "gradnorm", "gradsample"))
+                                                  and "/convnet." in k)}
+    conv_only = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample"))
+                 and "/convnet." in k}
+    frac, total, worst, per = unforced_fraction_above(fx, grads, rtol=2e-4)
+    print("%s: %d decisions differ from the unforced oracle's %s; %d of %d unforced fixture gradient entries beyond 2e-4 "
+          "(%.4f %%), worst %s %.2e" % (name, nflip, {k: v for k, v in flips.items() if v}, round(frac * total), total,
+                                        100 * frac, worst, per[worst][2]))
+    if nflip == 0:
+        check_grads(head, grads, rtol=2e-4)
+        check_grads(conv_only, grads, rtol=2e-4)
+        assert frac == 0.0, (frac, worst, per[worst])
+    else:
+        check_grads(head, grads, rtol=1e-2)
+        check_grads(conv_only, grads, rtol=5e-2)
     for k, buf in m.named_buffers():
         if "buf/" + k in fx:
             assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k

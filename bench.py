@@ -594,6 +594,12 @@ def run(args, guard, rank, local_rank, world):
                        "boxes_per_gpu": n_boxes, "world_size": world, "collective_backend": "rccl" if backend == "nccl" else backend,
                        "rccl_ranks_seen": ranks_seen, "gpus_visible": n_dev,
                        "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") + diag,
+                       "arithmetic": "f32 throughout (weights, activations, gradients, accumulation).  3x3 convolutions, GEMMs: "
+                                     "f32 MFMA.  conv1 (7x7) forward and weight gradient%s: each f32 operand as three bf16 pieces "
+                                     "(<= 2^-26 left), six bf16-MFMA products accumulated in f32 -- error against fp64 equal to "
+                                     "the f32-MFMA kernels' (tools/conv1_bench.py), same parity gates"
+                                     % (" run on the f32-MFMA kernels (COVA_CONV1_F32=1)" if os.environ.get("COVA_CONV1_F32") == "1"
+                                        else ""),
                        "loss": round(loss_val, 3)},
             "roofline": roof, "step": step, "other_kernels": others,
             "forward_only": {"value": round(global_pages * args.steps / dt_fwd, 2), "unit": "webpages/s",

@@ -1062,3 +1062,91 @@ def test_conv3x3_winograd_f4x4(B, H, W):
         close(nchw(o3), refp, 2e-5, "wino4 prologue relu=%d" % relu)
         close(p3[:, 0].double().sum(0), refp.sum((0, 2, 3)), 1e-4, "wino4 prologue stat sum")
     query("cova_set_option", 2, 0)
+
+
+# ------------------------------------------------------------------------------------ conv1 on the bf16 matrix pipe
+@pytest.mark.parametrize("B,H,W,cap", [(2, 250, 333, 0), (3, 150, 330, 5)])
+def test_conv1_bf16_split_error_class(B, H, W, cap):
+    """conv1 forward and weight gradient as six bf16-MFMA products of three-piece operands (csrc/conv.hip,
+    conv1_7x7_bf3_kernel / conv1_wgrad_bf3_kernel) against a float64 convolution: the error is the f32-MFMA kernels'
+    (cova_set_option(7, 1)), not a reduced-precision one; results are bit-reproducible; edge and multi-tile paths."""
+    g = torch.Generator().manual_seed(H + 7 * W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    wr = w.double().requires_grad_(True)
+    ref = F.conv2d(x.double(), wr, stride=2, padding=3)
+    H1, W1 = ref.shape[2], ref.shape[3]
+    dy = torch.randn(B, 64, H1, W1, generator=g)
+    (ref * dy.double()).sum().backward()
+    xg, wg, dyg = x.to(DEV), w.to(DEV), nhwc(dy)
+    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
+    err = {}
+    query("cova_set_option", 2, cap)
+    try:
+        for f32 in (1, 0):
+            query("cova_set_option", 7, f32)
+            outs = []
+            for _ in range(2):
+                nt = query("cova_conv1_num_partials", B, H, W)
+                out, part = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+                call("cova_conv1_fwd_tail", xg, wg, out, part, B, H, W, None)
+                dw = torch.zeros(64, 3, 7, 7, device=DEV)
+                call("cova_conv1_wgrad", xg, dyg, dw, ws, B, H, W)
+                outs.append((out, part, dw))
+            assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "not bit-reproducible"
+            out, part, dw = outs[0]
+            e_y = float((nchw(out).double().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+            e_w = float((dw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())
+            e_q = float((part[:, 1].double().sum(0).cpu() - (ref.detach() ** 2).sum((0, 2, 3))).abs().max()
+                        / (ref.detach() ** 2).sum((0, 2, 3)).max())
+            err[f32] = (e_y, e_w, e_q)
+    finally:
+        query("cova_set_option", 7, 0)
+        query("cova_set_option", 2, 0)
+    print("conv1 error against fp64 (output, weight gradient, channel sums of squares): f32 MFMA %.2e %.2e %.2e | "
+          "bf16 split %.2e %.2e %.2e" % (err[1] + err[0]))
+    for a, b in zip(err[0], err[1]):
+        assert a <= 2.0 * b + 2e-7, (err[0], err[1])
+    assert err[0][0] < 2e-6 and err[0][1] < 2e-6
+
+
+def test_conv1_kernels_do_not_depend_on_the_batch_partition():
+    """The conv1 kernels on a 4-page batch in one call against two 2-page calls with bit-identical operands: forward
+    outputs and statistics rows are bitwise the same, the weight gradient (BatchNorm + ReLU + MaxPool backward folded
+    in) is the sum of the halves' to fp32 re-association -- what the data-parallel / SyncBN tests rely on (their own
+    residual differences are decisions that fall the other way, tests/test_syncbn_gpu.py)."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 4, 128, 160
+    x = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
+    H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
+    y = (torch.randn(B, H1, W1, 64, generator=g) * 3).to(DEV)
+    scale, shift = (torch.rand(64, generator=g) - 0.3).to(DEV), (torch.randn(64, generator=g) * 0.2).to(DEV)
+    p1 = torch.empty(B, H2, W2, 64, device=DEV)
+    idx = torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
+    call("cova_bn_relu_maxpool_fwd", y, scale, shift, p1, idx, None, B, H1, W1)
+    dp = torch.randn(B, H2, W2, 64, generator=g).to(DEV) * (p1 > 0)
+    abc = (torch.randn(3, 64, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).to(DEV)
+
+    def wgrad(sl):
+        n = sl.stop - sl.start
+        ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", n, H, W), device=DEV)
+        dw = torch.zeros(64, 3, 7, 7, device=DEV)
+        call("cova_conv1_wgrad_poolbwd", x[sl].contiguous(), y[sl].contiguous(), dp[sl].contiguous(),
+             idx[sl].contiguous(), abc, dw, ws, n, H, W)
+        return dw
+
+    def fwd(sl):
+        n = sl.stop - sl.start
+        out = torch.zeros(n, H1, W1, 64, device=DEV)
+        part = torch.zeros(query("cova_conv1_num_partials", n, H, W), 2, 64, device=DEV)
+        call("cova_conv1_fwd_tail", x[sl].contiguous(), w, out, part, n, H, W, None)
+        return out, part
+
+    full, halves = wgrad(slice(0, 4)), wgrad(slice(0, 2)) + wgrad(slice(2, 4))
+    assert float((full - halves).abs().max()) <= 3e-7 * float(full.abs().max())
+    of, pf = fwd(slice(0, 4))
+    (o0, p0), (o1, p1_) = fwd(slice(0, 2)), fwd(slice(2, 4))
+    assert torch.equal(of, torch.cat((o0, o1)))
+    assert torch.equal(pf, torch.cat((p0, p1_)))          # (one tile per block at this size: the rows are per tile)

@@ -324,7 +324,11 @@ def test_training_trajectory_follows_the_cpu_oracle(request):
     # where the loss is 20-100x below its start (profiles/r03_trajectory.txt)
     for it, a, r in curve:
         assert abs(a - r) <= 0.05 * abs(r) + 2e-3 * first[2], "loss curves drifted apart at step %d: %.5f vs %.5f" % (it, a, r)
-    assert max(abs(a - r) / abs(r) for _, a, r in curve[:4]) < 5e-5        # the first steps agree to fp32 round-off,
+    # the first steps: Adam's first update is +-lr whatever the size of a gradient, so entries whose gradient is rounding
+    # noise step either way and the runs separate from step 1 on -- measured 1e-6 at steps 1-2 and 3e-6 / 9e-5 at step 3
+    # (conv1 on the f32-MFMA / bf16-split kernels: which noise-level signs differ is chance), <= 9e-4 up to step 11
+    assert max(abs(a - r) / abs(r) for _, a, r in curve[:3]) < 2e-5
+    assert max(abs(a - r) / abs(r) for _, a, r in curve[:5]) < 3e-4
     assert max(abs(a - r) / abs(r) for _, a, r in curve[:12]) < 2e-3       # the early ones tightly
     # decisions, eval mode, on every batch: half-way (step 40, where the two parameter sets are still within ~1 % in
     # logit space) on rows whose margin exceeds 10x the observed difference, and at the end on the rows that are still

@@ -56,15 +56,20 @@ typedef struct cova_bn_tail {
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 /* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
- * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2) */
+ * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2),
+ * 7 = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): A/B */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
 int cova_conv1_prep_weights(const float *w_oihw /*[64,3,7,7]*/, float *w_k /*[154,64]*/, void *stream);
 
 /* nn.Conv2d(3,64,7,stride 2,pad 3,bias=False): img NCHW -> out NHWC [B,H1,W1,64].
- * stat_part (nullable) [cova_conv1_num_tiles][2][64]: per-tile channel sum / sum of squares of
- * the output (feeds cova_bn_finalize_fwd: train-mode BatchNorm2d statistics). */
+ * stat_part (nullable) [cova_conv1_num_partials][2][64]: per-block channel sum / sum of squares of
+ * the output (feeds cova_bn_finalize_fwd: train-mode BatchNorm2d statistics).
+ * Arithmetic (forward and cova_conv1_wgrad*): f32 in, f32 out, f32 accumulation; the products run on the bf16 matrix
+ * pipe with every f32 operand taken as three bf16 pieces (x = x0 + x1 + x2 up to 2^-26 |x|) and the six products of
+ * order <= 2 -- the error against a float64 convolution is that of the f32-MFMA kernels (cova_set_option 7 selects
+ * those; tests/test_kernels_gpu.py::test_conv1_bf16_split_error_class), gfx950 having no faster f32 matrix path. */
 int cova_conv1_num_tiles(int B, int H, int W);
 /* rows of the statistics partials written by cova_conv1_fwd (per tile, or per persistent block) */
 int cova_conv1_num_partials(int B, int H, int W);

@@ -1119,9 +1119,19 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
     // as many windows: with the parity in bit 0 of the wave index two SIMDs carried both heavy waves), and the heavy one
     // is the older wave, which the SIMD's arbitration favours (the other way round the phase was 1,000 cycles longer)
     const int cc = (((qx & 3) << 1) | (((qx >> 4) & 1) ^ 1)) + 8 * ((qx >> 2) & 3);
-    auto issue_slot = [&](int n, int t) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
+    // tile -> (image, first output row, first output column): computed ONCE per tile (three scalar divisions; recomputed in
+    // each of the 27 prefetch slots they were ~2,000 scalar instructions per tile and wave in the MFMA loop's stream)
+    struct TileC { int b, y0, x0; };
+    auto coords = [&](int t) {
+        TileC c;
+        const int r_ = t / tiles_x;
+        c.x0 = (t - r_ * tiles_x) * TW;
+        c.b = r_ / tiles_y;
+        c.y0 = (r_ - c.b * tiles_y) * TH;
+        return c;
+    };
+    auto issue_slot = [&](int n, const TileC &tc) {
+        const int b = tc.b, y0 = tc.y0, x0 = tc.x0;
         int t_ = tid;
         asm volatile("" : "+v"(t_));          // the slot's index math stays here
         if (n < NPRE_P) {                     // rows (r, r+2) of patch column j, channel c
@@ -1301,14 +1311,15 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
 
     int tile = blockIdx.x;
     if (tile < ntiles) {
+        const TileC t0 = coords(tile);
 #pragma unroll
         for (int n = 0; n < NSLOT; ++n)
-            if (n < NPRE_P + 8 + NPOOL) issue_slot(n, tile);
+            if (n < NPRE_P + 8 + NPOOL) issue_slot(n, t0);
         stage_tile();
     }
     for (; tile < ntiles; tile += gridDim.x) {
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const int next = has_next ? tile + (int)gridDim.x : tile;       // (last tile: re-reads itself, unused)
+        const TileC next = coords(has_next ? tile + (int)gridDim.x : tile);      // (last tile: re-reads itself, unused)
         // Operands double-buffered in registers; every MFMA is followed by ONE of: a 4-dword operand read for the next
         // group (A of the next K-step | B of the next group of tap blocks) or one prefetch slot of the next tile.
         // The 20 (K-step, tap block) units of a tile are taken in PAIRS whose MFMAs alternate (two accumulators: a chain

@@ -326,9 +326,13 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                 for (int bc = 0; bc < NB; ++bc) piece(it, edge, phi, br, bc);
             }
         };
-        // side output (gradient role, position half 0): the operand as formed on load, written once -- the data-gradient
-        // launch of the same convolution then reads ONE tensor with no prologue instead of forming it again per tap
-        const bool emit = !VROLE && PROD != 0 && HALF == 0 && a.dz_out != nullptr;
+        // side output (gradient role): the operand as formed on load, written once -- the data-gradient launch of the same
+        // convolution then reads ONE tensor with no prologue instead of forming it again per tap.  The two position halves
+        // of a walk (blocks b, b + 8: same tiles, same order) take TURNS, tile by tile: with all the stores in half 0 that
+        // block fell behind its partner, the pair stopped meeting in L2 and the launch fetched every pixel twice (FETCH_SIZE
+        // of the step's launches 2.5 GB against 1.3 GB stand-alone without the side output: 3 GB moved in 0.59 ms)
+        const bool emit = !VROLE && PROD != 0 && a.dz_out != nullptr;
+        int emit_k = 0;                                      // tiles transformed so far by this wave
         unsigned emit_lane = (unsigned)lane * 4u;
         asm volatile("" : "+v"(emit_lane));
         unsigned cur_org = 0;                                // element offset of the current tile's pixel (0, 0)
@@ -353,6 +357,8 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
             if (WG4_ABL & 8) { fetch(nxt, nedge, nphi); phi = nphi; return; }
             WG4_STAMP(1);
             float t[3][NR];
+            const bool emit_now = emit && ((emit_k & 1) == HALF);
+            ++emit_k;
             auto stage1 = [&](auto cedge_t) __attribute__((always_inline)) {
             constexpr bool cedge = decltype(cedge_t)::value;
 #pragma unroll
@@ -367,9 +373,9 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                     if (!VROLE && PROD == 1) v = fmaf(pA, v, pC);
                     if (cedge && !(((crm >> r) & (ccm >> c) & 1u) != 0u)) v = 0.f;              // zero padding stays zero
                     d[r] = v;
-                    if (!VROLE && PROD != 0 && HALF == 0) {
+                    if (!VROLE && PROD != 0) {
                         // (scalar base of the pixel + ONE lane offset: global_store with an SGPR pair, no per-lane pointers)
-                        if (emit && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u))) {
+                        if (emit_now && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u))) {
                             unsigned ob = (cur_org + (unsigned)((r * W + c) * 64)) * 4u;
                             asm volatile("" : "+s"(ob));
                             *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dz_out) + ob + emit_lane) = v;

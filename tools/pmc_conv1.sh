@@ -12,6 +12,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
   i=$((i+1))
   rocprofv3 --pmc $set -d /tmp/pmc_c1_$i -- python $root/tools/conv1_bench.py --time-only > /tmp/pmc_c1_$i.log 2>&1 || tail -3 /tmp/pmc_c1_$i.log
   db=$(find /tmp/pmc_c1_$i -name "*.db" | head -1)
-  [ -n "$db" ] && python $root/tools/rocpd_pmc.py --raw $db | grep -E "conv1_7x7"
+  [ -n "$db" ] && python $root/tools/rocpd_pmc.py --raw $db | grep -E "conv1_"
 done > $out/pmc_conv1.txt 2>&1
 cat $out/pmc_conv1.txt

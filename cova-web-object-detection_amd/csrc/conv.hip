@@ -1046,6 +1046,9 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 //   * LDS: 96 KB of packed dy1 + 48 KB shared in time by the pooled-gradient windows (while dy1 is finished) and the
 //     patch planes (during the MFMAs): four barriers per tile.
 // ------------------------------------------------------------------------------------
+#ifndef WG1B_ABL
+#define WG1B_ABL 0             // tools: 1 no prefetch slots in the MFMA loop, 2 no operand reads in it (stale registers)
+#endif
 #ifndef WG1B_PRIO
 #define WG1B_PRIO 0            // tools: 1 static priority for waves 4-7 in the MFMA loop, 2 alternating per pair of units
 #endif
@@ -1357,9 +1360,9 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
                 acc[tb] = mfma32bf(A[ks & 1][pa], Bq[u][pb], acc[tb]);
                 // what follows this MFMA
                 constexpr int nunit = 2 * (gp + 1) + u;              // the unit that takes this one's operand registers
-                if constexpr (m == 2 || m == 3) { if (more) load_bu(u, nunit, 1); }
-                else if constexpr (m == 4 || m == 5) { if (more) load_bu(u, nunit, 2); }
-                else if constexpr (m == 10 || m == 11) { if (more) load_bu(u, nunit, 0); }
+                if constexpr (m == 2 || m == 3) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 1); }
+                else if constexpr (m == 4 || m == 5) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 2); }
+                else if constexpr (m == 10 || m == 11) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 0); }
                 else {
                     // six free slots per pair (m = 0, 1, 6, 7, 8, 9): the next K-step's A operand in the pair that
                     // starts K-step ks' = (2 gp) / 5 (its last unit is >= 3 units away), then prefetch slots
@@ -1367,12 +1370,12 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
                     constexpr int ks0 = (2 * gp) / 5;
                     constexpr bool first_of_ks = (2 * gp) % 5 < 2;   // the pair holding unit 5 ks0 or 5 ks0 + 1
                     if constexpr (first_of_ks && (m < 2 || m == 6)) {
-                        if (ks0 + 1 < 4) load_a(ks0 + 1, m < 2 ? m : 2);
+                        if (ks0 + 1 < 4 && !(WG1B_ABL & 2)) load_a(ks0 + 1, m < 2 ? m : 2);
                     } else {
                         // slots in order over the remaining free positions
                         constexpr int used_a = 3 * ((2 * gp) / 5 + (first_of_ks ? 0 : 1));      // A positions before this pair
                         constexpr int n = f - used_a - (first_of_ks ? 3 : 0);
-                        if constexpr (n >= 0) { if (n < NPRE_P + 8 + NPOOL) issue_slot(n, next); }
+                        if constexpr (n >= 0) { if (n < NPRE_P + 8 + NPOOL && !(WG1B_ABL & 1)) issue_slot(n, next); }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -1402,6 +1402,362 @@ __global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
         }
 }
 
+// ------------------------------------------------------------------------------------
+// conv1 weight gradient, ROLE-SPLIT form of conv1_wgrad_bf3_kernel (same arithmetic, same operand layouts, a quarter of
+// its tile): of the two waves of every SIMD one multiplies and the other one stages.
+//   * tile = 4 x 16 output pixels.  Waves 0-3 (one per SIMD) = (channel block, row pair): 2 K-steps x 30 MFMAs per tile on
+//     the tile's operands in LDS; between the MFMAs they also bring in the NEXT tile's image patch (prefetch, split,
+//     packed row pairs -> the other patch buffer: ~3 instructions per MFMA).
+//   * Waves 4-7 finish dy1 of the next tile meanwhile -- thread = (column, 4 channels), all 4 rows: y1 and the 3 or 6
+//     pooling windows that can route into the column straight from global memory into registers (one tile ahead),
+//     A * route(dp) + B * y1 + C, split, packed row pairs -> the other dy1 buffer.  No windows in LDS, no phases.
+//   * everything double-buffered (2 x 24 KB dy1, 2 x 15.5 KB patch): ONE barrier per tile.
+// The phase trace of conv1_wgrad_bf3_kernel had shown 16,000 of a tile's 27,000 cycles in staging phases with the matrix
+// pipe idle and 11,200 in an MFMA loop of 7,700 cycles of pipe work that the two waves of a SIMD do not share evenly.
+// ------------------------------------------------------------------------------------
+#ifndef WG1R_ABL
+#define WG1R_ABL 0             // tools: 1 no dy1 operand loads, 2 no patch loads, 4 no dy1 arithmetic / LDS writes, 8 no MFMAs
+#endif
+
+namespace wg1r {
+constexpr int TH = 4, TW = 16, THREADS = 512;
+constexpr int D_DW = 32 * 3 * 64;               // dy1 planes [pair 2 x 16][piece][channel]: 6,144 dwords
+constexpr int PROW = 3 * 40;                    // dwords per (c, r) row of the patch planes: [piece][parity][20]
+constexpr int P_DW = 3 * 11 * PROW;             // 3,960 dwords
+constexpr int PATCH_ITEMS = 3 * 11 * 37;        // 1221 (c, r, column) pairs of rows (r, r+2)
+constexpr int NPRE_P = (PATCH_ITEMS + 255) / 256;                // 5 slots per MFMA-wave thread
+}  // namespace wg1r
+
+// -DC1B_TRACE: stamps of the eight waves of block 0, tiles 40..59: 0 tile start, 1 work done (before the barrier), 2 after the
+// barrier, 3 (staging waves) dy1 finished / loads not yet issued
+#ifdef C1B_TRACE
+#define WG1R_STAMP(slot)                                                                                      \
+    do {                                                                                                      \
+        if (blockIdx.x == 0 && tr_it >= 0 && tr_it < 20 && lane == 0)                                         \
+            g_wg1b_trace[(wave * 20 + tr_it) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#define WG1R_TRIT() ++tr_it
+#else
+#define WG1R_STAMP(slot) do { } while (0)
+#define WG1R_TRIT() do { } while (0)
+#endif
+
+template <bool POOL>
+__global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
+    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
+{
+    using namespace wg1r;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * D_DW + 2 * P_DW];
+    uint32_t *s_d = lds, *s_p = lds + 2 * D_DW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mm = wave < 4;                                        // multiplying | staging wave
+    struct TileC { int b, y0, x0; };
+    auto coords = [&](int t) {
+        TileC c;
+        const int tt = t < ntiles ? t : ntiles - 1;                  // (past the end: the last tile again, unused)
+        const int r_ = tt / tiles_x;
+        c.x0 = (tt - r_ * tiles_x) * TW;
+        c.b = r_ / tiles_y;
+        c.y0 = (r_ - c.b * tiles_y) * TH;
+        return c;
+    };
+    const int t0 = blockIdx.x, tstep = gridDim.x;
+#ifdef C1B_TRACE
+    int tr_it = -40;
+#endif
+
+    if (mm) {
+        // =================================================================== multiplying waves
+        const int li = lane & 31, kh2 = lane >> 5;
+        const int cob = wave & 1, q = wave >> 1;
+        const int mtid = tid;                                        // 0 .. 255
+        int toff[5];
+#pragma unroll
+        for (int tb = 0; tb < 5; ++tb) {
+            const int k = tb * 32 + li;
+            const int kk = k < 147 ? k : 0;                          // (columns 147..159 of the result are never read)
+            toff[tb] = ((kk / 49) * 11 + 4 * q + (kk % 49) / 7) * PROW + ((kk % 7) & 1) * 20 + ((kk % 7) >> 1) + 4 * kh2;
+        }
+        const int a_base = ((q * 16 + 4 * kh2) * 3) * 64 + cob * 32 + li;
+        f32x16 acc[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // patch slots: slot n of this thread = item n * 256 + mtid of the [c 3][r 11][column 37] grid -- the same element of
+        // every tile's patch, so what does not depend on the tile is computed once: the element's offset inside the image
+        // relative to the patch origin, its LDS destination, and (c, r, j) packed for the edge path.  (Recomputed per
+        // tile -- two divisions, clamps, validity -- the ten loads of a tile cost ~325 vector instructions in the MFMA
+        // waves' stream: 0.45 ms of the launch, ablation.)
+        int prel[NPRE_P], pldo[NPRE_P], pcrj[NPRE_P];
+#pragma unroll
+        for (int n = 0; n < NPRE_P; ++n) {
+            const int item = n * 256 + mtid;
+            const int itc = item < PATCH_ITEMS ? item : PATCH_ITEMS - 1;
+            const int seg = itc / 37, j = itc - seg * 37;
+            const int c = seg / 11, r = seg - c * 11;
+            prel[n] = (c * H + r) * W + j;
+            pldo[n] = seg * PROW + (j & 1) * 20 + (j >> 1);
+            pcrj[n] = c | (r << 2) | (j << 6) | (item < PATCH_ITEMS ? (1 << 12) : 0);
+        }
+        float preS[2][2 * NPRE_P];               // two register sets: a tile's patch is requested a whole tile before it is written
+        unsigned premaskS[2] = {0u, 0u};
+        // interior: the 13 x 37 patch of the tile lies inside the image (no clamps, no validity bits)
+        auto patch_interior = [&](const TileC &tc) {
+            return 2 * tc.y0 - 3 >= 0 && 2 * tc.y0 + 9 < H && 2 * tc.x0 - 3 >= 0 && 2 * tc.x0 + 33 < W;
+        };
+        auto patch_load = [&](auto setc, int n, const TileC &tc, bool fast) {
+            if (WG1R_ABL & 2) return;
+            auto &pre = preS[decltype(setc)::value];
+            unsigned &premask = premaskS[decltype(setc)::value];
+            const float *img_b = img + (size_t)tc.b * 3 * H * W;
+            if (fast) {
+                const float *org = img_b + ((2 * tc.y0 - 3) * W + 2 * tc.x0 - 3);       // wave-uniform
+                pre[2 * n] = org[prel[n]];
+                pre[2 * n + 1] = (org + 2 * W)[prel[n]];
+                premask |= 3u << (2 * n);
+                return;
+            }
+            const int c = pcrj[n] & 3, r = (pcrj[n] >> 2) & 15, j = (pcrj[n] >> 6) & 63;
+            const int gy = 2 * tc.y0 - 3 + r, gx = 2 * tc.x0 - 3 + j;
+            const bool okx = ((pcrj[n] >> 12) & 1) && gx >= 0 && gx < W;
+            const bool ok0 = okx && gy >= 0 && gy < H, ok1 = okx && gy + 2 >= 0 && gy + 2 < H;
+            const int cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const int cy0 = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cy1 = gy + 2 < 0 ? 0 : (gy + 2 >= H ? H - 1 : gy + 2);
+            pre[2 * n] = img_b[(unsigned)((c * H + cy0) * W + cx)];
+            pre[2 * n + 1] = img_b[(unsigned)((c * H + cy1) * W + cx)];
+            premask = (premask & ~(3u << (2 * n))) | ((ok0 ? 1u : 0u) << (2 * n)) | ((ok1 ? 2u : 0u) << (2 * n));
+        };
+        auto patch_write = [&](auto setc, int n, uint32_t *dst) {
+            auto &pre = preS[decltype(setc)::value];
+            const unsigned premask = premaskS[decltype(setc)::value];
+            if ((pcrj[n] >> 12) & 1) {
+                const float x0v = ((premask >> (2 * n)) & 1u) ? pre[2 * n] : 0.f;
+                const float x1v = ((premask >> (2 * n + 1)) & 1u) ? pre[2 * n + 1] : 0.f;
+                uint32_t q0, q1, q2;
+                bf3_split_pair(x0v, x1v, q0, q1, q2);
+                uint32_t *d_ = dst + pldo[n];
+                d_[0] = q0;
+                d_[40] = q1;
+                d_[80] = q2;
+            }
+        };
+        TileC c1 = coords(t0);
+        if (t0 < ntiles) {                       // prologue: the first tile's patch -> buffer 0; the second tile's in registers
+#pragma unroll
+            for (int n = 0; n < NPRE_P; ++n) patch_load(std::integral_constant<int, 1>{}, n, c1, false);
+#pragma unroll
+            for (int n = 0; n < NPRE_P; ++n) patch_write(std::integral_constant<int, 1>{}, n, s_p);
+            c1 = coords(t0 + tstep);
+#pragma unroll
+            for (int n = 0; n < NPRE_P; ++n) patch_load(std::integral_constant<int, 0>{}, n, c1, false);
+        }
+        __syncthreads();
+        int cur = 0;
+        // tile n (parity par): set par holds the patch of tile n + 1 (requested during tile n - 1) and is written to the other
+        // LDS buffer; the patch of tile n + 2 is requested into set par ^ 1 first thing
+        auto tile_body = [&](int tile, auto parc) {
+            constexpr int par = decltype(parc)::value;
+            WG1R_STAMP(0);
+            const TileC c2 = coords(tile + 2 * tstep);
+            const bool pfast = patch_interior(c2);
+            const uint32_t *sd = s_d + cur * D_DW, *sx = s_p + cur * P_DW;
+            uint32_t *sxn = s_p + (cur ^ 1) * P_DW;
+            u32x4 A[2][3], Bq[2][3];                                 // [K-step][piece] | [unit of the pair][piece]
+            auto load_a = [&](int ks, int pc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) A[ks][pc][i] = sd[a_base + ((8 * ks + i) * 3 + pc) * 64];
+            };
+            auto load_bu = [&](int u, int unit, int pc) {            // unit = 5 ks + tb
+                const uint32_t *p_ = sx + toff[unit % 5] + pc * 40 + 8 * (unit / 5);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bq[u][pc][i] = p_[i];
+            };
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) { load_a(0, pc); load_bu(0, 0, pc); load_bu(1, 1, pc); }
+            // 5 pairs of (K-step, tap block) units, 12 MFMAs each (product order a0 b1, a1 b1, a0 b2, a0 b0, a1 b0, a2 b0: a
+            // unit's B pieces 1 / 2 / 0 are dead after MFMAs 3 / 5 / 11 of its pair and replaced right there); the six free
+            // slots of a pair carry K-step 1's A operand (pair 0), the next tile's patch into the other buffer (split + LDS
+            // writes from one register set) and the prefetch of the tile after it into the other set
+            c1b_static_for<5>([&](auto gc) {
+                constexpr int gp = decltype(gc)::value;
+                constexpr bool more = gp + 1 < 5;
+                c1b_static_for<12>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, pr = m >> 1, u = m & 1, unit = 2 * gp + u;
+                    constexpr int ks = unit / 5, tb = unit % 5;
+                    constexpr int pa = (pr == 1 || pr == 4) ? 1 : (pr == 5 ? 2 : 0), pb = pr < 2 ? 1 : (pr == 2 ? 2 : 0);
+                    if (!(WG1R_ABL & 8)) acc[tb] = mfma32bf(A[ks][pa], Bq[u][pb], acc[tb]);
+                    constexpr int nunit = 2 * (gp + 1) + u;
+                    if constexpr (m == 2 || m == 3) { if (more) load_bu(u, nunit, 1); }
+                    else if constexpr (m == 4 || m == 5) { if (more) load_bu(u, nunit, 2); }
+                    else if constexpr (m == 10 || m == 11) { if (more) load_bu(u, nunit, 0); }
+                    else {
+                        constexpr int f = gp * 6 + (m < 2 ? m : m - 4);          // 0 .. 29
+                        if constexpr (f < 3) load_a(1, f);
+                        else if constexpr (f < 3 + NPRE_P) patch_load(std::integral_constant<int, par ^ 1>{}, f - 3, c2, pfast);
+                        else if constexpr (f >= 12 && f < 12 + NPRE_P) patch_write(std::integral_constant<int, par>{}, f - 12, sxn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            WG1R_STAMP(1);
+            c1b_lds_barrier();
+            WG1R_STAMP(2);
+            cur ^= 1;
+#ifdef C1B_TRACE
+            ++tr_it;
+#endif
+        };
+        for (int tile = t0; tile < ntiles; tile += 2 * tstep) {
+            tile_body(tile, std::integral_constant<int, 0>{});
+            if (tile + tstep < ntiles) tile_body(tile + tstep, std::integral_constant<int, 1>{});
+        }
+        // partial layout: part[(block*2 + q)][co 64][k 160]
+        float *dst = part + ((size_t)(blockIdx.x * 2 + q)) * (64 * 160);
+#pragma unroll
+        for (int tb = 0; tb < 5; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cor = cob * 32 + mfma32_row(r, lane);
+                dst[cor * 160 + tb * 32 + li] = acc[tb][r];
+            }
+        return;
+    }
+    // ======================================================================= staging waves
+    {
+        const int st = tid - 256;                                    // 0 .. 255
+        const int pw = wave - 4, c4 = st & 15;
+        const bool codd = (pw & 1) != 0;                             // this wave's four columns are odd | even
+        const int cc = 2 * ((pw >> 1) * 4 + ((st >> 4) & 3)) + (pw & 1);
+        f32x4 cA = {0.f, 0.f, 0.f, 0.f}, cB = cA, cC = cA;
+        if (POOL) {
+            cA = *reinterpret_cast<const f32x4 *>(pool.abc + c4 * 4);
+            cB = *reinterpret_cast<const f32x4 *>(pool.abc + 64 + c4 * 4);
+            cC = *reinterpret_cast<const f32x4 *>(pool.abc + 128 + c4 * 4);
+        }
+        struct Ops {                             // what a thread loads for its column of a tile
+            f32x4 yv[4];                         // dy (POOL: y1) of rows 0..3, 4 channels
+            f32x4 dpv[3][2];                     // POOL: pooled gradient of windows (P0, P0+1, P0+2) x (W0 [, W0+1])
+            uint32_t cdv[3][2];                  //       their four arg-max codes
+            unsigned ok;                         // bits 0-3 rows inside the map (with the column), bits 4-9 windows inside
+        };
+        Ops opa, opb, opc;                       // three sets: a tile's operands are requested two tiles before they are used
+        auto load_tile = [&](Ops &o_, const TileC &tc) {
+            if (WG1R_ABL & 1) return;
+            auto &yv = o_.yv; auto &dpv = o_.dpv; auto &cdv = o_.cdv;
+            unsigned ok = 0u;
+            const float *yb = dy + (size_t)tc.b * H1 * W1 * 64;
+            const int gx = tc.x0 + cc, cx = gx < W1 ? gx : W1 - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = tc.y0 + r, cy = gy < H1 ? gy : H1 - 1;
+                yv[r] = *reinterpret_cast<const f32x4 *>(yb + (unsigned)(((cy * W1 + cx) << 6) + c4 * 4));
+                ok |= (gy < H1 && gx < W1) ? (1u << r) : 0u;
+            }
+            if (POOL) {
+                const float *db = pool.dp + (size_t)tc.b * pool.H2 * pool.W2 * 64;
+                const uint8_t *ib = pool.idx + (size_t)tc.b * pool.H2 * pool.W2 * 64;
+                const int P0 = tc.y0 >> 1, W0 = codd ? (gx - 1) >> 1 : gx >> 1;
+#pragma unroll
+                for (int p_ = 0; p_ < 3; ++p_) {
+                    const int ph = P0 + p_, cph = ph < pool.H2 ? ph : pool.H2 - 1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e == 1 && !codd) continue;
+                        const int pwc = W0 + e, cpw = pwc < pool.W2 ? pwc : pool.W2 - 1;
+                        const unsigned o = (unsigned)((cph * pool.W2 + cpw) * 64 + c4 * 4);
+                        dpv[p_][e] = *reinterpret_cast<const f32x4 *>(db + o);
+                        cdv[p_][e] = *reinterpret_cast<const uint32_t *>(ib + o);
+                        ok |= (ph < pool.H2 && pwc < pool.W2) ? (1u << (4 + p_ * 2 + e)) : 0u;
+                    }
+                }
+            }
+            o_.ok = ok;
+        };
+        // rows 0, 1 | 2, 3 of the column -> dy1, split by row pairs -> dst
+        auto finish = [&](const Ops &o_, uint32_t *dst) {
+            if (WG1R_ABL & 4) return;
+            const auto &yv = o_.yv; const auto &dpv = o_.dpv; const auto &cdv = o_.cdv;
+            const unsigned ok = o_.ok;
+            const int kx0 = codd ? 2 : 1;                            // kx of window column W0; W0 + 1 (odd columns): kx 0
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {                         // row pair hp: rows 2 hp (even), 2 hp + 1 (odd)
+                float d[2][4];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int r = 2 * hp + rr;
+                    float g[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (POOL) {
+                        // even row: window row hp with ky 1; odd row: window row hp with ky 2, hp + 1 with ky 0
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            if (rr == 0 && k == 1) continue;
+                            const int p_ = hp + k;
+                            const uint32_t ky = rr == 0 ? 1u : (k == 0 ? 2u : 0u);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                if (e == 1 && !codd) continue;
+                                const uint32_t code = ky * 3u + (e == 0 ? (uint32_t)kx0 : 0u);
+                                const bool win = (ok >> (4 + p_ * 2 + e)) & 1u;
+#pragma unroll
+                                for (int jx = 0; jx < 4; ++jx)
+                                    g[jx] += (win && ((cdv[p_][e] >> (8 * jx)) & 255u) == code) ? dpv[p_][e][jx] : 0.f;
+                            }
+                        }
+                    }
+                    const bool in = (ok >> r) & 1u;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        float v = yv[r][jx];
+                        if (POOL) v = fmaf(cA[jx], g[jx], fmaf(cB[jx], v, cC[jx]));
+                        d[rr][jx] = in ? v : 0.f;
+                    }
+                }
+                u32x4 w0, w1, w2;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    uint32_t u0, u1, u2;
+                    bf3_split_pair(d[0][jx], d[1][jx], u0, u1, u2);
+                    w0[jx] = u0; w1[jx] = u1; w2[jx] = u2;
+                }
+                u32x4 *o_ = reinterpret_cast<u32x4 *>(dst + ((hp * 16 + cc) * 3) * 64 + c4 * 4);
+                o_[0] = w0;
+                o_[16] = w1;
+                o_[32] = w2;
+            }
+        };
+        if (t0 < ntiles) {                       // prologue: the first tile's dy1 -> buffer 0; the next two tiles' operands in registers
+            load_tile(opa, coords(t0));
+            finish(opa, s_d);
+            load_tile(opb, coords(t0 + tstep));
+            load_tile(opc, coords(t0 + 2 * tstep));
+        }
+        __syncthreads();
+        // tiles in triples (three register sets rotate): request the tile three ahead, then finish the next tile's dy1 from
+        // operands requested two tiles ago (a one-tile lead, ~2,500 cycles, was less than the memory latency under load)
+        int nb = 1;                              // dy1 buffer of the tile being finished
+        for (int tile = t0; tile < ntiles; tile += 3 * tstep) {
+#define WG1R_PSTEP(A_, B_, K_)                                                                   \
+            WG1R_STAMP(0);                                                                       \
+            finish(A_, s_d + nb * D_DW);                                                         \
+            WG1R_STAMP(3);                                                                       \
+            load_tile(B_, coords(tile + (K_) * tstep));                                          \
+            WG1R_STAMP(1);                                                                       \
+            c1b_lds_barrier();                                                                   \
+            WG1R_STAMP(2);                                                                       \
+            nb ^= 1;                                                                             \
+            WG1R_TRIT();
+            WG1R_PSTEP(opb, opa, 3)              // finishes tile + tstep, requests tile + 3 tstep
+            if (tile + tstep >= ntiles) break;   // (block-uniform: the multiplying waves leave their loop at the same tile)
+            WG1R_PSTEP(opc, opb, 4)
+            if (tile + 2 * tstep >= ntiles) break;
+            WG1R_PSTEP(opa, opc, 5)
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *__restrict__ part,
                                                                   int nparts, float *__restrict__ dw)
 {
@@ -1443,6 +1799,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
 int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) instead of the bf16-split one (A/B, tests)
+int g_conv1_wgrad_phases = 0; // 1: conv1 weight gradient on the phase-structured bf16 kernel instead of the role-split one (A/B)
 
 }  // namespace
 
@@ -1463,6 +1820,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 5) { g_ablate = value; return COVA_OK; }
     if (key == 6) return cova_internal_set_wino_geometry(value);
     if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
+    if (key == 8) { g_conv1_wgrad_phases = value != 0; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1586,6 +1944,17 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
     const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
+    if (!g_conv1_f32 && !g_conv1_wgrad_phases) {
+        const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
+        const int rgrid = persistent_grid(B * rtx * rty);
+        hipLaunchKernelGGL(conv1_wgrad_rs_kernel<true>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, y1,
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{dp, idx, abc, H2, W2});
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
+                           rgrid * 2, dw);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     if (g_conv1_f32)
         hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
                            (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
@@ -1610,6 +1979,17 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
+    if (!g_conv1_f32 && !g_conv1_wgrad_phases) {
+        const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
+        const int rgrid = persistent_grid(B * rtx * rty);
+        hipLaunchKernelGGL(conv1_wgrad_rs_kernel<false>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, dy,
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+        COVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
+                           rgrid * 2, dw);
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     if (g_conv1_f32)
         hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
                            (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,

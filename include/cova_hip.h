@@ -57,7 +57,8 @@ typedef struct cova_bn_tail {
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 /* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
  * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2),
- * 7 = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): A/B */
+ * 7 = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): A/B,
+ * 8 = conv1 weight gradient (bf16-split) in its phase-structured form (1) instead of the role-split one (0, default): A/B */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */

@@ -1150,3 +1150,38 @@ def test_conv1_kernels_do_not_depend_on_the_batch_partition():
     (o0, p0), (o1, p1_) = fwd(slice(0, 2)), fwd(slice(2, 4))
     assert torch.equal(of, torch.cat((o0, o1)))
     assert torch.equal(pf, torch.cat((p0, p1_)))          # (one tile per block at this size: the rows are per tile)
+
+
+@pytest.mark.parametrize("B,H,W,cap", [(2, 150, 330, 0), (2, 150, 330, 7), (1, 70, 90, 0)])
+def test_conv1_wgrad_role_split_equals_phase_form(B, H, W, cap):
+    """The two bf16-split forms of the conv1 weight gradient (role-split waves, the default; phase-structured,
+    cova_set_option(8, 1)) and the f32-MFMA kernel on the same operands, pool backward folded in: equal to fp32
+    re-association, on maps with edge tiles, odd sizes and many tiles per block."""
+    g = torch.Generator().manual_seed(H + W + cap)
+    x = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
+    H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
+    y = (torch.randn(B, H1, W1, 64, generator=g) * 2).to(DEV)
+    scale, shift = (torch.rand(64, generator=g) - 0.3).to(DEV), (torch.randn(64, generator=g) * 0.2).to(DEV)
+    p1 = torch.empty(B, H2, W2, 64, device=DEV)
+    idx = torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
+    call("cova_bn_relu_maxpool_fwd", y, scale, shift, p1, idx, None, B, H1, W1)
+    dp = torch.randn(B, H2, W2, 64, generator=g).to(DEV) * (p1 > 0)
+    abc = (torch.randn(3, 64, generator=g) * 0.3).to(DEV)
+    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
+    out = {}
+    query("cova_set_option", 2, cap)
+    try:
+        for name, o7, o8 in (("f32", 1, 0), ("phases", 0, 1), ("roles", 0, 0)):
+            query("cova_set_option", 7, o7)
+            query("cova_set_option", 8, o8)
+            dw = torch.zeros(64, 3, 7, 7, device=DEV)
+            call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W)
+            out[name] = dw
+    finally:
+        query("cova_set_option", 7, 0)
+        query("cova_set_option", 8, 0)
+        query("cova_set_option", 2, 0)
+    s = float(out["f32"].abs().max())
+    assert float((out["roles"] - out["f32"]).abs().max()) <= 5e-7 * s
+    assert float((out["phases"] - out["f32"]).abs().max()) <= 5e-7 * s

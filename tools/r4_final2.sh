@@ -7,10 +7,11 @@ cd $GRAFT_REPO_ROOT
 o=gpurun_out/r4g
 mkdir -p $o gpurun_out/r4c
 timeout 120 ./build/mfma_probe > $o/mfma_probe.txt 2>&1
+timeout 120 ./build/mfma32_probe > $o/mfma32_probe.txt 2>&1
 timeout 300 python tools/conv1_bench.py > $o/conv1_bench.txt 2>&1
 bash tools/c1b_abl_run.sh 1 4 5 3 7 > $o/conv1_fwd_ablation.txt 2>&1
 timeout 120 python tools/c1b_trace.py > $o/conv1_fwd_trace.txt 2>&1
-timeout 120 python tools/wg1b_trace.py > $o/conv1_wgrad_trace.txt 2>&1
+timeout 120 python tools/wg1r_trace.py > $o/conv1_wgrad_trace.txt 2>&1
 bash tools/pmc_conv1.sh > /dev/null 2>&1; cp gpurun_out/pmc_conv1.txt $o/
 bash tools/profile_round.sh r4g/c2 --config 2
 bash tools/profile_round.sh r4g/c3 --config 3

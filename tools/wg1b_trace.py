@@ -24,6 +24,7 @@ dp = torch.randn(B, H2, W2, 64, device=dev, generator=g) * (p1 > 0)
 abc = torch.randn(3, 64, device=dev, generator=g) * 0.3
 ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=dev)
 dw = torch.zeros(64, 3, 7, 7, device=dev)
+call("cova_set_option", 8, 1)          # the phase-structured form (the default is the role-split one: tools/wg1r_trace.py)
 for _ in range(3):
     call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W)
 torch.cuda.synchronize()

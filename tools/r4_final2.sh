@@ -2,7 +2,8 @@
 # Round-4 evidence pass, second part (one gpurun call): the bench lines of all configs, kernel trace + HBM counters of the
 # bench step at configs[1] / configs[2], SQ counters of the F(4x4) kernels and of the conv1 kernels, the conv1 A/B tables
 # (error against fp64, time, ablations, phase traces), the matrix / vector pipe probe, the parity-margin table.
-# Results under gpurun_out/r4g; the summaries are copied to profiles/r04_* by hand.
+# Results under gpurun_out/r4g; the summaries are copied to profiles/r04_* by hand.  Before: tools/probe/build.sh,
+# tools/c1b_abl_build.sh 1 3 4 5 7, C1B_EXTRA=-DC1B_TRACE tools/c1b_abl_build.sh 0 (probe binaries, ablation and trace libraries).
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/r4g
 mkdir -p $o gpurun_out/r4c

@@ -12,6 +12,7 @@
 // Roofline bookkeeping: 2*64*64*9 = 73,728 FLOP per output pixel
 // for conv3x3 (fwd, dgrad and wgrad each), 2*64*147 = 18,816 FLOP per output pixel for conv1.
 #include "common.h"
+#include "bf3.h"
 #include "bn_tail.h"
 #include <utility>
 #include <type_traits>
@@ -354,40 +355,6 @@ constexpr int NPRE = (PLANE + THREADS - 1) / THREADS;        // 5 pair slots per
 constexpr int RF0 = 7;                         // K-step at which the prefetched patch starts going to LDS
 __host__ __device__ constexpr int row_off(int t) { return t < 21 ? ((t / 7) * PR + t % 7) * SEGW : 0; }
 }  // namespace c1b
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// (xe, xo) -> three dwords of packed bf16 pieces (even element in the low half): 11 operations.  Each piece is the
-// round-to-nearest-even bf16 of what is left (v_cvt_pk_bf16_f32), each residual is exact in f32; after three pieces
-// at most 2^-26 |x| is left.  (Pieces by truncation represent x exactly but are all of x's sign: the three dropped
-// cross products then add up coherently -- measured as a 10x larger error of the per-channel sums of the convolution.)
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t bf3_pack_rne(float xe, float xo)
-{
-    const f32x2 v = {xe, xo};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void bf3_split_pair(float xe, float xo, uint32_t &q0, uint32_t &q1, uint32_t &q2)
-{
-    q0 = bf3_pack_rne(xe, xo);
-    const float re = xe - __builtin_bit_cast(float, q0 << 16);
-    const float ro = xo - __builtin_bit_cast(float, q0 & 0xFFFF0000u);
-    q1 = bf3_pack_rne(re, ro);
-    const float se = re - __builtin_bit_cast(float, q1 << 16);
-    const float so = ro - __builtin_bit_cast(float, q1 & 0xFFFF0000u);
-    q2 = bf3_pack_rne(se, so);
-}
-
-__device__ __forceinline__ void bf3_split8(const float (&x)[8], u32x4 &p0, u32x4 &p1, u32x4 &p2)
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t a, b, c;
-        bf3_split_pair(x[2 * i], x[2 * i + 1], a, b, c);
-        p0[i] = a; p1[i] = b; p2[i] = c;
-    }
-}
 
 __device__ __forceinline__ f32x16 mfma32bf(u32x4 a, u32x4 b, f32x16 c)
 {
@@ -1816,6 +1783,7 @@ int cova_internal_ablate() { return g_ablate; }
 // ====================================================================================
 // test / tool hooks (not part of the path's contract): 2 = cap on persistent grids (tests force many tiles per
 // block), 5 = ablation mask of builds made with -DCOVA_ABLATE (tools/conv_bench.py), 6 = Winograd tile geometry
+int cova_internal_set_wino4_f32(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1823,6 +1791,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 6) return cova_internal_set_wino_geometry(value);
     if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
     if (key == 8) { g_conv1_wgrad_phases = value != 0; return COVA_OK; }
+    if (key == 9) return cova_internal_set_wino4_f32(value);
     return COVA_ERR_BAD_ARG;
 }
 

@@ -411,7 +411,7 @@ def conv3_weights(ws, like, wino4):
     with its kernel family; the F(4x4) operands of all of them come from ONE launch."""
     if wino4:
         n = len(ws)
-        uf, ud = _empty((n, 147456), like), _empty((n, 147456), like)
+        uf, ud = _empty((n, query("cova_conv3x3_wino4_u_floats")), like), _empty((n, query("cova_conv3x3_wino4_u_floats")), like)
         call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
         return [("w4", uf[i]) for i in range(n)], [("w4", ud[i]) for i in range(n)]
     pairs = [prep_wino(w, like) for w in ws]

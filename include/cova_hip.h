@@ -58,7 +58,9 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
 /* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
  * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2),
  * 7 = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): A/B,
- * 8 = conv1 weight gradient (bf16-split) in its phase-structured form (1) instead of the role-split one (0, default): A/B */
+ * 8 = conv1 weight gradient (bf16-split) in its phase-structured form (1) instead of the role-split one (0, default): A/B,
+ * 9 = F(4x4,3x3) forward / data-gradient launches on the f32-MFMA main loop (1) instead of the bf16-split one (0, default): A/B.
+ * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
@@ -155,12 +157,18 @@ int cova_conv3x3_wgrad4(const float *act, const float *dz, float *dw /*OIHW*/, f
                         void *stream);
 
 /* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
- * the output scale): u_fwd / u_dgrad 147,456 floats each (the per-wave register image written by the prep kernel);
- * stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2) */
+ * the output scale): u_fwd / u_dgrad cova_conv3x3_wino4_u_floats() floats each per convolution (the per-wave register
+ * images written by the prep kernels: the f32 image, then its three-bf16-piece image);
+ * stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2).
+ * Arithmetic: f32 in, f32 out, f32 transforms and accumulation; the transform-domain products run on the bf16 matrix pipe
+ * with both f32 operands taken as three round-to-nearest bf16 pieces and the six products of order <= 2 (as conv1, see
+ * above): f32-class error (tests/test_kernels_gpu.py::test_conv3x3_winograd_f4x4_split_error_class).  The launches with a
+ * SECOND input tensor (in2) and cova_set_option(9, 1) run the products on v_mfma_f32_16x16x4_f32. */
+int cova_conv3x3_wino4_u_floats(void);
 int cova_conv3x3_wino4_num_tiles(int B, int H, int W);
 int cova_conv3x3_wino4_num_partials(int B, int H, int W);
 int cova_conv3x3_wino4_prep(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
-/* ... of up to four convolutions in ONE launch (w1..w3 nullable): u_fwd / u_dgrad hold n x 147,456 floats */
+/* ... of up to four convolutions in ONE call (w1..w3 nullable): u_fwd / u_dgrad hold n x cova_conv3x3_wino4_u_floats() floats */
 int cova_conv3x3_wino4_prep_multi(const float *w0, const float *w1, const float *w2, const float *w3, float *u_fwd,
                                   float *u_dgrad, void *stream);
 int cova_conv3x3_wino4(const float *in, const float *u, float *out, float *stat_part /*nullable*/, int B, int H,

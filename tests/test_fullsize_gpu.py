@@ -41,7 +41,7 @@ def test_conv3x3_full_size_crops_adjoints_and_stats(fam):
 
     def prep(wt):
         if fam == "w4":
-            a, b_ = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+            a, b_ = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
             call("cova_conv3x3_wino4_prep", wt, a, b_)
         else:
             a, b_ = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)

@@ -416,7 +416,7 @@ def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
     u2f, u2d = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), u2f, u2d)
-    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    u4f, u4d = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
     R = B * H * W
     n = query("cova_colreduce_num_chunks", R, 64)
@@ -566,7 +566,7 @@ def test_conv3x3_winograd_f4x4_full_form(B, H, W, cap):
     abc = rnd(3, 64)
     u2f, u2d = torch.empty(16, 16, 4, 64, device=DEV), torch.empty(16, 16, 4, 64, device=DEV)
     call("cova_conv3x3_prep_weights_wino", w.to(DEV), u2f, u2d)
-    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    u4f, u4d = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
     query("cova_set_option", 2, cap)
     n2, n4 = query("cova_conv3x3_wino_num_partials", B, H, W), query("cova_conv3x3_wino4_num_partials", B, H, W)
@@ -623,7 +623,7 @@ def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
     rnd = lambda *s: torch.randn(*s, generator=g)
     x, x2, z = nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W))
     w = rnd(64, 64, 3, 3) * 0.05
-    u4f, u4d = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    u4f, u4d = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), u4f, u4d)
     gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), rnd(64).to(DEV)
     query("cova_set_option", 2, cap)
@@ -754,7 +754,7 @@ def test_conv3x3_winograd_f4x4_inference_epilogue(B, H, W):
     w = rnd(64, 64, 3, 3) * 0.05
     sc, sh = (rnd(64) * 0.5 + 1.0).to(DEV), (rnd(64) * 0.3).to(DEV)
     abc = rnd(3, 64).to(DEV)
-    uf, ud = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    uf, ud = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
     R = B * H * W
     for pro in (None, abc):
@@ -1032,7 +1032,7 @@ def test_conv3x3_winograd_f4x4(B, H, W):
     g = torch.Generator().manual_seed(H * W + 1)
     x = torch.randn(B, 64, H, W, generator=g).clamp_min(0)
     w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
-    uf, ud = torch.empty(147456, device=DEV), torch.empty(147456, device=DEV)
+    uf, ud = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=DEV)
     call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
     if B == 3:
         query("cova_set_option", 2, 5)          # several tiles per persistent block

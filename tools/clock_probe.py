@@ -14,7 +14,7 @@ w1 = torch.randn(64, 3, 7, 7, device=dev, generator=g) * 0.05
 y1 = torch.empty(B, 640, 640, 64, device=dev)
 x = torch.randn(B, 320, 320, 64, device=dev, generator=g)
 w = torch.randn(64, 64, 3, 3, device=dev, generator=g) * 0.05
-uf, ud = torch.empty(147456, device=dev), torch.empty(147456, device=dev)
+uf, ud = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=dev), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=dev)
 call("cova_conv3x3_wino4_prep", w, uf, ud)
 out = torch.empty_like(x)
 part = torch.empty(query("cova_conv3x3_wino4_num_partials", B, 320, 320), 2, 64, device=dev)

@@ -8,7 +8,7 @@ dev = "cuda:0"
 B, H, W = 16, 320, 320
 x = torch.randn(B, H, W, 64, device=dev).clamp_min(0)
 w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
-uf4, ud4 = torch.empty(16, 4, 64, 36, device=dev), torch.empty(16, 4, 64, 36, device=dev)
+uf4, ud4 = (torch.empty(query("cova_conv3x3_wino4_u_floats"), device=dev) for _ in range(2))
 call("cova_conv3x3_wino4_prep", w, uf4, ud4)
 uf2, ud2 = torch.empty(16, 4, 64, 16, device=dev), torch.empty(16, 4, 64, 16, device=dev)
 call("cova_conv3x3_prep_weights_wino", w, uf2, ud2)

@@ -23,7 +23,7 @@ def timeit(fn, n=20):
 
 x, x2, z, add, act = (torch.randn(B, H, W, 64, device=dev) for _ in range(5))
 w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
-uf, ud = torch.empty(147456, device=dev), torch.empty(147456, device=dev)
+uf, ud = torch.empty(query("cova_conv3x3_wino4_u_floats"), device=dev), torch.empty(query("cova_conv3x3_wino4_u_floats"), device=dev)
 call("cova_conv3x3_wino4_prep", w, uf, ud)
 out = torch.empty_like(x)
 part = torch.empty(query("cova_conv3x3_wino4_num_partials", B, H, W), 2, 64, device=dev)

@@ -35,9 +35,17 @@ constexpr int U_DWORDS = 2 * U_KSTEP_BYTES / 4;           // 221,184 dwords per 
 }  // namespace w4s
 
 // Ablation builds (COVA_EXTRA_FLAGS=-DW4S_ABL=<mask>; 0 in the product): 1 no transform (reads, arithmetic, stores),
-// 4 no MFMAs, 8 no plane copies, 16 no weight loads, 32 no tile epilogue, 64 no operand reads
+// 4 no MFMAs, 8 no plane copies, 16 no weight loads, 32 no tile epilogue, 64 no operand reads, 128 weight loads always from
+// position 0 (L1 hits), 256 weight operand read from LDS instead of global memory
 #ifndef W4S_ABL
 #define W4S_ABL 0
+#endif
+#ifndef W4S_VAR
+#define W4S_VAR 0
+#endif
+// weight positions in flight ahead of the one being multiplied; the register ring has W4S_LEAD + 1 slots (must divide 36)
+#ifndef W4S_LEAD
+#define W4S_LEAD 3
 #endif
 
 __device__ __forceinline__ f32x4 mfma16bf(u32x4 a, u32x4 b, f32x4 c)
@@ -224,10 +232,17 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
     // wave-uniform base + this lane's fixed byte offset
     const char *ubase = reinterpret_cast<const char *>(a.u) + (size_t)wave * (18 * 3 * 1024);
     const unsigned ulane = (unsigned)lane * 16u;
-    u32x4 Ub[4][3];
+    constexpr int UR = W4S_LEAD + 1;
+    static_assert(36 % UR == 0, "ring size must divide the 36-position stream");
+    u32x4 Ub[UR][3];
     auto load_u = [&](const int n, const int slot) {
         if (W4S_ABL & 16) return;
-        const int ks = n / 18, p = n - 18 * ks;
+        const int ks = (W4S_ABL & 128) ? 0 : n / 18, p = (W4S_ABL & 128) ? 0 : n - 18 * ks;     // 128: always position 0 (L1 hits)
+        if (W4S_ABL & 256) {                                         // 256: the operand from LDS (any 3 KB of the piece buffers)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Ub[slot][q] = *reinterpret_cast<const u32x4 *>(vr + ((n % 12) * 3 + q) * w4s::VBLK);
+            return;
+        }
         const char *bp = ubase + (size_t)ks * w4s::U_KSTEP_BYTES + p * 3072;
         unsigned ul = ulane;
         asm volatile("" : "+v"(ul));
@@ -242,12 +257,11 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 #pragma unroll
         for (int g = 0; g < 4; ++g) copy_piece(g, g, i);
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < UR; ++n)
 #pragma unroll
         for (int q = 0; q < 3; ++q) Ub[n][q] = u32x4{0u, 0u, 0u, 0u};
-    load_u(0, 0);
-    load_u(1, 1);
-    load_u(2, 2);
+#pragma unroll
+    for (int n = 0; n < W4S_LEAD; ++n) load_u(n, n);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (PRO) masks(0);
@@ -294,20 +308,39 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             constexpr int n0 = TI * 6;
-            const int n = n0 + j, ub = n & 3;
+            const int n = n0 + j, ub = n % UR;
             if (j < 5) read_v(j + 1, (j + 1) & 1);
             if (!(W4S_ABL & 4)) {
                 f32x4 c = acc[S * 6 + j];
                 const u32x4 *U = Ub[ub], *V = Vr[j & 1];
+#if W4S_VAR == 1
+                // the six products as ONE uninterrupted dependent chain: back-to-back MFMAs on one accumulator forward it
+                // inside the matrix pipe; anything scheduled between them costs the write-back round trip (~43 cycles each)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#if W4S_VAR == 2
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                d = mfma16bf(U[2], V[0], d);
+                c = mfma16bf(U[1], V[0], c);
+                d = mfma16bf(U[0], V[2], d);
+                c = mfma16bf(U[0], V[1], c);
+                d = mfma16bf(U[1], V[1], d);
+                c = mfma16bf(U[0], V[0], c);
+                c += d;
+#else
                 c = mfma16bf(U[2], V[0], c);            // smallest terms first
                 c = mfma16bf(U[0], V[2], c);
                 c = mfma16bf(U[1], V[1], c);
                 c = mfma16bf(U[1], V[0], c);
                 c = mfma16bf(U[0], V[1], c);
                 c = mfma16bf(U[0], V[0], c);
+#endif
+#if W4S_VAR == 1
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 acc[S * 6 + j] = c;
             }
-            load_u((n + 3) % 36, (n + 3) & 3);
+            load_u((n + W4S_LEAD) % 36, (n + W4S_LEAD) % UR);
             // this position's share of the transform work
             if (S == 0) {
                 split_write(j, PAR ^ 1, o);

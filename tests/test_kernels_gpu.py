@@ -1110,6 +1110,64 @@ def test_conv1_bf16_split_error_class(B, H, W, cap):
     assert err[0][0] < 2e-6 and err[0][1] < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,cap,relu_in", [(1, 8, 32, 0, False), (2, 19, 45, 0, True), (3, 100, 200, 5, True), (2, 320, 320, 0, True)])
+def test_conv3x3_winograd_f4x4_split_error_class(B, H, W, cap, relu_in):
+    """The F(4x4,3x3) forward / data-gradient launches with the transform-domain products as six bf16-MFMA products of
+    three-piece operands (csrc/conv_wino4_split.h, the default) against a float64 convolution: the error is the f32-MFMA main
+    loop's (cova_set_option(9, 1)), not a reduced-precision one; the statistics rows agree; the ReLU masks of the data-gradient
+    epilogue are identical; results are bit-reproducible; one-tile, ragged, multi-tile-per-block and full-width cases."""
+    g = torch.Generator().manual_seed(3 * H + W + B)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    xc = rnd(B, 64, H, W)
+    if relu_in:
+        xc = xc.clamp_min(0)
+    x, add, z = nhwc(xc), nhwc(rnd(B, 64, H, W)), nhwc(rnd(B, 64, H, W))
+    w = rnd(64, 64, 3, 3) * 0.05
+    abc = rnd(3, 64).to(DEV)
+    msc, msh = rnd(64).to(DEV), rnd(64).to(DEV) * 0.3
+    mean, invstd = rnd(64).to(DEV) * 0.2, (torch.rand(64, generator=g) + 0.5).to(DEV)
+    nu = query("cova_conv3x3_wino4_u_floats")
+    uf, ud = torch.empty(nu, device=DEV), torch.empty(nu, device=DEV)
+    call("cova_conv3x3_wino4_prep", w.to(DEV), uf, ud)
+    ref_f = F.conv2d(xc.double(), w.double(), padding=1)
+    ref_d = F.conv2d(xc.double(), w.double().flip(2, 3).transpose(0, 1), padding=1)
+    pre = torch.relu(abc[0].cpu().double().view(1, -1, 1, 1) * xc.double() + abc[2].cpu().double().view(1, -1, 1, 1))
+    ref_p = F.conv2d(pre, w.double(), padding=1)
+    N = None
+    err, keep = {}, {}
+    query("cova_set_option", 2, cap)
+    try:
+        n4 = query("cova_conv3x3_wino4_num_partials", B, H, W)
+        for f32 in (1, 0):
+            query("cova_set_option", 9, f32)
+            runs = []
+            for _ in range(2):
+                o_f, p_f = torch.zeros_like(x), torch.zeros(n4, 2, 64, device=DEV)
+                call("cova_conv3x3_wino4_full", x, N, N, 0, uf, N, N, N, N, N, N, N, o_f, p_f, B, H, W)
+                o_p, p_p = torch.zeros_like(x), torch.zeros(n4, 2, 64, device=DEV)
+                call("cova_conv3x3_wino4_full", x, N, abc, 1, uf, N, N, N, N, N, N, N, o_p, p_p, B, H, W)
+                o_d, p_d = torch.zeros_like(x), torch.zeros(n4, 2, 64, device=DEV)
+                call("cova_conv3x3_wino4_full", x, N, N, 0, ud, add, N, msc, msh, z, mean, invstd, o_d, p_d, B, H, W)
+                runs.append((o_f, p_f, o_p, p_p, o_d, p_d))
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])), "not bit-reproducible"
+            o_f, p_f, o_p, p_p, o_d, p_d = runs[0]
+            rel = lambda got, ref: float((nchw(got).double().cpu() - ref).abs().max() / ref.abs().max())
+            e_q = float((p_f[:, 1].double().sum(0).cpu() - (ref_f ** 2).sum((0, 2, 3))).abs().max() / (ref_f ** 2).sum((0, 2, 3)).max())
+            gate = (nchw(z).cpu().double() * msc.cpu().double().view(1, -1, 1, 1) + msh.cpu().double().view(1, -1, 1, 1)) > 0
+            e_d = float(((nchw(o_d).double().cpu() - (ref_d + nchw(add).double().cpu()) * gate).abs() * gate).max() / ref_d.abs().max())
+            err[f32] = (rel(o_f, ref_f), rel(o_p, ref_p), e_q, e_d)
+            keep[f32] = o_d
+    finally:
+        query("cova_set_option", 9, 0)
+        query("cova_set_option", 2, 0)
+    print("F(4x4,3x3) error against fp64 (forward, BatchNorm+ReLU on load, channel sums of squares, data gradient): f32 MFMA "
+          "%.2e %.2e %.2e %.2e | bf16 split %.2e %.2e %.2e %.2e" % (err[1] + err[0]))
+    assert torch.equal(keep[0] == 0, keep[1] == 0), "ReLU masks of the two main loops differ"
+    for a, b in zip(err[0], err[1]):
+        assert a <= 1.5 * b + 2e-7, (err[0], err[1])
+    assert max(err[0][0], err[0][1], err[0][3]) < 2e-5
+
+
 def test_conv1_kernels_do_not_depend_on_the_batch_partition():
     """The conv1 kernels on a 4-page batch in one call against two 2-page calls with bit-identical operands: forward
     outputs and statistics rows are bitwise the same, the weight gradient (BatchNorm + ReLU + MaxPool backward folded

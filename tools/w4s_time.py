@@ -24,6 +24,8 @@ def timeit(fn, n=20):
 B, H, W = 16, 320, 320
 x, z, add, act = (torch.randn(B, H, W, 64, device=dev) for _ in range(4))
 w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+if "--zeros" in sys.argv:          # data-dependent power: all-zero operands (guide: DVFS give-back)
+    x.zero_(); w.zero_()
 uf, ud = torch.empty(NU, device=dev), torch.empty(NU, device=dev)
 call("cova_conv3x3_wino4_prep", w, uf, ud)
 out = torch.empty_like(x)

@@ -139,19 +139,37 @@ class HotPathTrainer:
             sd[k] = (self.params[k] if k in self.params else self.buffers[k]).detach().clone()
         return sd
 
-    def load_state_dict(self, state_dict):
+    def _all_ranks_ok(self, ok, what):
+        """Collective: every rank learns whether ALL ranks validated `what`; raises the same error everywhere instead of
+        leaving the ranks that did validate blocked in the broadcast that follows."""
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            raise KeyError("%s: at least one rank could not validate its argument (this rank: %s)" % (what, "ok" if ok else "failed"))
+
+    def load_state_dict(self, state_dict, broadcast=False):
         """Restore parameters and BatchNorm buffers from a reference-layout state_dict -- the save-best /
         reload-best cycle of train.py:84,94 (`torch.save(model.state_dict())`, `load_state_dict(torch.load(...))`).
-        The flat buffers keep their addresses (views, moments and bucket stay valid)."""
+        The flat buffers keep their addresses (views, moments and bucket stay valid).
+
+        Local by default: a rank-0-only reload ("reload best, evaluate on rank 0") involves no collective.  With
+        `broadcast=True` the call IS a collective that EVERY rank must make: the keys are validated on all ranks first
+        (one all-reduce of an ok flag, so a KeyError on one rank raises on all of them), then rank 0's parameters and
+        buffers -- what was loaded, not the Adam moments or the step count -- replace every rank's."""
         missing = [k for k in list(self.params) + list(self.buffers) if k not in state_dict]
+        if broadcast and self.world_size > 1:
+            self._all_ranks_ok(not missing, "load_state_dict")
         if missing:
             raise KeyError("state_dict lacks %s" % missing[:4])
         for k, p in self.params.items():
             p.copy_(state_dict[k].to(p.device).view_as(p))
         for k in self.buffers:
             self.buffers[k].copy_(state_dict[k].to(self.device))
-        if self.world_size > 1:             # every rank calls it (a collective): replicas continue from rank 0's copy
-            self.broadcast_state(src=0)
+        if broadcast and self.world_size > 1:
+            import torch.distributed as dist
+            for t in [self.pbucket.flat] + [self.buffers[k] for k in sorted(self.buffers)]:
+                dist.broadcast(t, src=0, group=self.group)
 
     def optimizer_state_dict(self):
         """Adam moments + step count (the reference keeps no optimizer state in its checkpoints, train.py:84;
@@ -159,13 +177,30 @@ class HotPathTrainer:
         return dict(step=self.step_count, exp_avg=self.exp_avg.detach().clone(),
                     exp_avg_sq=self.exp_avg_sq.detach().clone(), hp=dict(self.hp))
 
-    def load_optimizer_state_dict(self, state):
+    def load_optimizer_state_dict(self, state, broadcast=False):
+        """Adam moments, step count and hyper-parameters.  Local by default; `broadcast=True` makes it a collective every
+        rank must call (validated on all ranks first) after which every rank holds rank 0's moments, step count and
+        hyper-parameters."""
+        ok = all(k in state for k in ("step", "exp_avg", "exp_avg_sq"))
+        if broadcast and self.world_size > 1:
+            self._all_ranks_ok(ok, "load_optimizer_state_dict")
+        if not ok:
+            raise KeyError("optimizer state lacks one of step / exp_avg / exp_avg_sq")
         self.step_count = int(state["step"])
         self.exp_avg.copy_(state["exp_avg"].to(self.device))
         self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device))
         self.hp.update(state.get("hp", {}))
-        if self.world_size > 1:             # (collective, as load_state_dict)
-            self.broadcast_state(src=0)
+        if broadcast and self.world_size > 1:
+            import torch.distributed as dist
+            for t in (self.exp_avg, self.exp_avg_sq):
+                dist.broadcast(t, src=0, group=self.group)
+            b1, b2 = self.hp["betas"]
+            meta = torch.tensor([float(self.step_count), self.hp["lr"], self.hp["weight_decay"], b1, b2, self.hp["eps"]],
+                                dtype=torch.float64, device=self.device)
+            dist.broadcast(meta, src=0, group=self.group)
+            m = meta.tolist()
+            self.step_count = int(m[0])
+            self.hp.update(lr=m[1], weight_decay=m[2], betas=(m[3], m[4]), eps=m[5])
 
     def forward_backward(self, batch, masks=None):
         """Forward + CE(sum) + backward into the flat gradient bucket.  Returns (loss, pred)."""

@@ -95,3 +95,56 @@ def test_gloo_allreduce_of_flat_bucket_equals_sum_of_shard_gradients(tmp_path):
     for k, v in expect.items():
         assert torch.equal(r0[k], r1[k]), k                       # every rank holds the same sum
         assert torch.allclose(r0[k], v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max()))), k  # thread-count dependent summation order
+
+
+def _state_worker(rank, world, port, out_dir):
+    """load_state_dict / load_optimizer_state_dict of HotPathTrainer across two ranks (flat buckets on the CPU: no device work)."""
+    from cova_web_object_detection_amd.trainer import HotPathTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wcfg = {k: v for k, v in CFG.items() if k != "drop_prob"}
+    res = {}
+    tr = HotPathTrainer(CFG, weights.seeded_state_dict(40 + rank, **wcfg), "cpu", world_size=world)
+    res["start"] = tr.pbucket.flat.clone()                       # rank 0's weights everywhere (start-up broadcast)
+    # a rank-0-only reload (train.py:94 "reload best" on one rank) is LOCAL: no collective, no hang
+    if rank == 0:
+        tr.load_state_dict(weights.seeded_state_dict(77, **wcfg))
+    res["after_local"] = tr.pbucket.flat.clone()
+    # broadcast=True: parameters and buffers of rank 0 everywhere, the Adam moments and step count stay this rank's
+    tr.exp_avg.fill_(float(rank + 1))
+    tr.step_count = 10 + rank
+    tr.load_state_dict(weights.seeded_state_dict(50 + rank, **wcfg), broadcast=True)
+    res["after_bcast"] = tr.pbucket.flat.clone()
+    res["moments_kept"] = bool((tr.exp_avg == float(rank + 1)).all()) and tr.step_count == 10 + rank
+    # a state_dict that only ONE rank cannot validate raises on BOTH (nobody is left inside the broadcast)
+    bad = weights.seeded_state_dict(60, **wcfg)
+    if rank == 1:
+        bad = {"convnet.0.weight": bad["convnet.0.weight"]}
+    try:
+        tr.load_state_dict(bad, broadcast=True)
+        res["raised"] = False
+    except KeyError:
+        res["raised"] = True
+    res["unchanged_after_error"] = torch.equal(tr.pbucket.flat, res["after_bcast"]) if rank == 1 else True
+    # optimizer state: moments, step count and hyper-parameters of rank 0
+    st = tr.optimizer_state_dict()
+    st["hp"]["lr"] = 1e-3 * (rank + 1)
+    tr.load_optimizer_state_dict(st, broadcast=True)
+    res["opt"] = (tr.step_count, tr.hp["lr"], float(tr.exp_avg[0]))
+    torch.save(res, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainer_state_loads_are_local_unless_broadcast_is_asked_for(tmp_path):
+    """load_state_dict / load_optimizer_state_dict involve a collective only with broadcast=True; then keys are
+    validated on every rank before the broadcast, which carries what was loaded and nothing else."""
+    world, port = 2, _free_port()
+    mp.spawn(_state_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(world))
+    assert torch.equal(r0["start"], r1["start"])
+    assert not torch.equal(r0["after_local"], r1["after_local"]) and torch.equal(r1["after_local"], r1["start"])
+    assert torch.equal(r0["after_bcast"], r1["after_bcast"]) and not torch.equal(r0["after_bcast"], r0["after_local"])
+    assert r0["moments_kept"] and r1["moments_kept"]
+    assert r0["raised"] and r1["raised"] and r1["unchanged_after_error"]
+    assert r0["opt"] == r1["opt"] == (10, 1e-3, 1.0)

@@ -14,11 +14,13 @@ bench.py --gpus N` launches itself through torch.distributed.run when it is not 
 (256 pages unless --global-pages) and splits it over the ranks.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- the dominant kernel family (Winograd conv3x3 64->64 on exact-f32 MFMA), timed live with HIP
-                  events on the launching stream inside the timed steps.  `frac` = EXECUTED MFMA FLOP/s over
-                  the 157.3 TFLOP/s f32-MFMA peak (<= 1 by construction); the algorithmic (direct-convolution,
-                  SURVEY.md 8d) rate of the same launches is reported beside it -- Winograd F(4x4,3x3)
-                  executes 4x fewer multiplies, so that rate may exceed the direct-form peak.
+  roofline     -- the dominant kernel family (Winograd F(4x4,3x3) conv3x3 64->64, forward + data gradient), timed live with
+                  HIP events on the launching stream inside the timed steps.  Since round 5 its transform-domain products run
+                  on the bf16 matrix pipe (f32 operands as three bf16 pieces, six products): the launch's matrix floor drops
+                  below its HBM floor, so `bound` = "hbm", `achieved` = ALGORITHMIC bytes per launch / mean launch time,
+                  `traffic` = the PMC bytes; the bf16-pipe rate, the f32-equivalent rate (the round-4 `frac`) and the
+                  per-floor times are reported beside it.  COVA_W4_F32=1 selects the f32-MFMA main loop (`bound` = "mfma").
+  ab           -- same process, same trainer: 10 steps each with conv1 / the 3x3 main loop on their f32-MFMA forms.
   sustained    -- >= 5 s of back-to-back train steps after the headline measurement (same batch), reported
                   separately: long enough for an external utilisation sampler to see the GPU work.
   step         -- whole-step FLOP accounting: algorithmic TFLOP/s, fraction of the direct-convolution MFMA
@@ -45,10 +47,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0                     # ... dense bf16 MFMA (the three-piece split kernels run six products per f32 product)
 PEAK_HBM_TBS = 8.0
+SPLIT_PRODUCTS = 6                                 # bf16 MFMA products per f32 multiply-add of the split kernels
 WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3): the weight gradients
 WINO4_RATIO = 4.0                                  # ... / Winograd F(4x4,3x3): forward and data-gradient launches
-TRAFFIC_FILES = [os.path.join("profiles", "r04_hbm_traffic.json"), os.path.join("profiles", "r03_hbm_traffic.json")]
+TRAFFIC_FILES = [os.path.join("profiles", "r05_hbm_traffic.json"), os.path.join("profiles", "r04_hbm_traffic.json"),
+                 os.path.join("profiles", "r03_hbm_traffic.json")]
 
 WORKLOADS = {
     2: dict(name="configs[1]", H=1280, W=1280, pages=16, boxes=90, cs=12, backbone="resnet18", n_heads=1,
@@ -119,16 +124,19 @@ def flop_model(wl):
 
 def read_traffic(kernel_key, pages):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate FETCH_SIZE /
-    WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/hbm_traffic.py writes the file)."""
+    WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/hbm_traffic.py writes the file).  Since round 5
+    the file holds the launches of ONE train step keyed by kernel variant (`step_kernels`) and their per-family means
+    (`step_families`): the number is the mean over the variant mix the step launches, not over every launch of the
+    profiling run (which also carried the eval and drop-in legs' variants)."""
     for rel in TRAFFIC_FILES:          # the newest PMC pass that has the kernel (an older round's file is a stale number:
         path = os.path.join(ROOT, rel)  # the source is named in the line)
         if not os.path.exists(path):
             continue
         try:
             d = json.load(open(path))
-            e = d["kernels"][kernel_key]
+            e = d.get("step_families", {}).get(kernel_key) or d["kernels"][kernel_key]
             step = d.get("step_traffic_bytes")
-            return (e["traffic_bytes_per_launch"] * pages / d["pages"], rel,
+            return (e["traffic_bytes_per_launch"] * pages / d["pages"], rel + (":step_families" if "step_families" in d else ""),
                     step * pages / d["pages"] if step else None)
         except Exception:
             continue
@@ -461,6 +469,35 @@ def run(args, guard, rank, local_rank, world):
     barrier()
     dt_fwd = max_over_ranks(time.perf_counter() - t1)
 
+    # A/B legs in the same process, same trainer (the engine queries workspace sizes per step): the f32-MFMA forms of the
+    # kernels that run on the bf16 matrix pipe by default -- conv1 forward + weight gradient (cova_set_option 7) and the
+    # F(4x4,3x3) forward / data-gradient main loop (option 9) -- each 3 warm-up + 10 timed steps
+    ab = {}
+    if world == 1:
+        guard.enter("A/B legs")
+        pre7, pre9 = os.environ.get("COVA_CONV1_F32") == "1", os.environ.get("COVA_W4_F32") == "1"
+        for key, opt, pre, what in (("conv1_f32", 7, pre7, "conv1 forward + weight gradient on v_mfma_f32_32x32x2_f32"),
+                                    ("wino4_f32", 9, pre9, "3x3 forward + data gradient on v_mfma_f32_16x16x4_f32")):
+            if pre:
+                continue
+            _lib.query("cova_set_option", opt, 1)
+            try:
+                for _ in range(3):
+                    trainer.train_step(batch)
+                barrier()
+                ta = time.perf_counter()
+                for _ in range(10):
+                    trainer.train_step(batch)
+                barrier()
+                dta = time.perf_counter() - ta
+            finally:
+                _lib.query("cova_set_option", opt, 0)
+            ab[key] = {"value": round(pages * 10 / dta, 2), "unit": "webpages/s", "ms_per_step": round(1e3 * dta / 10, 3),
+                       "steps": 10, "what": what + ", everything else as the headline"}
+        for _ in range(2):                      # back on the default kernels before the next leg
+            trainer.train_step(batch)
+        barrier()
+
     # the drop-in nn.Module route with the reference's loop cadence (train.py:45-60: zero_grad, forward,
     # argmax + .item(), CE-sum + .item(), backward, torch.optim.Adam.step) -- two host reads per step
     dropin = None
@@ -511,49 +548,75 @@ def run(args, guard, rank, local_rank, world):
         w4_ms, w4_n = mean_ms(["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail"])
         w2_ms, w2_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
         use4 = w4_n > 0
+        split = use4 and os.environ.get("COVA_W4_F32") != "1"        # the bf16 three-piece main loop (default since round 5)
         conv_ms, conv_n, ratio = (w4_ms, w4_n, WINO4_RATIO) if use4 else (w2_ms, w2_n, WINO_RATIO)
-        kname = "conv3x3_c64_wino4_kernel" if use4 else "conv3x3_c64_wino_kernel"
+        kname = ("conv3x3_c64_wino4s_kernel" if split else "conv3x3_c64_wino4_kernel") if use4 else "conv3x3_c64_wino_kernel"
         alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
-        executed = alg / ratio
+        executed = alg / ratio                                            # f32 multiply-adds the Winograd form executes
         map_bytes = 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4)
-        roof = {"bound": "mfma", "kernel": kname + " (forward + data-gradient launches of the step)",
-                "algorithm": "winograd %s, exact f32 MFMA (v_mfma_f32_16x16x4_f32)" % ("F(4x4,3x3)" if use4 else "F(2x2,3x3)"),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches_timed": conv_n}
+        # compulsory bytes of the launches as they run in the step: besides one input and one output map the fused
+        # variants read the residual-branch gradient and the mask / xhat operands of their epilogues --
+        # per train step 27 maps over 8 launches (ResNet-18) or 18 over 6 (ResNet-50 stem)
+        alg_bytes = int((27 / 8 if wl["backbone"] == "resnet18" else 18 / 6) * map_bytes)
+        roof = {"kernel": kname + " (forward + data-gradient launches of the step)", "launches_timed": conv_n}
         if conv_n:
-            ach = executed / conv_ms / 1e9
             traffic, src, step_traffic = read_traffic(kname, px_pages)
+            f32_equiv = executed / conv_ms / 1e9                          # TFLOP/s of f32 multiply-adds executed
+            if split:
+                # Six bf16-MFMA products per f32 multiply-add at 16x the f32-MFMA rate: the matrix floor of a launch is
+                # 6 * executed / 2.5 PFLOP/s = 0.07 ms against algorithmic_bytes / 8 TB/s = 0.18 ms -- in this
+                # formulation the launch is bounded by HBM, and that is the roof it is priced against.
+                ach = alg_bytes / conv_ms / 1e6                           # GB/s
+                roof.update(bound="hbm", algorithm="winograd F(4x4,3x3); transform-domain products on the bf16 matrix pipe, f32 "
+                            "operands as three bf16 pieces, six products accumulated in f32 (v_mfma_f32_16x16x32_bf16)",
+                            achieved=round(ach, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s", frac=round(ach / (PEAK_HBM_TBS * 1e3), 4),
+                            achieved_is="ALGORITHMIC bytes per launch (mean over the step's eight launches) / mean launch time",
+                            floors_ms={"hbm_algorithmic_bytes_at_8_TBps": round(alg_bytes / PEAK_HBM_TBS / 1e9, 4),
+                                       "bf16_mfma_six_products_at_2.5_PFLOPs": round(SPLIT_PRODUCTS * executed / PEAK_BF16_MFMA_TFLOPS / 1e9, 4),
+                                       "weight_stream_L2_to_registers_at_64_B_per_clk_CU": round(
+                                           884736.0 * (px_pages * (wl["H"] // 4) * (wl["W"] // 4) / 256.0) / (256 * 64 * 2.4e9) * 1e3, 4)},
+                            mfma={"pipe": "bf16", "executed_tflops": round(SPLIT_PRODUCTS * f32_equiv, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                  "frac": round(SPLIT_PRODUCTS * f32_equiv / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  "note": "six bf16 products per f32 multiply-add of the F(4x4) form"},
+                            f32_equivalent={"executed_tflops": round(f32_equiv, 2), "frac_of_f32_mfma_peak": round(f32_equiv / PEAK_F32_MFMA_TFLOPS, 4),
+                                            "note": "the round-4 line's `frac` (f32 multiply-adds executed over the 157.3 TFLOP/s the f32-MFMA "
+                                                    "main loop is bounded by); the wino4_f32 A/B leg runs that loop"})
+            else:
+                roof.update(bound="mfma", algorithm="winograd %s, exact f32 MFMA (v_mfma_f32_16x16x4_f32)" % ("F(4x4,3x3)" if use4 else "F(2x2,3x3)"),
+                            achieved=round(f32_equiv, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(f32_equiv / PEAK_F32_MFMA_TFLOPS, 4),
+                            achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio)
             if traffic:
-                roof.update(hbm_achieved_tb_per_s=round(traffic / conv_ms / 1e9, 3),
-                            hbm_frac=round(traffic / conv_ms / 1e9 / PEAK_HBM_TBS, 4))
+                roof.update(hbm_achieved_tb_per_s=round(traffic / conv_ms / 1e9, 3), hbm_frac=round(traffic / conv_ms / 1e9 / PEAK_HBM_TBS, 4))
             if step_traffic:
                 roof.update(step_traffic_bytes=int(step_traffic))
-            roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio, avg_launch_ms=round(conv_ms, 4),
-                        executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
+            roof.update(avg_launch_ms=round(conv_ms, 4), executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
                         algorithmic_achieved=round(alg / conv_ms / 1e9, 2),
                         algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=traffic, traffic_unit="B/launch", traffic_source=src,
-                        # compulsory bytes of the launches as they run in the step: besides one input and one
-                        # output map the fused variants read the prologue's second operand, the residual-branch
-                        # gradient and the mask / xhat operands of their epilogues -- per train
-                        # step 27 maps over 8 launches (ResNet-18) or 18 over 6 (ResNet-50 stem)
-                        algorithmic_bytes=int((27 / 8 if wl["backbone"] == "resnet18" else 18 / 6) * map_bytes),
-                        algorithmic_bytes_plain_launch=2 * map_bytes)
+                        traffic=traffic, traffic_unit="B/launch", traffic_source=src, algorithmic_bytes=alg_bytes,
+                        algorithmic_bytes_plain_launch=2 * map_bytes,
+                        profiling="per-launch HIP events on the launching stream inside the timed region (~45 launches per step are "
+                                  "bracketed; the `sustained` leg runs without them)")
         step_alg = fm["total"] * pages                                   # per rank
-        # executed multiplies: weight gradients as F(2x2,3x3), forward + data gradients as F(4x4,3x3) when those kernels ran
-        step_exec = (fm["total"] - fm["wino"] + fm["wino"] / 3 / WINO_RATIO + 2 * fm["wino"] / 3 / ratio) * pages
+        # executed multiply-adds: every 3x3 convolution at the Winograd share of the kernel that ran
+        _, wg4_n = mean_ms(["cova_conv3x3_wgrad4_partial"])
+        wg_ratio = WINO4_RATIO if wg4_n else WINO_RATIO
+        step_exec = (fm["total"] - fm["wino"] + fm["wino"] / 3 / wg_ratio + 2 * fm["wino"] / 3 / ratio) * pages
         step = {"algorithmic_gflop_per_page": round(fm["total"] / 1e9, 2),
                 "algorithmic_tflops": round(step_alg / (ms_per_step * 1e-3) / 1e12, 2),
                 "frac_of_direct_ceiling": round(step_alg / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "executed_gflop_per_page": round(step_exec / pages / 1e9, 2),
                 "frac_of_executed_floor": round(step_exec / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "per GPU; executed = 3x3 convolutions counted at Winograd's share of the direct multiplies "
-                        "(weight gradient 1/2.25, forward and data gradient 1/%g)" % ratio}
+                "note": "per GPU; executed = 3x3 convolutions counted at Winograd's share of the direct multiplies (weight "
+                        "gradient 1/%g, forward and data gradient 1/%g), priced against the f32-MFMA peak although conv1 and the "
+                        "3x3 forward / data-gradient launches run six bf16 products per multiply-add on the 16x faster pipe"
+                        % (wg_ratio, ratio)}
         others = {}
         hw = (wl["H"] // 4) * (wl["W"] // 4)
         f_conv1 = 2 * 64 * 147 * pages * (wl["H"] // 2) * (wl["W"] // 2)
-        specs = [("conv1_7x7_fwd", ["cova_conv1_fwd", "cova_conv1_fwd_tail"], None, f_conv1, 0),
-                 ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0),
+        c1_split = os.environ.get("COVA_CONV1_F32") != "1"
+        specs = [("conv1_7x7_fwd", ["cova_conv1_fwd", "cova_conv1_fwd_tail"], None, f_conv1, 0, c1_split),
+                 ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0, c1_split),
                  ("conv3x3_wgrad_winograd_f2x2", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
                                                   "cova_conv3x3_wgrad_wino_partial"], None,
                   fm["conv3_launch_per_page"] * pages / WINO_RATIO, 0),
@@ -572,11 +635,16 @@ def run(args, guard, rank, local_rank, world):
                               (lambda a, ci=cin, co=cout: a[-2:] == (ci, co)), 2 * cin * cout * R, 4 * (cin + cout) * R))
                 specs.append(("conv1x1_wgrad_%dx%d" % (cout, cin), ["cova_conv1x1_wgrad"],
                               (lambda a, ci=cin, co=cout: a[-2:] == (co, ci)), 2 * cin * cout * R, 4 * (cin + cout) * R))
-        for key, names, pred, flop, nbytes in specs:
+        for spec in specs:
+            key, names, pred, flop, nbytes = spec[:5]
+            on_bf16 = len(spec) > 5 and spec[5]
             ms, n = mean_ms(names, pred)
             if n:
                 o = {"avg_launch_ms": round(ms, 4), "launches_timed": n}
-                if flop:
+                if flop and on_bf16:       # six bf16 products per f32 multiply-add, against the pipe the kernel uses
+                    o.update(f32_equivalent_tflops=round(flop / ms / 1e9, 1), executed_tflops_bf16_pipe=round(SPLIT_PRODUCTS * flop / ms / 1e9, 1),
+                             frac_of_bf16_mfma_peak=round(SPLIT_PRODUCTS * flop / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 3))
+                elif flop:
                     o.update(executed_tflops=round(flop / ms / 1e9, 1), frac_of_f32_mfma_peak=round(flop / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 3))
                 if nbytes:
                     o.update(compulsory_tb_per_s=round(nbytes / ms / 1e9, 2), frac_of_hbm_peak=round(nbytes / ms / 1e9 / PEAK_HBM_TBS, 3))
@@ -594,18 +662,22 @@ def run(args, guard, rank, local_rank, world):
                        "boxes_per_gpu": n_boxes, "world_size": world, "collective_backend": "rccl" if backend == "nccl" else backend,
                        "rccl_ranks_seen": ranks_seen, "gpus_visible": n_dev,
                        "parallelism": "dp%d" % world + ("+syncbn" if args.sync_bn and world > 1 else "") + diag,
-                       "arithmetic": "f32 throughout (weights, activations, gradients, accumulation).  3x3 convolutions, GEMMs: "
-                                     "f32 MFMA.  conv1 (7x7) forward and weight gradient%s: each f32 operand as three bf16 pieces "
-                                     "(<= 2^-26 left), six bf16-MFMA products accumulated in f32 -- error against fp64 equal to "
-                                     "the f32-MFMA kernels' (tools/conv1_bench.py), same parity gates"
-                                     % (" run on the f32-MFMA kernels (COVA_CONV1_F32=1)" if os.environ.get("COVA_CONV1_F32") == "1"
-                                        else ""),
+                       "arithmetic": "f32 throughout (weights, activations, gradients, transforms, accumulation).  3x3 weight gradients, "
+                                     "1x1 convolutions, GEMMs: f32 MFMA.  conv1 (7x7) forward and weight gradient%s and the 3x3 forward / "
+                                     "data-gradient launches' transform-domain products%s: each f32 operand as three round-to-nearest bf16 "
+                                     "pieces (<= 2^-26 left), six bf16-MFMA products accumulated in f32 -- error against fp64 at or below "
+                                     "the f32-MFMA kernels' (tests/test_kernels_gpu.py::test_conv1_bf16_split_error_class, "
+                                     "::test_conv3x3_winograd_f4x4_split_error_class), same parity gates; the `ab` legs time the f32-MFMA forms"
+                                     % (" [here: f32-MFMA kernels, COVA_CONV1_F32=1]" if os.environ.get("COVA_CONV1_F32") == "1" else "",
+                                        " [here: f32-MFMA main loop, COVA_W4_F32=1]" if os.environ.get("COVA_W4_F32") == "1" else ""),
                        "loss": round(loss_val, 3)},
             "roofline": roof, "step": step, "other_kernels": others,
             "forward_only": {"value": round(global_pages * args.steps / dt_fwd, 2), "unit": "webpages/s",
                              "ms_per_step": round(1e3 * dt_fwd / args.steps, 3),
                              "mode": "eval forward (running statistics) + per-box argmax, same batch"},
         }
+        if ab:
+            out["ab"] = ab
         if sustained:
             out["sustained"] = sustained
         out["per_rank"] = {"ms_per_step": per_rank_ms, "allreduce_exposed_ms": exposed_ms,

@@ -60,6 +60,10 @@ class _Lib:
             self.fn[name] = f
         if os.environ.get("COVA_CONV1_F32") == "1":      # A/B: conv1 on the f32-MFMA kernels instead of the bf16-split ones
             self.cdll.cova_set_option(7, 1)
+        if os.environ.get("COVA_W4_F32") == "1":         # A/B: F(4x4,3x3) forward / data gradient on the f32-MFMA main loop
+            self.cdll.cova_set_option(9, 1)
+        if os.environ.get("COVA_WG4_PAIR_SYNC") in ("0", "1"):   # A/B: pacing of the weight gradient's block pairs
+            self.cdll.cova_set_option(10, int(os.environ["COVA_WG4_PAIR_SYNC"]))
 
 
     def load_extra(self, header, lib_path):

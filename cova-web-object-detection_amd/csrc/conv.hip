@@ -1784,6 +1784,7 @@ int cova_internal_ablate() { return g_ablate; }
 // test / tool hooks (not part of the path's contract): 2 = cap on persistent grids (tests force many tiles per
 // block), 5 = ablation mask of builds made with -DCOVA_ABLATE (tools/conv_bench.py), 6 = Winograd tile geometry
 int cova_internal_set_wino4_f32(int v);
+int cova_internal_set_wgrad4_pair_sync(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1792,6 +1793,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
     if (key == 8) { g_conv1_wgrad_phases = value != 0; return COVA_OK; }
     if (key == 9) return cova_internal_set_wino4_f32(value);
+    if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
     return COVA_ERR_BAD_ARG;
 }
 

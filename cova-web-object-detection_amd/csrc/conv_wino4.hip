@@ -106,6 +106,7 @@ struct W4Epi {
     const float *addend, *act, *z, *mean, *invstd, *msc, *msh;
     const uint32_t *act_bits;       // BN == 2: the mask as one bit per element ([pixel][2] words) instead of act
     int inf_relu;                   // BN == 3 (inference epilogue  out = f(msc*y + msh + addend)): f = ReLU
+    int inference;                  // 1: the inference epilogue (set by cova_conv3x3_wino4_bnact only)
 };
 
 struct W4Args {
@@ -668,7 +669,7 @@ void launch_w4_pro(const W4Args &a, int grid, hipStream_t st)
 {
     const bool add = a.epi.addend != nullptr;
     const int bn = a.epi.z == nullptr ? 0 : (a.epi.act == nullptr && a.epi.act_bits == nullptr ? 1 : 2);
-    if (a.epi.z == nullptr && a.epi.msc != nullptr) {          // inference epilogue (no statistics)
+    if (a.epi.inference) {                                     // inference epilogue (no statistics)
         if (add) launch_w4<false, PRO, true, 3>(a, grid, st); else launch_w4<false, PRO, false, 3>(a, grid, st);
     } else if (bn == 0) {
         if (a.stat_part) { if (add) launch_w4<true, PRO, true, 0>(a, grid, st); else launch_w4<true, PRO, false, 0>(a, grid, st); }
@@ -693,7 +694,8 @@ int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu
     COVA_REQUIRE(in && u && out && B > 0 && H > 0 && W > 0);
     COVA_REQUIRE((long long)H * W * 64 < (1ll << 31));          // 32-bit in-image offsets in the epilogue
     COVA_REQUIRE(epi.z == nullptr || ((epi.act || epi.act_bits || (epi.msc && epi.msh)) && epi.mean && epi.invstd && stat_part));
-    COVA_REQUIRE(epi.z != nullptr || epi.msc == nullptr || (epi.msh != nullptr && stat_part == nullptr));     // inference epilogue
+    COVA_REQUIRE(!epi.inference || (epi.z == nullptr && epi.msc != nullptr && epi.msh != nullptr && stat_part == nullptr));
+    COVA_REQUIRE(epi.inference || epi.z != nullptr || (epi.msc == nullptr && epi.msh == nullptr));     // scale / shift need z, or the inference form
     COVA_REQUIRE(!(epi.act && epi.act_bits));
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
     const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi, t};
@@ -749,7 +751,7 @@ COVA_API int cova_conv3x3_wino4_bnact(const float *in, const float *pro_abc, int
 {
     COVA_REQUIRE(scale && shift);
     return run_w4(in, nullptr, pro_abc, pro_relu, u,
-                  W4Epi{addend, nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, relu}, out, nullptr, B, H, W, stream);
+                  W4Epi{addend, nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, relu, 1}, out, nullptr, B, H, W, stream);
 }
 
 // act_bits (instead of act): the mask source as one bit per element, [B*H*W][2] words as cova_bn_act_fwd_bits writes them

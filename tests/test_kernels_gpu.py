@@ -791,7 +791,8 @@ def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
     query("cova_set_option", 2, cap)
     try:
         ws = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", B, H, W), device=DEV)
-        assert ws.numel() == query("cova_conv3x3_wgrad4_num_partials", B, H, W) * 18 * 4096
+        nblk = query("cova_conv3x3_wgrad4_num_partials", B, H, W)
+        assert ws.numel() == nblk * 18 * 4096 + ((nblk + 63) // 64) * 64       # partial sums + one progress word per block
         dw = torch.zeros(64, 64, 3, 3, device=DEV)
         call("cova_conv3x3_wgrad4", x, dy, dw, ws, B, H, W)
         close(dw, wr.grad, 5e-5, "F(4x4) wgrad vs fp64")      # (random data: no coherent signal; the F(2x2) test allows 2e-4)
@@ -811,9 +812,9 @@ def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
             call("cova_conv3x3_wgrad4_partial", x, abc_a if pa else None, 1, dy, z if pd == 2 else None,
                  abc_d if pd else None, dzo, ws2, B, H, W)
             call("cova_conv3x3_wgrad4_finish", ws2, got, None, None, None, None, None, None, B, H, W)
-            if pd == 2:     # the side output = the operand the data-gradient kernel's prologue would form: same fma, every pixel once
-                assert torch.isfinite(dzo).all()
-                close(dzo, dz2, 1e-6, "materialised gradient operand")
+            if pd:          # the side output = the operand the data-gradient kernel's prologue would form: same fma, every pixel once
+                assert torch.isfinite(dzo).all(), "side output has unwritten pixels (pd = %d)" % pd
+                close(dzo, dz2 if pd == 2 else dz1, 1e-6, "materialised gradient operand (pd = %d)" % pd)
             # (pd != 0: torch.addcmul rounds the products, the kernel's fma does not -- an ulp on the operand)
             close(got, ref, 2e-6 if pd == 0 else 1e-5, "F(4x4) wgrad affine-on-load %s %s" % (pa, pd))
         # one finish launch for two convolutions

@@ -18,8 +18,7 @@ def per_kernel(path, counter):
                       "where counter_name = ? group by kernel_name", (counter,)).fetchall()
     out = {}
     for name, calls, v, dur in rows:
-        name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-        out[name] = (calls, v, dur / 1e3)
+        out[clean(name)] = (calls, v, dur / 1e3)
     return out
 
 
@@ -27,8 +26,8 @@ def family(name):
     return name.split("<")[0]
 
 
-def step_total(path, counter, which=2):
-    """Sum of `counter` over the launches of ONE training step (delimited by the Adam launches, as tools/rocpd_step.py),
+def step_rows(path, counter, which=2):
+    """(kernel name, value) of every launch of ONE training step (delimited by the Adam launches, as tools/rocpd_step.py),
     or None when the database has no usable launch order."""
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
@@ -40,7 +39,11 @@ def step_total(path, counter, which=2):
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
     if len(adam) <= which:
         return None
-    return sum(v for _, v in rows[adam[which - 1] + 1:adam[which] + 1])
+    return [(clean(n), v) for n, v in rows[adam[which - 1] + 1:adam[which] + 1]]
+
+
+def clean(name):
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def main():
@@ -65,11 +68,24 @@ def main():
                       "traffic_bytes_per_launch": round((2.0 * fk + wk) / calls * 1024.0), "avg_us": round(us / calls, 1)}
     doc = {"pages": pages, "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 half-count of 16-B/lane reads)",
            "kernels": kernels}
-    sf, sw = step_total(fetch_db, "FETCH_SIZE"), step_total(write_db, "WRITE_SIZE")
-    if sf is not None and sw is not None:         # every launch of one training step (Adam to Adam), the same correction
-        doc["step_traffic_bytes"] = round((2.0 * sf + sw) * 1024.0)
+    rf, rw = step_rows(fetch_db, "FETCH_SIZE"), step_rows(write_db, "WRITE_SIZE")
+    if rf is not None and rw is not None and [n for n, _ in rf] == [n for n, _ in rw]:
+        # every launch of one training step (Adam to Adam), the same correction: per kernel VARIANT (template instance) and
+        # per family over the variant mix the step launches -- what bench.py's roofline.traffic reads
+        doc["step_traffic_bytes"] = round((2.0 * sum(v for _, v in rf) + sum(v for _, v in rw)) * 1024.0)
         doc["step_traffic_note"] = "sum over the launches of one training step of the trace (second one), KiB counters * 1024"
+        sk, sfam = {}, {}
+        for (n, fv), (_, wv) in zip(rf, rw):
+            for key, table in ((n, sk), (family(n), sfam)):
+                e = table.setdefault(key, [0, 0.0])
+                e[0] += 1
+                e[1] += (2.0 * fv + wv) * 1024.0
+        doc["step_kernels"] = {k: {"launches_in_step": c, "traffic_bytes_per_launch": round(t / c)} for k, (c, t) in sk.items()}
+        doc["step_families"] = {k: {"launches_in_step": c, "traffic_bytes_per_launch": round(t / c)} for k, (c, t) in sfam.items()}
         lines.append("# one training step (Adam to Adam): 2*FETCH + WRITE = %.2f GB" % (doc["step_traffic_bytes"] / 1e9))
+        lines.append("# launches of that step by kernel variant: count, traffic MB per launch")
+        for k, (c, t) in sorted(sk.items(), key=lambda kv: -kv[1][1]):
+            lines.append("#   %-100s %3d %10.1f" % (k[:100], c, t / c / 1e6))
     json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
     if txt:
         open(txt, "w").write("\n".join(lines) + "\n")

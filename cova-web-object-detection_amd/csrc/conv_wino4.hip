@@ -561,6 +561,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
 // position (i = 3 ph + p / 6, j = p % 6) for output channel cog*16 + l15 and input channel 8 s + 4 kg + kq:
 // (G g G^T)[i][j].   fwd: g = w[co][ci][:, :];   dgrad: output channel = ci, input channel = co, g rotated by 180 degrees
 struct PrepW { const float *w[4]; };
+// element idx of the bf16-piece image of one convolution (conv_wino4_split.h): the same launch writes both images
+__device__ void prep_wino4s_element(const float *__restrict__ w, uint16_t *__restrict__ u_fwd, uint16_t *__restrict__ u_dgrad, int idx);
 __global__ void prep_wino4_kernel(const PrepW pw, float *__restrict__ u_fwd, float *__restrict__ u_dgrad)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,6 +594,7 @@ __global__ void prep_wino4_kernel(const PrepW pw, float *__restrict__ u_fwd, flo
         }
     u_fwd[idx] = (float)uf;
     u_dgrad[idx] = (float)ud;
+    prep_wino4s_element(w, reinterpret_cast<uint16_t *>(u_fwd + w4::U_FLOATS), reinterpret_cast<uint16_t *>(u_dgrad + w4::U_FLOATS), idx);
 }
 
 #include "conv_wino4_split.h"
@@ -636,9 +639,6 @@ COVA_API int cova_conv3x3_wino4_prep_multi(const float *w0, const float *w1, con
     const int n = w1 == nullptr ? 1 : w2 == nullptr ? 2 : w3 == nullptr ? 3 : 4;
     hipLaunchKernelGGL(prep_wino4_kernel, dim3(cdiv(w4::U_FLOATS, 256), n), dim3(256), 0, (hipStream_t)stream, pw, u_fwd,
                        u_dgrad);
-    hipLaunchKernelGGL(prep_wino4s_kernel, dim3(cdiv(2 * 8 * 18 * 64 * 8, 256), n), dim3(256), 0, (hipStream_t)stream, pw,
-                       reinterpret_cast<uint16_t *>(u_fwd + w4::U_FLOATS), reinterpret_cast<uint16_t *>(u_dgrad + w4::U_FLOATS),
-                       (size_t)2 * w4::U_TOTAL);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

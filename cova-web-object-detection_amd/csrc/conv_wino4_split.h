@@ -379,13 +379,9 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 // [e 8] bf16.  Wave w = (cog = w & 3, ph = w >> 2), lane = (kq = lane >> 4, l15 = lane & 15): the MFMA A operand of position
 // (i = row il = p / 6 of half ph, j = p % 6) for output channel cog*16 + l15 and input channels 32 ks + 8 kq + e, as the
 // three round-to-nearest bf16 pieces of (G g G^T)[i][j].
-__global__ void prep_wino4s_kernel(const PrepW pw, uint16_t *__restrict__ u_fwd, uint16_t *__restrict__ u_dgrad, size_t stride_elems)
+static_assert(2 * 8 * 18 * 64 * 8 == w4::U_FLOATS, "one thread of prep_wino4_kernel per element of either image");
+__device__ void prep_wino4s_element(const float *__restrict__ w, uint16_t *__restrict__ u_fwd, uint16_t *__restrict__ u_dgrad, int idx)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (ks, w, p, lane, e)
-    if (idx >= 2 * 8 * 18 * 64 * 8) return;
-    const float *__restrict__ w = pw.w[blockIdx.y];
-    u_fwd += (size_t)blockIdx.y * stride_elems;
-    u_dgrad += (size_t)blockIdx.y * stride_elems;
     const int e = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9;
     const int p = rest % 18, wv = (rest / 18) & 7, ks = rest / (18 * 8);
     const int cog = wv & 3, ph = wv >> 2, kq = lane >> 4, l15 = lane & 15;

@@ -6,9 +6,11 @@ profiles/r04_parity_margin.txt -- SURVEY.md section 8c's starting point was 1e-4
   forward logits (eval and train) 5e-5 of the logit scale (measured 3e-6 .. 9e-6), CE-sum loss 2e-5 (measured <= 1.4e-6);
   gradients, every discrete decision forced to the HIP forward's: 1e-4 of each tensor's scale (measured 1.1e-5 .. 4e-5;
   scale floored at 1 % of the largest gradient: several parameters have analytically zero gradient);
-  gradients against the reference's own fixtures with NOTHING forced: head 2e-3 / conv stack 5e-2 as hard bounds (one
-  near-tie flip moves a few conv-stack entries by ~1e-3) AND the fraction of fixture entries beyond 2e-4 is printed and
-  bounded (<= 2 %; measured 0 .. 0.6 %);
+  gradients against the reference's own fixtures with NOTHING forced: 2e-4 when every discrete decision of the HIP forward
+  is the unforced oracle's; otherwise bounded by the number and the place of the decisions that fell the other way (each
+  within round-off of its threshold, asserted): 2e-4 + 5e-3 per head gate + 2e-3 per conv-stack gate on the tensors
+  upstream of a flip (the head keeps 2e-4 under conv-stack flips, the last Linear always), and the fraction of fixture
+  entries beyond 2e-4 at most 0.25 per head gate + 0.001 per conv-stack gate (measured footprints, see the test);
   integer outputs exact on rows whose top-2 logit margin exceeds 10x the observed fp error.
 """
 import os
@@ -141,13 +143,26 @@ def test_full_model_matches_reference_fixture(name):
     print("%s: %d decisions differ from the unforced oracle's %s; %d of %d unforced fixture gradient entries beyond 2e-4 "
           "(%.4f %%), worst %s %.2e" % (name, nflip, {k: v for k, v in flips.items() if v}, round(frac * total), total,
                                         100 * frac, worst, per[worst][2]))
+    # Bound by the COUNT and the LOCATION of the flips (measured footprints: one decoder / positional-encoder / attention gate
+    # that falls the other way moves up to 22 % of all entries by more than 2e-4, worst 4e-3 of a tensor's scale; one gate in
+    # the conv stack moves ~450 entries of a 36,864-entry conv weight -- 0.03 % of the 1.6 M entries -- by ~1e-3):
+    #   * a conv-stack flip changes nothing downstream of the stack: the head's gradients keep the tight bound;
+    #   * the last Linear (behind the decoder's gate: its gradient does not pass through any gate) always keeps it;
+    #   * per tensor upstream of a flip: 2e-4 + 5e-3 per head flip + 2e-3 per conv-stack flip; fraction of entries beyond
+    #     2e-4: 0.25 per head flip + 0.001 per conv-stack flip.
+    n_head = sum(v for k, v in flips.items() if k in ("gate_dec", "gate_bbox") or k.endswith("leaky"))
+    n_conv = nflip - n_head
+    last = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample")) and "/decoder.4." in k}
+    check_grads(last, grads, rtol=2e-4)
     if nflip == 0:
         check_grads(head, grads, rtol=2e-4)
         check_grads(conv_only, grads, rtol=2e-4)
         assert frac == 0.0, (frac, worst, per[worst])
     else:
-        check_grads(head, grads, rtol=1e-2)
-        check_grads(conv_only, grads, rtol=5e-2)
+        loose = 2e-4 + 5e-3 * n_head + 2e-3 * n_conv
+        check_grads(head, grads, rtol=2e-4 if n_head == 0 else loose)
+        check_grads(conv_only, grads, rtol=loose)
+        assert frac <= min(1.0, 0.25 * n_head + 1e-3 * n_conv), (frac, flips, worst, per[worst])
     for k, buf in m.named_buffers():
         if "buf/" + k in fx:
             assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k

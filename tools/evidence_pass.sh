@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-5 evidence pass (one gpurun call): the bench lines of all configs, kernel trace + step cut + HBM counters of the bench step
+# at configs[1] / configs[2], SQ counters of the F(4x4) kernels (split and f32 main loops), the interleaved A/B of the two loops,
+# the matrix-pipe probes, the parity-margin table, the two-rank gloo DIAGNOSTIC line.  Results under gpurun_out/r5g; the summaries
+# are copied to profiles/r05_* by hand.  Before: tools/probe/build.sh.
+cd $GRAFT_REPO_ROOT
+o=gpurun_out/r5g
+mkdir -p $o
+timeout 120 ./build/mfma16_probe > $o/mfma16_probe.txt 2>&1
+timeout 300 python tools/ab_step.py 9 4 2>&1 | grep round > $o/ab_step_wino4.txt
+timeout 300 python tools/ab_step.py 7 3 2>&1 | grep round > $o/ab_step_conv1.txt
+timeout 300 python tools/w4s_time.py --f32 2>&1 | grep loop > $o/w4s_time.txt
+timeout 300 python tools/w4s_check.py 2>&1 | grep -v amdgpu.ids > $o/w4s_check.txt
+bash tools/profile_round.sh r5g/c2 --config 2
+bash tools/profile_round.sh r5g/c3 --config 3
+PMC_OUT=r5g bash tools/pmc_wino4.sh > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+timeout 900 python tools/wino4_margin.py $o/r05_parity_margin.txt > $o/margin.log 2>&1
+for c in 3 5 4; do timeout 600 python bench.py --no-cpu-baseline --sustained-seconds 0 --config $c > $o/bench_c$c.json 2> $o/bench_c$c.err; done
+COVA_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --sustained-seconds 0 > $o/bench_gloo2.json 2> $o/bench_gloo2.err
+timeout 1200 python bench.py > $o/bench_c2.json 2> $o/bench_c2.err
+ls $o

@@ -9,7 +9,7 @@ NU = query("cova_conv3x3_wino4_u_floats")
 
 
 def timeit(fn, n=20):
-    for _ in range(5):
+    for _ in range(40):          # (the first case timed in a process otherwise runs on a chip that has not clocked up yet)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

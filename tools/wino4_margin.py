@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import cova_amd  # noqa: F401
-from cova_web_object_detection_amd import engine, synthetic, weights
+from cova_web_object_detection_amd import _lib, engine, synthetic, weights
 from cova_web_object_detection_amd.models import CoVA
 from helpers import FULL_CASES, load_case, routing_from_saved
 from oracle import cova_oracle as O
@@ -33,8 +33,9 @@ def relerr(a, b):
 
 def run(cfg, img_h, sd, batch, ref_logits=None, ref_loss=None, img_w=None):
     out = {}
-    for name, w4 in (("F(2x2,3x3)", False), ("F(4x4,3x3)", True)):
+    for name, w4, f32loop in (("F(2x2,3x3)", False, 0), ("F(4x4) f32 loop", True, 1), ("F(4x4) bf16x3", True, 0)):
         engine.OPTIONS.wino4 = w4
+        _lib.query("cova_set_option", 9, f32loop)
         m = CoVA(cfg["roi_output_size"], img_h, cfg["n_classes"], cfg["use_context"], cfg["hidden_dim"],
                  cfg["bbox_hidden_dim"], cfg["n_additional_feat"], cfg["drop_prob"], None)
         m.load_state_dict(sd, strict=True)
@@ -81,20 +82,21 @@ def run(cfg, img_h, sd, batch, ref_logits=None, ref_loss=None, img_w=None):
 
 def show(title, res):
     emit(title)
-    emit("  %-12s %12s %12s %12s %12s %12s  %-28s %10s %12s %10s" % (
+    emit("  %-16s %12s %12s %12s %12s %12s  %-28s %10s %12s %10s" % (
         "kernels", "logit/ref", "loss/ref", "logit/oracle", "loss/oracle", "worst grad", "(parameter)", "gate flips",
         "worst |pre|", "pool flips"))
     for name, r in res.items():
         f = lambda v: "%12.2e" % v if v is not None else "%12s" % "-"
-        emit("  %-12s %s %s %s %s %s  %-28s %4d/%-7d %12.2e %10d" % (
+        emit("  %-16s %s %s %s %s %s  %-28s %4d/%-7d %12.2e %10d" % (
             name, f(r["logits_vs_reference"]), f(r["loss_vs_reference"]), f(r["logits_vs_oracle"]), f(r["loss_vs_oracle"]),
             f(r["worst_grad"]), r["worst_grad_key"][:28], r["gate_flips"], r["gates"], r["worst_flipped_gate"],
             r["pool_flips"]))
     emit()
 
 
-emit("# Parity margins of the 3x3 convolution kernels: F(2x2,3x3) (csrc/conv_wino.hip) vs F(4x4,3x3) (csrc/conv_wino4.hip),")
-emit("# tools/wino4_margin.py on one MI355X.  Test gates (round 4): logits 5e-5, loss 2e-5, gradients 1e-4 of")
+emit("# Parity margins of the 3x3 convolution kernels: F(2x2,3x3) (csrc/conv_wino.hip), F(4x4,3x3) with the transform-domain products")
+emit("# on the f32 MFMA (csrc/conv_wino4.hip, cova_set_option(9, 1)) and on the bf16 matrix pipe with three-piece operands (the default,")
+emit("# csrc/conv_wino4_split.h); tools/wino4_margin.py on one MI355X.  Test gates: logits 5e-5, loss 2e-5, gradients 1e-4 of")
 emit("# each tensor's scale against the forced-routing oracle; flipped gates must sit within 2e-5 of zero and be fewer than")
 emit("# 1e-4 of a layer's decisions (tests/helpers.py).  'ref' = the fixture captured from the imported reference.")
 emit()
@@ -109,5 +111,6 @@ sd = weights.seeded_state_dict(123, logit_gain=4.0, **{k: v for k, v in cfg.item
 batch = synthetic.make_batch(1, img_h=1280, boxes_per_page=[90], context_size=12, seed=123)
 show("one 1280 x 1280 page, 90 boxes, K = 24 (oracle only; no reference fixture at this size)", run(cfg, 1280, sd, batch))
 engine.OPTIONS.wino4 = True
+_lib.query("cova_set_option", 9, 0)
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write("\n".join(lines) + "\n")

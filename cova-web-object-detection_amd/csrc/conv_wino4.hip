@@ -68,7 +68,7 @@ constexpr int VROW = 36;                       // V row (ci, tile): [positions 0
 constexpr int V_FLOATS = 8 * 16 * VROW;        // 18,432 B
 constexpr int U_FLOATS = 8 * 8 * 9 * 64 * 4;   // [chunk 8][wave 8][quad 9][lane 64][4]: 147,456 floats
 constexpr int U_SPLIT_DWORDS = 2 * 8 * 18 * 3 * 256;     // the bf16-piece image of the split main loop (conv_wino4_split.h): 221,184
-constexpr int U_TOTAL = U_FLOATS + U_SPLIT_DWORDS;        // one convolution, one direction: [f32 image | piece image] = 368,640 floats
+constexpr int U_TOTAL = U_FLOATS + 2 * U_SPLIT_DWORDS;    // one convolution, one direction: [f32 image | piece image | piece image of -U] = 589,824 floats
 }  // namespace w4
 
 __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c)
@@ -545,6 +545,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
         W4_STAMP(g - 32, 6);
     };
 
+    constexpr bool W4_SIGNED_TILES = false;
 #include "conv_wino4_epi.h"
 
 #pragma unroll 1

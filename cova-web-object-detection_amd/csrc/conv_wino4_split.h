@@ -230,20 +230,32 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 
     // ---- weights: position n = 18 ks + p of the 36-position stream is three 1 KB rows (pieces) of this wave's image;
     // wave-uniform base + this lane's fixed byte offset
-    const char *ubase = reinterpret_cast<const char *>(a.u) + (size_t)wave * (18 * 3 * 1024);
+    // Tiles with odd tx + ty are multiplied with the image of -U and un-negated in the epilogue: the bf16 MFMA's accumulation is
+    // not sign-symmetric (its adder drops low product bits toward -inf: every output came out 7e-8 of the mean magnitude low,
+    // whatever its sign -- tools/w4s_bias.py, tools/probe/mfma_round_probe2.hip), a COHERENT offset that reductions over a map
+    // (BatchNorm sums, weight gradients) add up; alternating the sign by tile makes it cancel there.
+    const char *ubase0 = reinterpret_cast<const char *>(a.u) + (size_t)wave * (18 * 3 * 1024);
+    auto tile_ubase = [&](int k) {
+        const int tile_ = tile_of(k);
+        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y;
+        return ubase0 + (((tx + ty) & 1) ? (size_t)w4::U_SPLIT_DWORDS * 4 : (size_t)0);
+    };
+    const char *ubase = tile_ubase(0), *ubase_next = tile_ubase(1);
     const unsigned ulane = (unsigned)lane * 16u;
     constexpr int UR = W4S_LEAD + 1;
     static_assert(36 % UR == 0, "ring size must divide the 36-position stream");
     u32x4 Ub[UR][3];
-    auto load_u = [&](const int n, const int slot) {
+    auto load_u = [&](const int n_, const int slot) {        // n_ >= 36: the position belongs to the NEXT tile of the stream
         if (W4S_ABL & 16) return;
+        const int n = n_ % 36;
+        const char *ub_t = n_ >= 36 ? ubase_next : ubase;
         const int ks = (W4S_ABL & 128) ? 0 : n / 18, p = (W4S_ABL & 128) ? 0 : n - 18 * ks;     // 128: always position 0 (L1 hits)
         if (W4S_ABL & 256) {                                         // 256: the operand from LDS (any 3 KB of the piece buffers)
 #pragma unroll
             for (int q = 0; q < 3; ++q) Ub[slot][q] = *reinterpret_cast<const u32x4 *>(vr + ((n % 12) * 3 + q) * w4s::VBLK);
             return;
         }
-        const char *bp = ubase + (size_t)ks * w4s::U_KSTEP_BYTES + p * 3072;
+        const char *bp = ub_t + (size_t)ks * w4s::U_KSTEP_BYTES + p * 3072;
         unsigned ul = ulane;
         asm volatile("" : "+v"(ul));
 #pragma unroll
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 #endif
                 acc[S * 6 + j] = c;
             }
-            load_u((n + W4S_LEAD) % 36, (n + W4S_LEAD) % UR);
+            load_u(n + W4S_LEAD, (n + W4S_LEAD) % UR);
             // this position's share of the transform work
             if (S == 0) {
                 split_write(j, PAR ^ 1, o);
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
         lds_barrier();
     };
 
+    constexpr bool W4_SIGNED_TILES = true;
 #include "conv_wino4_epi.h"
 
     using I0 = std::integral_constant<int, 0>;
@@ -369,6 +382,8 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
         step(k, I1{}, I0{});
         step(k, I1{}, I1{});
         step(k, I1{}, I2{});
+        ubase = ubase_next;
+        ubase_next = tile_ubase(k + 2);
         tile_epilogue(k);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the copies of the tile past the end have landed before the LDS is released)
@@ -406,10 +421,14 @@ __device__ void prep_wino4s_element(const float *__restrict__ w, uint16_t *__res
     const size_t base = ((((size_t)ks * 8 + wv) * 18 + p) * 3) * 512 + lane * 8 + e;       // piece q: + q * 512
     uint32_t q0, q1, q2;
     bf3_split_pair((float)uf, (float)ud, q0, q1, q2);        // low half: forward, high half: data gradient
-    u_fwd[base] = (uint16_t)(q0 & 0xFFFFu);
-    u_fwd[base + 512] = (uint16_t)(q1 & 0xFFFFu);
-    u_fwd[base + 1024] = (uint16_t)(q2 & 0xFFFFu);
-    u_dgrad[base] = (uint16_t)(q0 >> 16);
-    u_dgrad[base + 512] = (uint16_t)(q1 >> 16);
-    u_dgrad[base + 1024] = (uint16_t)(q2 >> 16);
+    constexpr size_t NEG = 2 * (size_t)w4::U_SPLIT_DWORDS;       // the image of -U (sign bits flipped: the split is sign-symmetric) behind it
+    const uint32_t q[3] = {q0, q1, q2};
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) {
+        const uint16_t f = (uint16_t)(q[p3] & 0xFFFFu), d = (uint16_t)(q[p3] >> 16);
+        u_fwd[base + 512 * p3] = f;
+        u_dgrad[base + 512 * p3] = d;
+        u_fwd[NEG + base + 512 * p3] = f ^ 0x8000u;
+        u_dgrad[NEG + base + 512 * p3] = d ^ 0x8000u;
+    }
 }

@@ -160,7 +160,9 @@ int cova_conv3x3_wgrad4(const float *act, const float *dz, float *dw /*OIHW*/, f
 
 /* F(4x4,3x3) form of the same convolution (csrc/conv_wino4.hip; 1.78x fewer MFMAs than F(2x2,3x3), fp32 error 2.9e-6 of
  * the output scale): u_fwd / u_dgrad cova_conv3x3_wino4_u_floats() floats each per convolution (the per-wave register
- * images written by the prep kernels: the f32 image, then its three-bf16-piece image);
+ * images written by the prep kernel: the f32 image, its three-bf16-piece image, and the piece image of -U -- tiles with odd
+ * tx + ty are multiplied with the negated weights and un-negated in the epilogue, so that the bf16 MFMA's sign-asymmetric
+ * accumulation (7e-8 of the mean magnitude toward -inf on every output, tools/w4s_bias.py) cancels in sums over a map);
  * stat_part (nullable) [cova_conv3x3_wino4_num_partials][2][64] = (sum y, sum y^2).
  * Arithmetic: f32 in, f32 out, f32 transforms and accumulation; the transform-domain products run on the bf16 matrix pipe
  * with both f32 operands taken as three round-to-nearest bf16 pieces and the six products of order <= 2 (as conv1, see

@@ -152,7 +152,8 @@ def test_full_model_matches_reference_fixture(name):
     #     2e-4: 0.25 per head flip + 0.001 per conv-stack flip.
     n_head = sum(v for k, v in flips.items() if k in ("gate_dec", "gate_bbox") or k.endswith("leaky"))
     n_conv = nflip - n_head
-    last = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample")) and "/decoder.4." in k}
+    last = {k: v for k, v in fx.items() if k.startswith(("grad", "gradnorm", "gradsample")) and "/decoder.5." in k}
+    assert last, "the fixture holds the last Linear's gradients"
     check_grads(last, grads, rtol=2e-4)
     if nflip == 0:
         check_grads(head, grads, rtol=2e-4)

@@ -1158,6 +1158,12 @@ def test_conv3x3_winograd_f4x4_split_error_class(B, H, W, cap, relu_in):
             e_d = float(((nchw(o_d).double().cpu() - (ref_d + nchw(add).double().cpu()) * gate).abs() * gate).max() / ref_d.abs().max())
             err[f32] = (rel(o_f, ref_f), rel(o_p, ref_p), e_q, e_d)
             keep[f32] = o_d
+            if not f32 and B * ((H + 7) // 8) * ((W + 31) // 32) >= 200:
+                # the bf16 MFMA's accumulation is not sign-symmetric (every output 7e-8 of the mean magnitude low when all tiles
+                # multiply with +U); tiles of alternating sign make the offset cancel in sums over the map: the mean SIGNED
+                # error must be at the f32 loop's level (measured 1e-9), not 7e-8
+                bias = float((nchw(o_f).double().cpu() - ref_f).sum() / ref_f.abs().sum())
+                assert abs(bias) < 1.5e-8, "coherent offset of the split loop's outputs: %.2e of the mean magnitude" % bias
     finally:
         query("cova_set_option", 9, 0)
         query("cova_set_option", 2, 0)

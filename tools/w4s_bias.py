@@ -54,3 +54,26 @@ for f32 in (1, 0):
           % ("f32 loop  " if f32 else "split loop", bool(torch.equal(o[1], -o[0])), bool(torch.equal(o[2], -o[0])),
              float((e[0] - ref).sum() / ref.abs().sum()), float((e[1] + ref).sum() / ref.abs().sum()), float((e[2] + ref).sum() / ref.abs().sum())))
 query("cova_set_option", 9, 0)
+
+# ---- the same question for conv1 (7x7 / stride 2, bf16-split since round 4): forward output and weight gradient
+B, H, W = 2, 640, 640
+g = torch.Generator().manual_seed(3)
+img = torch.rand(B, 3, H, W, generator=g)
+w7 = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+wr = w7.double().requires_grad_(True)
+ref = F.conv2d(img.double(), wr, stride=2, padding=3)
+H1, W1 = ref.shape[2], ref.shape[3]
+dy = torch.randn(B, 64, H1, W1, generator=g) * 1e-3
+(ref * dy.double()).sum().backward()
+ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=dev)
+for f32 in (1, 0):
+    query("cova_set_option", 7, f32)
+    out = torch.zeros(B, H1, W1, 64, device=dev)
+    call("cova_conv1_fwd_tail", img.to(dev), w7.to(dev), out, None, B, H, W, None)
+    dw = torch.zeros(64, 3, 7, 7, device=dev)
+    call("cova_conv1_wgrad", img.to(dev), nhwc(dy), dw, ws, B, H, W)
+    d = nchw(out).double() - ref.detach()
+    print("conv1 %s: forward max |err| / max|ref| %.2e, mean signed err / mean|ref| %+.2e;  weight gradient max err %.2e, mean signed %+.2e"
+          % ("f32 MFMA  " if f32 else "bf16 split", float(d.abs().max() / ref.detach().abs().max()), float(d.sum() / ref.detach().abs().sum()),
+             float((dw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max()), float((dw.double().cpu() - wr.grad).sum() / wr.grad.abs().sum())))
+query("cova_set_option", 7, 0)

@@ -6,7 +6,10 @@
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/r5g
 mkdir -p $o
+timeout 900 python -m pytest tests -m gpu -q > $o/gpu_tests.log 2>&1; tail -1 $o/gpu_tests.log
 timeout 120 ./build/mfma16_probe > $o/mfma16_probe.txt 2>&1
+timeout 60 ./build/mfma_round_probe2 > $o/mfma_round_probe2.txt 2>&1
+timeout 300 python tools/w4s_bias.py 2>&1 | grep -v amdgpu.ids > $o/w4s_bias.txt
 timeout 300 python tools/ab_step.py 9 4 2>&1 | grep round > $o/ab_step_wino4.txt
 timeout 300 python tools/ab_step.py 7 3 2>&1 | grep round > $o/ab_step_conv1.txt
 timeout 300 python tools/w4s_time.py --f32 2>&1 | grep loop > $o/w4s_time.txt

@@ -317,9 +317,47 @@ class Options:
     bn_tail = os.environ.get("COVA_BN_TAIL", "1") != "0"
     # weight gradients of the 3x3 convolutions as F(4x4,3x3) (csrc/conv_wgrad4.hip) instead of F(2x2,3x3)
     wgrad4 = os.environ.get("COVA_WGRAD4", "1") != "0"
+    # small launches that nothing on the critical path waits for on a side stream under the big kernels: the Winograd
+    # weight images (under conv1 + pool), the transposed neighbour index of the GAT backward (under the conv stack), the fold of
+    # the 3x3 weight-gradient partials (under conv1's weight gradient).  OFF by default: measured 0.1-0.2 ms SLOWER per step
+    # (tools/ab_step.py 0 4: 9.40-9.57 against 9.27-9.41 ms) -- the big kernels are persistent grids of one block per CU with
+    # most of its LDS, a co-running block of another kernel delays one of their blocks and with it the launch's tail
+    side_stream = os.environ.get("COVA_SIDE_STREAM", "0") != "0"
 
 
 OPTIONS = Options()
+
+_SIDE_STREAMS = {}
+
+
+def side_stream_of(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def side_run(like, fn, after=None):
+    """Enqueue fn()'s launches on `like`'s device's side stream -- behind `after` (an event of the main stream) or, when None,
+    behind everything enqueued on the main stream so far -- and return (fn's result, the event the consumer waits for with
+    side_wait).  Outputs must be allocated by the caller BEFORE `after` is recorded (the allocator knows only the main
+    stream); inputs that the main stream frees while the side work may still read them need record_stream()."""
+    dev = like.device
+    main, side = torch.cuda.current_stream(dev), side_stream_of(dev)
+    if after is None:
+        side.wait_stream(main)
+    else:
+        side.wait_event(after)
+    with torch.cuda.stream(side):
+        out = fn()
+        done = torch.cuda.Event()
+        done.record(side)
+    return out, done
+
+
+def side_wait(like, done):
+    if done is not None:
+        torch.cuda.current_stream(like.device).wait_event(done)
 
 
 CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "convnet.4.1.conv2"]
@@ -357,6 +395,13 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
     bottleneck = is_bottleneck(params)
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
+    # the Winograd images of the 3x3 weights: one small launch, on the side stream under conv1 + pool
+    if bottleneck:
+        w4 = OPTIONS.wino4 and training
+        sv["_w3"] = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], images, w4, side=True)
+    else:
+        w4 = OPTIONS.wino4 and (training or (not training and not save))
+        sv["_w3"] = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4, side=True)
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
     nt1 = query("cova_conv1_num_partials", B, H, W)
@@ -406,16 +451,25 @@ def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, 
              B, H, W)
 
 
-def conv3_weights(ws, like, wino4):
+def conv3_weights(ws, like, wino4, side=False):
     """3x3 weights (a list of up to four OIHW tensors) -> ([forward operands], [data-gradient operands]), each tagged
-    with its kernel family; the F(4x4) operands of all of them come from ONE launch."""
+    with its kernel family; the F(4x4) operands of all of them come from ONE launch.  side=True: that launch goes to the side
+    stream behind everything enqueued so far (call it BEFORE the stem is enqueued) and the result carries a third element,
+    the event to side_wait for in front of the first 3x3 launch."""
     if wino4:
         n = len(ws)
         uf, ud = _empty((n, query("cova_conv3x3_wino4_u_floats")), like), _empty((n, query("cova_conv3x3_wino4_u_floats")), like)
-        call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
-        return [("w4", uf[i]) for i in range(n)], [("w4", ud[i]) for i in range(n)]
+        prep = lambda: call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
+        done = None
+        if side and OPTIONS.side_stream:
+            _, done = side_run(like, prep)
+        else:
+            prep()
+        res = [("w4", uf[i]) for i in range(n)], [("w4", ud[i]) for i in range(n)]
+        return res + (done,) if side else res
     pairs = [prep_wino(w, like) for w in ws]
-    return [("w2", a) for a, _ in pairs], [("w2", b) for _, b in pairs]
+    res = [("w2", a) for a, _ in pairs], [("w2", b) for _, b in pairs]
+    return res + (None,) if side else res
 
 
 def conv_bn_fwd(u, inp, abc, relu, out, prefix, params, buffers, training, part, nt, R, B, H, W):
@@ -441,7 +495,8 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     infer = not training and not save
     w4 = OPTIONS.wino4 and (training or infer)        # (an eval-mode forward that keeps its graph runs F(2x2,3x3))
-    wf, wd = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4)
+    wf, wd, w3_done = sv.pop("_w3")                   # (requested in front of the stem, convstack_fwd)
+    side_wait(images, w3_done)
     sv["wd"], sv["w4"] = wd, w4
     R = B * H2 * W2
     nt = conv3_num_partials(B, H2, W2, w4)
@@ -528,7 +583,8 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     def bn(prefix, C, part, n):
         return bn_params(prefix, params, buffers, C, p1, training, part, n, R, unit="pages")
 
-    ufs, uds = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], p1, w4)
+    ufs, uds, w3_done = sv.pop("_w3")
+    side_wait(p1, w3_done)
     x, cin, blocks, feat = p1, C64, [], None
     pending = None      # (z3, other, abc): the previous block's output relu(abc . (z3, other)), not yet written
     for blk in (0, 1, 2):
@@ -848,7 +904,12 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     fin = []
     for i in range(4):
         fin += [ws_all[i], jobs[i]]
-    call(wg + "_finish", *fin, B, H2, W2)
+    if OPTIONS.side_stream:
+        # the fold of the partials (0.1 ms, 0.3 GB) under conv1's weight gradient: convstack_bwd waits for it at its end
+        _, sv["_wg_done"] = side_run(dfeat, lambda: call(wg + "_finish", *fin, B, H2, W2))
+        ws_all.record_stream(side_stream_of(dfeat.device))       # (freed on return: not to be reused before the fold has read it)
+    else:
+        call(wg + "_finish", *fin, B, H2, W2)
     return dA
 
 
@@ -915,6 +976,7 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
         call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
     grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
     grads["convnet.0.weight"] = dw1
+    side_wait(dfeat, sv.pop("_wg_done", None))          # the 3x3 weight gradients' fold (side stream) is part of this call's result
     return grads
 
 
@@ -1153,11 +1215,16 @@ def gat_stack_fwd(comb, T, N, F, D, ctx, params, n_heads=1, n_gat_layers=1):
     return layers
 
 
-def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
-    """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F]."""
+def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None, csr_side=None):
+    """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F].  csr_side: (index, event) of a
+    transposed neighbour index already built on the side stream (model_fwd)."""
     grads = {}
     g, ldg = dcomb[:, F:], T
-    csr = gat_transpose(layers[0]["heads"][0]["ctx"])
+    if csr_side is not None:
+        csr, done = csr_side
+        side_wait(dcomb, done)
+    else:
+        csr = gat_transpose(layers[0]["heads"][0]["ctx"])
     for l in reversed(range(len(layers))):
         heads = layers[l]["heads"]
         dh = D // len(heads)
@@ -1246,6 +1313,19 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     D = cfg["hidden_dim"] if cfg["use_context"] else 0
     T = F + D
     align = cfg.get("roi_op", "pool") == "align"
+    csr_side = None
+    if (save and training and D > 0 and N > 0 and OPTIONS.side_stream and context_indices.dtype == torch.int64
+            and context_indices.is_contiguous() and context_indices.device == images.device):
+        # the transposed neighbour index of the GAT backward depends on context_indices only: three small launches, on the
+        # side stream under the conv stack.  A COPY of the cached workspace (the side stream's own) goes into the saved
+        # state: another forward before this one's backward would overwrite the workspace.
+        main_stream = torch.cuda.current_stream(images.device)
+
+        def build_csr():
+            c = gat_transpose(context_indices).clone()
+            c.record_stream(main_stream)        # allocated under the side stream, read (and freed) under the main one
+            return c
+        csr_side = side_run(images, build_csr)
     feat, sv_conv = convstack_fwd(images, params, buffers, training, save, lazy_out=not align)
     comb = _empty((N, T), images)
     scale = cfg.get("spatial_scale") or feat.shape[1] / images.shape[2]   # models.py:56
@@ -1265,6 +1345,7 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     if D > 0:
         sv["gat"] = gat_stack_fwd(comb, T, N, F, D, context_indices, params, cfg.get("n_heads", 1),
                                   cfg.get("n_gat_layers", 1))
+        sv["gat_csr"] = csr_side
     logits, sv["dec"] = decoder_fwd(comb, N, T, params, buffers, training, cfg["drop_prob"], seeds,
                                     masks)
     return logits, (sv if save else None)
@@ -1279,7 +1360,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
     dcomb, grads = decoder_bwd(sv["dec"], dlogits, params, gout)
     if D > 0:
-        grads.update(gat_stack_bwd(sv["gat"], dcomb, T, N, F, D, params, gout))
+        grads.update(gat_stack_bwd(sv["gat"], dcomb, T, N, F, D, params, gout, sv.get("gat_csr")))
     if A > 0:
         st = sv["addl"]
         dz = _empty((N, A), dcomb)

@@ -931,8 +931,9 @@ def masked_grad_and_sums(dout, last, R):
 
 
 @on_device_of(1)
-def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
-    """dfeat NHWC [B,Hf,Wf,C] -> {state_dict key: grad} for the convs and BatchNorms of the stack.
+def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None, want_dimg=False):
+    """dfeat NHWC [B,Hf,Wf,C] -> {state_dict key: grad} for the convs and BatchNorms of the stack; with ``want_dimg`` also
+    the gradient w.r.t. the images (NCHW) under the key "__images__" (needs ``params``: conv1's weight).
 
     The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
     in front of them in their epilogue (and its finalize in their tail), so only the last block's bn2
@@ -962,6 +963,9 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
         # apply is folded into conv1's weight-gradient kernel, dy1 is never written
         dg, db, abc = pool_abc
         call("cova_conv1_wgrad_poolbwd", sv["images"], sv["y1"], dA, sv["idx"], abc, dw1, ws1, B, H, W)
+        if want_dimg:                   # images.requires_grad: dy1 written out once, then the transposed convolution
+            dy1 = torch.empty_like(sv["y1"])
+            call("cova_pool_bwd_dy1", dA, sv["idx"], sv["y1"], abc, dy1, B, H1, W1)
     else:
         npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
         part = _empty((npart, 2, C64), dfeat)
@@ -976,6 +980,10 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None):
         call("cova_conv1_wgrad", sv["images"], dy1, dw1, ws1, B, H, W)
     grads["convnet.1.weight"], grads["convnet.1.bias"] = dg, db
     grads["convnet.0.weight"] = dw1
+    if want_dimg:
+        dimg = torch.empty_like(sv["images"])
+        call("cova_conv1_dgrad", dy1, params["convnet.0.weight"], dimg, B, H, W)
+        grads["__images__"] = dimg
     side_wait(dfeat, sv.pop("_wg_done", None))          # the 3x3 weight gradients' fold (side stream) is part of this call's result
     return grads
 
@@ -1352,9 +1360,9 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
 
 
 @on_device_of(1)
-def model_bwd(sv, dlogits, params, gout=None, after_head=None):
-    """-> {state_dict key: gradient} for every trainable parameter.  ``gout`` (optional) maps
-    keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket.
+def model_bwd(sv, dlogits, params, gout=None, after_head=None, want_dimg=False):
+    """-> {state_dict key: gradient} for every trainable parameter (+ "__images__" with ``want_dimg``).  ``gout`` (optional)
+    maps keys to pre-allocated destinations, e.g. views into one flat all-reduce bucket.
     ``after_head`` (optional callable) runs once every gradient outside the conv stack is final
     (the trainer starts their all-reduce there, under the conv-stack backward)."""
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
@@ -1374,10 +1382,10 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None):
     conv = sv["conv"]
     if N > 0 and sv["roi"]["zmax"] is not None:
         dfeat, head_part = roipool_bwd_bn(sv["roi"], dcomb, T, conv["last"], gout)
-        grads.update(convstack_bwd(conv, dfeat, gout, head_part, params))
+        grads.update(convstack_bwd(conv, dfeat, gout, head_part, params, want_dimg))
     else:
         dfeat = roialign_bwd(sv["roi"], dcomb, T) if sv["roi"].get("kind") == "align" else roipool_bwd(sv["roi"], dcomb, T)
-        grads.update(convstack_bwd(conv, dfeat, gout, None, params))
+        grads.update(convstack_bwd(conv, dfeat, gout, None, params, want_dimg))
     return grads
 
 

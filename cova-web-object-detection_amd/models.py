@@ -131,9 +131,10 @@ class _CoVAFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         _saved_or_raise(ctx.sv)
-        grads = engine.model_bwd(ctx.sv, dlogits.contiguous(), ctx.params)
+        want_dimg = bool(ctx.needs_input_grad[2])            # images.requires_grad (the reference gets it from autograd)
+        grads = engine.model_bwd(ctx.sv, dlogits.contiguous(), ctx.params, want_dimg=want_dimg)
         ctx.sv = None
-        return (None, None, None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
+        return (None, None, grads.get("__images__"), None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
 
 class _VisualFn(torch.autograd.Function):
@@ -159,8 +160,8 @@ class _VisualFn(torch.autograd.Function):
     def backward(ctx, gout):
         bwd = engine.roialign_bwd if ctx.rsv.get("kind") == "align" else engine.roipool_bwd
         gfeat = bwd(ctx.rsv, gout.contiguous(), ctx.nv)
-        grads = engine.convstack_bwd(ctx.sv, gfeat, params=ctx.params)
-        return (None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
+        grads = engine.convstack_bwd(ctx.sv, gfeat, params=ctx.params, want_dimg=bool(ctx.needs_input_grad[2]))
+        return (None, None, grads.get("__images__"), None) + tuple(grads.get(k) for k in ctx.keys)
 
 
 class _BBoxFn(torch.autograd.Function):
@@ -435,13 +436,10 @@ class CoVA(nn.Module):
         [N,A] f32, context_indices int64 [N,K] (-1 pads) -> scores [N,n_classes] (models.py:94-122)."""
         _require_cuda(images, bboxes, additional_feats, context_indices)
         engine.check_batch(self._cfg, images, bboxes, additional_feats, context_indices, self.training)
-        if torch.is_grad_enabled() and images.requires_grad:
-            raise NotImplementedError("the HIP path does not produce a gradient w.r.t. the page images "
-                                      "(conv1 computes its weight gradient only); detach them")
         if bboxes.shape[0] == 0:
             return torch.empty((0, self.n_classes), device=images.device)
         values = [p for _, p in self.named_parameters()]
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
+        need_grad = torch.is_grad_enabled() and (images.requires_grad or any(p.requires_grad for p in values))
         return _CoVAFn.apply(self, need_grad, images, bboxes, additional_feats, context_indices,
                              *values)
 
@@ -452,7 +450,7 @@ class CoVA(nn.Module):
                                % (tuple(images.shape), tuple(bboxes.shape)))
         named = dict(self.named_parameters())
         values = [named[k] for k in self._conv_keys]
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in values)
+        need_grad = torch.is_grad_enabled() and (images.requires_grad or any(p.requires_grad for p in values))
         return _VisualFn.apply(self, need_grad, images, bboxes, *values)
 
     def _get_bbox_features(self, bboxes):

@@ -88,6 +88,13 @@ int cova_conv1_fwd_tail(const float *img, const float *w_oihw, float *out, float
 int cova_conv1_wgrad_workspace_floats(int B, int H, int W);
 int cova_conv1_wgrad(const float *img, const float *dy /*NHWC*/, float *dw, float *ws, int B, int H,
                      int W, void *stream);
+/* gradient w.r.t. the image -- what autograd gives the reference when `images.requires_grad` (models.py:94-122 through
+ * nn.Conv2d(3,64,7,2,3)); not on the training hot path (train.py never asks for it): plain kernels.
+ * cova_pool_bwd_dy1 writes out dy1 = abc[0]*route(dp, idx) + abc[1]*y1 + abc[2] (NHWC [B,H1,W1,64]), the operand
+ * cova_conv1_wgrad_poolbwd forms on load; cova_conv1_dgrad: dimg NCHW [B,3,H,W] from dy1 and the OIHW weight */
+int cova_pool_bwd_dy1(const float *dp, const uint8_t *idx, const float *y1, const float *abc, float *dy1, int B, int H1,
+                      int W1, void *stream);
+int cova_conv1_dgrad(const float *dy1, const float *w_oihw, float *dimg, int B, int H, int W, void *stream);
 /* same with the BatchNorm+ReLU+MaxPool backward apply folded into the gradient operand:
  * dy1 = abc[0]*route(dp, idx) + abc[1]*y1 + abc[2]; dp [B,H2,W2,64] already ReLU-masked */
 int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const float *dp, const uint8_t *idx,

@@ -1250,3 +1250,41 @@ def test_conv1_wgrad_role_split_equals_phase_form(B, H, W, cap):
     s = float(out["f32"].abs().max())
     assert float((out["roles"] - out["f32"]).abs().max()) <= 5e-7 * s
     assert float((out["phases"] - out["f32"]).abs().max()) <= 5e-7 * s
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 14, 18), (2, 37, 52), (1, 64, 64)])
+def test_conv1_data_gradient_and_pool_backward_operand(B, H, W):
+    """cova_conv1_dgrad against torch's autograd of conv2d(3, 64, 7, stride 2, pad 3) w.r.t. its input (fp64), odd sizes
+    included; cova_pool_bwd_dy1 against the formula it restates, abc[0]*route(dp, idx) + abc[1]*y1 + abc[2], with the
+    arg-max codes of cova_bn_relu_maxpool_fwd."""
+    g = torch.Generator().manual_seed(7 * H + W)
+    x = torch.randn(B, 3, H, W, generator=g).double().requires_grad_(True)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    y = F.conv2d(x, w.double(), stride=2, padding=3)
+    H1, W1 = y.shape[2], y.shape[3]
+    dy = torch.randn(B, 64, H1, W1, generator=g)
+    (y * dy.double()).sum().backward()
+    dimg = torch.full((B, 3, H, W), 7.0, device=DEV)
+    call("cova_conv1_dgrad", nhwc(dy), w.to(DEV), dimg, B, H, W)
+    close(dimg, x.grad, 2e-6, "conv1 data gradient")
+    # ---- the materialised pool-backward operand
+    H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
+    y1 = nhwc(torch.randn(B, 64, H1, W1, generator=g) * 2)
+    scale, shift = (torch.rand(64, generator=g) - 0.3).to(DEV), (torch.randn(64, generator=g) * 0.2).to(DEV)
+    p1 = torch.empty(B, H2, W2, 64, device=DEV)
+    idx = torch.empty(B, H2, W2, 64, device=DEV, dtype=torch.uint8)
+    call("cova_bn_relu_maxpool_fwd", y1, scale, shift, p1, idx, None, B, H1, W1)
+    dp = nhwc(torch.randn(B, 64, H2, W2, generator=g)) * (p1 > 0)
+    abc = (torch.randn(3, 64, generator=g) * 0.3).to(DEV)
+    got = torch.full_like(y1, float("nan"))
+    call("cova_pool_bwd_dy1", dp, idx, y1, abc, got, B, H1, W1)
+    # reference: scatter every window's gradient to its arg-max position (code = ky*3 + kx, window rows 2*oy-1+ky)
+    route = torch.zeros(B, H1 + 2, W1 + 2, 64, dtype=torch.float64)
+    code = idx.cpu().long()
+    ky, kx = code // 3, code % 3
+    bb, oy, ox, cc = torch.meshgrid(torch.arange(B), torch.arange(H2), torch.arange(W2), torch.arange(64), indexing="ij")
+    route.index_put_((bb, 2 * oy + ky, 2 * ox + kx, cc), dp.cpu().double(), accumulate=True)      # (+1 pad offset folded: 2*oy-1+ky+1)
+    route = route[:, 1:H1 + 1, 1:W1 + 1]
+    want = abc[0].cpu().double() * route + abc[1].cpu().double() * y1.cpu().double() + abc[2].cpu().double()
+    assert torch.isfinite(got).all()
+    close(got, want, 1e-6, "pool-backward operand")

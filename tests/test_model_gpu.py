@@ -683,8 +683,6 @@ def test_malformed_input_raises_like_the_reference_forward():
             m(*bad)
     with pytest.raises(IndexError):
         m(img, bb, af, ctx.float())
-    with pytest.raises(NotImplementedError):
-        m(img.clone().requires_grad_(True), bb, af, ctx)
     with pytest.raises(RuntimeError):
         m.gat(torch.rand(24, 7, device=DEV), ctx)
     out = m(img, bb, af, ctx)
@@ -750,3 +748,48 @@ def test_f2x2_conv_path_keeps_reference_parity(name, monkeypatch):
     for k, buf in m.named_buffers():
         if "buf/" + k in fx:
             assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+def test_gradient_with_respect_to_the_images(training):
+    """`images.requires_grad` (the reference gets d loss / d images from autograd through nn.Conv2d, models.py:94-122): the
+    module returns it too -- cova_pool_bwd_dy1 + cova_conv1_dgrad behind the conv stack's backward -- and the parameter
+    gradients of that backward are the ones of a call without it.  Against the CPU oracle forced to the HIP forward's
+    discrete decisions; also through _get_visual_features."""
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.0)
+    sd = weights.seeded_state_dict(5, logit_gain=2.0, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    batch = synthetic.make_batch(2, img_h=96, boxes_per_page=[14, 9], context_size=3, seed=6)
+    img, bb, af, ctx = dev_batch(batch)
+    m = build(cfg, 96, sd)
+    m.train(training)
+    x = img.clone().requires_grad_(True)
+    logits = m(x, bb, af, ctx)
+    routing = routing_from_saved(logits.grad_fn.sv)
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
+    loss.backward()
+    assert x.grad is not None and x.grad.shape == img.shape and torch.isfinite(x.grad).all()
+    xi = batch["images"].clone().requires_grad_(True)
+    _, _, grads_ref, _, _ = O.loss_and_grads(sd, xi, batch["bboxes"], batch["additional_feats"], batch["context_indices"],
+                                             batch["labels"], cfg, None, routing, training=training)
+    scale = float(xi.grad.abs().max())
+    err = float((x.grad.cpu() - xi.grad).abs().max()) / scale
+    print("d loss / d images (%s): max error %.2e of the scale %.3e" % ("train" if training else "eval", err, scale))
+    assert err < GRAD_TOL, err
+    compare_grads({k: p.grad for k, p in m.named_parameters()}, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
+    # the same parameter gradients without the image gradient
+    m2 = build(cfg, 96, sd)
+    m2.train(training)
+    torch.nn.CrossEntropyLoss(reduction="sum")(m2(img, bb, af, ctx), batch["labels"].to(DEV)).backward()
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if training:                    # the train step's backward is bit-reproducible
+            assert torch.equal(p.grad, p2.grad), k
+        else:                           # (eval-mode / frozen-BatchNorm backward: some reductions pick their vector width by the
+            # buffers' alignment, so two calls agree to an ulp of the sums, not bit for bit -- measured 1e-7 of the scale)
+            assert float((p.grad - p2.grad).abs().max()) <= 2e-6 * max(float(p.grad.abs().max()), 1e-6), k
+    # the piecewise surface (extract_attn_wts_and_visualize.py:117 calls it under no_grad; autograd works through it too)
+    x3 = img.clone().requires_grad_(True)
+    vis = m2._get_visual_features(x3, bb)
+    vis.square().sum().backward()
+    assert x3.grad is not None and torch.isfinite(x3.grad).all() and float(x3.grad.abs().max()) > 0

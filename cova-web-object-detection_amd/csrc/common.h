@@ -32,8 +32,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define COVA_API extern "C" __attribute__((visibility("default")))
 
-// neighbour slots per node the wave-per-node GAT kernels hold in registers: four 64-lane passes (-cs <= 128)
-#define COVA_GAT_MAX_K 256
+// neighbour slots per node the wave-per-node GAT kernels hold in registers: up to sixteen 64-lane passes (-cs <= 512: far
+// beyond the boxes of a page -- slots past a page's size are pads; models.py:171-177 itself takes any n_context)
+#define COVA_GAT_MAX_K 1024
 
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 FMA chain.
 // lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];

@@ -9,7 +9,7 @@
 // dense projections Wh = h [W_i;W_j]^T are one GEMM per node (gemm.hip) and this file does the
 // O(N*K) part: e_ik = LeakyReLU(s_i + t_ctx(i,k)), s = a_i.Wh_i + b, t = a_j.Wh_j (t = 0 for the
 // -1 pad row), mask -> -9e15, softmax over the K slots, h'_i = sum_k alpha_ik Wh_j[ctx(i,k)].
-// One wavefront per node: the K neighbour slots live in lanes (ceil(K / 64) passes, K <= 256) for the softmax (shuffle
+// One wavefront per node: the K neighbour slots live in lanes (ceil(K / 64) passes, K <= 1024) for the softmax (shuffle
 // reductions), the D hidden channels live in lanes for the gather (256-byte coalesced rows).
 #include "bn_tail.h"
 
@@ -1207,7 +1207,13 @@ COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const fl
     case 1: COVA_GAT_FWD(1); break;
     case 2: COVA_GAT_FWD(2); break;
     case 3: COVA_GAT_FWD(3); break;
-    default: COVA_GAT_FWD(4); break;
+    case 4: COVA_GAT_FWD(4); break;
+    case 5: COVA_GAT_FWD(5); break;
+    case 6: COVA_GAT_FWD(6); break;
+    case 7: COVA_GAT_FWD(7); break;
+    case 8: COVA_GAT_FWD(8); break;
+    case 9: case 10: case 11: case 12: COVA_GAT_FWD(12); break;
+    default: COVA_GAT_FWD(16); break;
     }
 #undef COVA_GAT_FWD
     COVA_LAUNCH_CHECK();
@@ -1276,7 +1282,13 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
         case 1: COVA_GAT_SRC(1); break;
         case 2: COVA_GAT_SRC(2); break;
         case 3: COVA_GAT_SRC(3); break;
-        default: COVA_GAT_SRC(4); break;
+        case 4: COVA_GAT_SRC(4); break;
+        case 5: COVA_GAT_SRC(5); break;
+        case 6: COVA_GAT_SRC(6); break;
+        case 7: COVA_GAT_SRC(7); break;
+        case 8: COVA_GAT_SRC(8); break;
+        case 9: case 10: case 11: case 12: COVA_GAT_SRC(12); break;
+        default: COVA_GAT_SRC(16); break;
         }
 #undef COVA_GAT_SRC
         COVA_LAUNCH_CHECK();
@@ -1294,7 +1306,13 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
         case 1: COVA_GAT_BWD(1); break;
         case 2: COVA_GAT_BWD(2); break;
         case 3: COVA_GAT_BWD(3); break;
-        default: COVA_GAT_BWD(4); break;
+        case 4: COVA_GAT_BWD(4); break;
+        case 5: COVA_GAT_BWD(5); break;
+        case 6: COVA_GAT_BWD(6); break;
+        case 7: COVA_GAT_BWD(7); break;
+        case 8: COVA_GAT_BWD(8); break;
+        case 9: case 10: case 11: case 12: COVA_GAT_BWD(12); break;
+        default: COVA_GAT_BWD(16); break;
         }
 #undef COVA_GAT_BWD
         COVA_LAUNCH_CHECK();

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .weights import BACKBONE_CHANNELS as C64
 
-GAT_MAX_K = 256        # COVA_GAT_MAX_K of csrc/common.h: neighbour slots per node (four 64-lane passes of a wavefront)
+GAT_MAX_K = 1024       # COVA_GAT_MAX_K of csrc/common.h: neighbour slots per node (up to sixteen 64-lane passes of a wavefront)
 
 call, query = _lib.call, _lib.query
 BN_MOMENTUM, BN_EPS, LEAKY_SLOPE = 0.1, 1e-5, 0.2   # nn.BatchNorm defaults; models.py:156

@@ -351,18 +351,18 @@ def test_context_size_32_fills_the_wave_wide_neighbour_table():
     run_case(dict(), 64, 64, [70, 9], 32, 52, hidden=384)
 
 
-@pytest.mark.parametrize("cs,boxes", [(50, [130, 9]), (100, [230, 40])])
+@pytest.mark.parametrize("cs,boxes", [(50, [130, 9]), (100, [230, 40]), (150, [330, 25]), (290, [600]), (512, [70, 520])])
 def test_context_size_beyond_one_wavefront(cs, boxes):
-    """`-cs 50` / `-cs 100` => K = 100 / 200 neighbour slots (/root/reference models.py:171-177 and utils.py:19 take any
-    value): two / four 64-lane passes per node in the GAT kernels, against the reference-pinned oracle at model level
-    (eval logits + decisions, train loss, every gradient)."""
+    """`-cs 50` ... `-cs 512` => K = 100 ... 1024 neighbour slots (/root/reference models.py:171-177 and utils.py:19 take any
+    value): two, four, five, twelve (K = 580) and sixteen 64-lane passes per node in the GAT kernels, against the
+    reference-pinned oracle at model level (eval logits + decisions, train loss, every gradient)."""
     run_case(dict(), 64, 64, boxes, cs, 53, hidden=96)
 
 
 def test_context_size_beyond_the_kernel_limit_is_refused():
     m = CoVA((3, 3), 64, 4, True, 32, 16, 0, 0.0, None).to(DEV)
-    batch = synthetic.make_batch(1, img_h=64, boxes_per_page=[12], context_size=129, seed=5)
-    with pytest.raises(ValueError, match="n_context > 256"):
+    batch = synthetic.make_batch(1, img_h=64, boxes_per_page=[12], context_size=513, seed=5)
+    with pytest.raises(ValueError, match="n_context > 1024"):
         m(*[batch[k].to(DEV) for k in ("images", "bboxes", "additional_feats", "context_indices")])
 
 

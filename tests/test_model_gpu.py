@@ -443,7 +443,7 @@ def test_trainer_evaluate_matches_oracle_decision_rule():
     assert bool(correct[0, 0]) == bool(int(topk[0, 1, 0]) == first1)
 
 
-@pytest.mark.parametrize("K", [2, 64, 256])
+@pytest.mark.parametrize("K", [2, 64, 256, 1024])
 def test_gat_extreme_neighbour_counts(K):
     rs = np.random.RandomState(K)
     N, Fd, D = 70, 48, 24

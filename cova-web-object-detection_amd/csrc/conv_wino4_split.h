@@ -40,9 +40,6 @@ constexpr int U_DWORDS = 2 * U_KSTEP_BYTES / 4;           // 221,184 dwords per 
 #ifndef W4S_ABL
 #define W4S_ABL 0
 #endif
-#ifndef W4S_VAR
-#define W4S_VAR 0
-#endif
 // weight positions in flight ahead of the one being multiplied; the register ring has W4S_LEAD + 1 slots (must divide 36)
 #ifndef W4S_LEAD
 #define W4S_LEAD 3
@@ -325,31 +322,15 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
             if (!(W4S_ABL & 4)) {
                 f32x4 c = acc[S * 6 + j];
                 const u32x4 *U = Ub[ub], *V = Vr[j & 1];
-#if W4S_VAR == 1
-                // the six products as ONE uninterrupted dependent chain: back-to-back MFMAs on one accumulator forward it
-                // inside the matrix pipe; anything scheduled between them costs the write-back round trip (~43 cycles each)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-#if W4S_VAR == 2
-                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-                d = mfma16bf(U[2], V[0], d);
-                c = mfma16bf(U[1], V[0], c);
-                d = mfma16bf(U[0], V[2], d);
-                c = mfma16bf(U[0], V[1], c);
-                d = mfma16bf(U[1], V[1], d);
-                c = mfma16bf(U[0], V[0], c);
-                c += d;
-#else
-                c = mfma16bf(U[2], V[0], c);            // smallest terms first
+                // the six products as one dependent chain on the position's accumulator, smallest terms first (a chain on one
+                // accumulator issues at the pipe's rate, tools/probe/mfma16_probe.hip; two interleaved half-chains + an add
+                // measured 30 % slower)
+                c = mfma16bf(U[2], V[0], c);
                 c = mfma16bf(U[0], V[2], c);
                 c = mfma16bf(U[1], V[1], c);
                 c = mfma16bf(U[1], V[0], c);
                 c = mfma16bf(U[0], V[1], c);
                 c = mfma16bf(U[0], V[0], c);
-#endif
-#if W4S_VAR == 1
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 acc[S * 6 + j] = c;
             }
             load_u(n + W4S_LEAD, (n + W4S_LEAD) % UR);

@@ -1129,9 +1129,14 @@ def bbox_bwd(sv, g, ldg, gout=None):
 
 # ------------------------------------------------------------------------------- GAT
 def _adjacent(a, b):
-    """b starts right where a ends (views of one flat bucket): [a; b] is one row-major matrix"""
+    """b starts right where a ends AND both are views of ONE storage (the trainer's flat bucket): [a; b] is one row-major
+    matrix.  Two separately allocated tensors that the allocator happened to place back to back do not count: the
+    one-GEMM and the two-GEMM forms associate their sums differently (an ulp), and which one a model instance takes
+    must not depend on where its parameters landed in memory (found with two instances of the drop-in module built from
+    one state_dict: bit-different gradients, tests/test_model_gpu.py::test_gradient_with_respect_to_the_images)."""
     return (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:] and
-            b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+            b.data_ptr() == a.data_ptr() + a.numel() * a.element_size() and
+            a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
 
 
 def gat_fwd(h, ldh, N, F, ctx, params, hprime, ldo, prefix="gat."):

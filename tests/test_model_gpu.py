@@ -791,3 +791,46 @@ def test_gradient_with_respect_to_the_images(training):
     vis = m2._get_visual_features(x3, bb)
     vis.square().sum().backward()
     assert x3.grad is not None and torch.isfinite(x3.grad).all() and float(x3.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_no_kernel_reads_memory_nobody_wrote_and_steps_do_not_depend_on_the_allocation_pattern(monkeypatch):
+    """Every buffer the engine allocates is NaN-filled at allocation: a kernel that reads an element nobody wrote shows up as a
+    NaN gradient.  Then the same step with its parameters in freshly allocated tensors, twice, with differently sized
+    allocations in between: bit-identical gradients (tools/poison_check.py runs this over seven model configurations)."""
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def poisoned(t):
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        elif t.dtype != torch.bool:
+            t.fill_(0x7F if t.dtype == torch.uint8 else 0x3FFFFFFF)
+        return t
+
+    proxy = type(os)("torch_proxy")
+    proxy.__dict__.update(torch.__dict__)
+    proxy.empty = lambda *a, **k: poisoned(real_empty(*a, **k))
+    proxy.empty_like = lambda *a, **k: poisoned(real_empty_like(*a, **k))
+    monkeypatch.setattr(engine, "torch", proxy)
+    cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16,
+               n_additional_feat=0, drop_prob=0.2)
+    sd = weights.seeded_state_dict(5, logit_gain=2.0, **{k: v for k, v in cfg.items() if k != "drop_prob"})
+    batch = synthetic.make_batch(2, img_h=96, boxes_per_page=[14, 9], context_size=3, seed=6)
+    keys = O.param_keys(sd)
+    args = dev_batch(batch)
+    labels = batch["labels"].to(DEV)
+    runs = []
+    for rep in range(3):
+        junk = [torch.full((1 + 37 * rep, 129), float("nan"), device=DEV) for _ in range(3 * rep)]     # shift the allocation pattern
+        params = {k: sd[k].to(DEV) for k in keys}
+        buffers = {k: v.to(DEV) for k, v in sd.items() if k not in params}
+        logits, sv = engine.model_fwd(cfg, params, buffers, *args, True, (11, 12))
+        loss, dl, _ = engine.ce_sum(logits, labels)
+        grads = engine.model_bwd(sv, dl, params)
+        torch.cuda.synchronize()
+        del junk
+        assert torch.isfinite(loss).all() and all(torch.isfinite(g).all() for g in grads.values()), \
+            [k for k, g in grads.items() if not torch.isfinite(g).all()]
+        runs.append({k: g.clone() for k, g in grads.items()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k

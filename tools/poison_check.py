@@ -11,9 +11,21 @@ from oracle import cova_oracle as O
 mode = sys.argv[1] if len(sys.argv) > 1 else "nan"
 img_h = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 dev = "cuda:0"
-cfg = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.0)
-sd = weights.seeded_state_dict(5, logit_gain=2.0, **{k: v for k, v in cfg.items() if k != "drop_prob"})
-batch = synthetic.make_batch(2, img_h=img_h, boxes_per_page=[14, 9], context_size=3, seed=6)
+BASE = dict(roi_output_size=(3, 3), n_classes=4, use_context=True, hidden_dim=48, bbox_hidden_dim=16, n_additional_feat=0, drop_prob=0.0)
+CASES = [("resnet18, 1 head (the reference's model)", {}, True),
+         ("resnet18, eval-mode backward (frozen BatchNorm)", {}, False),
+         ("dropout 0.2", dict(drop_prob=0.2), True),
+         ("CoVA++ (3 additional features), no positional encoder", dict(n_additional_feat=3, bbox_hidden_dim=0), True),
+         ("no context", dict(use_context=False), True),
+         ("resnet50 stem, 2 heads x 2 layers", dict(backbone="resnet50", n_heads=2, n_gat_layers=2), True),
+         ("RoIAlign", dict(roi_op="align", sampling_ratio=2, roi_aligned=False), True)]
+case = int(os.environ.get("CASE", "0"))
+cfg = dict(BASE, **CASES[case][1])
+TRAINING = CASES[case][2]
+print("== case %d: %s" % (case, CASES[case][0]))
+wkeys = [k for k in cfg if k not in ("drop_prob", "roi_op", "sampling_ratio", "roi_aligned")]
+sd = weights.seeded_state_dict(5, logit_gain=2.0, **{k: cfg[k] for k in wkeys})
+batch = synthetic.make_batch(2, img_h=img_h, boxes_per_page=[14, 9], context_size=3, seed=6, n_additional_feat=cfg["n_additional_feat"])
 keys = O.param_keys(sd)
 args = [batch[k].to(dev) for k in ("images", "bboxes", "additional_feats", "context_indices")]
 labels = batch["labels"].to(dev)
@@ -36,7 +48,7 @@ def poison(value):
 def step(want_dimg=False):
     params = {k: sd[k].to(dev) for k in keys}
     buffers = {k: v.to(dev) for k, v in sd.items() if k not in params}
-    logits, sv = engine.model_fwd(cfg, params, buffers, *args, True)
+    logits, sv = engine.model_fwd(cfg, params, buffers, *args, TRAINING, (11, 12))
     loss, dl, pred = engine.ce_sum(logits, labels)
     grads = engine.model_bwd(sv, dl, params, want_dimg=want_dimg)
     torch.cuda.synchronize()

@@ -324,3 +324,27 @@ COVA_API int cova_probe_lane_pattern(const float *in, float *out, long long npix
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+// ---- LDS poison: every CU's 160 KB of LDS filled with a bit pattern (a quiet NaN as float, a huge value as int) in front of a
+// product launch -- a kernel that reads LDS it did not write then produces NaN instead of silently inheriting its predecessor's
+// data (tools/poison_check.py with POISON_LDS=1)
+__global__ __launch_bounds__(1024) void lds_fill_kernel(unsigned pattern, unsigned *sink)
+{
+    extern __shared__ unsigned s_all[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) s_all[i] = pattern;
+    __syncthreads();
+    if (sink != nullptr && s_all[(threadIdx.x * 37) % (160 * 1024 / 4)] != pattern) sink[0] = 1;       // (keeps the stores)
+}
+
+COVA_API int cova_probe_lds_fill(int pattern_bits, int blocks, void *stream)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return 1;
+        attr = true;
+    }
+    hipLaunchKernelGGL(lds_fill_kernel, dim3(blocks), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned)pattern_bits,
+                       (unsigned *)nullptr);
+    return (int)hipGetLastError();
+}

@@ -21,6 +21,9 @@ int cova_probe_mix(float *scratch, const float *buf, long long n4, int mfma_bloc
 int cova_probe_lane_pattern(const float *in, float *out, long long npix, int mode, int loads_only,
                             int blocks, int lds_bytes, void *stream);
 
+/* fills the whole LDS (160 KB) of `blocks` workgroups -- one per CU -- with a bit pattern (tools/poison_check.py POISON_LDS=1) */
+int cova_probe_lds_fill(int pattern_bits, int blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ train step of a small model; a kernel that reads memory nobody wrote then shows 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import cova_amd  # noqa: F401
 from cova_web_object_detection_amd import engine, synthetic, weights
@@ -72,6 +73,20 @@ if os.environ.get("POISON_ALLOC", "1") == "1":
     engine.torch.__dict__.update(torch.__dict__)
     engine.torch.empty = lambda *a, **k: _poisoned(_real_empty(*a, **k))
     engine.torch.empty_like = lambda *a, **k: _poisoned(_real_empty_like(*a, **k))
+if os.environ.get("POISON_LDS") == "1":
+    # ... and every CU's LDS is NaN-filled in front of EVERY product launch (LDS keeps its predecessor's data otherwise)
+    import probe_lib
+    from cova_web_object_detection_amd import _lib
+    probe_lib.load()
+    _real_launch = _lib._launch
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def _launch_poisoned(L, name, a, stream):
+        if not name.startswith("cova_probe"):
+            _real_launch(L, "cova_probe_lds_fill", (0x7FC00000, 2 * n_cu), stream)
+        return _real_launch(L, name, a, stream)
+    _lib._launch = _launch_poisoned
+    print("(LDS of every CU NaN-filled in front of every launch)")
 ref_loss, ref = step()
 print("first step with every engine buffer NaN-filled at allocation: loss %.6f, NaN gradients: %s" % (
     ref_loss, [k for k, v in ref.items() if torch.isnan(v).any()] or "none"))

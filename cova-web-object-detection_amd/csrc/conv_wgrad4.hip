@@ -74,12 +74,12 @@ constexpr int ROW = 10;                              // floats per operand row (
 constexpr int TILE_FLOATS = 128 * ROW + 32;          // the two tiles of a 32-lane read group sit 32 banks apart: conflict-free ds_read_b64
 constexpr int BUF_FLOATS = 2 * 4 * TILE_FLOATS;      // [position group 2][tile 4][channel 128 = co | ci][10]: 41,984 B
 constexpr int RAW_FLOATS = 36 * 64;                  // a wave's pixel buffer: 36 pixels x 64 channels = 9,216 B
-constexpr int PART_FLOATS = 18 * 4096;               // one block's partial: [position 18][co 64][ci 64]
+constexpr int PART_FLOATS = 9 * 4096;                // one block's partial, output-transformed: [r * 3 + t][co 64][ci 64]
 }  // namespace wg4
 
 struct Wg4Args {
     const float *act, *dz, *dz2;     // NHWC [B,H,W,64]; dz2 nullable
-    float *part;                     // [grid][18][64][64]
+    float *part;                     // [grid][9][64][64]
     const float *act_abc, *dz_abc;   // [3][64] = A | B | C, or nullptr (plain operand)
     float *dz_out;                   // nullable: the gradient operand as formed on load (A*dz + B*dz2 + C), NHWC [B,H,W,64]
     unsigned *prog;                  // [grid] progress words of the blocks (launch tag << 16 | K-steps transformed), or nullptr
@@ -517,80 +517,104 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
             else run(Fl{}, H1{});
         }
     }
-    // ---- this block's partial: part[block][position 9 pg + q][co][ci]
-    float *dst = a.part + (size_t)blockIdx.x * PART_FLOATS;
+    // ---- this block's partial, already through the output transform (linear, so the sum over blocks commutes with it):
+    //        part[block][r * 3 + t][co][ci] = sum over the half's positions (a, b) of G[a][r] * G[b][t] * Q[a][b][co][ci]
+    // in fp64 on the f32 accumulators (rows first: c[t] = sum_b G[b][t] Q[a][b], then T[r][t] += G[a][r] c[t]; zero
+    // coefficients dropped at compile time: 33 / 39 fused multiply-adds per entry for the two position groups), rounded to
+    // f32 once.  The two position groups of a (co, ci) block are the waves w and w ^ 1: group 1 hands its nine values per
+    // entry over through the operand buffers (idle now), group 0 adds and stores -- 9 x 4096 floats per block instead of
+    // 18 x 4096: half the partial traffic of the launch and a quarter for the fold kernel, which no longer transforms.
+    auto fold = [&](auto hsel, auto psel) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(hsel)::value, PG = decltype(psel)::value;
+        constexpr double G[6][3] = {{0.25, 0.0, 0.0},         {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+        float *dst = a.part + (size_t)blockIdx.x * PART_FLOATS;
 #pragma unroll
-    for (int q = 0; q < 9; ++q)
+        for (int e = 0; e < 4; ++e) {
+            float *xch = s_op + (e & 1) * (4 * 36 * 64) + (wave >> 1) * (36 * 64) + lane;       // [entry r][k 9][lane 64]
+            float tv[4][9];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 4; ++r) {
+                double T[9];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 9; ++k) T[k] = 0.0;
+#pragma unroll
+                for (int al = 0; al < 3; ++al) {
+                    constexpr int p0 = 9 * PG, p1 = 9 * PG + 9;
+                    if (6 * al + 6 <= p0 || 6 * al >= p1) continue;              // the row is not in this group
+                    const int arow = HALF == 0 ? al : (al == 0 ? 5 : 2 + al);     // half 1 holds rows 5, 3, 4
+                    double c[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const int pos = 6 * al + b;
+                        if (pos < p0 || pos >= p1) continue;
+                        const double qv = (double)acc[pos - p0][e][r];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            if (G[b][t] != 0.0) c[t] = fma(G[b][t], qv, c[t]);
+                    }
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            if (G[arow][r3] != 0.0) T[r3 * 3 + t] = fma(G[arow][r3], c[t], T[r3 * 3 + t]);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) tv[r][k] = (float)T[k];
+            }
+            if (PG == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dst[(9 * pg + q) * 4096 + (16 * (2 * cp + i) + 4 * kq + r) * 64 + 16 * (2 * np + j) + l15] =
-                        acc[q][i * 2 + j][r];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) xch[(r * 9 + k) * 64] = tv[r][k];
+            }
+            __syncthreads();              // (area e & 1 is written again in round e + 2: the barrier of round e + 1 lies between)
+            if (PG == 0) {
+                const int i = e >> 1, j = e & 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        dst[k * 4096 + (16 * (2 * cp + i) + 4 * kq + r) * 64 + 16 * (2 * np + j) + l15] =
+                            tv[r][k] + xch[(r * 9 + k) * 64];
+            }
+        }
+    };
+    __syncthreads();                      // every wave is out of its last operand reads (blocks without K-steps included)
+    {
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        if (half == 0) { if (pg == 0) fold(H0{}, H0{}); else fold(H0{}, H1{}); }
+        else           { if (pg == 0) fold(H1{}, H0{}); else fold(H1{}, H1{}); }
+    }
 }
 
-// Fold of the per-block partials and the final transform, up to four convolutions in one launch:
-//   Q[a][b][co][ci] = sum over the walkers of part[block(half of a, walker)][position][co][ci]      (fp64, fixed order)
-//   dW[co][ci][r][t] = sum_{a,b} G[a][r] * Q[a][b] * G[b][t]                                         (OIHW)
-// block = 16 (co, ci) pairs x 16 slices of walkers
+// Fold of the per-block partials (already transformed: part[block][r * 3 + t][co][ci]), up to four convolutions in one launch:
+//   dW[co][ci][r][t] = sum over the blocks of part[block][r * 3 + t][co][ci]       (fp64, fixed order; OIHW)
+// block = 16 (co, ci) pairs x 16 slices of blocks
 struct Wg4FinishJobs { const float *part[4]; float *dw[4]; };
 __global__ __launch_bounds__(256) void wgrad4_finish_kernel(const Wg4FinishJobs jobs, int grid)
 {
-    __shared__ double s_acc[36][16][16];         // [position][slice][pair]: 73,728 B
+    __shared__ double s_acc[9][16][16];          // [r * 3 + t][slice][pair]
     const float *__restrict__ part = jobs.part[blockIdx.y];
     float *__restrict__ dw = jobs.dw[blockIdx.y];
     const int tx = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + tx;        // (co, ci) pair
-    const int NW = grid >> 1;
-    const bool xcd = (grid & 15) == 0;
-    double acc[36];
+    double acc[9];
 #pragma unroll
-    for (int p = 0; p < 36; ++p) acc[p] = 0.0;
-    for (int w = slice; w < NW; w += 16) {
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int blk = slice; blk < grid; blk += 16) {
+        const float *row = part + (size_t)blk * wg4::PART_FLOATS + idx;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int blk = xcd ? 8 * (2 * (w >> 3) + h) + (w & 7) : 2 * w + h;
-            const float *row = part + (size_t)blk * wg4::PART_FLOATS + idx;
-#pragma unroll
-            for (int p = 0; p < 18; ++p) acc[h * 18 + p] += (double)row[p * 4096];
-        }
+        for (int k = 0; k < 9; ++k) acc[k] += (double)row[k * 4096];
     }
 #pragma unroll
-    for (int p = 0; p < 36; ++p) s_acc[p][slice][tx] = acc[p];
+    for (int k = 0; k < 9; ++k) s_acc[k][slice][tx] = acc[k];
     __syncthreads();
-    if (slice == 0) {
-        const double G[6][3] = {{0.25, 0.0, 0.0},
-                                {-1.0 / 6, -1.0 / 6, -1.0 / 6},
-                                {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                {1.0 / 24, 1.0 / 12, 1.0 / 6},
-                                {1.0 / 24, -1.0 / 12, 1.0 / 6},
-                                {0.0, 0.0, 1.0}};
-        double Q[6][6];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int al = 0; al < 3; ++al) {
-                const int ar = h == 0 ? al : (al == 0 ? 5 : 2 + al);      // half 1 holds rows 5, 3, 4
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    double t = 0.0;
-                    for (int j = 0; j < 16; ++j) t += s_acc[h * 18 + al * 6 + b][j][tx];
-                    Q[ar][b] = t;
-                }
-            }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                double sm = 0.0;
-#pragma unroll
-                for (int ar = 0; ar < 6; ++ar)
-#pragma unroll
-                    for (int b = 0; b < 6; ++b) sm += G[ar][r] * G[b][t] * Q[ar][b];
-                dw[idx * 9 + r * 3 + t] = (float)sm;
-            }
+    if (slice < 9) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += s_acc[slice][j][tx];
+        dw[idx * 9 + slice] = (float)t;
     }
 }
 
@@ -651,7 +675,7 @@ COVA_API int cova_conv3x3_wgrad4_num_partials(int B, int H, int W) { return wg4_
 COVA_API int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W)
 {
     const int grid = wg4_geometry(B, H, W).grid;
-    return grid * wg4::PART_FLOATS + ((grid + 63) & ~63);          // <= 256 blocks x 73,728 floats + one progress word per block
+    return grid * wg4::PART_FLOATS + ((grid + 63) & ~63);          // <= 256 blocks x 36,864 floats + one progress word per block
 }
 
 // Per-block partial sums of the weight gradient in the F(4x4,3x3) domain; operands transformed on load as

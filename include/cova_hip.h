@@ -153,7 +153,8 @@ int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
  * convolutions (torchvision BasicBlock conv1 / conv2, models.py:49-51; loss.backward() at train.py:59).  Same two-step
  * contract as cova_conv3x3_wgrad_wino_partial / _finish: activation = relu?(A*act + C) on load (act_abc nullable),
  * gradient = A*dz + B*dz2 + C on load (dz_abc, dz2 nullable), per-block partials into ws
- * (cova_conv3x3_wgrad4_workspace_floats), then the fp64 fold + G^T Q G of up to four convolutions in one launch. */
+ * (cova_conv3x3_wgrad4_workspace_floats; each block applies G^T . G to its own sums in fp64 and writes [9][64][64]),
+ * then the fp64 fold of up to four convolutions in one launch. */
 int cova_conv3x3_wgrad4_num_partials(int B, int H, int W);
 int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W);
 int cova_conv3x3_wgrad4_partial(const float *act, const float *act_abc /*nullable*/, int act_relu, const float *dz,

@@ -792,7 +792,7 @@ def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
     try:
         ws = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", B, H, W), device=DEV)
         nblk = query("cova_conv3x3_wgrad4_num_partials", B, H, W)
-        assert ws.numel() == nblk * 18 * 4096 + ((nblk + 63) // 64) * 64       # partial sums + one progress word per block
+        assert ws.numel() == nblk * 9 * 4096 + ((nblk + 63) // 64) * 64        # transformed partial sums + one progress word per block
         dw = torch.zeros(64, 64, 3, 3, device=DEV)
         call("cova_conv3x3_wgrad4", x, dy, dw, ws, B, H, W)
         close(dw, wr.grad, 5e-5, "F(4x4) wgrad vs fp64")      # (random data: no coherent signal; the F(2x2) test allows 2e-4)

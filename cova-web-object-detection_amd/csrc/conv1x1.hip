@@ -28,11 +28,16 @@
 // Roofline bookkeeping: 2*Cin*Cout FLOP and 4*(Cin+Cout) compulsory bytes per pixel --
 // 64->256 / 256->64: 32,768 FLOP vs 1,280 B (25.6 FLOP/B: at the f32-MFMA / HBM ridge),
 // 64->64: 8,192 FLOP vs 512 B (HBM bound).
-#include "common.h"
+#include "bf3.h"
 
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 
 namespace {
+
+__device__ __forceinline__ f32x16 c11_mfma_bf(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 struct C11Args {
     const float *in, *in2, *pro;          // pro [3][Cin] = A | B | C (nullable)
@@ -58,7 +63,7 @@ struct C11Args {
     const unsigned *act_bits;             // mask source of the EPI 3 epilogue in that form (instead of `act`)
 };
 
-template <int CIN, int COUT, bool EXT = false>
+template <int CIN, int COUT, bool EXT = false, bool BF_OK = true>
 struct C11Geo {
     static constexpr int XK = EXT ? 64 : 0;            // extra K channels (second operand tensor)
     static constexpr int WSTR = CIN + XK + 4;
@@ -67,7 +72,14 @@ struct C11Geo {
     static constexpr int NT = COUT / 32;               // 32-column accumulators per row tile
     static constexpr int NTP = NT > 4 ? 4 : NT;        // accumulators per pass (register budget)
     static constexpr int PASSES = NT / NTP;
-    static constexpr int W_FLOATS = COUT * WSTR;
+    // BF (Cin = 64): the product runs on the bf16 matrix pipe, every f32 operand as three round-to-nearest bf16 pieces and
+    // the six products of order <= 2 accumulated in f32 (bf3.h; DESIGN.md sections 11.8 / 12.8) -- 2.67x less matrix time than
+    // v_mfma_f32_32x32x2_f32, on a pipe the vector work does not share: the 64 -> 256 / 64 -> 64 launches become HBM bound.
+    // The weights sit in LDS as [piece 3][co][8 slots of 8 channels as packed bf16] with rows of 144 B (9 slots: the 16 lanes
+    // of a ds_read_b128 group hit 16 distinct slots).
+    static constexpr bool BF = CIN == 64 && !EXT && BF_OK;
+    static constexpr int WROW = 36;                    // dwords per (piece, co) row of the bf16 image
+    static constexpr int W_FLOATS = BF ? 3 * COUT * WROW : COUT * WSTR;
     static constexpr int RED_FLOATS = 8 * 3 * COUT;    // aliased onto the weights after the tile loop (<= 8 waves)
     static constexpr int LDS_FLOATS = W_FLOATS + 3 * CIN + 3 * XK;
 };
@@ -79,7 +91,10 @@ template <int CIN, int COUT, int PRO, int EPI, bool HAS_ADD, bool MASK_ACT, bool
           int NW = 4, bool SIDE = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const C11Args a)
 {
-    using G = C11Geo<CIN, COUT, EXT>;
+    // (the 64 -> 256 data-gradient variants WITH BatchNorm sums stay on the f32 MFMA: their epilogue keeps up to four operands
+    // per output in flight and the bf16 path's operand pieces would spill 35-160 registers; the step does not launch them
+    // when the linear form of conv1x1_lin.hip is on)
+    using G = C11Geo<CIN, COUT, EXT, !(EPI == 2 && COUT == 256)>;
     constexpr int NTHR = NW * 64;
     // CO: the 256-channel operand is fetched COALESCED -- 8 adjacent lanes on one 128-byte line of a row -- and brought
     // into the MFMA layout (lane = row) through a wave-private 8 KB LDS transposer.  Row-per-lane loads (8 x 16 bytes
@@ -87,15 +102,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
     // 6.2 TB/s (tools/lane_pattern_probe2.py); the element-wise prologue and the side output run in the coalesced layout
     // (per-lane channel constants, 128-byte stores).  Needs the 8-wave / one-block-per-CU geometry for the LDS room.
     constexpr bool CO = NW == 8;
-    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + (CO ? NW * 2048 : 0)];
-    float4 *s_tr = reinterpret_cast<float4 *>(lds + G::LDS_FLOATS) + (threadIdx.x >> 6) * 512;      // this wave's transposer
+    // (BF: the transposer takes the tile's 32 rows in two rounds of 16 -- 4 KB per wave -- which is what lets the 110 KB
+    // piece image of a 64 -> 256 weight and eight transposers share the CU's 160 KB)
+    constexpr bool BF = G::BF;
+    constexpr int TRF4 = BF ? 256 : 512;                    // float4 slots of a wave's transposer
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + (CO ? NW * TRF4 * 4 : 0)];
+    float4 *s_tr = reinterpret_cast<float4 *>(lds + G::LDS_FLOATS) + (threadIdx.x >> 6) * TRF4;     // this wave's transposer
     const int ca = (threadIdx.x & 63) >> 4, chh = ((threadIdx.x & 63) >> 3) & 1, cq = threadIdx.x & 7;   // CO lane -> (row & 3, K-half, 16-byte piece)
     float *Ws = lds, *s_pro = lds + G::W_FLOATS, *s_pro3 = lds + G::W_FLOATS + 3 * CIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
 
     // ---- stage the weight [co][WSTR] (+ the prologue table) once per block
-    if (!a.w_trans) {
+    if constexpr (BF) {                                    // (co, slot g = channels 8g .. 8g+7) -> three packed-bf16 u32x4
+        u32x4 *Wp = reinterpret_cast<u32x4 *>(lds);
+        for (int i = tid; i < COUT * 8; i += NTHR) {
+            const int co = i >> 3, g = i & 7;
+            float wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv[k] = a.w_trans ? a.w[(size_t)(8 * g + k) * COUT + co] : a.w[(size_t)co * CIN + 8 * g + k];
+            u32x4 q0, q1, q2;
+            bf3_split8(wv, q0, q1, q2);
+            Wp[(0 * COUT + co) * (G::WROW / 4) + g] = q0;
+            Wp[(1 * COUT + co) * (G::WROW / 4) + g] = q1;
+            Wp[(2 * COUT + co) * (G::WROW / 4) + g] = q2;
+        }
+    } else if (!a.w_trans) {
         for (int i = tid; i < COUT * (CIN / 4); i += NTHR) {
             const int co = i / (CIN / 4), c4 = i - co * (CIN / 4);
             *reinterpret_cast<float4 *>(Ws + co * G::WSTR + 4 * c4) =
@@ -196,12 +228,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                 // transposer slot of (row r, half, piece q): (2 r + half) * 8 + (q ^ (r & 7)) -- the eight lanes of a line
                 // write one 128-byte row, the eight readers of consecutive rows hit eight different 16-byte bank groups
                 const int rl = 4 * j + ca;
-                s_tr[(2 * rl + chh) * 8 + (cq ^ (rl & 7))] = e4;
-            }
+                if constexpr (BF) {                     // two rounds of 16 rows through a 4 KB transposer (same wave: LDS operations stay in order)
+                    const int rr = rl & 15;
+                    s_tr[(2 * rr + chh) * 8 + (cq ^ (rr & 7))] = e4;
+                    if (j == 3 || j == 7) {
+                        if ((p >> 4) == (j >> 2)) {
+                            const int pr = p & 15;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 t = s_tr[(2 * p + h) * 8 + (q ^ (p & 7))];
-                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+                            for (int q = 0; q < 8; ++q) {
+                                const float4 t = s_tr[(2 * pr + h) * 8 + (q ^ (pr & 7))];
+                                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+                            }
+                        }
+                    }
+                } else {
+                    s_tr[(2 * rl + chh) * 8 + (cq ^ (rl & 7))] = e4;
+                }
+            }
+            if constexpr (!BF) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 t = s_tr[(2 * p + h) * 8 + (q ^ (p & 7))];
+                    x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+                }
             }
             return;
         }
@@ -267,6 +316,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
     // CONSECUTIVE CHANNELS (32n + 8j + 4h ..+3), so the epilogue moves float4s (a quarter of the memory
     // instructions of the channel-per-lane layout, whose 4-byte accesses bound the 256-channel epilogues).
     constexpr bool TR = EPI == 3 && COUT == 256 && !EXT;
+    // accumulators per pass.  BF + TR (the block-input gradient 64 -> 256 with addend and mask): two, and the pass's epilogue
+    // operands are requested BEFORE its MFMAs -- that launch moves 5x more bytes through its epilogue than through the MFMA
+    // operand and was bound by loads in flight (two waves per SIMD), not by the matrix pipe
+    constexpr bool EARLY = BF && TR;
+    constexpr int NTP = EARLY ? 2 : G::NTP, PASSES = G::NT / NTP;
     constexpr int TC = G::CHUNKS + (EXT ? 1 : 0);          // register chunks per tile incl. the extra operand
     long long tile = (long long)blockIdx.x * NW + wave;
     float4 nv[8], nv2[8];
@@ -282,11 +336,76 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
             prologue(tile, 0, nv, nv2, x);
             if (PREFETCH && tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);      // next tile in flight
         }
+        // BF: the tile's operand as three packed-bf16 pieces (A operand of v_mfma_f32_32x32x16_bf16: K-step s = the lane's
+        // channels 8s .. 8s+7).  The bf16 MFMA drops product bits below ~2^-26 of the largest exponent of a step toward
+        // -infinity (tools/probe/mfma_round_probe.hip): every second row tile is multiplied with NEGATED activations and its
+        // accumulators are negated back, so that the bias has no common sign over the map (as conv_wino4_split.h).
+        u32x4 xp[3][4];
+        const bool neg = BF && (tile & 1);
+        if constexpr (BF) {
 #pragma unroll
-        for (int ps = 0; ps < G::PASSES; ++ps) {
-            f32x16 acc[G::NTP];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float t8[8];
 #pragma unroll
-            for (int n = 0; n < G::NTP; ++n)
+                for (int k = 0; k < 8; ++k) t8[k] = neg ? -x[8 * s4 + k] : x[8 * s4 + k];
+                bf3_split8(t8, xp[0][s4], xp[1][s4], xp[2][s4]);
+            }
+        }
+        // TR epilogue in two halves: the requests (addend, mask source) and the arithmetic + stores
+        long long trow = r0 + p;
+        const bool tr_ok = trow < a.R;
+        if (!tr_ok) trow = a.R - 1;
+        const size_t rbase = (size_t)trow * COUT + 4 * h;
+        const bool bits = a.act_bits != nullptr;                  // (wave-uniform)
+        auto tr_request = [&](int ps, int nn, float4 (&ad)[2][4], float4 (&mk)[2][4], unsigned (&mb)[2]) __attribute__((always_inline)) {
+            if (EPI != 3) return;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (bits) mb[u] = a.act_bits[(size_t)trow * (COUT / 32) + ps * NTP + nn + u] >> (4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t o = rbase + (ps * NTP + nn + u) * 32 + 8 * j;
+                    if (HAS_ADD) ad[u][j] = *reinterpret_cast<const float4 *>(a.addend + o);
+                    if (!bits) mk[u][j] = *reinterpret_cast<const float4 *>(a.act + o);
+                }
+            }
+        };
+        auto tr_finish = [&](int ps, int nn, const f32x16 (&acc)[NTP], const float4 (&ad)[2][4], const float4 (&mk)[2][4],
+                             const unsigned (&mb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 v = make_float4(acc[nn + u][4 * j], acc[nn + u][4 * j + 1], acc[nn + u][4 * j + 2], acc[nn + u][4 * j + 3]);
+                    if (EPI == 3) {
+                        if (HAS_ADD) { v.x += ad[u][j].x; v.y += ad[u][j].y; v.z += ad[u][j].z; v.w += ad[u][j].w; }
+                        if (bits) {                    // bit 8j + 4h + k of the word = channel 32n + 8j + 4h + k
+                            const unsigned q = mb[u] >> (8 * j);
+                            if (!(q & 1u)) v.x = 0.f;
+                            if (!(q & 2u)) v.y = 0.f;
+                            if (!(q & 4u)) v.z = 0.f;
+                            if (!(q & 8u)) v.w = 0.f;
+                        } else {
+                            if (!(mk[u][j].x > 0.f)) v.x = 0.f;
+                            if (!(mk[u][j].y > 0.f)) v.y = 0.f;
+                            if (!(mk[u][j].z > 0.f)) v.z = 0.f;
+                            if (!(mk[u][j].w > 0.f)) v.w = 0.f;
+                        }
+                    }
+                    if (tr_ok) *reinterpret_cast<float4 *>(a.out + rbase + (ps * NTP + nn + u) * 32 + 8 * j) = v;
+                }
+        };
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            f32x16 acc[NTP];
+            float4 e_ad[2][4], e_mk[2][4];
+            unsigned e_mb[2] = {0u, 0u};
+            if constexpr (EARLY) {
+                tr_request(ps, 0, e_ad, e_mk, e_mb);
+                __builtin_amdgcn_sched_barrier(0);         // the requests stay ahead of the MFMAs (not sunk to their uses)
+            }
+#pragma unroll
+            for (int n = 0; n < NTP; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 #pragma unroll
@@ -302,80 +421,69 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                 }
                 // weight columns of this chunk: the lane's K-half of the main operand, or of the extra one
                 const int wcol = (EXT && c == G::CHUNKS) ? CIN + h * 32 : h * G::KH + c * 32;
+                if constexpr (BF) {
+                    const u32x4 *Wp = reinterpret_cast<const u32x4 *>(lds);
+                    // one accumulator at a time (a dependent chain of bf16 MFMAs issues back to back: tools/probe/mfma32_probe.hip):
+                    // three weight pieces = 12 registers in flight instead of 48
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            u32x4 b[3];
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc)
+                                b[pc] = Wp[(pc * COUT + (ps * NTP + n) * 32 + p) * (G::WROW / 4) + h * 4 + s4];
+                            // the six products of order <= 2, smallest first: x2 w0, x0 w2, x1 w1, x1 w0, x0 w1, x0 w0
+                            auto mf = [&](int xi, int wi) __attribute__((always_inline)) {
+                                acc[n] = TR ? c11_mfma_bf(b[wi], xp[xi][s4], acc[n]) : c11_mfma_bf(xp[xi][s4], b[wi], acc[n]);
+                            };
+                            mf(2, 0); mf(0, 2); mf(1, 1); mf(1, 0); mf(0, 1); mf(0, 0);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float4 b[G::NTP];
+                    float4 b[NTP];
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n)
+                    for (int n = 0; n < NTP; ++n)
                         b[n] = *reinterpret_cast<const float4 *>(
-                            Ws + ((ps * G::NTP + n) * 32 + p) * G::WSTR + wcol + 4 * q);
+                            Ws + ((ps * NTP + n) * 32 + p) * G::WSTR + wcol + 4 * q);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n)
+                    for (int n = 0; n < NTP; ++n)
                         acc[n] = TR ? mfma32(b[n].x, x[4 * q + 0], acc[n]) : mfma32(x[4 * q + 0], b[n].x, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n)
+                    for (int n = 0; n < NTP; ++n)
                         acc[n] = TR ? mfma32(b[n].y, x[4 * q + 1], acc[n]) : mfma32(x[4 * q + 1], b[n].y, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n)
+                    for (int n = 0; n < NTP; ++n)
                         acc[n] = TR ? mfma32(b[n].z, x[4 * q + 2], acc[n]) : mfma32(x[4 * q + 2], b[n].z, acc[n]);
 #pragma unroll
-                    for (int n = 0; n < G::NTP; ++n)
+                    for (int n = 0; n < NTP; ++n)
                         acc[n] = TR ? mfma32(b[n].w, x[4 * q + 3], acc[n]) : mfma32(x[4 * q + 3], b[n].w, acc[n]);
                 }
             }
+            if (neg) {
+#pragma unroll
+                for (int n = 0; n < NTP; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][r] = -acc[n][r];
+            }
             if (TR) {
                 // ---- float4 epilogue: register quad j of accumulator nn = channels 32n + 8j + 4h ..+3 of row r0 + p
-                long long row = r0 + p;
-                const bool ok = row < a.R;
-                if (!ok) row = a.R - 1;
-                const size_t rbase = (size_t)row * COUT + 4 * h;
 #pragma unroll
-                for (int nn = 0; nn < G::NTP; nn += 2) {       // two accumulators = 8 float4 per tensor in flight
+                for (int nn = 0; nn < NTP; nn += 2) {       // two accumulators = 8 float4 per tensor in flight
                     float4 ad[2][4], mk[2][4];
-                    const bool bits = a.act_bits != nullptr;          // (wave-uniform)
                     unsigned mb[2] = {0u, 0u};
-                    if (EPI == 3) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            if (bits) mb[u] = a.act_bits[(size_t)row * (COUT / 32) + ps * G::NTP + nn + u] >> (4 * h);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const size_t o = rbase + (ps * G::NTP + nn + u) * 32 + 8 * j;
-                                if (HAS_ADD) ad[u][j] = *reinterpret_cast<const float4 *>(a.addend + o);
-                                if (bits) {            // bit 8j + 4h + k of the word = channel 32n + 8j + 4h + k
-                                    const unsigned q = mb[u] >> (8 * j);
-                                    mk[u][j] = make_float4((float)(q & 1u), (float)((q >> 1) & 1u), (float)((q >> 2) & 1u),
-                                                           (float)((q >> 3) & 1u));
-                                } else {
-                                    mk[u][j] = *reinterpret_cast<const float4 *>(a.act + o);
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float4 v = make_float4(acc[nn + u][4 * j], acc[nn + u][4 * j + 1], acc[nn + u][4 * j + 2],
-                                                   acc[nn + u][4 * j + 3]);
-                            if (EPI == 3) {
-                                if (HAS_ADD) { v.x += ad[u][j].x; v.y += ad[u][j].y; v.z += ad[u][j].z; v.w += ad[u][j].w; }
-                                if (!(mk[u][j].x > 0.f)) v.x = 0.f;
-                                if (!(mk[u][j].y > 0.f)) v.y = 0.f;
-                                if (!(mk[u][j].z > 0.f)) v.z = 0.f;
-                                if (!(mk[u][j].w > 0.f)) v.w = 0.f;
-                            }
-                            if (ok)
-                                *reinterpret_cast<float4 *>(a.out + rbase + (ps * G::NTP + nn + u) * 32 + 8 * j) = v;
-                        }
+                    if (!EARLY) tr_request(ps, nn, ad, mk, mb);
+                    tr_finish(ps, nn, acc, EARLY ? e_ad : ad, EARLY ? e_mk : mk, EARLY ? e_mb : mb);
                 }
                 continue;                                      // next pass
             }
             // ---- epilogue of this pass: lane owns channel n*32 + p of rows mfma32_row(r, lane); 8 rows at
             // a time so that the operands in flight (up to 4 per row) stay within the register budget
 #pragma unroll
-            for (int nn = 0; nn < G::NTP; ++nn) {
-                const int n = ps * G::NTP + nn;
+            for (int nn = 0; nn < NTP; ++nn) {
+                const int n = ps * NTP + nn;
                 const int cn = n * 32 + p;
                 float mu = 0.f, is = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f, cv = 0.f;
                 if (EPI == 2) {

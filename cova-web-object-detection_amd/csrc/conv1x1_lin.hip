@@ -15,7 +15,7 @@
 // maps per Bottleneck, at +25 % MFMA work (the Gram matrix / the 64 extra K channels).  Same exact-f32
 // MFMA arithmetic; the result differs from the direct form by summation order only (measured against
 // fp64: 4e-7 relative, the direct form 1.4e-6).
-#include "common.h"
+#include "bf3.h"
 
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
 
@@ -31,110 +31,151 @@ struct VPArgs {
     int act_relu;
 };
 
-// GEMM M = 256 (v channels), N = 64 (a channels), K = pixels on v_mfma_f32_32x32x2_f32, operands straight
-// from HBM (conv1x1_wgrad_kernel's layout: a k-step is a pixel pair, half-wave h takes pixel 2s+h, lane p
-// supplies channels {2p, 2p+1}).  Wave u owns v channels 64u..64u+63; the Gram matrix of a (the same
-// operand on both sides) is spread over the four waves by batch of 8 k-steps (batch & 3 == u), as are the sums of a.
-template <bool PRO_ACT>
+// GEMM M = 256 (v channels), N = 64 (a channels), K = pixels, on the bf16 matrix pipe: every f32 operand as three
+// round-to-nearest bf16 pieces, the six products of order <= 2 accumulated in f32 (bf3.h; DESIGN.md sections 11.8 / 12.8) --
+// with v_mfma_f32_32x32x2_f32 the launch was bound by the matrix pipe (134 GFLOP = 0.86 ms of f32-MFMA time for 4.2 GB of
+// operands); six bf16 products of K = 16 take 0.32 ms and leave it to HBM.
+// A K-step = 16 pixels: half-wave h takes pixels 8h .. 8h+7, lane p loads channels {2p, 2p+1} of each as one float2 (operands
+// straight from HBM, 256 contiguous bytes per half-wave and load) -- the eight pixels of a channel are the eight consecutive
+// k of an MFMA operand, so accumulator (i, j) holds co = 64u + 2 row + i, ci = 2 col + j as before.  Wave u owns v channels
+// 64u .. 64u+63; the Gram matrix of a (the same operand on both sides) is taken by wave (K-step & 3), as are the sums of a.
+// The bf16 MFMA drops low product bits toward -infinity (tools/probe/mfma_round_probe.hip): odd blocks multiply with the
+// NEGATED a on the B side and negate their partial sums back, so that the bias has no common sign over the blocks.
+__device__ __forceinline__ f32x16 vp_mfma(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// (one instantiation: without act_abc the prologue runs with A = 1, C = 0 -- exact; the variant without it made the register
+// allocator spill the Gram accumulators)
 __global__ __launch_bounds__(256, 2) void conv1x1_vprod_kernel(const VPArgs a)
 {
+    constexpr bool PRO_ACT = true;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 31, h = lane >> 5;
     const int cob = wave * 64;
     float aA[2] = {1.f, 1.f}, aC[2] = {0.f, 0.f};
-    if (PRO_ACT) {
+    if (a.act_abc != nullptr) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             aA[k] = a.act_abc[2 * p + k];
             aC[k] = a.act_abc[2 * CI + 2 * p + k];
         }
     }
-    f32x16 acc[2][2], accg[2][2];
+    // (the Gram matrix: wave u takes its quadrant (i, j) = (u >> 1, u & 1) of every K-step -- one accumulator instead of four:
+    // with all four the register allocator spilled ~120 registers)
+    f32x16 acc[2][2], accg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accg[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = accg[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float su[2] = {0.f, 0.f}, sa[2] = {0.f, 0.f};
+    const bool relu = a.act_abc != nullptr && a.act_relu != 0;
+    const int gi = wave >> 1, gj = wave & 1;                   // (wave-uniform)
+    const bool neg = (blockIdx.x & 1) != 0;
+    const float sgn = neg ? -1.f : 1.f;
+    const uint32_t flip = neg ? 0x80008000u : 0u;
 
-    const long long npairs = (a.R + 1) / 2;
-    const long long per = (npairs + gridDim.x - 1) / gridDim.x;
-    const long long s_lo = (long long)blockIdx.x * per;
-    long long s_hi = s_lo + per;
-    if (s_hi > npairs) s_hi = npairs;
-    constexpr int U = 8;
-    float2 g[2][U], x[2][U];
-    const int lz = h * CO + cob + 2 * p, lx = h * CI + 2 * p;
-    auto issue = [&](long long s0, float2 (&gg)[U], float2 (&xx)[U]) {
-        const float *bz = a.v + (size_t)(2 * s0) * CO, *bx = a.act + (size_t)(2 * s0) * CI;
+    // K-steps of this block: a contiguous range
+    const long long nsteps = (a.R + 15) / 16;
+    const long long per = (nsteps + gridDim.x - 1) / gridDim.x;
+    const long long k_lo = (long long)blockIdx.x * per;
+    long long k_hi = k_lo + per;
+    if (k_hi > nsteps) k_hi = nsteps;
+    float2 g[8], x[8];
+    // lane offsets inside a K-step (loop invariant): a uniform base per K-step + these + t rows as the instruction's immediate
+    const unsigned ov = (unsigned)((8 * h) * CO + cob + 2 * p), ox = (unsigned)((8 * h) * CI + 2 * p);
+    auto issue = [&](long long ks) {                           // a K-step entirely inside the map
+        const float *vb = a.v + (size_t)ks * 16 * CO, *xb = a.act + (size_t)ks * 16 * CI;
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            gg[k] = *reinterpret_cast<const float2 *>(bz + lz + k * 2 * CO);
-            xx[k] = *reinterpret_cast<const float2 *>(bx + lx + k * 2 * CI);
+        for (int t = 0; t < 8; ++t) {
+            g[t] = *reinterpret_cast<const float2 *>(vb + ov + t * CO);
+            x[t] = *reinterpret_cast<const float2 *>(xb + ox + t * CI);
         }
     };
-    auto mac = [&](float d0, float d1, float x0, float x1, bool valid, bool gram) {
-        if (PRO_ACT) {
-            x0 = fmaf(aA[0], x0, aC[0]);
-            x1 = fmaf(aA[1], x1, aC[1]);
-            if (a.act_relu) { x0 = x0 > 0.f ? x0 : 0.f; x1 = x1 > 0.f ? x1 : 0.f; }
-        }
-        if (!valid) d0 = d1 = x0 = x1 = 0.f;
-        acc[0][0] = mfma32(d0, x0, acc[0][0]);
-        acc[0][1] = mfma32(d0, x1, acc[0][1]);
-        acc[1][0] = mfma32(d1, x0, acc[1][0]);
-        acc[1][1] = mfma32(d1, x1, acc[1][1]);
-        su[0] += d0;
-        su[1] += d1;
-        if (gram) {                        // wave-uniform
-            accg[0][0] = mfma32(x0, x0, accg[0][0]);
-            accg[0][1] = mfma32(x0, x1, accg[0][1]);
-            accg[1][0] = mfma32(x1, x0, accg[1][0]);
-            accg[1][1] = mfma32(x1, x1, accg[1][1]);
-            sa[0] += x0;
-            sa[1] += x1;
-        }
-    };
-    // The Gram matrix of a batch (8 pixel pairs) is taken by wave (batch & 3): one uniform branch per batch.
-    auto consume = [&](const float2 (&gg)[U], const float2 (&xx)[U], long long batch) {
-        const bool gram = (int)(batch & 3) == wave;          // wave-uniform
+    // one K-step from the operands in g / x: prologue, validity, sums, pieces; then `next` (the following requests); MFMAs
+    auto step = [&](long long ks, bool ragged, auto next) __attribute__((always_inline)) {
+        const bool gram = (int)(ks & 3) == wave;               // wave-uniform: this wave takes the K-step's sums of a
+        float gv[2][8], xv[2][8];
+        const long long r0 = ks * 16 + 8 * h;
 #pragma unroll
-        for (int k = 0; k < U; ++k) mac(gg[k].x, gg[k].y, xx[k].x, xx[k].y, true, gram);
-    };
-    // full batches [s_lo + b*U, +U) inside the block's range AND inside the map.  Every load in the loop is
-    // unconditional (the last batch re-requests itself): a load under a branch would make the compiler wait
-    // for vmcnt(0) at the join, i.e. for the batch that was only just requested.
-    long long full_hi = s_hi;
-    if (2 * full_hi > a.R) full_hi = a.R / 2;
-    const long long nfull = full_hi > s_lo ? (full_hi - s_lo) / U : 0;
-    long long s0 = s_lo;
-    if (nfull > 0) {
-        issue(s_lo, g[0], x[0]);
-        for (long long b = 0; b < nfull; b += 2) {
-            const long long b1 = b + 1 < nfull ? b + 1 : nfull - 1;
-            issue(s_lo + b1 * U, g[1], x[1]);
-            __builtin_amdgcn_sched_barrier(0);             // keep the requests ahead of the MFMAs (not sunk to their uses)
-            consume(g[0], x[0], b);
-            if (b + 1 >= nfull) break;
-            const long long b2 = b + 2 < nfull ? b + 2 : nfull - 1;
-            issue(s_lo + b2 * U, g[0], x[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(g[1], x[1], b + 1);
+        for (int t = 0; t < 8; ++t) {
+            float d0 = g[t].x, d1 = g[t].y, x0 = x[t].x, x1 = x[t].y;
+            if (PRO_ACT) {
+                x0 = fmaf(aA[0], x0, aC[0]);
+                x1 = fmaf(aA[1], x1, aC[1]);
+                if (relu) { x0 = x0 > 0.f ? x0 : 0.f; x1 = x1 > 0.f ? x1 : 0.f; }
+            }
+            if (ragged && r0 + t >= a.R) d0 = d1 = x0 = x1 = 0.f;
+            su[0] += d0;
+            su[1] += d1;
+            if (gram) { sa[0] += x0; sa[1] += x1; }
+            gv[0][t] = d0; gv[1][t] = d1;
+            xv[0][t] = x0 * sgn; xv[1][t] = x1 * sgn;
         }
-        s0 = s_lo + nfull * U;
+        u32x4 ap[2][3], bp[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf3_split8(gv[i], ap[i][0], ap[i][1], ap[i][2]);
+            bf3_split8(xv[i], bp[i][0], bp[i][1], bp[i][2]);
+        }
+        next();
+        __builtin_amdgcn_sched_barrier(0);                     // keep the requests ahead of the MFMAs (not sunk to their uses)
+        // the six products of order <= 2, smallest first: a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = vp_mfma(ap[i][2], bp[j][0], c);
+                c = vp_mfma(ap[i][0], bp[j][2], c);
+                c = vp_mfma(ap[i][1], bp[j][1], c);
+                c = vp_mfma(ap[i][1], bp[j][0], c);
+                c = vp_mfma(ap[i][0], bp[j][1], c);
+                c = vp_mfma(ap[i][0], bp[j][0], c);
+                acc[i][j] = c;
+            }
+        {                                                      // Gram quadrant; A side: the pieces of +a (= the B pieces with the block's sign undone)
+            u32x4 ag[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ag[pc][e] = (gi ? bp[1][pc][e] : bp[0][pc][e]) ^ flip;
+            const u32x4 b0 = gj ? bp[1][0] : bp[0][0], b1 = gj ? bp[1][1] : bp[0][1], b2 = gj ? bp[1][2] : bp[0][2];
+            f32x16 c = accg;
+            c = vp_mfma(ag[2], b0, c);
+            c = vp_mfma(ag[0], b2, c);
+            c = vp_mfma(ag[1], b1, c);
+            c = vp_mfma(ag[1], b0, c);
+            c = vp_mfma(ag[0], b1, c);
+            c = vp_mfma(ag[0], b0, c);
+            accg = c;
+        }
+    };
+    // K-steps entirely inside the map: the next one's operands are in flight during this one's MFMAs (the last one re-requests
+    // itself: every load in the loop is unconditional -- a load under a branch makes the compiler wait for all of them at the join)
+    long long k_full = a.R / 16;
+    if (k_full > k_hi) k_full = k_hi;
+    if (k_lo < k_full) {
+        issue(k_lo);
+#pragma unroll 1
+        for (long long ks = k_lo; ks < k_full; ++ks) step(ks, false, [&]() { issue(ks + 1 < k_full ? ks + 1 : ks); });
     }
-    for (; s0 < s_hi; s0 += U) {           // ragged tail: clamped, predicated
-        for (int k = 0; k < U; ++k) {
-            const long long sp = s0 + k;
-            long long row = 2 * sp + h;
-            const bool valid = sp < s_hi && row < a.R;
+    if (k_full < k_hi && k_full >= k_lo) {                     // the map's last, ragged K-step (one block, once): clamped rows, zeroed
+        const long long r0 = k_full * 16 + 8 * h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            long long row = r0 + t;
             if (row >= a.R) row = a.R - 1;
-            const float2 d = *reinterpret_cast<const float2 *>(a.v + (size_t)row * CO + cob + 2 * p);
-            const float2 xv = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + 2 * p);
-            mac(d.x, d.y, xv.x, xv.y, valid, ((int)(s0 / U) & 3) == wave);
+            g[t] = *reinterpret_cast<const float2 *>(a.v + (size_t)row * CO + cob + 2 * p);
+            x[t] = *reinterpret_cast<const float2 *>(a.act + (size_t)row * CI + 2 * p);
         }
+        step(k_full, true, []() {});
     }
     const size_t nb = gridDim.x, b = blockIdx.x;
     float *wsP = a.ws + b * (CO * CI);
@@ -148,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_vprod_kernel(const VPArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 2 * mfma32_row(r, lane) + i, col = 2 * p + j;
-                wsP[(size_t)(cob + row) * CI + col] = acc[i][j][r];
-                wsG[row * CI + col] = accg[i][j][r];
+                wsP[(size_t)(cob + row) * CI + col] = acc[i][j][r] * sgn;
+                wsG[row * CI + col] = (i == gi && j == gj) ? accg[r] * sgn : 0.f;     // (the fold sums the four waves' matrices)
             }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -260,8 +301,7 @@ COVA_API int cova_conv1x1_vprod(const float *v, const float *act, const float *a
     const VPArgs a{v, act, act_abc, ws, R, act_relu};
     const int grid = vprod_grid(R);
     hipStream_t st = (hipStream_t)stream;
-    if (act_abc) hipLaunchKernelGGL(conv1x1_vprod_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv1x1_vprod_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv1x1_vprod_kernel, dim3(grid), dim3(256), 0, st, a);
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(vprod_reduce_kernel, dim3(cdiv(LIN_FLOATS, 64)), dim3(1024), 0, st, ws, grid, lin);
     COVA_LAUNCH_CHECK();

@@ -72,13 +72,13 @@ struct C11Geo {
     static constexpr int NT = COUT / 32;               // 32-column accumulators per row tile
     static constexpr int NTP = NT > 4 ? 4 : NT;        // accumulators per pass (register budget)
     static constexpr int PASSES = NT / NTP;
-    // BF (Cin = 64): the product runs on the bf16 matrix pipe, every f32 operand as three round-to-nearest bf16 pieces and
-    // the six products of order <= 2 accumulated in f32 (bf3.h; DESIGN.md sections 11.8 / 12.8) -- 2.67x less matrix time than
-    // v_mfma_f32_32x32x2_f32, on a pipe the vector work does not share: the 64 -> 256 / 64 -> 64 launches become HBM bound.
-    // The weights sit in LDS as [piece 3][co][8 slots of 8 channels as packed bf16] with rows of 144 B (9 slots: the 16 lanes
-    // of a ds_read_b128 group hit 16 distinct slots).
-    static constexpr bool BF = CIN == 64 && !EXT && BF_OK;
-    static constexpr int WROW = 36;                    // dwords per (piece, co) row of the bf16 image
+    // BF: the product runs on the bf16 matrix pipe, every f32 operand as three round-to-nearest bf16 pieces and the six
+    // products of order <= 2 accumulated in f32 (bf3.h; DESIGN.md sections 11.8 / 12.8) -- 2.67x less matrix time than
+    // v_mfma_f32_32x32x2_f32, on a pipe the vector work does not share: the launches become HBM bound.
+    // The weights sit in LDS as [piece 3][co][slots of 8 channels as packed bf16] with one slot of padding per row (an odd
+    // number of 16-byte slots: the 16 lanes of a ds_read_b128 group hit 16 distinct slots).
+    static constexpr bool BF = BF_OK;
+    static constexpr int WROW = (CIN + XK) / 2 + 4;    // dwords per (piece, co) row of the bf16 image
     static constexpr int W_FLOATS = BF ? 3 * COUT * WROW : COUT * WSTR;
     static constexpr int RED_FLOATS = 8 * 3 * COUT;    // aliased onto the weights after the tile loop (<= 8 waves)
     static constexpr int LDS_FLOATS = W_FLOATS + 3 * CIN + 3 * XK;
@@ -116,11 +116,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
     // ---- stage the weight [co][WSTR] (+ the prologue table) once per block
     if constexpr (BF) {                                    // (co, slot g = channels 8g .. 8g+7) -> three packed-bf16 u32x4
         u32x4 *Wp = reinterpret_cast<u32x4 *>(lds);
-        for (int i = tid; i < COUT * 8; i += NTHR) {
-            const int co = i >> 3, g = i & 7;
+        constexpr int SL = (CIN + G::XK) / 8;
+        for (int i = tid; i < COUT * SL; i += NTHR) {
+            const int co = i / SL, g = i - co * SL;
             float wv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wv[k] = a.w_trans ? a.w[(size_t)(8 * g + k) * COUT + co] : a.w[(size_t)co * CIN + 8 * g + k];
+            for (int k = 0; k < 8; ++k) {
+                const int ci = 8 * g + k;
+                if (EXT && ci >= CIN) wv[k] = a.w3[(size_t)(ci - CIN) * COUT + co];               // w3 [k 64][COUT]
+                else wv[k] = a.w_trans ? a.w[(size_t)ci * COUT + co] : a.w[(size_t)co * CIN + ci];
+            }
             u32x4 q0, q1, q2;
             bf3_split8(wv, q0, q1, q2);
             Wp[(0 * COUT + co) * (G::WROW / 4) + g] = q0;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
         }
     }
     if (EXT) {
-        for (int i = tid; i < 64 * COUT; i += NTHR) {          // w3 [k 64][COUT]
+        for (int i = tid; i < (BF ? 0 : 64 * COUT); i += NTHR) {          // w3 [k 64][COUT] (BF: staged above)
             const int k = i / COUT, co = i - k * COUT;
             Ws[co * G::WSTR + CIN + k] = a.w3[i];
         }
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
         // accumulators are negated back, so that the bias has no common sign over the map (as conv_wino4_split.h).
         u32x4 xp[3][4];
         const bool neg = BF && (tile & 1);
-        if constexpr (BF) {
+        auto split_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 float t8[8];
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                 for (int k = 0; k < 8; ++k) t8[k] = neg ? -x[8 * s4 + k] : x[8 * s4 + k];
                 bf3_split8(t8, xp[0][s4], xp[1][s4], xp[2][s4]);
             }
-        }
+        };
+        if constexpr (BF && TC == 1) split_x();
         // TR epilogue in two halves: the requests (addend, mask source) and the arithmetic + stores
         long long trow = r0 + p;
         const bool tr_ok = trow < a.R;
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                     // next chunk (or the next tile's first chunk) in flight during this chunk's MFMAs
                     if (c + 1 < TC) issue(tile, c + 1, nv, nv2);
                     else if (tile + stride < ntiles) issue(tile + stride, 0, nv, nv2);
+                    if constexpr (BF) split_x();
                     __builtin_amdgcn_sched_barrier(0);     // one chunk of loads in flight, not all four
                 }
                 // weight columns of this chunk: the lane's K-half of the main operand, or of the extra one
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_kernel(const
                             u32x4 b[3];
 #pragma unroll
                             for (int pc = 0; pc < 3; ++pc)
-                                b[pc] = Wp[(pc * COUT + (ps * NTP + n) * 32 + p) * (G::WROW / 4) + h * 4 + s4];
+                                b[pc] = Wp[(pc * COUT + (ps * NTP + n) * 32 + p) * (G::WROW / 4) + wcol / 8 + s4];
                             // the six products of order <= 2, smallest first: x2 w0, x0 w2, x1 w1, x1 w0, x0 w1, x0 w0
                             auto mf = [&](int xi, int wi) __attribute__((always_inline)) {
                                 acc[n] = TR ? c11_mfma_bf(b[wi], xp[xi][s4], acc[n]) : c11_mfma_bf(xp[xi][s4], b[wi], acc[n]);

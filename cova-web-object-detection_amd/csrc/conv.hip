@@ -1785,6 +1785,7 @@ int cova_internal_ablate() { return g_ablate; }
 // block), 5 = ablation mask of builds made with -DCOVA_ABLATE (tools/conv_bench.py), 6 = Winograd tile geometry
 int cova_internal_set_wino4_f32(int v);
 int cova_internal_set_wgrad4_pair_sync(int v);
+int cova_internal_set_sgemm_f32(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1794,6 +1795,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 8) { g_conv1_wgrad_phases = value != 0; return COVA_OK; }
     if (key == 9) return cova_internal_set_wino4_f32(value);
     if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
+    if (key == 11) return cova_internal_set_sgemm_f32(value);
     return COVA_ERR_BAD_ARG;
 }
 

@@ -11,7 +11,17 @@
 // next k-tile is fetched into registers (4 x float4 per operand per thread) while the current one
 // feeds 32 MFMAs per wave (these GEMMs are a few GFLOP each: the loop is latency bound, so fewer, longer
 // k-tiles -- half the barriers and round trips of BK = 32 -- matter more than occupancy).  ~3 GFLOP per call on this path: latency bound, not roofline relevant.
-#include "common.h"
+//
+// Round 5, measured and NOT the default: sgemm_bf_kernel runs the product on the bf16 matrix pipe -- every f32 operand as three
+// round-to-nearest bf16 pieces, the six products of order <= 2 accumulated in f32 (bf3.h; DESIGN.md sections 11.8 / 12.6): same
+// error class as the f32 chain, 2.67x less matrix time -- and is SLOWER on this path's GEMMs (configs[1]: step 9.65 against
+// 9.52 ms alternated in one process; configs[2]: 0.85 / 1.00 / 1.11 ms against 0.77 / 0.70 / 0.67 ms for the three layouts):
+// these launches are bound by the k-tile round trip (fetch, barrier, stash, barrier), not by the matrix pipe, and splitting
+// the tile on its way into LDS (88 vector operations per thread and tile, cross-lane pairing for the row-contiguous
+// layouts, 4-way conflicting dword stores) lengthens exactly that.  Kept behind cova_set_option(11, 0) for A/B.  Same tiling (64 x 64 x 64, four waves 2 x 2, two k-groups per block); every element is split ONCE, by the thread
+// that fetched it, on its way into LDS: tiles are [piece 3][row 64][32 packed k-pairs + 4 pad] dwords, so an operand of
+// v_mfma_f32_32x32x16_bf16 (8 consecutive k of a row) is one ds_read_b128 per piece (rows of 144 B: conflict-free).
+#include "bf3.h"
 
 namespace {
 
@@ -144,9 +154,147 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
     }
 }
 
+constexpr int PROW = 36;                           // dwords per (piece, row) of a bf16 tile: 32 k-pairs + 4 pad (144 B)
+constexpr int PTILE = 3 * 64 * PROW;               // one operand tile: 27,648 B
+
+__device__ __forceinline__ f32x16 gemm_mfma_bf(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// The fetched elements of a tile (fetch_tile's ownership) -> packed bf16 pieces in LDS.  `flip`: sign bits of both halves
+// (0x80008000) for the operand of a block that multiplies with the negated matrix (see the kernel), else 0.
+//  k-contiguous: the thread holds k = k0 .. k0+15 of row r: eight k-pairs, two 16-byte stores per piece.
+//  row-contiguous: the thread holds rows r0 .. r0+15 of ONE k; its neighbour four lanes up holds k + 1 of the same rows.
+//  The even-k thread pairs rows r0 .. r0+7 (its values below, the neighbour's above), the odd-k thread rows r0+8 .. r0+15.
+template <bool KCONTIG>
+__device__ __forceinline__ void stash_tile_bf(uint32_t *S, int tid, const float (&v)[EPT], uint32_t flip)
+{
+    if (KCONTIG) {
+        const int r = tid & 63, kp = (tid >> 6) * (EPT / 2);
+        u32x4 q[3][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t a, b, c;
+            bf3_split_pair(v[2 * i], v[2 * i + 1], a, b, c);
+            q[0][i >> 2][i & 3] = a ^ flip; q[1][i >> 2][i & 3] = b ^ flip; q[2][i >> 2][i & 3] = c ^ flip;
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            u32x4 *d = reinterpret_cast<u32x4 *>(S + (pc * 64 + r) * PROW + kp);
+            d[0] = q[pc][0];
+            d[1] = q[pc][1];
+        }
+    } else {
+        const int k = tid >> 2, r0 = (tid & 3) * EPT, odd = k & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // even k: pair (own v[j], neighbour's v[j]); odd k: pair (neighbour's v[8 + j], own v[8 + j])
+            const float mine = odd ? v[8 + j] : v[j];
+            const float give = odd ? v[j] : v[8 + j];                  // what the neighbour pairs with its own
+            const float got = __shfl_xor(give, 4, 64);
+            uint32_t a, b, c;
+            bf3_split_pair(odd ? got : mine, odd ? mine : got, a, b, c);
+            uint32_t *d = S + (size_t)(r0 + 8 * odd + j) * PROW + (k >> 1);
+            d[0] = a ^ flip;
+            d[64 * PROW] = b ^ flip;
+            d[2 * 64 * PROW] = c ^ flip;
+        }
+    }
+}
+
+// Same tiling and k-group scheme as sgemm_kernel.  The bf16 MFMA drops low product bits toward -infinity
+// (tools/probe/mfma_round_probe.hip): blocks of odd (x + y) multiply with the NEGATED A tile and negate their sums back, so
+// that the bias has no common sign over the output.
+template <bool TA, bool TB, int KS>
+__global__ __launch_bounds__(256 * KS) void sgemm_bf_kernel(const float *__restrict__ A, int lda,
+                                                            const float *__restrict__ Bm, int ldb,
+                                                            float *__restrict__ C, int ldc,
+                                                            const float *__restrict__ bias, int M, int N,
+                                                            int K, int accumulate, int vecA, int vecB)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t As_[KS][PTILE];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs_[KS][PTILE];
+    const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;       // k-group of this wave
+    uint32_t *As = As_[grp], *Bs = Bs_[grp];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int li = lane & 31, kh2 = lane >> 5;
+    const bool neg = ((blockIdx.x + blockIdx.y) & 1) != 0;
+    const uint32_t flip = neg ? 0x80008000u : 0u;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    constexpr int KSTEP = BK * KS;
+    float va[EPT], vb[EPT];
+    fetch_tile<!TA>(A, lda, m0, M, grp * BK, K, tid, vecA != 0, va);
+    fetch_tile<TB>(Bm, ldb, n0, N, grp * BK, K, tid, vecB != 0, vb);
+    const u32x4 *pa = reinterpret_cast<const u32x4 *>(As + (wm * 32 + li) * PROW) + kh2;      // + 2 s: K-step s
+    const u32x4 *pb = reinterpret_cast<const u32x4 *>(Bs + (wn * 32 + li) * PROW) + kh2;
+    constexpr int PSTR = 64 * PROW / 4;                          // u32x4 per piece plane
+    for (int k0 = grp * BK; k0 - grp * BK < K; k0 += KSTEP) {
+        __syncthreads();                    // previous tile fully consumed
+        stash_tile_bf<!TA>(As, tid, va, flip);
+        stash_tile_bf<TB>(Bs, tid, vb, 0u);
+        __syncthreads();
+        if (k0 + KSTEP - grp * BK < K) {    // this group's next tile in flight while this one computes
+            fetch_tile<!TA>(A, lda, m0, M, k0 + KSTEP, K, tid, vecA != 0, va);
+            fetch_tile<TB>(Bm, ldb, n0, N, k0 + KSTEP, K, tid, vecB != 0, vb);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < BK / 16; ++s4) {
+            const u32x4 a0 = pa[2 * s4], a1 = pa[PSTR + 2 * s4], a2 = pa[2 * PSTR + 2 * s4];
+            const u32x4 b0 = pb[2 * s4], b1 = pb[PSTR + 2 * s4], b2 = pb[2 * PSTR + 2 * s4];
+            // the six products of order <= 2, smallest first
+            acc = gemm_mfma_bf(a2, b0, acc);
+            acc = gemm_mfma_bf(a0, b2, acc);
+            acc = gemm_mfma_bf(a1, b1, acc);
+            acc = gemm_mfma_bf(a1, b0, acc);
+            acc = gemm_mfma_bf(a0, b1, acc);
+            acc = gemm_mfma_bf(a0, b0, acc);
+        }
+    }
+    if (neg) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = -acc[r];
+    }
+    if (KS == 2) {                          // group 1 hands its accumulator over (its A tile area is free now)
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(&As_[0][0]) + wave * (16 * 64);         // [wave][r][lane]: 4 x 4 KB <= one A tile
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+    }
+    const int gn = n0 + wn * 32 + li;
+    if (gn < N) {
+        const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 32 + mfma32_row(r, lane);
+            if (gm < M) {
+                float v = acc[r] + bv;
+                float *dst = C + (size_t)gm * ldc + gn;
+                if (accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+int g_sgemm_f32 = 1;          // default: the f32-MFMA kernel (the bf16-split one measured slower, see the header)
+
 inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 }  // namespace
+
+int cova_internal_set_sgemm_f32(int v) { g_sgemm_f32 = v != 0; return COVA_OK; }
 
 COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias,
@@ -161,7 +309,10 @@ COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float
     const bool split = K >= 4 * BK && (long long)grid.x * grid.y < 2 * 4 * 256;
 #define SGEMM_LAUNCH(TA_, TB_)                                                                                              \
     do {                                                                                                                    \
-        if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
+        if (!g_sgemm_f32) {                                                                                                 \
+            if (split) hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
+            else hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
+        } else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
         else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
     } while (0)
     if (!transA && !transB) SGEMM_LAUNCH(false, false);

@@ -36,21 +36,27 @@ def nchw(x):   # NHWC gpu -> NCHW cpu
     return x.cpu().permute(0, 3, 1, 2).contiguous()
 
 
+@pytest.mark.parametrize("f32", [1, 0])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3)])
-def test_sgemm(ta, tb, M, N, K):
+def test_sgemm(ta, tb, M, N, K, f32):
+    """f32 = 1: the f32-MFMA kernel (the path's default); 0: the bf16-split kernel kept for A/B (cova_set_option(11, 0))."""
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
     B = torch.randn((N, K) if tb else (K, N), generator=g)
     bias = torch.randn(N, generator=g)
-    ref = (A.t() if ta else A) @ (B.t() if tb else B) + bias
+    ref = ((A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()).float()
     C = torch.full((M, N + 3), 7.0, device=DEV)
-    call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3,
-         bias.to(DEV), 0)
-    close(C[:, :N], ref, 2e-5, "sgemm")
-    assert (C[:, N:] == 7.0).all()
-    call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, None, 1)
-    close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
+    query("cova_set_option", 11, f32)
+    try:
+        call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3,
+             bias.to(DEV), 0)
+        close(C[:, :N], ref, 2e-5, "sgemm")
+        assert (C[:, N:] == 7.0).all()
+        call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, None, 1)
+        close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
+    finally:
+        query("cova_set_option", 11, 1)
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 16, 64), (2, 37, 50), (1, 64, 64)])

@@ -681,6 +681,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     if (STATS) bn_tail_run(tail, stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
 }
 
+#include "conv1_fwd_w4.h"
+
 // ------------------------------------------------------------------------------------
 // weight layout transforms (tiny; run once per step because the weights change every step)
 // ------------------------------------------------------------------------------------
@@ -1767,6 +1769,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
+int g_conv1_w4 = 0;          // 1: conv1 forward (bf16 split) with one wave per SIMD (conv1_fwd_w4.h: measured slower, A/B); 0: the 8-wave kernel
 int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) instead of the bf16-split one (A/B, tests)
 int g_conv1_wgrad_phases = 0; // 1: conv1 weight gradient on the phase-structured bf16 kernel instead of the role-split one (A/B)
 
@@ -1796,6 +1799,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 9) return cova_internal_set_wino4_f32(value);
     if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
     if (key == 11) return cova_internal_set_sgemm_f32(value);
+    if (key == 12) { g_conv1_w4 = value != 0; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1857,6 +1861,16 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
         const int tiles_x = cdiv(W1, c1b::TW), tiles_y = cdiv(H1, c1b::TH);
         const int ntiles = B * tiles_x * tiles_y;
         const dim3 pgrid(persistent_grid(ntiles, 1)), block(c1b::THREADS);
+        if (g_conv1_w4) {
+            if (stat_part)
+                hipLaunchKernelGGL(conv1_7x7_bf3w_kernel<true>, pgrid, dim3(c1w::THREADS), 0, (hipStream_t)stream, img, w_k, out,
+                                   stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+            else
+                hipLaunchKernelGGL(conv1_7x7_bf3w_kernel<false>, pgrid, dim3(c1w::THREADS), 0, (hipStream_t)stream, img, w_k, out,
+                                   stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+            COVA_LAUNCH_CHECK();
+            return COVA_OK;
+        }
         if (stat_part)
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out, stat_part,
                                H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);

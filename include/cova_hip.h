@@ -62,7 +62,8 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
  * 9 = F(4x4,3x3) forward / data-gradient launches on the f32-MFMA main loop (1) instead of the bf16-split one (0, default): A/B,
  * 10 = F(4x4,3x3) weight gradient: the two position halves of a walk pace each other through progress words (1) or run free
  *      (0, default: the pacing measured 3 % slower at the same HBM traffic, profiles/r05_pmc_wgrad4_pair_pacing.txt): A/B,
- * 11 = cova_sgemm on the f32-MFMA kernel (1, default) or the bf16-split one (0: measured slower, csrc/gemm.hip): A/B.
+ * 11 = cova_sgemm on the f32-MFMA kernel (1, default) or the bf16-split one (0: measured slower, csrc/gemm.hip): A/B,
+ * 12 = conv1 forward (bf16 split) with one wave per SIMD (1: measured slower, csrc/conv1_fwd_w4.h) or the 8-wave kernel (0, default): A/B.
  * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);
 

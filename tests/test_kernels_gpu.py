@@ -1110,6 +1110,19 @@ def test_conv1_bf16_split_error_class(B, H, W, cap):
     finally:
         query("cova_set_option", 7, 0)
         query("cova_set_option", 2, 0)
+    # the one-wave-per-SIMD form of the forward (csrc/conv1_fwd_w4.h, cova_set_option(12, 1); measured slower, kept for A/B)
+    # accumulates every output in the same order: bit-identical output, statistics within their summation order
+    query("cova_set_option", 2, cap)
+    query("cova_set_option", 12, 1)
+    try:
+        nt = query("cova_conv1_num_partials", B, H, W)
+        out4, part4 = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+        call("cova_conv1_fwd_tail", xg, wg, out4, part4, B, H, W, None)
+        assert torch.equal(out4, outs[0][0])
+        close(part4.double().sum(0), outs[0][1].double().sum(0), 1e-5, "statistics of the 4-wave conv1 forward")
+    finally:
+        query("cova_set_option", 12, 0)
+        query("cova_set_option", 2, 0)
     print("conv1 error against fp64 (output, weight gradient, channel sums of squares): f32 MFMA %.2e %.2e %.2e | "
           "bf16 split %.2e %.2e %.2e" % (err[1] + err[0]))
     for a, b in zip(err[0], err[1]):

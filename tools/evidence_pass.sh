@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-5 evidence pass (one gpurun call): the bench lines of all configs, kernel trace + step cut + HBM counters of the bench step
 # at configs[1] / configs[2], SQ counters of the F(4x4) kernels (split and f32 main loops), the interleaved A/B of the two loops,
-# the matrix-pipe probes, the parity-margin table, the two-rank gloo DIAGNOSTIC line.  Results under gpurun_out/r5g; the summaries
+# the matrix-pipe probes, the parity-margin table, the two-rank gloo DIAGNOSTIC line, the error class of the bf16-pipe 1x1 products and
+# the full-page parity report of the ResNet-50 extension.  Results under gpurun_out/r5g; the summaries
 # are copied to profiles/r05_* by hand.  Before: tools/probe/build.sh.
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/r5g
@@ -14,6 +15,10 @@ timeout 300 python tools/ab_step.py 9 4 2>&1 | grep round > $o/ab_step_wino4.txt
 timeout 300 python tools/ab_step.py 7 3 2>&1 | grep round > $o/ab_step_conv1.txt
 timeout 300 python tools/w4s_time.py --f32 2>&1 | grep loop > $o/w4s_time.txt
 timeout 300 python tools/w4s_check.py 2>&1 | grep -v amdgpu.ids > $o/w4s_check.txt
+timeout 300 python tools/ab_step.py 11 2 2>&1 | grep round > $o/ab_step_sgemm.txt
+timeout 300 python tools/ab_step.py 12 2 2>&1 | grep round > $o/ab_step_conv1w4.txt
+timeout 300 python tools/c11_error.py 2>&1 | grep -v amdgpu.ids > $o/c11_error.txt
+timeout 900 python tests/tools_grad_report_r50.py 4 2>&1 | grep -v amdgpu.ids > $o/grad_parity_1280_r50.txt
 bash tools/profile_round.sh r5g/c2 --config 2
 bash tools/profile_round.sh r5g/c3 --config 3
 PMC_OUT=r5g bash tools/pmc_wino4.sh > /dev/null 2>&1

@@ -103,42 +103,60 @@ __global__ __launch_bounds__(256) void linear_small_bwd_x_kernel(const float *__
 // dW[k][c] = sum_n dy[n][k]*x[n][c]; block = 64 columns x 16 row slices; db by block 0
 // V = 4: a thread owns 4 adjacent input columns (one float4 per row): 16 threads cover the block's 64 columns and a
 // wave walks 4 row slices, the block 64 (V = 1: 16 slices, any alignment) -- see colsum_kernel.
-template <int V>
+// KN: compile-time bound of the class count (4: the reference's; MAXNC otherwise) -- the register budget of the row batches
+template <int V, int KN>
 __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *__restrict__ dy,
                                                                   const float *__restrict__ x, int ldx,
                                                                   float *__restrict__ dW,
                                                                   float *__restrict__ db, int N,
                                                                   int Cin, int NC)
 {
-    __shared__ float s[16][MAXNC][64];
+    __shared__ float s[16][KN][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int TX = 64 / V, SPW = 64 / TX;               // column threads; row slices per wave
     const int tx = lane % TX, slice = wave * SPW + lane / TX;
     const int c = blockIdx.x * 64 + tx * V;
-    float acc[MAXNC][V];
+    float acc[KN][V];
 #pragma unroll
-    for (int k = 0; k < MAXNC; ++k)
+    for (int k = 0; k < KN; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
+    // Eight rows of the slice are requested before the first is used (unconditional loads at a clamped row, the value zeroed):
+    // the launch has 16 blocks and ~22 rows per thread -- one row per round trip was 22 dependent memory latencies (27.8 us
+    // at configs[1]).  Same rows in the same order per thread: bit-identical sums.
+    constexpr int U = KN <= 4 ? 8 : 2, RSTEP = 16 * SPW;
     if (c < Cin)
-        for (int n = slice; n < N; n += 16 * SPW) {
-            float xv[4];
-            if (V == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)n * ldx + c);
-                xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-            } else {
-                xv[0] = x[(size_t)n * ldx + c];
+        for (int n0 = slice; n0 < N; n0 += RSTEP * U) {
+            float xv[U][4], dv[U][KN];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + u * RSTEP;
+                const bool ok = n < N;
+                const int nn = ok ? n : n0;
+                if (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)nn * ldx + c);
+                    xv[u][0] = v.x; xv[u][1] = v.y; xv[u][2] = v.z; xv[u][3] = v.w;
+                } else {
+                    xv[u][0] = x[(size_t)nn * ldx + c];
+                }
+#pragma unroll
+                for (int k = 0; k < KN; ++k) dv[u][k] = (k < NC) ? dy[(size_t)nn * NC + k] : 0.f;
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) dv[u][k] = 0.f;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < MAXNC; ++k)
-                if (k < NC) {
-                    const float d = dy[(size_t)n * NC + k];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < V; ++j) acc[k][j] += d * xv[j];
-                }
+                for (int k = 0; k < KN; ++k)
+                    if (k < NC) {
+#pragma unroll
+                        for (int j = 0; j < V; ++j) acc[k][j] += dv[u][k] * xv[u][j];
+                    }
         }
 #pragma unroll
-    for (int k = 0; k < MAXNC; ++k)
+    for (int k = 0; k < KN; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float v = acc[k][j];
@@ -157,15 +175,15 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
         }
     if (blockIdx.x == 0) {                  // db[k] = sum_n dy[n][k]: all 1024 threads, LDS tree
         __syncthreads();
-        float pk[MAXNC];
+        float pk[KN];
 #pragma unroll
-        for (int k = 0; k < MAXNC; ++k) pk[k] = 0.f;
+        for (int k = 0; k < KN; ++k) pk[k] = 0.f;
         for (int n = threadIdx.x; n < N; n += 1024)
 #pragma unroll
-            for (int k = 0; k < MAXNC; ++k)
+            for (int k = 0; k < KN; ++k)
                 if (k < NC) pk[k] += dy[(size_t)n * NC + k];
 #pragma unroll
-        for (int k = 0; k < MAXNC; ++k) s[wave][k][lane] = pk[k];
+        for (int k = 0; k < KN; ++k) s[wave][k][lane] = pk[k];
         __syncthreads();
         if (wave == 0)
             for (int k = 0; k < NC; ++k) {
@@ -359,8 +377,9 @@ COVA_API int cova_linear_small_bwd(const float *dy, const float *x, int ldx, con
                        dy, W, dx, lddx, N, Cin, NC);
     COVA_LAUNCH_CHECK();
     const bool v4 = (Cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4> : linear_small_bwd_w_kernel<1>), dim3(cdiv(Cin, 64)), dim3(1024), 0, st, dy, x, ldx,
-                       dW, db, N, Cin, NC);
+    const dim3 wgrid(cdiv(Cin, 64)), wblock(1024);
+    if (NC <= 4) hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, 4> : linear_small_bwd_w_kernel<1, 4>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC);
+    else hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, MAXNC> : linear_small_bwd_w_kernel<1, MAXNC>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

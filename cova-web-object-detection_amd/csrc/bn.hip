@@ -384,7 +384,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // fetched from HBM once per strip instead of once per output row that touches it (round 2 measured 1.56x read
 // over-fetch with one thread per output: rows 2 oy - 1 / 2 oy + 1 were read by two blocks, usually on different XCDs).
 // Neighbouring columns are neighbouring 16-lane groups of the same wave (L1 hits).
-constexpr int POOL_STRIP = 16;
+// STRIP / PRE (cova_set_option(13, v), tools/ew_bench.py): rows per strip; PRE: the two new input rows of output row
+// oy + 1 are requested before output row oy is reduced and stored (12 instead of 6 loads of a thread in flight).
+int g_pool_variant = 0;
+template <int POOL_STRIP, bool PRE, bool XCD = false>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
     float *__restrict__ out, uint8_t *__restrict__ idx, float *__restrict__ ymax, int B, int H1, int W1,
@@ -392,8 +395,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
 {
     const int nstrips = (H2 + POOL_STRIP - 1) / POOL_STRIP;
     const long long total = (long long)B * nstrips * W2 * 16;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    // XCD: consecutive blocks go to the eight XCDs in turn -- block b takes work block (b % 8) * (grid / 8) + b / 8, so that
+    // an XCD walks ONE contiguous eighth of the maps and the input row two neighbouring strips share is met in its own L2
+    long long wb = blockIdx.x;
+    if (XCD) {
+        const long long per = gridDim.x / 8;
+        if (wb < per * 8) wb = (wb % 8) * per + wb / 8;
+    }
+    for (long long i = wb * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i & 15);
         long long p = i >> 4;
         const int ox = (int)(p % W2);
@@ -414,11 +423,18 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
             }
         };
         const int oy0 = strip * POOL_STRIP, oy1 = min(oy0 + POOL_STRIP, H2);
-        float4 top[3], mid[3], bot[3];
+        float4 top[3], mid[3], bot[3], nmid[3], nbot[3];
         load_row(2 * oy0 - 1, top);
+        if (PRE) { load_row(2 * oy0, nmid); load_row(2 * oy0 + 1, nbot); }
         for (int oy = oy0; oy < oy1; ++oy) {
-            load_row(2 * oy, mid);
-            load_row(2 * oy + 1, bot);
+            if (PRE) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) { mid[kx] = nmid[kx]; bot[kx] = nbot[kx]; }
+                if (oy + 1 < oy1) { load_row(2 * oy + 2, nmid); load_row(2 * oy + 3, nbot); }      // (rows clamped in load_row)
+            } else {
+                load_row(2 * oy, mid);
+                load_row(2 * oy + 1, bot);
+            }
             const bool oky[3] = {2 * oy - 1 >= 0, true, 2 * oy + 1 < H1};
             float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             float my[4] = {0.f, 0.f, 0.f, 0.f};          // raw conv output at the arg-max position
@@ -688,6 +704,8 @@ inline bool vec4_ok(const void *p, int ld)
 
 }  // namespace
 
+int cova_internal_set_pool_variant(int v) { g_pool_variant = v; return COVA_OK; }
+
 // ====================================================================================
 // C ABI
 // ====================================================================================
@@ -886,9 +904,30 @@ COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const 
 {
     COVA_REQUIRE(y && scale && shift && out && idx && B > 0 && H1 > 0 && W1 > 0);
     const int H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel,
-                       dim3(ew_grid((long long)B * cdiv(H2, POOL_STRIP) * W2 * 16)),
-                       dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B, H1, W1, H2, W2);
+    auto launch = [&](auto kern, int strip, bool capped) {
+        const long long threads = (long long)B * cdiv(H2, strip) * W2 * 16;
+        long long g = capped ? ew_grid(threads) : cdivll(threads, 256);
+        if (g > 0x7fffffffll) g = 0x7fffffffll;                      // (the kernel strides over what is left)
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B,
+                           H1, W1, H2, W2);
+    };
+    switch (g_pool_variant) {
+    case 1: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, false); break;
+    case 2: launch(bn_relu_maxpool_fwd_kernel<8, false>, 8, false); break;
+    case 3: launch(bn_relu_maxpool_fwd_kernel<16, true>, 16, false); break;
+    case 4: launch(bn_relu_maxpool_fwd_kernel<8, true>, 8, false); break;
+    case 5: launch(bn_relu_maxpool_fwd_kernel<16, true>, 16, true); break;
+    case 6: launch(bn_relu_maxpool_fwd_kernel<4, true>, 4, false); break;
+    case 7: launch(bn_relu_maxpool_fwd_kernel<2, true>, 2, false); break;
+    case 8: launch(bn_relu_maxpool_fwd_kernel<4, false>, 4, false); break;
+    case 9: launch(bn_relu_maxpool_fwd_kernel<4, true, true>, 4, false); break;
+    case 10: launch(bn_relu_maxpool_fwd_kernel<2, true, true>, 2, false); break;
+    case 11: launch(bn_relu_maxpool_fwd_kernel<8, true, true>, 8, false); break;
+    case 12: launch(bn_relu_maxpool_fwd_kernel<1, false, true>, 1, false); break;
+    case 13: launch(bn_relu_maxpool_fwd_kernel<2, false, true>, 2, false); break;
+    case 14: launch(bn_relu_maxpool_fwd_kernel<16, true, true>, 16, false); break;
+    default: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, true); break;
+    }
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

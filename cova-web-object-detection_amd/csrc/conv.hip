@@ -1789,6 +1789,10 @@ int cova_internal_ablate() { return g_ablate; }
 int cova_internal_set_wino4_f32(int v);
 int cova_internal_set_wgrad4_pair_sync(int v);
 int cova_internal_set_sgemm_f32(int v);
+int cova_internal_set_pool_variant(int v);
+int cova_internal_set_bn1d_variant(int v);
+int cova_internal_set_sgemm_direct(int v);
+int cova_internal_set_gat_wide(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1800,6 +1804,10 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
     if (key == 11) return cova_internal_set_sgemm_f32(value);
     if (key == 12) { g_conv1_w4 = value != 0; return COVA_OK; }
+    if (key == 13) return cova_internal_set_pool_variant(value);
+    if (key == 14) return cova_internal_set_bn1d_variant(value);
+    if (key == 15) return cova_internal_set_sgemm_direct(value);
+    if (key == 16) return cova_internal_set_gat_wide(value);
     return COVA_ERR_BAD_ARG;
 }
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
                                                          const float *__restrict__ Bm, int ldb,
                                                          float *__restrict__ C, int ldc,
                                                          const float *__restrict__ bias, int M, int N,
-                                                         int K, int accumulate, int vecA, int vecB)
+                                                         int K, int accumulate, int vecA, int vecB,
+                                                         const uint8_t *__restrict__ emask, float einv)
 {
     __shared__ __attribute__((aligned(16))) float As_[KS][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs_[KS][BK][LDT];
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
                 float v = acc[r] + bv;
                 float *dst = C + (size_t)gm * ldc + gn;
                 if (accumulate) v += *dst;
+                if (emask != nullptr) v = emask[(size_t)gm * N + gn] ? v * einv : 0.f;      // cova_dropout_bwd on the result
                 *dst = v;
             }
         }
@@ -288,6 +290,159 @@ __global__ __launch_bounds__(256 * KS) void sgemm_bf_kernel(const float *__restr
     }
 }
 
+
+// ---- register-direct form (cova_set_option(15, 1)) ----
+// No LDS tiles, no barriers in the k loop: every wave streams the operands of its own 32 x 32 accumulator straight from
+// L1 / L2 into registers, one 64-deep k-tile ahead of the MFMAs that use it (two register sets, ping-pong).  The K index of
+// an MFMA slot is free as long as both operands agree: slot kk of lane half kh is k = 8 (kk >> 2) + 4 kh + (kk & 3) of the
+// tile, so that a k-contiguous operand (X[row][k]) is eight float4 loads per lane and tile at constant offsets, and a
+// row-contiguous one (X[k][row]) 32 coalesced dword loads (lanes 0..31 one row of 128 B, lanes 32..63 the row four below)
+// through per-slot byte offsets kept in registers (uniform base + 32-bit lane offset: no address arithmetic in the loop).
+// KS k-groups of four waves take alternate k-tiles of the same 64 x 64 output tile and meet through LDS at the end (fixed
+// order).  Needs K % 4 == 0 and 16-byte aligned k-contiguous operands; everything else takes sgemm_kernel.
+template <bool KC>
+struct DirectOperand {
+    const char *base;          // k-contiguous: this lane's row at k = 4 kh (lane pointer); row-contiguous: the matrix (uniform)
+    uint32_t lane_off;         // row-contiguous: bytes of (row 4 kh, this lane's column)
+    long long ld4;             // row-contiguous: bytes per k row (uniform)
+};
+
+__device__ __forceinline__ int direct_kmap(int kk) { return 8 * (kk >> 2) + (kk & 3); }      // (+ 4 kh)
+
+template <bool KC>
+__device__ __forceinline__ void direct_init(DirectOperand<KC> &o, const float *X, int ld, int row0, int nrows, int li, int kh)
+{
+    int r = row0 + li;
+    if (r > nrows - 1) r = nrows - 1;                 // rows past the matrix: a valid address, the result is not stored
+    if (KC) {
+        o.base = reinterpret_cast<const char *>(X + (size_t)r * ld + 4 * kh);
+        o.lane_off = 0u;
+        o.ld4 = 0;
+    } else {
+        o.base = reinterpret_cast<const char *>(X);
+        o.lane_off = (uint32_t)(((size_t)4 * kh * ld + r) * 4);
+        o.ld4 = (long long)ld * 4;
+    }
+}
+
+// tile t (k0 = 64 t) -> v[32]; slots at or past K are zero
+template <bool KC>
+__device__ __forceinline__ void direct_load(const DirectOperand<KC> &o, int t, int ntiles, int K, int kh, float (&v)[32])
+{
+    const int k0 = t * 64;                             // (t < ntiles: the caller's wave-uniform guard)
+    const bool full = k0 + 64 <= K;                    // (wave-uniform) every tile but the last: no per-slot predicate
+    if (KC) {
+        const char *p = o.base + (long long)t * 256;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q = *reinterpret_cast<const float4 *>(p + 32 * j);
+                v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = k0 + 8 * j + 4 * kh < K;   // (K % 4 == 0: a float4 is inside or outside)
+            const float4 q = *reinterpret_cast<const float4 *>(ok ? p + 32 * j : o.base);
+            v[4 * j] = ok ? q.x : 0.f; v[4 * j + 1] = ok ? q.y : 0.f; v[4 * j + 2] = ok ? q.z : 0.f; v[4 * j + 3] = ok ? q.w : 0.f;
+        }
+    } else {
+        const char *p = o.base + (long long)k0 * o.ld4;           // uniform: the per-slot row offsets below stay scalar
+        if (full) {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk)
+                v[kk] = *reinterpret_cast<const float *>(p + (long long)direct_kmap(kk) * o.ld4 + o.lane_off);
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const bool ok = k0 + direct_kmap(kk) + 4 * kh < K;
+            const char *pk = ok ? p + (long long)direct_kmap(kk) * o.ld4 : o.base;
+            const float q = *reinterpret_cast<const float *>(pk + o.lane_off);
+            v[kk] = ok ? q : 0.f;
+        }
+    }
+}
+
+template <bool TA, bool TB, int KS>
+__global__ __launch_bounds__(256 * KS) void sgemm_direct_kernel(const float *__restrict__ A, int lda,
+                                                                const float *__restrict__ Bm, int ldb,
+                                                                float *__restrict__ C, int ldc,
+                                                                const float *__restrict__ bias, int M, int N,
+                                                                int K, int accumulate,
+                                                                const uint8_t *__restrict__ emask, float einv)
+{
+    __shared__ float s_red[KS > 1 ? (KS - 1) * 4 * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM + wm * 32, n0 = blockIdx.x * BN + wn * 32;
+    const int li = lane & 31, kh = lane >> 5;
+    const int ntiles = (K + 63) / 64;
+    DirectOperand<!TA> oa;
+    DirectOperand<TB> ob;
+    direct_init<!TA>(oa, A, lda, m0, M, li, kh);
+    direct_init<TB>(ob, Bm, ldb, n0, N, li, kh);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a0[32], b0[32], a1[32], b1[32];
+    if (grp < ntiles) {
+        direct_load<!TA>(oa, grp, ntiles, K, kh, a0);
+        direct_load<TB>(ob, grp, ntiles, K, kh, b0);
+    }
+    for (int t = grp; t < ntiles; t += 2 * KS) {        // (every guard below is wave-uniform)
+        const bool second = t + KS < ntiles;
+        if (second) {
+            direct_load<!TA>(oa, t + KS, ntiles, K, kh, a1);
+            direct_load<TB>(ob, t + KS, ntiles, K, kh, b1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = mfma32(a0[kk], b0[kk], acc);
+        if (t + 2 * KS < ntiles) {
+            direct_load<!TA>(oa, t + 2 * KS, ntiles, K, kh, a0);
+            direct_load<TB>(ob, t + 2 * KS, ntiles, K, kh, b0);
+        }
+        if (second) {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) acc = mfma32(a1[kk], b1[kk], acc);
+        }
+    }
+    if (KS > 1) {                            // groups 1.. hand their accumulators to group 0 (fixed order)
+        if (grp > 0) {
+            float *red = s_red + ((grp - 1) * 4 + wave) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float *red = s_red + ((g - 1) * 4 + wave) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+        }
+    }
+    const int gn = n0 + li;
+    if (gn < N) {
+        const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + mfma32_row(r, lane);
+            if (gm < M) {
+                float v = acc[r] + bv;
+                float *dst = C + (size_t)gm * ldc + gn;
+                if (accumulate) v += *dst;
+                if (emask != nullptr) v = emask[(size_t)gm * N + gn] ? v * einv : 0.f;
+                *dst = v;
+            }
+        }
+    }
+}
+
+int g_sgemm_direct = 0;
+
 int g_sgemm_f32 = 1;          // default: the f32-MFMA kernel (the bf16-split one measured slower, see the header)
 
 inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
@@ -295,10 +450,11 @@ inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && 
 }  // namespace
 
 int cova_internal_set_sgemm_f32(int v) { g_sgemm_f32 = v != 0; return COVA_OK; }
+int cova_internal_set_sgemm_direct(int v) { g_sgemm_direct = v; return COVA_OK; }
 
-COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda,
+static int sgemm_launch(int transA, int transB, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias,
-                        int accumulate, void *stream)
+                        int accumulate, const uint8_t *emask, float einv, void *stream)
 {
     COVA_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0);
     if (M == 0 || N == 0) return COVA_OK;
@@ -307,13 +463,32 @@ COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float
     const int va = vec_ok(A, lda), vb = vec_ok(B, ldb);
     // two k-groups per block when there are at least four k-tiles and the grid alone does not fill the chip twice over
     const bool split = K >= 4 * BK && (long long)grid.x * grid.y < 2 * 4 * 256;
+    // register-direct form: k-contiguous operands as float4 (K % 4 == 0, aligned rows); 32-bit lane offsets of the others
+    const bool direct_ok = g_sgemm_direct != 0 && K % 4 == 0 && K >= 64 && (transA || va) && (!transB || vb) &&
+                           (long long)(transA ? K : 1) * lda * 4 + (long long)M * 4 < (1ll << 31) &&
+                           (long long)(transB ? 1 : K) * ldb * 4 + (long long)N * 4 < (1ll << 31);
+    if (direct_ok) {
+        const int ks = g_sgemm_direct == 2 ? 2 : g_sgemm_direct == 3 ? 1 : (split ? 2 : 1);       // (2 / 3: force two / one k-group)
+#define SGEMM_DIRECT(TA_, TB_)                                                                                              \
+        do {                                                                                                                \
+            if (ks >= 2) hipLaunchKernelGGL((sgemm_direct_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, emask, einv); \
+            else hipLaunchKernelGGL((sgemm_direct_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, emask, einv); \
+        } while (0)
+        if (!transA && !transB) SGEMM_DIRECT(false, false);
+        else if (!transA && transB) SGEMM_DIRECT(false, true);
+        else if (transA && !transB) SGEMM_DIRECT(true, false);
+        else SGEMM_DIRECT(true, true);
+#undef SGEMM_DIRECT
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
 #define SGEMM_LAUNCH(TA_, TB_)                                                                                              \
     do {                                                                                                                    \
-        if (!g_sgemm_f32) {                                                                                                 \
+        if (!g_sgemm_f32 && emask == nullptr) {                                                                             \
             if (split) hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
             else hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
-        } else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
-        else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
+        } else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
+        else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
     } while (0)
     if (!transA && !transB) SGEMM_LAUNCH(false, false);
     else if (!transA && transB) SGEMM_LAUNCH(false, true);
@@ -322,4 +497,22 @@ COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float
 #undef SGEMM_LAUNCH
     COVA_LAUNCH_CHECK();
     return COVA_OK;
+}
+
+COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda,
+                        const float *B, int ldb, float *C, int ldc, const float *bias,
+                        int accumulate, void *stream)
+{
+    return sgemm_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, nullptr, 1.f, stream);
+}
+
+// cova_sgemm followed by cova_dropout_bwd on its result, in the GEMM's epilogue: C = keep ? (op(A) op(B)) / (1 - p) : 0 with
+// keep [M, N] uint8 (contiguous) -- the decoder's first Dropout backward (models.py:84) behind the data gradient of its
+// Linear (models.py:85).  Same arithmetic per element as the two launches (bit-identical); always the f32-MFMA kernel.
+COVA_API int cova_sgemm_dropout_bwd(int transA, int transB, int M, int N, int K, const float *A, int lda,
+                                    const float *B, int ldb, float *C, int ldc, const uint8_t *keep, float p,
+                                    void *stream)
+{
+    COVA_REQUIRE(keep && p >= 0.f && p < 1.f);
+    return sgemm_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, keep, 1.f / (1.f - p), stream);
 }

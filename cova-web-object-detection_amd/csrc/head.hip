@@ -84,15 +84,14 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float *__re
         }
 }
 
-// dx[n][c] = sum_k dy[n][k] * W[k][c]
-__global__ __launch_bounds__(256) void linear_small_bwd_x_kernel(const float *__restrict__ dy,
-                                                                 const float *__restrict__ W,
-                                                                 float *__restrict__ dx, int ldx,
-                                                                 int N, int Cin, int NC)
+// dx[n][c] = sum_k dy[n][k] * W[k][c]: elements first, first + nthreads, ... (the blocks behind the weight-gradient
+// blocks of linear_small_bwd_w_kernel: one launch for both gradients of the layer)
+__device__ __forceinline__ void linear_small_bwd_x_body(const float *__restrict__ dy, const float *__restrict__ W,
+                                                        float *__restrict__ dx, int ldx, int N, int Cin, int NC,
+                                                        long long first, long long nthreads)
 {
     const long long total = (long long)N * Cin;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = first; i < total; i += nthreads) {
         const int n = (int)(i / Cin), c = (int)(i - (long long)n * Cin);
         float a = 0.f;
         for (int k = 0; k < NC; ++k) a += dy[(size_t)n * NC + k] * W[(size_t)k * Cin + c];
@@ -109,9 +108,15 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
                                                                   const float *__restrict__ x, int ldx,
                                                                   float *__restrict__ dW,
                                                                   float *__restrict__ db, int N,
-                                                                  int Cin, int NC)
+                                                                  int Cin, int NC, const float *__restrict__ Wt,
+                                                                  float *__restrict__ dx, int lddx, int nwblocks)
 {
     __shared__ float s[16][KN][64];
+    if ((int)blockIdx.x >= nwblocks) {      // blocks behind the weight-gradient blocks: the input gradient
+        linear_small_bwd_x_body(dy, Wt, dx, lddx, N, Cin, NC, (long long)(blockIdx.x - nwblocks) * 1024 + threadIdx.x,
+                                (long long)(gridDim.x - nwblocks) * 1024);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int TX = 64 / V, SPW = 64 / TX;               // column threads; row slices per wave
     const int tx = lane % TX, slice = wave * SPW + lane / TX;
@@ -373,13 +378,15 @@ COVA_API int cova_linear_small_bwd(const float *dy, const float *x, int ldx, con
 {
     COVA_REQUIRE(dy && x && W && dx && dW && db && NC > 0 && NC <= MAXNC && Cin > 0 && N > 0);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(linear_small_bwd_x_kernel, dim3(ew_grid((long long)N * Cin)), dim3(256), 0, st,
-                       dy, W, dx, lddx, N, Cin, NC);
-    COVA_LAUNCH_CHECK();
     const bool v4 = (Cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    const dim3 wgrid(cdiv(Cin, 64)), wblock(1024);
-    if (NC <= 4) hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, 4> : linear_small_bwd_w_kernel<1, 4>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC);
-    else hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, MAXNC> : linear_small_bwd_w_kernel<1, MAXNC>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC);
+    // one launch: cdiv(Cin, 64) weight-gradient blocks, then the blocks of the input gradient (same arithmetic per element
+    // as the two launches this replaces: bit-identical results)
+    const int nw = cdiv(Cin, 64);
+    long long nx = cdivll((long long)N * Cin, 1024);
+    if (nx > 1024) nx = 1024;
+    const dim3 wgrid(nw + (int)nx), wblock(1024);
+    if (NC <= 4) hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, 4> : linear_small_bwd_w_kernel<1, 4>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC, W, dx, lddx, nw);
+    else hipLaunchKernelGGL((v4 ? linear_small_bwd_w_kernel<4, MAXNC> : linear_small_bwd_w_kernel<1, MAXNC>), wgrid, wblock, 0, st, dy, x, ldx, dW, db, N, Cin, NC, W, dx, lddx, nw);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -662,6 +662,62 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
     }
 }
 
+// K <= 64 (the reference's range), D <= 64 ND: the same wave-per-node arithmetic as gat_fwd_kernel<1> with the loops of the
+// aggregation exchanged -- neighbour batches outside, the ND 64-channel chunks of a row inside -- so that one batch has
+// 8 ND loads in flight instead of 8 and a node makes ceil(K / 8) dependent round trips instead of ceil(K / 8) * D / 64
+// (18 -> 3 at configs[1]: 18.7 us of latency).  Every output still adds its neighbours in slot order: identical bits.
+template <int ND>
+__global__ __launch_bounds__(256) void gat_fwd_wide_kernel(
+    const float *__restrict__ Wh, int ldw, const float *__restrict__ s, const float *__restrict__ t,
+    const int64_t *__restrict__ ctx, int N, int K, int D, float slope, float *__restrict__ attn,
+    float *__restrict__ hprime, int ldh)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float e = -INFINITY;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;                                 // out-of-range id: memory-safe, acts as a pad
+        const float u = s[n] + (j >= 0 ? t[j] : 0.f);
+        const float lr = u > 0.f ? u : slope * u;
+        e = j >= 0 ? lr : -9e15f;                           // models.py:202-203
+    }
+    const int jj = (int)j;
+    const float m = wave_max(e);
+    const float pr = lane < K ? expf(e - m) : 0.f;
+    const float denom = wave_sum(pr);
+    const float alpha = pr / denom;
+    if (lane < K) attn[(size_t)n * K + lane] = alpha;
+    const float aw = jj >= 0 ? alpha : 0.f;                 // pads: weight 0 on a valid (clamped) row
+    float acc[ND];
+    int dd[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+        acc[c] = 0.f;
+        dd[c] = 64 * c + lane < D ? 64 * c + lane : 0;
+    }
+    for (int k0 = 0; k0 < K; k0 += 8) {                     // 8 neighbour rows x ND chunks in flight, added in slot order
+        float v[ND][8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = min(k0 + u, K - 1);
+            const int jk = __shfl(jj, kk, 64);
+            a[u] = k0 + u < K ? __shfl(aw, kk, 64) : 0.f;
+            const float *row = Wh + (size_t)(jk >= 0 ? jk : 0) * ldw + D;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) v[c][u] = row[dd[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[c] = a[u] != 0.f ? fmaf(a[u], v[c][u], acc[c]) : acc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+        if (64 * c + lane < D) hprime[(size_t)n * ldh + 64 * c + lane] = acc[c];
+}
+
 // backward of the sparse part.  g = dL/dh' [N, D] (ld = ldg).
 //   dalpha_k = g . Wh_j[ctx_k];  de = alpha*(dalpha - sum alpha*dalpha) (0 on masked slots);
 //   du = de * LeakyReLU'(u);  ds_i = sum_k du_k;  dt[ctx_k] += du_k;
@@ -946,6 +1002,116 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
     }
 }
 
+// gat_bwd_src_kernel<1> / gat_bwd_dst_kernel with every 64-channel chunk of a row in flight per neighbour batch (see
+// gat_fwd_wide_kernel): K <= 64, D <= 64 ND; identical bits (each sum keeps its order: channels ascending inside a dot
+// product, edges ascending inside a gathered row).
+template <int ND>
+__global__ __launch_bounds__(256) void gat_bwd_src_wide_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ Wh, int ldw,
+    const float *__restrict__ s, const float *__restrict__ t, const float *__restrict__ attn,
+    const int64_t *__restrict__ ctx, const float *__restrict__ att_w, int N, int K, int D,
+    float slope, float *__restrict__ dWh, int lddw, float *__restrict__ ds, float *__restrict__ du_out)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    long long j = -1;
+    float alpha = 0.f, dalpha = 0.f;
+    if (lane < K) {
+        j = ctx[(size_t)n * K + lane];
+        if (j >= N) j = -1;
+        alpha = attn[(size_t)n * K + lane];
+    }
+    const int jj = (int)j;
+    float gv[ND];
+    int dd[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+        const bool in = 64 * c + lane < D;
+        dd[c] = in ? 64 * c + lane : 0;
+        gv[c] = in ? g[(size_t)n * ldg + dd[c]] : 0.f;       // (channels past D: weight 0 on a valid address)
+    }
+    for (int k0 = 0; k0 < K; k0 += 4) {                      // four neighbour rows x ND chunks in flight
+        int jk[4];
+        float w[ND][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            jk[u] = __shfl(jj, min(k0 + u, K - 1), 64);
+            const float *row = Wh + (size_t)(jk[u] >= 0 ? jk[u] : 0) * ldw + D;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) w[c][u] = row[dd[c]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+                part = 64 * c + lane < D ? fmaf(gv[c], w[c][u], part) : part;      // (the channels gat_bwd_src_kernel's loop visits)
+            const float tot = wave_sum(part);
+            if (lane == k0 + u && jk[u] >= 0) dalpha = tot;
+        }
+    }
+    const float dot = wave_sum(alpha * dalpha);
+    float du = 0.f;
+    if (lane < K && jj >= 0) {
+        const float de = alpha * (dalpha - dot);
+        const float u = s[n] + t[jj];
+        du = de * (u > 0.f ? 1.f : slope);
+    }
+    if (lane < K) du_out[(size_t)n * K + lane] = du;
+    const float dsn = wave_sum(du);
+    if (lane == 0) ds[n] = dsn;
+    for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void gat_bwd_dst_wide_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ attn, const float *__restrict__ du,
+    const int *__restrict__ row_ptr, const int *__restrict__ edges, const float *__restrict__ att_w, int N,
+    int K, int D, float *__restrict__ dWh, int lddw, float *__restrict__ dt)
+{
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const int lo = row_ptr[j], deg = row_ptr[j + 1] - lo;
+    float dtj = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) dtj += wave_sum(c0 + lane < deg ? du[edges[lo + c0 + lane]] : 0.f);
+    if (lane == 0) dt[j] = dtj;
+    float accv[ND];
+    int dd[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+        accv[c] = 0.f;
+        dd[c] = 64 * c + lane < D ? 64 * c + lane : 0;
+    }
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+        const int e = c0 + lane < deg ? edges[lo + c0 + lane] : 0;
+        const float al = c0 + lane < deg ? attn[e] : 0.f;         // 0 weight on the padding lanes
+        const int cnt = min(64, deg - c0);
+        for (int q0 = 0; q0 < cnt; q0 += 8) {                      // 8 neighbour rows x ND chunks in flight, added in edge order
+            float gq[ND][8], aq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int qq = min(q0 + u, 63);
+                const int i = __shfl(e, qq, 64) / K;
+                const bool in = q0 + u < cnt;
+                aq[u] = in ? __shfl(al, qq, 64) : 0.f;
+                const float *row = g + (size_t)i * ldg;
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    const float gl = row[dd[c]];                   // (unconditional load; padding slots read row 0 ...)
+                    gq[c][u] = in ? gl : 0.f;                      // ... and must not turn a non-finite g[0] into NaN: 0 * inf
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) accv[c] = fmaf(aq[u], gq[c][u], accv[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+        if (64 * c + lane < D) dWh[(size_t)j * lddw + D + 64 * c + lane] = accv[c] + dtj * att_w[D + 64 * c + lane];
+}
+
 // dWh_j[n] += dt[n]*a_j  (elementwise), and the attention-vector gradients
 //   d att_w[d] = sum_n ds[n]*Wh[n][d] (d < D), sum_n dt[n]*Wh[n][d] (d >= D); d att_b = sum ds
 __global__ void gat_bwd_addt_kernel(float *__restrict__ dWh, int lddw, const float *__restrict__ dt,
@@ -997,7 +1163,19 @@ __global__ __launch_bounds__(1024) void gat_bwd_att_kernel(const float *__restri
     }
 }
 
+// 64-channel chunks per row the wide GAT kernels are instantiated for (0: D too large, or switched off by
+// cova_set_option(16, 0): the chunk-at-a-time kernels)
+int g_gat_wide = 1;
+inline int gat_wide_nd(int D)
+{
+    const int nd = (D + 63) / 64;
+    if (!g_gat_wide || nd > 8) return 0;
+    return nd <= 4 ? nd : (nd <= 6 ? 6 : 8);
+}
+
 }  // namespace
+
+int cova_internal_set_gat_wide(int v) { g_gat_wide = v != 0; return COVA_OK; }
 
 // ====================================================================================
 // C ABI
@@ -1202,6 +1380,20 @@ COVA_API int cova_gat_fwd(const float *Wh, int ldw, const float *att_w, const fl
     COVA_LAUNCH_CHECK();
     const dim3 grid(cdiv(N, 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    if (K <= 64 && gat_wide_nd(D) > 0) {        // every 64-channel chunk of a neighbour row in flight (identical bits)
+#define COVA_GAT_FWD_WIDE(ND) hipLaunchKernelGGL(gat_fwd_wide_kernel<ND>, grid, blk, 0, st, Wh, ldw, s, t, ctx, N, K, D, slope, attn, hprime, ldh)
+        switch (gat_wide_nd(D)) {
+        case 1: COVA_GAT_FWD_WIDE(1); break;
+        case 2: COVA_GAT_FWD_WIDE(2); break;
+        case 3: COVA_GAT_FWD_WIDE(3); break;
+        case 4: COVA_GAT_FWD_WIDE(4); break;
+        case 6: COVA_GAT_FWD_WIDE(6); break;
+        default: COVA_GAT_FWD_WIDE(8); break;
+        }
+#undef COVA_GAT_FWD_WIDE
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
 #define COVA_GAT_FWD(KP) hipLaunchKernelGGL(gat_fwd_kernel<KP>, grid, blk, 0, st, Wh, ldw, s, t, ctx, N, K, D, slope, attn, hprime, ldh)
     switch ((K + 63) / 64) {        // one wave per node, K slots in ceil(K / 64) passes over the lanes
     case 1: COVA_GAT_FWD(1); break;
@@ -1275,7 +1467,26 @@ COVA_API int cova_gat_bwd(const float *g, int ldg, const float *Wh, int ldw, con
     COVA_REQUIRE(!csr || du);
     hipStream_t st = (hipStream_t)stream;
     const int kp = (K + 63) / 64;
-    if (csr != nullptr) {
+    if (csr != nullptr && K <= 64 && gat_wide_nd(D) > 0) {
+        const dim3 grid(cdiv(N, 4)), blk(256);
+#define COVA_GAT_BWD_WIDE(ND)                                                                                               \
+        do {                                                                                                                \
+            hipLaunchKernelGGL(gat_bwd_src_wide_kernel<ND>, grid, blk, 0, st, g, ldg, Wh, ldw, s, t, attn, ctx, att_w, N, K, D, \
+                               slope, dWh, lddw, ds, du);                                                                   \
+            hipLaunchKernelGGL(gat_bwd_dst_wide_kernel<ND>, grid, blk, 0, st, g, ldg, attn, du, csr, csr + N + 1, att_w, N, K, \
+                               D, dWh, lddw, dt);                                                                           \
+        } while (0)
+        switch (gat_wide_nd(D)) {
+        case 1: COVA_GAT_BWD_WIDE(1); break;
+        case 2: COVA_GAT_BWD_WIDE(2); break;
+        case 3: COVA_GAT_BWD_WIDE(3); break;
+        case 4: COVA_GAT_BWD_WIDE(4); break;
+        case 6: COVA_GAT_BWD_WIDE(6); break;
+        default: COVA_GAT_BWD_WIDE(8); break;
+        }
+#undef COVA_GAT_BWD_WIDE
+        COVA_LAUNCH_CHECK();
+    } else if (csr != nullptr) {
 #define COVA_GAT_SRC(KP) hipLaunchKernelGGL(gat_bwd_src_kernel<KP>, dim3(cdiv(N, 4)), dim3(256), 0, st, g, ldg, Wh, ldw, s, t, \
                                             attn, ctx, att_w, N, K, D, slope, dWh, lddw, ds, du)
         switch (kp) {

@@ -1301,13 +1301,11 @@ def decoder_bwd(sv, dlogits, params, gout=None):
                          drop=(sv["m2"], p) if sv["drop"] else None, colsum=db1)
     dW1 = _gbuf(gout, "decoder.1.weight", (T, T), dlogits)
     call("cova_sgemm", 1, 0, T, T, N, dz, T, sv["xd"], T, dW1, T, None, 0)
-    dxd = _empty((N, T), dlogits)
-    call("cova_sgemm", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dxd, T, None, 0)
-    if sv["drop"]:
-        dx = dyd    # reuse
-        call("cova_dropout_bwd", dxd, T, sv["m1"], dx, T, N, T, float(p))
+    dx = dyd        # (dead by now: reuse)
+    if sv["drop"]:  # the first Dropout's backward in the GEMM's epilogue (one launch less, same bits)
+        call("cova_sgemm_dropout_bwd", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dx, T, sv["m1"], float(p))
     else:
-        dx = dxd
+        call("cova_sgemm", 0, 0, N, T, T, dz, T, params["decoder.1.weight"], T, dx, T, None, 0)
     grads = {"decoder.1.weight": dW1, "decoder.1.bias": db1, "decoder.2.weight": dg,
              "decoder.2.bias": db, "decoder.5.weight": dW2, "decoder.5.bias": db2}
     return dx, grads

@@ -63,7 +63,11 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
  * 10 = F(4x4,3x3) weight gradient: the two position halves of a walk pace each other through progress words (1) or run free
  *      (0, default: the pacing measured 3 % slower at the same HBM traffic, profiles/r05_pmc_wgrad4_pair_pacing.txt): A/B,
  * 11 = cova_sgemm on the f32-MFMA kernel (1, default) or the bf16-split one (0: measured slower, csrc/gemm.hip): A/B,
- * 12 = conv1 forward (bf16 split) with one wave per SIMD (1: measured slower, csrc/conv1_fwd_w4.h) or the 8-wave kernel (0, default): A/B.
+ * 12 = conv1 forward (bf16 split) with one wave per SIMD (1: measured slower, csrc/conv1_fwd_w4.h) or the 8-wave kernel (0, default): A/B,
+ * 13 = cova_bn_relu_maxpool_fwd launch shape (strip height / grid cap / row prefetch, csrc/bn.hip): A/B,
+ * 14 = cova_bn1d_fwd / _bwd in the float4 form with every row of a thread in registers (1, default) or the 128-slice form (0): A/B,
+ * 15 = cova_sgemm in the register-direct form (1; 2 / 3: two / one k-group forced) or on the LDS-tiled kernel (0): A/B (csrc/gemm.hip),
+ * 16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0): A/B.
  * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);
 
@@ -414,6 +418,11 @@ int cova_bbox_linear_bwd(const float *dz, const float *raw, float *dW, float *db
 int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
                int ldb, float *C, int ldc, const float *bias /*nullable [N]*/, int accumulate,
                void *stream);
+/* cova_sgemm (no bias, no accumulate) with cova_dropout_bwd applied to its result in the epilogue:
+ * C = keep ? op(A) op(B) / (1 - p) : 0, keep [M,N] uint8 contiguous -- the decoder's first Dropout backward
+ * (models.py:84) behind the data gradient of decoder.1 (models.py:85); bit-identical to the two launches */
+int cova_sgemm_dropout_bwd(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
+                           int ldb, float *C, int ldc, const uint8_t *keep /*[M,N]*/, float p, void *stream);
 
 /* ------------------------------------------------------------------ graph attention (models.py:171-212)
  * replaces: GraphAttentionLayer.forward after the projections: gather, score, LeakyReLU, mask,

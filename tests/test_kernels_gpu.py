@@ -36,6 +36,35 @@ def nchw(x):   # NHWC gpu -> NCHW cpu
     return x.cpu().permute(0, 3, 1, 2).contiguous()
 
 
+@pytest.mark.parametrize("direct", [1, 2, 3])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(130, 992, 608), (1440, 976, 976), (976, 976, 1440), (45, 72, 64), (33, 100, 196), (64, 64, 1028)])
+def test_sgemm_register_direct_form(ta, tb, M, N, K, direct):
+    """cova_set_option(15, .): the GEMM whose waves stream their operands straight into registers (no LDS tiles, no barriers
+    in the k loop; 1 = k-groups chosen as usual, 2 / 3 = two / one forced) against fp64 and against the LDS-tiled kernel."""
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = ((A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()).float()
+    Ag, Bg = A.to(DEV), B.to(DEV)
+    C0, C = torch.full((M, N + 4), 7.0, device=DEV), torch.full((M, N + 4), 7.0, device=DEV)
+    call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C0, N + 4, bias.to(DEV), 0)
+    query("cova_set_option", 15, direct)
+    try:
+        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C, N + 4, bias.to(DEV), 0)
+        close(C[:, :N], ref, 2e-5, "sgemm direct")
+        close(C[:, :N], C0[:, :N], 1e-5, "sgemm direct against the tiled kernel")
+        assert (C[:, N:] == 7.0).all()
+        C2 = C.clone()
+        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C2, N + 4, bias.to(DEV), 0)
+        assert torch.equal(C2, C)                                  # deterministic
+        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C, N + 4, None, 1)
+        close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm direct accumulate")
+    finally:
+        query("cova_set_option", 15, 0)
+
+
 @pytest.mark.parametrize("f32", [1, 0])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3)])
@@ -123,9 +152,13 @@ def test_batchnorm_train_fwd_bwd(R, C, relu, res):
           1e-5, "bn eval")
 
 
-@pytest.mark.parametrize("R,C,relu,drop", [(300, 64, 1, 1), (77, 16, 1, 0), (1440, 976, 1, 1), (50, 6, 0, 0),
-                                           (2100, 33, 1, 1)])
-def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop):
+@pytest.mark.parametrize("R,C,relu,drop,pad", [(300, 64, 1, 1, 5), (77, 16, 1, 0, 5), (1440, 976, 1, 1, 5), (50, 6, 0, 0, 5),
+                                               (2100, 33, 1, 1, 5),
+                                               # 16-byte aligned rows: the float4 kernels (3 / 6 / 8 rows per thread; a
+                                               # ragged last column block; no ReLU / no Dropout forms)
+                                               (1440, 976, 1, 1, 8), (300, 64, 1, 1, 4), (77, 16, 1, 0, 0), (1440, 32, 1, 0, 8),
+                                               (2880, 100, 1, 1, 4), (3500, 36, 0, 1, 0), (1537, 12, 0, 0, 4)])
+def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop, pad):
     """cova_bn1d_fwd / cova_bn1d_bwd (statistics + finalize + apply, with the Dropout behind the layer and the column sums
     of dz riding along) against torch autograd on the CPU, and against the separate-launch path they replace."""
     g = torch.Generator().manual_seed(R + 3 * C)
@@ -146,17 +179,17 @@ def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop):
     buffers = {"bn.running_mean": rm.to(DEV), "bn.running_var": rv.to(DEV),
                "bn.num_batches_tracked": torch.zeros((), dtype=torch.long, device=DEV)}
     xg = x.detach().to(DEV)
-    out = torch.full((R, C + 5), 9.0, device=DEV)            # ld > C: the layer writes into a wider matrix
+    out = torch.full((R, C + pad), 9.0, device=DEV)            # ld > C: the layer writes into a wider matrix
     mask = keep.to(torch.uint8).to(DEV)
     assert engine.bn1d_fused(True)
     if drop:
-        st, dropped, m = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + 5, relu, drop=(p, 0, mask))
+        st, dropped, m = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + pad, relu, drop=(p, 0, mask))
         close(dropped, yd, 1e-5, "bn1d dropped")
         assert m is mask
     else:
-        st = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + 5, relu)
+        st = engine.bn1d_fwd(xg, C, R, C, "bn.", params, buffers, True, out, C + pad, relu)
     close(out[:, :C], y, 1e-5, "bn1d fwd")
-    assert (out[:, C:] == 9.0).all()
+    assert pad == 0 or (out[:, C:] == 9.0).all()
     close(buffers["bn.running_mean"], rm_ref, 1e-5, "running_mean")
     close(buffers["bn.running_var"], rv_ref, 1e-5, "running_var")
     assert int(buffers["bn.num_batches_tracked"]) == 1
@@ -169,7 +202,7 @@ def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop):
     close(st.mean, st2.mean, 2e-6, "mean")
     dz = torch.empty(R, C, device=DEV)
     colsum = torch.empty(C, device=DEV)
-    dg, db = engine.bn_backward(dout.to(DEV), C, out if relu else None, C + 5, xg, C, st, R, dz, C,
+    dg, db = engine.bn_backward(dout.to(DEV), C, out if relu else None, C + pad, xg, C, st, R, dz, C,
                                 drop=(mask, p) if drop else None, colsum=colsum)
     close(dz, x.grad, 1e-4, "bn1d dz")
     close(dg, gamma.grad, 1e-4, "bn1d dgamma")
@@ -183,9 +216,34 @@ def test_batchnorm1d_single_launch_fwd_bwd(R, C, relu, drop):
              d2, C, gen, p, 1234, 0, st.scale, st.shift, st.mean, st.invstd)
         ref_o, ref_m = engine.dropout_fwd(o2, C, R, C, p, 1234)
         assert torch.equal(gen, ref_m) and torch.equal(d2, ref_o)
+    # the two kernel forms (cova_set_option(14, .): float4 / register-resident rows against 128 row slices) agree to the
+    # association of their fp64 sums
+    if C % 4 == 0 and pad % 4 == 0:
+        res = {}
+        for variant in (0, 1):
+            query("cova_set_option", 14, variant)
+            try:
+                o3, d3 = torch.empty(R, C + pad, device=DEV), torch.empty(R, C, device=DEV)
+                stv = [torch.empty(C, device=DEV) for _ in range(4)]
+                call("cova_bn1d_fwd", xg, C, R, C, params["bn.weight"], params["bn.bias"], None, None, None, 0.1, 1e-5, relu,
+                     o3, C + pad, d3 if drop else None, C, mask if drop else None, p, 0, 1, *stv)
+                dz3, cs3, dg3, db3 = (torch.empty(R, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV),
+                                      torch.empty(C, device=DEV))
+                call("cova_bn1d_bwd", dout.to(DEV), C, mask if drop else None, p, o3 if relu else None, C + pad, xg, C, stv[2],
+                     stv[3], stv[0], R, C, dg3, db3, dz3, C, cs3)
+                res[variant] = (o3[:, :C].clone(), d3, stv[0], stv[1], dz3, cs3, dg3, db3)
+            finally:
+                query("cova_set_option", 14, 1)
+        for a, b, nm in zip(res[0], res[1], ("out", "dropped", "scale", "shift", "dz", "colsum", "dgamma", "dbeta")):
+            if nm == "dropped" and not drop:
+                continue
+            if nm == "colsum":      # the column sums of dz are zero up to rounding (BatchNorm backward): an absolute bound
+                assert float((b - a).abs().max()) <= 1e-4 * max(float(res[0][4].abs().max()), 1.0) * (R ** 0.5)
+                continue
+            close(b, a, 2e-6, "bn1d forms: " + nm)
 
 
-@pytest.mark.parametrize("B,H1,W1", [(1, 8, 8), (2, 13, 21), (1, 32, 32)])
+@pytest.mark.parametrize("B,H1,W1", [(1, 8, 8), (2, 13, 21), (1, 32, 32), (2, 70, 46)])
 def test_bn_relu_maxpool(B, H1, W1):
     g = torch.Generator().manual_seed(H1 * 7 + W1)
     y = torch.randn(B, 64, H1, W1, generator=g).requires_grad_(True)
@@ -208,6 +266,14 @@ def test_bn_relu_maxpool(B, H1, W1):
     call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, out, idx, ymax, B, H1, W1)
     close(nchw(out), ref, 1e-5, "maxpool fwd")
     close(torch.relu(ymax * st.scale + st.shift), out, 1e-6, "arg-max pre-activation")
+    for variant in range(1, 15):       # launch shapes of the same arithmetic (cova_set_option(13, .)): identical bits
+        query("cova_set_option", 13, variant)
+        try:
+            o2, i2, y2 = torch.empty_like(out), torch.empty_like(idx), torch.empty_like(ymax)
+            call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, o2, i2, y2, B, H1, W1)
+        finally:
+            query("cova_set_option", 13, 0)
+        assert torch.equal(o2, out) and torch.equal(i2, idx) and torch.equal(y2, ymax), variant
     npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
     bpart = torch.empty(npart, 2, 64, device=DEV)
     dpg = nhwc(dp)
@@ -367,6 +433,19 @@ def test_dropout():
     dx = torch.empty(n, T, device=DEV)
     call("cova_dropout_bwd", x, T, given, dx, T, n, T, p)
     assert torch.equal(dx, out4)
+
+
+@pytest.mark.parametrize("M,N,K", [(311, 992, 992), (45, 70, 33), (1440, 976, 976)])
+def test_sgemm_with_dropout_backward_epilogue(M, N, K):
+    """cova_sgemm_dropout_bwd = cova_sgemm followed by cova_dropout_bwd, bit for bit (decoder_bwd's dL/d(comb))."""
+    g = torch.Generator().manual_seed(M + N)
+    A, B = torch.randn(M, K, generator=g).to(DEV), torch.randn(K, N, generator=g).to(DEV)
+    keep = (torch.rand(M, N, generator=g) > 0.2).to(torch.uint8).to(DEV)
+    tmp, ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV), torch.full((M, N + 4), 7.0, device=DEV)
+    call("cova_sgemm", 0, 0, M, N, K, A, K, B, N, tmp, N, None, 0)
+    call("cova_dropout_bwd", tmp, N, keep, ref, N, M, N, 0.2)
+    call("cova_sgemm_dropout_bwd", 0, 0, M, N, K, A, K, B, N, got, N + 4, keep, 0.2)
+    assert torch.equal(got[:, :N], ref) and (got[:, N:] == 7.0).all()
 
 
 def test_adam_matches_torch():
@@ -959,6 +1038,35 @@ def test_gat_backward_gather_is_deterministic_for_arbitrary_graphs(kind):
     assert np.array_equal(one.cpu().numpy()[:used], csr[:used])
     assert np.array_equal(engine.gat_transpose(ctx.to(DEV)).cpu().numpy()[:used], csr[:used])
     assert int(engine.gat_transpose(ctx.to(DEV))[N + 1 + 2 * E:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("D,K", [(96, 24), (384, 24), (64, 1), (200, 64), (330, 48), (512, 7), (40, 13)])
+def test_gat_wide_kernels_equal_the_chunk_kernels_bit_for_bit(D, K):
+    """cova_set_option(16, .): the GAT forward / backward kernels with every 64-channel chunk of a neighbour row in flight
+    (K <= 64, D <= 512) against the chunk-at-a-time kernels: the same sums in the same order."""
+    N, Fd = 211, 72
+    rs = np.random.RandomState(D + K)
+    c = rs.randint(-1, N, (N, K))
+    c[3] = -1
+    c[:, 0] = 17                                             # a hub
+    ctx = torch.from_numpy(c.astype(np.int64))
+    h, sd, g = _gat_case(N, K, Fd, D, ctx, 5)
+    params = {k: v.to(DEV) for k, v in sd.items()}
+    res = []
+    for wide in (0, 1):
+        query("cova_set_option", 16, wide)
+        try:
+            hp = torch.empty(N, D, device=DEV)
+            sv = engine.gat_fwd(h.to(DEV), Fd, N, Fd, ctx.to(DEV), params, hp, D)
+            dh = torch.empty(N, Fd, device=DEV)
+            grads = engine.gat_bwd(sv, g.to(DEV), D, params, dh, Fd, False)
+            res.append((hp, sv["attn"], dh, grads))
+        finally:
+            query("cova_set_option", 16, 1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
+    assert bool(torch.isfinite(res[1][0]).all()) and bool(torch.isfinite(res[1][2]).all())
 
 
 def test_roipool_backward_rows_are_deterministic_and_cover_the_map():

@@ -39,5 +39,11 @@ for tA, tB, M, Nn, K, what in shapes:
     ref = (A.t() if tA else A) @ (B.t() if tB else B)
     err = float((C - ref).abs().max() / ref.abs().max())
     t2 = timeit(lambda: torch.matmul(A.t() if tA else A, B.t() if tB else B))
-    print("%-32s M%5d N%5d K%5d  %6.1f us  %5.1f TF/s  (torch/hipBLASLt %6.1f us)  rel err %.1e"
-          % (what, M, Nn, K, t * 1e3, 2 * M * Nn * K / t / 1e9, t2 * 1e3, err))
+    td = []
+    for v in (1, 2, 3):            # the register-direct form: usual k-groups / two / one
+        _lib.query("cova_set_option", 15, v)
+        td.append(timeit(lambda: call("cova_sgemm", tA, tB, M, Nn, K, A, lda, B, ldb, C, Nn, None, 0)) * 1e3)
+    errd = float((C - ref).abs().max() / ref.abs().max())
+    _lib.query("cova_set_option", 15, 0)
+    print("%-32s M%5d N%5d K%5d  %6.1f us  %5.1f TF/s  (torch/hipBLASLt %6.1f us)  rel err %.1e | direct %5.1f / %5.1f / %5.1f us  rel err %.1e"
+          % (what, M, Nn, K, t * 1e3, 2 * M * Nn * K / t / 1e9, t2 * 1e3, err, td[0], td[1], td[2], errd))

@@ -386,15 +386,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // Neighbouring columns are neighbouring 16-lane groups of the same wave (L1 hits).
 // STRIP / PRE (cova_set_option(13, v), tools/ew_bench.py): rows per strip; PRE: the two new input rows of output row
 // oy + 1 are requested before output row oy is reduced and stored (12 instead of 6 loads of a thread in flight).
-int g_pool_variant = 0;
-template <int POOL_STRIP, bool PRE, bool XCD = false>
+int g_pool_variant = 12;     // one output row per thread, XCD-contiguous work blocks: measured fastest (tools/ew_bench.py)
+template <int POOL_STRIP, bool PRE, bool XCD = false, bool TILE2D = false>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
     float *__restrict__ out, uint8_t *__restrict__ idx, float *__restrict__ ymax, int B, int H1, int W1,
     int H2, int W2)
 {
+    // TILE2D (POOL_STRIP = 1): a block is 4 x 4 outputs x 16 channel quads (a wave = 4 adjacent columns of one output row)
+    // instead of 16 adjacent columns of one row: 81 instead of 99 input pixels per block, the rest are L1 hits
+    static_assert(!TILE2D || POOL_STRIP == 1, "TILE2D: one output row per thread");
     const int nstrips = (H2 + POOL_STRIP - 1) / POOL_STRIP;
-    const long long total = (long long)B * nstrips * W2 * 16;
+    const int tiles_x = (W2 + 3) / 4, tiles_y = (H2 + 3) / 4;
+    const long long total = TILE2D ? (long long)B * tiles_y * tiles_x * 256 : (long long)B * nstrips * W2 * 16;
     // XCD: consecutive blocks go to the eight XCDs in turn -- block b takes work block (b % 8) * (grid / 8) + b / 8, so that
     // an XCD walks ONE contiguous eighth of the maps and the input row two neighbouring strips share is met in its own L2
     long long wb = blockIdx.x;
@@ -405,10 +409,22 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     for (long long i = wb * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i & 15);
         long long p = i >> 4;
-        const int ox = (int)(p % W2);
-        p /= W2;
-        const int strip = (int)(p % nstrips);
-        const int b = (int)(p / nstrips);
+        int ox, strip, b;
+        if (TILE2D) {
+            const int px = (int)(p & 3), py = (int)((p >> 2) & 3);
+            p >>= 4;                                               // tile index
+            const int tx = (int)(p % tiles_x);
+            p /= tiles_x;
+            ox = 4 * tx + px;
+            strip = 4 * (int)(p % tiles_y) + py;                   // (= the output row)
+            b = (int)(p / tiles_y);
+            if (ox >= W2 || strip >= H2) continue;
+        } else {
+            ox = (int)(p % W2);
+            p /= W2;
+            strip = (int)(p % nstrips);
+            b = (int)(p / nstrips);
+        }
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c4 * 4);
         const float4 sh = *reinterpret_cast<const float4 *>(shift + c4 * 4);
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -911,6 +927,12 @@ COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const 
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B,
                            H1, W1, H2, W2);
     };
+    auto launch2d = [&](auto kern) {
+        long long g = (long long)B * cdiv(H2, 4) * cdiv(W2, 4);
+        if (g > 0x7fffffffll) g = 0x7fffffffll;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B,
+                           H1, W1, H2, W2);
+    };
     switch (g_pool_variant) {
     case 1: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, false); break;
     case 2: launch(bn_relu_maxpool_fwd_kernel<8, false>, 8, false); break;
@@ -923,10 +945,13 @@ COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const 
     case 9: launch(bn_relu_maxpool_fwd_kernel<4, true, true>, 4, false); break;
     case 10: launch(bn_relu_maxpool_fwd_kernel<2, true, true>, 2, false); break;
     case 11: launch(bn_relu_maxpool_fwd_kernel<8, true, true>, 8, false); break;
-    case 12: launch(bn_relu_maxpool_fwd_kernel<1, false, true>, 1, false); break;
     case 13: launch(bn_relu_maxpool_fwd_kernel<2, false, true>, 2, false); break;
     case 14: launch(bn_relu_maxpool_fwd_kernel<16, true, true>, 16, false); break;
-    default: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, true); break;
+    case 15: launch(bn_relu_maxpool_fwd_kernel<1, false, false>, 1, false); break;
+    case 16: launch2d(bn_relu_maxpool_fwd_kernel<1, false, true, true>); break;
+    case 17: launch2d(bn_relu_maxpool_fwd_kernel<1, false, false, true>); break;
+    case 12: launch(bn_relu_maxpool_fwd_kernel<1, false, true>, 1, false); break;
+    default: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, true); break;     // (0: the round-2 shape)
     }
     COVA_LAUNCH_CHECK();
     return COVA_OK;

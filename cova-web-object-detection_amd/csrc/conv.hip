@@ -1736,7 +1736,17 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *_
     const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + tx;                    // over [co][160]
     double s = 0.0;
-    for (int p = slice; p < nparts; p += 16) s += (double)part[(size_t)p * (64 * 160) + idx];
+    for (int p0 = slice; p0 < nparts; p0 += 16 * 8) {        // eight rows in flight, added in the same order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 16 * u;
+            v[u] = part[(size_t)(p < nparts ? p : p0) * (64 * 160) + idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + 16 * u < nparts) s += (double)v[u];
+    }
     s_acc[slice][tx] = s;
     __syncthreads();
     if (slice == 0) {

@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
 // Block (0,0) also builds the per-page box ranges the rows kernel needs (page_range != NULL), and -- TAIL (C = 64) -- the
 // last block to finish turns the partial rows into dgamma / dbeta / the dz coefficients (bn_tail.h): no launch of its own
 // for either.
-template <bool STATS, bool TAIL>
+// NB = 9: the reference's 3 x 3 bins as a compile-time constant -- the 36 operands of a box are requested before the first is
+// used (one round trip per box instead of nine; same sums in the same order); NB = 0: any bin count.
+template <bool STATS, bool TAIL, int NB = 0>
 __global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
     const float *__restrict__ gout, int ld_g, const float *__restrict__ pooled, int ld_p,
     const float *__restrict__ zmax, const int32_t *__restrict__ argmax, int n_rois, int C, int bins,
@@ -340,6 +342,30 @@ __global__ __launch_bounds__(256) void roipool_bwd_prep_kernel(
     float su = 0.f, sq = 0.f;
     for (int n = blockIdx.x * 4 + wave; n < n_rois; n += gridDim.x * 4) {
         const size_t e = (size_t)c * bins;
+        if (NB > 0) {
+            int mi[NB > 0 ? NB : 1];
+            float g[NB > 0 ? NB : 1], pl[NB > 0 ? NB : 1], zm[NB > 0 ? NB : 1];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                mi[q] = argmax[(size_t)n * C * NB + e + q];
+                g[q] = gout[(size_t)n * ld_g + e + q];
+                if (STATS) {
+                    pl[q] = pooled[(size_t)n * ld_p + e + q];
+                    zm[q] = zmax[(size_t)n * C * NB + e + q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                if (STATS) {
+                    if (!(mi[q] >= 0 && pl[q] > 0.f)) g[q] = 0.f;
+                    su += g[q];
+                    sq += g[q] * ((zm[q] - mu) * is);
+                }
+                gT[((size_t)n * NB + q) * C + c] = g[q];
+                amT[((size_t)n * NB + q) * C + c] = mi[q];
+            }
+            continue;
+        }
         for (int q = 0; q < bins; ++q) {
             const int mi = argmax[(size_t)n * C * bins + e + q];
             float g = gout[(size_t)n * ld_g + e + q];
@@ -686,7 +712,9 @@ __global__ __launch_bounds__(256) void gat_fwd_wide_kernel(
     const int jj = (int)j;
     const float m = wave_max(e);
     const float pr = lane < K ? expf(e - m) : 0.f;
-    const float denom = wave_sum(pr);
+    float psum = 0.f;
+    psum += pr;
+    const float denom = wave_sum(psum);
     const float alpha = pr / denom;
     if (lane < K) attn[(size_t)n * K + lane] = alpha;
     const float aw = jj >= 0 ? alpha : 0.f;                 // pads: weight 0 on a valid (clamped) row
@@ -1050,7 +1078,12 @@ __global__ __launch_bounds__(256) void gat_bwd_src_wide_kernel(
             if (lane == k0 + u && jk[u] >= 0) dalpha = tot;
         }
     }
-    const float dot = wave_sum(alpha * dalpha);
+    // (the sum below is gat_bwd_src_kernel's statement for statement: written as wave_sum(alpha * dalpha), hipcc's default
+    // -ffp-contract=fast fuses the product into the first add of the reduction -- an unrounded product, and for K > 32,
+    // where the partner lane holds a value, other bits than the chunk kernel's)
+    float ad = 0.f;
+    ad += alpha * dalpha;
+    const float dot = wave_sum(ad);
     float du = 0.f;
     if (lane < K && jj >= 0) {
         const float de = alpha * (dalpha - dot);
@@ -1058,7 +1091,9 @@ __global__ __launch_bounds__(256) void gat_bwd_src_wide_kernel(
         du = de * (u > 0.f ? 1.f : slope);
     }
     if (lane < K) du_out[(size_t)n * K + lane] = du;
-    const float dsn = wave_sum(du);
+    float dus = 0.f;
+    dus += du;
+    const float dsn = wave_sum(dus);
     if (lane == 0) ds[n] = dsn;
     for (int d = lane; d < D; d += 64) dWh[(size_t)n * lddw + d] = dsn * att_w[d];
 }
@@ -1260,7 +1295,16 @@ static int launch_roipool_bwd(const float *gout, int ld_g, const float *pooled, 
         if (!(partial && C == 64 && tail->mode == 2)) return COVA_ERR_BAD_ARG;
         t = *tail;
     }
-    if (t.mode != 0)
+    if (PH * PW == 9 && t.mode != 0)
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<true, true, 9>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, 9, mean, invstd, gT, amT, partial, rois, B, page_range, t);
+    else if (PH * PW == 9 && partial)
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<true, false, 9>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, 9, mean, invstd, gT, amT, partial, rois, B, page_range, t);
+    else if (PH * PW == 9)
+        hipLaunchKernelGGL((roipool_bwd_prep_kernel<false, false, 9>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
+                           argmax, n_rois, C, 9, mean, invstd, gT, amT, partial, rois, B, page_range, t);
+    else if (t.mode != 0)
         hipLaunchKernelGGL((roipool_bwd_prep_kernel<true, true>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
                            argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
     else if (partial)

@@ -10,6 +10,7 @@ from cova_web_object_detection_amd import _lib, weights
 from cova_web_object_detection_amd.trainer import HotPathTrainer
 key = int(sys.argv[1]) if len(sys.argv) > 1 else 9          # key 0: engine.OPTIONS.side_stream on (value 0) / off (value 1)
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+vals = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 1)      # the two option values that alternate
 dev = torch.device("cuda", 0)
 wl = bench.WORKLOADS[2]
 cfg = bench.model_cfg(wl)
@@ -23,7 +24,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 # option value 1 = the A/B alternative (f32 kernels for keys 7 and 9, pair pacing for key 10)
 for r in range(rounds):
-    for val in (0, 1):
+    for val in vals:
         if key == 0:
             from cova_web_object_detection_amd import engine
             engine.OPTIONS.side_stream = val == 0

@@ -273,19 +273,35 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
 // decisions as one bit per element: bits[r][w] bit k = (out[r][32 w + k] > 0).  The data gradient that needs this map
 // only as its mask source (conv_wino4.hip, `act_bits`) then reads 1/32 of the bytes.  A thread owns 4 channels; the 8
 // lanes of a 32-channel word combine their nibbles with three lane exchanges.
+// U: elements a thread has in flight per trip (cova_set_option(17, u); the stride is a multiple of 8 lanes, so the 8 lanes of a
+// word stay together in every one of them)
+int g_bnact_unroll = 1;
+template <int U>
 __global__ __launch_bounds__(256) void bn_act_fwd_bits_kernel(
     const float *__restrict__ z, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ res, float *__restrict__ out, uint32_t *__restrict__ bits, long long R)
 {
     const long long total = R * 16;                      // multiple of 16: the 8 lanes of a word are active together
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i & 15) * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(z + i * 4);
-        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int c = (int)(threadIdx.x & 15) * 4;           // (blockDim.x and the stride are multiples of 16)
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * U) {
+      float4 vv[U], rr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = i0 + u * stride;
+        const long long ic = i < total ? i : i0;
+        vv[u] = *reinterpret_cast<const float4 *>(z + ic * 4);
+        if (res != nullptr) rr[u] = *reinterpret_cast<const float4 *>(res + ic * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = i0 + u * stride;
+        if (i >= total) break;                           // (uniform over the 8 lanes of a word)
+        const float4 v = vv[u];
         float y[4] = {fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y), fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w)};
         if (res != nullptr) {
-            const float4 r4 = *reinterpret_cast<const float4 *>(res + i * 4);
+            const float4 r4 = rr[u];
             y[0] += r4.x; y[1] += r4.y; y[2] += r4.z; y[3] += r4.w;
         }
         uint32_t word = 0u;
@@ -300,6 +316,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_bits_kernel(
         word |= __shfl_xor(word, 2, 64);
         word |= __shfl_xor(word, 4, 64);
         if ((threadIdx.x & 7) == 0) bits[i >> 3] = word;          // (i >> 3 = row * 2 + word of the row)
+      }
     }
 }
 
@@ -721,6 +738,7 @@ inline bool vec4_ok(const void *p, int ld)
 }  // namespace
 
 int cova_internal_set_pool_variant(int v) { g_pool_variant = v; return COVA_OK; }
+int cova_internal_set_bnact_unroll(int v) { g_bnact_unroll = v; return COVA_OK; }
 
 // ====================================================================================
 // C ABI
@@ -822,8 +840,15 @@ COVA_API int cova_bn_act_fwd_bits(const float *z, const float *scale, const floa
 {
     COVA_REQUIRE(z && scale && shift && out && bits && R > 0);
     COVA_REQUIRE(vec4_ok(z, 64) && vec4_ok(res, 64) && vec4_ok(out, 64) && vec4_ok(scale, 0) && vec4_ok(shift, 0));
-    hipLaunchKernelGGL(bn_act_fwd_bits_kernel, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
-                       res, out, bits, R);
+    if (g_bnact_unroll == 4)
+        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<4>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                           res, out, bits, R);
+    else if (g_bnact_unroll == 2)
+        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<2>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                           res, out, bits, R);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<1>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                           res, out, bits, R);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

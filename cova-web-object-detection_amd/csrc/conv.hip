@@ -1803,6 +1803,8 @@ int cova_internal_set_pool_variant(int v);
 int cova_internal_set_bn1d_variant(int v);
 int cova_internal_set_sgemm_direct(int v);
 int cova_internal_set_gat_wide(int v);
+int cova_internal_set_bnact_unroll(int v);
+int cova_internal_set_roipool_variant(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1818,6 +1820,8 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 14) return cova_internal_set_bn1d_variant(value);
     if (key == 15) return cova_internal_set_sgemm_direct(value);
     if (key == 16) return cova_internal_set_gat_wide(value);
+    if (key == 17) return cova_internal_set_bnact_unroll(value);
+    if (key == 18) return cova_internal_set_roipool_variant(value);
     return COVA_ERR_BAD_ARG;
 }
 

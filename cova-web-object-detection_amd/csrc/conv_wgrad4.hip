@@ -591,20 +591,22 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
 
 // Fold of the per-block partials (already transformed: part[block][r * 3 + t][co][ci]), up to four convolutions in one launch:
 //   dW[co][ci][r][t] = sum over the blocks of part[block][r * 3 + t][co][ci]       (fp64, fixed order; OIHW)
-// block = 16 (co, ci) pairs x 16 slices of blocks
+// block = 64 (co, ci) pairs x 16 slices of blocks: a wave is ONE slice over 64 adjacent pairs (256 contiguous bytes per load;
+// round 4's 16 pairs x 16 slices read 64-byte pieces: 50 us for the 151 MB of a step, 3 TB/s), the sums are taken per slice in
+// block order and over the slices in slice order exactly as before (identical bits)
 struct Wg4FinishJobs { const float *part[4]; float *dw[4]; };
-__global__ __launch_bounds__(256) void wgrad4_finish_kernel(const Wg4FinishJobs jobs, int grid)
+__global__ __launch_bounds__(1024) void wgrad4_finish_kernel(const Wg4FinishJobs jobs, int grid)
 {
-    __shared__ double s_acc[9][16][16];          // [r * 3 + t][slice][pair]
+    __shared__ double s_acc[9][16][64];          // [r * 3 + t][slice][pair]
     const float *__restrict__ part = jobs.part[blockIdx.y];
     float *__restrict__ dw = jobs.dw[blockIdx.y];
-    const int tx = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + tx;        // (co, ci) pair
+    const int tx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;        // (co, ci) pair
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
     // eight blocks' rows (72 loads) are requested before the first is added: two dependent round trips per thread for the 256
-    // blocks of a launch instead of sixteen (the kernel was latency bound: 50 us for 151 MB); same adds in the same order
+    // blocks of a launch; same adds in the same order
     for (int blk0 = slice; blk0 < grid; blk0 += 16 * 8) {
         float v[8][9];
 #pragma unroll
@@ -719,7 +721,7 @@ COVA_API int cova_conv3x3_wgrad4_finish(const float *ws0, float *dw0, const floa
     for (int i = 0; i < 4; ++i)
         if (ws[i]) { jobs.part[n] = ws[i]; jobs.dw[n] = dw[i]; ++n; }
     const int grid = wg4_geometry(B, H, W).grid;
-    hipLaunchKernelGGL(wgrad4_finish_kernel, dim3(4096 / 16, n), dim3(256), 0, (hipStream_t)stream, jobs, grid);
+    hipLaunchKernelGGL(wgrad4_finish_kernel, dim3(4096 / 64, n), dim3(1024), 0, (hipStream_t)stream, jobs, grid);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
             fetch_tile<!TA>(A, lda, m0, M, k0 + KSTEP, K, tid, vecA != 0, va);
             fetch_tile<TB>(Bm, ldb, n0, N, k0 + KSTEP, K, tid, vecB != 0, vb);
         }
+        // (measured: requesting all 64 operands of the k-tile from LDS before the first MFMA -- instead of hipcc's read, read,
+        // wait, two MFMAs -- is SLOWER, 43 against 38 us and 65 against 55 us per launch: the second wave of the SIMD
+        // already covers the LDS latencies, and 64 more registers cost a resident block)
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const float a = As[2 * kk + kh2][wm * 32 + li];
@@ -142,15 +145,24 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
     const int gn = n0 + wn * 32 + li;
     if (gn < N) {
         const float bv = bias ? bias[gn] : 0.f;
+        // what the epilogue reads (the old values under `accumulate`, the keep mask of the Dropout epilogue) is requested for
+        // all 16 rows before the first is used: one round trip instead of sixteen
+        float old[16];
+        uint8_t keep[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = min(m0 + wm * 32 + mfma32_row(r, lane), M - 1);       // (clamped: a valid address; not stored)
+            old[r] = accumulate ? C[(size_t)gm * ldc + gn] : 0.f;
+            keep[r] = emask != nullptr ? emask[(size_t)gm * N + gn] : (uint8_t)1;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int gm = m0 + wm * 32 + mfma32_row(r, lane);
             if (gm < M) {
                 float v = acc[r] + bv;
-                float *dst = C + (size_t)gm * ldc + gn;
-                if (accumulate) v += *dst;
-                if (emask != nullptr) v = emask[(size_t)gm * N + gn] ? v * einv : 0.f;      // cova_dropout_bwd on the result
-                *dst = v;
+                if (accumulate) v += old[r];
+                if (emask != nullptr) v = keep[r] ? v * einv : 0.f;             // cova_dropout_bwd on the result
+                C[(size_t)gm * ldc + gn] = v;
             }
         }
     }

@@ -64,10 +64,13 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
  *      (0, default: the pacing measured 3 % slower at the same HBM traffic, profiles/r05_pmc_wgrad4_pair_pacing.txt): A/B,
  * 11 = cova_sgemm on the f32-MFMA kernel (1, default) or the bf16-split one (0: measured slower, csrc/gemm.hip): A/B,
  * 12 = conv1 forward (bf16 split) with one wave per SIMD (1: measured slower, csrc/conv1_fwd_w4.h) or the 8-wave kernel (0, default): A/B,
- * 13 = cova_bn_relu_maxpool_fwd launch shape (strip height / grid cap / row prefetch, csrc/bn.hip): A/B,
+ * 13 = cova_bn_relu_maxpool_fwd launch shape (0..17: strip height / grid cap / row prefetch / XCD-contiguous blocks / 4 x 4 tiles,
+ *      csrc/bn.hip; default 12 = one output row per thread on XCD-contiguous blocks): A/B,
  * 14 = cova_bn1d_fwd / _bwd in the float4 form with every row of a thread in registers (1, default) or the 128-slice form (0): A/B,
  * 15 = cova_sgemm in the register-direct form (1; 2 / 3: two / one k-group forced) or on the LDS-tiled kernel (0): A/B (csrc/gemm.hip),
- * 16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0): A/B.
+ * 16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0): A/B,
+ * 17 = cova_bn_act_fwd_bits: elements of a thread in flight per trip (1, 2, 4): A/B,
+ * 18 = cova_roipool_fwd(_bn): 0 = 4 loads per lane and map in flight, 1 = 8, 2 = 4 on XCD-contiguous work blocks, 3 = both (default): A/B.
  * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);
 

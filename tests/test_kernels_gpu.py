@@ -328,6 +328,17 @@ def test_roipool_matches_oracle_bit_exact():
     call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_m, 576, arg_m)
     call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_l, 576, arg_l, zmax)
     assert torch.equal(out_l, out_m) and torch.equal(arg_l, arg_m)
+    for variant in (0, 1, 2):          # cova_set_option(18, .): 4 / 8 loads in flight, XCD-contiguous work blocks or not: same bits
+        query("cova_set_option", 18, variant)
+        try:
+            o2, a2 = torch.empty_like(out_m), torch.empty_like(arg_m)
+            o3, a3, z3 = torch.empty_like(out_l), torch.empty_like(arg_l), torch.empty_like(zmax)
+            call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, o2, 576, a2)
+            call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, o3, 576, a3, z3)
+        finally:
+            query("cova_set_option", 18, 3)
+        assert torch.equal(o2, out_m) and torch.equal(a2, arg_m), variant
+        assert torch.equal(o3, out_l) and torch.equal(a3, arg_l) and torch.equal(z3[arg_l >= 0], zmax[arg_l >= 0]), variant
     valid = arg_l >= 0
     pos = arg_l.clamp_min(0).long()
     page = rois[:, 0].long().to(DEV).view(n, 1)
@@ -752,6 +763,14 @@ def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
             call("cova_bn_act_fwd", z, 64, msc, msh, x2, 64, act, 64, B * H * W, 64, 1)
             call("cova_bn_act_fwd_bits", z, msc, msh, x2, act2, bits, B * H * W)
             assert torch.equal(act, act2)
+            for un in (2, 4):                  # cova_set_option(17, .): two / four elements of a thread in flight
+                query("cova_set_option", 17, un)
+                try:
+                    act3, bits3 = torch.empty_like(x), torch.empty_like(bits)
+                    call("cova_bn_act_fwd_bits", z, msc, msh, x2, act3, bits3, B * H * W)
+                finally:
+                    query("cova_set_option", 17, 1)
+                assert torch.equal(act3, act2) and torch.equal(bits3, bits)
             sh = torch.arange(32, device=DEV, dtype=torch.int32).view(1, 1, 32)
             assert torch.equal(((bits.view(-1, 2, 1) >> sh) & 1).view(B, H, W, 64).bool(), act > 0)
             add = x2 * 0.5

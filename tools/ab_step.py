@@ -18,7 +18,8 @@ sd = weights.seeded_state_dict(123, **bench.weight_cfg(cfg))
 tr = HotPathTrainer(cfg, sd, dev, dropout_seed=123)
 batch = bench.make_device_batch(123, dev, wl["pages"], 2)
 names = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv3x3_wgrad4_partial", "cova_conv1_fwd_tail",
-         "cova_conv1_wgrad_poolbwd", "cova_bn_relu_maxpool_fwd", "cova_bn_act_fwd_bits", "cova_bn1d_fwd", "cova_bn1d_bwd", "cova_gat_fwd", "cova_gat_bwd", "cova_sgemm"]
+         "cova_conv1_wgrad_poolbwd", "cova_bn_relu_maxpool_fwd", "cova_bn_act_fwd_bits", "cova_bn1d_fwd", "cova_bn1d_bwd", "cova_gat_fwd", "cova_gat_bwd", "cova_sgemm", "cova_roipool_fwd_bn", "cova_roipool_bwd_bn_tail",
+         "cova_conv3x3_wgrad4_finish"]
 for _ in range(5):
     tr.train_step(batch)
 torch.cuda.synchronize()

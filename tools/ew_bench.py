@@ -40,8 +40,11 @@ for variant in (0, 7, 10, 12, 13, 15, 16, 17, 0, 12, 16):      # cova_set_option
     print("bn_relu_maxpool_fwd (+ymax) variant %d: %.3f ms  %.2f TB/s" % (variant, t, (4 * T + 2 * T + T / 4) / t))
 query("cova_set_option", 13, 12)
 bits = torch.empty(R, 2, device=dev, dtype=torch.int32)
-t = timeit(lambda: call("cova_bn_act_fwd_bits", z, sc, sh, x, out, bits, R))
-print("bn_act_fwd_bits +res (3 maps): %.3f ms  %.2f TB/s" % (t, 3 * T / t))
+for un in (1, 2, 4, 1, 2, 4):                  # cova_set_option(17, .): elements of a thread in flight
+    query("cova_set_option", 17, un)
+    t = timeit(lambda: call("cova_bn_act_fwd_bits", z, sc, sh, x, out, bits, R))
+    print("bn_act_fwd_bits +res (3 maps) unroll %d: %.3f ms  %.2f TB/s" % (un, t, 3 * T / t))
+query("cova_set_option", 17, 1)
 # the head's BatchNorm1d launches at configs[1]: 128-slice form (0) against the float4 form (1)
 N, Tc = 1440, 976
 for Cc, drop in ((Tc, 1), (32, 0)):

@@ -1805,6 +1805,8 @@ int cova_internal_set_sgemm_direct(int v);
 int cova_internal_set_gat_wide(int v);
 int cova_internal_set_bnact_unroll(int v);
 int cova_internal_set_roipool_variant(int v);
+int cova_internal_set_sgemm_pf2(int v);
+int cova_internal_set_roipool_bwd_nbx(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1822,6 +1824,8 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 16) return cova_internal_set_gat_wide(value);
     if (key == 17) return cova_internal_set_bnact_unroll(value);
     if (key == 18) return cova_internal_set_roipool_variant(value);
+    if (key == 19) return cova_internal_set_sgemm_pf2(value);
+    if (key == 20) return cova_internal_set_roipool_bwd_nbx(value);
     return COVA_ERR_BAD_ARG;
 }
 

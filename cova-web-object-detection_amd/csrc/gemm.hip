@@ -83,7 +83,9 @@ __device__ __forceinline__ void stash_tile(float (*S)[LDT], int tid, const float
 // 64x64 output tile and add their accumulators up at the end (through LDS, fixed order).  These GEMMs leave ~1.4 waves
 // per SIMD and every k-tile is a dependent chain (barrier, LDS round trip, 32 MFMAs on one accumulator): two chains per
 // output tile halve the serial length and give every SIMD a second wave to switch to.
-template <bool TA, bool TB, int KS>
+// PF2: the operand tiles are fetched TWO k-tiles ahead (two register sets, the loop body twice per trip): a tile's loads
+// have two MFMA phases to land instead of one (cova_set_option(19, 1))
+template <bool TA, bool TB, int KS, bool PF2 = false>
 __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Bm, int ldb,
                                                          float *__restrict__ C, int ldc,
@@ -111,6 +113,42 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
     float va[EPT], vb[EPT];
     fetch_tile<!TA>(A, lda, m0, M, grp * BK, K, tid, vecA != 0, va);
     fetch_tile<TB>(Bm, ldb, n0, N, grp * BK, K, tid, vecB != 0, vb);
+    if (PF2) {
+        float va1[EPT], vb1[EPT];
+        fetch_tile<!TA>(A, lda, m0, M, grp * BK + KSTEP, K, tid, vecA != 0, va1);      // (past K: zeros, no loads)
+        fetch_tile<TB>(Bm, ldb, n0, N, grp * BK + KSTEP, K, tid, vecB != 0, vb1);
+        auto mma = [&]() {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const float a = As[2 * kk + kh2][wm * 32 + li];
+                const float b = Bs[2 * kk + kh2][wn * 32 + li];
+                acc = mfma32(a, b, acc);
+            }
+        };
+        // (every condition below is the same for both k-groups: k0 - grp * BK does not depend on the group)
+        for (int k0 = grp * BK; k0 - grp * BK < K; k0 += 2 * KSTEP) {
+            __syncthreads();
+            stash_tile<!TA>(As, tid, va);
+            stash_tile<TB>(Bs, tid, vb);
+            __syncthreads();
+            if (k0 + 2 * KSTEP - grp * BK < K) {
+                fetch_tile<!TA>(A, lda, m0, M, k0 + 2 * KSTEP, K, tid, vecA != 0, va);
+                fetch_tile<TB>(Bm, ldb, n0, N, k0 + 2 * KSTEP, K, tid, vecB != 0, vb);
+            }
+            mma();
+            if (k0 + KSTEP - grp * BK < K) {
+                __syncthreads();
+                stash_tile<!TA>(As, tid, va1);
+                stash_tile<TB>(Bs, tid, vb1);
+                __syncthreads();
+                if (k0 + 3 * KSTEP - grp * BK < K) {
+                    fetch_tile<!TA>(A, lda, m0, M, k0 + 3 * KSTEP, K, tid, vecA != 0, va1);
+                    fetch_tile<TB>(Bm, ldb, n0, N, k0 + 3 * KSTEP, K, tid, vecB != 0, vb1);
+                }
+                mma();
+            }
+        }
+    } else
     for (int k0 = grp * BK; k0 - grp * BK < K; k0 += KSTEP) {
         __syncthreads();                    // previous tile fully consumed
         stash_tile<!TA>(As, tid, va);
@@ -454,6 +492,7 @@ __global__ __launch_bounds__(256 * KS) void sgemm_direct_kernel(const float *__r
 }
 
 int g_sgemm_direct = 0;
+int g_sgemm_pf2 = 0;
 
 int g_sgemm_f32 = 1;          // default: the f32-MFMA kernel (the bf16-split one measured slower, see the header)
 
@@ -463,6 +502,7 @@ inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && 
 
 int cova_internal_set_sgemm_f32(int v) { g_sgemm_f32 = v != 0; return COVA_OK; }
 int cova_internal_set_sgemm_direct(int v) { g_sgemm_direct = v; return COVA_OK; }
+int cova_internal_set_sgemm_pf2(int v) { g_sgemm_pf2 = v != 0; return COVA_OK; }
 
 static int sgemm_launch(int transA, int transB, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias,
@@ -499,7 +539,8 @@ static int sgemm_launch(int transA, int transB, int M, int N, int K, const float
         if (!g_sgemm_f32 && emask == nullptr) {                                                                             \
             if (split) hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
             else hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
-        } else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
+        } else if (split && g_sgemm_pf2) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2, true>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
+        else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
         else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
     } while (0)
     if (!transA && !transB) SGEMM_LAUNCH(false, false);

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(1024) void roipool_page_range_block_kernel(const fl
 // the arg-max, so this is the ReLU mask of the map's producer without reading the map.
 // gT / amT: the (masked) contributions and arg-max positions in [box][bin][channel] order (roipool_bwd_prep_kernel)
 // so that a wave's loads are 256 contiguous bytes.
-template <bool P33>                               // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
+int g_roipool_bwd_nbx = 4;                        // cova_set_option(20, 2 | 4): boxes of a row segment visited per round trip
+template <bool P33, int NBX = 2>                  // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gT, const int32_t *__restrict__ amT, const float *__restrict__ rois,
     const int *__restrict__ page_range, int n_rois, int B, int C, int H, int W, int PH_, int PW_,
@@ -261,15 +262,15 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
             }
             unsigned long long m = __ballot(hit);
             if (P33) {
-                // boxes touching this segment, ascending (fixed order); two at a time so that their geometry
-                // and arg-max / gradient operands are one round trip
+                // boxes touching this segment, ascending (fixed order); NBX at a time so that their geometry
+                // and arg-max / gradient operands are one round trip (2 until round 5; 4: 72 loads in flight)
                 while (m) {
-                    int nb[2];
-                    RoiGeo g[2];
-                    int mi[2][9];
-                    float gg[2][9];
+                    int nb[NBX];
+                    RoiGeo g[NBX];
+                    int mi[NBX][9];
+                    float gg[NBX][9];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NBX; ++u) {
                         nb[u] = m ? n0 + __ffsll((long long)m) - 1 : -1;
                         m &= m - 1;                          // (0 & anything stays 0)
                         const int nn = nb[u] >= 0 ? nb[u] : n_lo;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NBX; ++u) {
 #pragma unroll
                         for (int ph = 0; ph < 3; ++ph) {
                             const bool rowhit = nb[u] >= 0 && y >= bin_lo(ph, g[u].bin_h, g[u].rs_h, H) &&
@@ -1223,6 +1224,7 @@ inline int gat_wide_nd(int D)
 
 int cova_internal_set_gat_wide(int v) { g_gat_wide = v != 0; return COVA_OK; }
 int cova_internal_set_roipool_variant(int v) { g_roipool_variant = v; return COVA_OK; }
+int cova_internal_set_roipool_bwd_nbx(int v) { g_roipool_bwd_nbx = v == 4 ? 4 : 2; return COVA_OK; }
 
 // ====================================================================================
 // C ABI
@@ -1341,7 +1343,8 @@ static int launch_roipool_bwd(const float *gout, int ld_g, const float *pooled, 
         hipLaunchKernelGGL((roipool_bwd_prep_kernel<false, false>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
                            argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true> : roipool_bwd_rows_kernel<false>),
+    hipLaunchKernelGGL((PH == 3 && PW == 3 ? (g_roipool_bwd_nbx == 4 ? roipool_bwd_rows_kernel<true, 4> : roipool_bwd_rows_kernel<true, 2>)
+                                           : roipool_bwd_rows_kernel<false>),
                        dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gT, amT, rois, page_range, n_rois,
                        B, C, H, W, PH, PW, spatial_scale, gfeat);
     COVA_LAUNCH_CHECK();

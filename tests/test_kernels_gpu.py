@@ -65,6 +65,24 @@ def test_sgemm_register_direct_form(ta, tb, M, N, K, direct):
         query("cova_set_option", 15, 0)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(130, 992, 608), (1440, 992, 992), (992, 992, 1440), (45, 70, 257), (64, 64, 1028), (70, 33, 640)])
+def test_sgemm_two_tiles_ahead_is_bit_identical(ta, tb, M, N, K):
+    """cova_set_option(19, 1): operand tiles fetched two k-tiles ahead (two register sets): the same products in the same order."""
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C0, C1 = torch.full((M, N + 3), 7.0, device=DEV), torch.full((M, N + 3), 7.0, device=DEV)
+    call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C0, N + 3, bias, 0)
+    query("cova_set_option", 19, 1)
+    try:
+        call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C1, N + 3, bias, 0)
+    finally:
+        query("cova_set_option", 19, 0)
+    assert torch.equal(C0, C1)
+
+
 @pytest.mark.parametrize("f32", [1, 0])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3)])
@@ -347,6 +365,13 @@ def test_roipool_matches_oracle_bit_exact():
     scratch = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV)
     g_plain = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_plain, scratch)
+    query("cova_set_option", 20, 2)        # two boxes per round trip instead of four: the same adds in the same order
+    try:
+        g_two = torch.empty(B, H, W, C, device=DEV)
+        call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_two, scratch)
+    finally:
+        query("cova_set_option", 20, 4)
+    assert torch.equal(g_two, g_plain)
     npart = query("cova_roipool_bwd_bn_num_partials", n)
     part = torch.empty(npart, 2, C, device=DEV)
     gmask = torch.empty(B, H, W, C, device=DEV)

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(1024) void roipool_page_range_block_kernel(const fl
 // the arg-max, so this is the ReLU mask of the map's producer without reading the map.
 // gT / amT: the (masked) contributions and arg-max positions in [box][bin][channel] order (roipool_bwd_prep_kernel)
 // so that a wave's loads are 256 contiguous bytes.
-int g_roipool_bwd_nbx = 4;                        // cova_set_option(20, 2 | 4): boxes of a row segment visited per round trip
+int g_roipool_bwd_nbx = 2;                        // cova_set_option(20, 2 | 4): boxes of a row segment visited per round trip (4 measured
+                                                  // slower: 0.146 against 0.123 ms for entry pass + rows -- 72 loads of which most bins miss the row)
 template <bool P33, int NBX = 2>                  // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gT, const int32_t *__restrict__ amT, const float *__restrict__ rois,
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
             unsigned long long m = __ballot(hit);
             if (P33) {
                 // boxes touching this segment, ascending (fixed order); NBX at a time so that their geometry
-                // and arg-max / gradient operands are one round trip (2 until round 5; 4: 72 loads in flight)
+                // and arg-max / gradient operands are one round trip (NBX = 4, 72 loads in flight: measured slower)
                 while (m) {
                     int nb[NBX];
                     RoiGeo g[NBX];
@@ -1242,7 +1243,9 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
                        (hipStream_t)stream, F_, rois, n_rois, B, C, H, W, PH, PW, spatial_scale, out, ld_out, argmax, ZM_, LZ_)
     {
         const LazyFeat none{nullptr, nullptr, nullptr};
-        switch (g_roipool_variant) {
+        // (wider maps: the channel-block loop multiplies the trips, the launch is bandwidth bound and loses occupancy with eight
+        // loads per lane -- configs[2]: 1.51 ms with variant 0, 1.59 with 3; the default applies to 64-channel maps only)
+        switch (g_roipool_variant == 3 && C > 64 ? 0 : g_roipool_variant) {
         case 1: COVA_ROIPOOL_FWD(false, 8, false, feat, nullptr, none); break;
         case 2: COVA_ROIPOOL_FWD(false, 4, true, feat, nullptr, none); break;
         case 3: COVA_ROIPOOL_FWD(false, 8, true, feat, nullptr, none); break;
@@ -1264,7 +1267,9 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
     if (n_rois == 0) return COVA_OK;
     {
         const LazyFeat lzf{x, scale, shift};
-        switch (g_roipool_variant) {
+        // (wider maps: the channel-block loop multiplies the trips, the launch is bandwidth bound and loses occupancy with eight
+        // loads per lane -- configs[2]: 1.51 ms with variant 0, 1.59 with 3; the default applies to 64-channel maps only)
+        switch (g_roipool_variant == 3 && C > 64 ? 0 : g_roipool_variant) {
         case 1: COVA_ROIPOOL_FWD(true, 8, false, z, zmax, lzf); break;
         case 2: COVA_ROIPOOL_FWD(true, 4, true, z, zmax, lzf); break;
         case 3: COVA_ROIPOOL_FWD(true, 8, true, z, zmax, lzf); break;

@@ -365,12 +365,12 @@ def test_roipool_matches_oracle_bit_exact():
     scratch = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV)
     g_plain = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_plain, scratch)
-    query("cova_set_option", 20, 2)        # two boxes per round trip instead of four: the same adds in the same order
+    query("cova_set_option", 20, 4)        # four boxes per round trip instead of two: the same adds in the same order
     try:
         g_two = torch.empty(B, H, W, C, device=DEV)
         call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_two, scratch)
     finally:
-        query("cova_set_option", 20, 4)
+        query("cova_set_option", 20, 2)
     assert torch.equal(g_two, g_plain)
     npart = query("cova_roipool_bwd_bn_num_partials", n)
     part = torch.empty(npart, 2, C, device=DEV)

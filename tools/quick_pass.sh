@@ -1,9 +1,17 @@
 #!/bin/bash
-# Quick GPU pass: GPU tests, timing tools, A/B of options inside the step.
+# Quick GPU pass: A/B of two library builds on one box (kernel trace of the bench step with each), then the GPU tests.
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/${1:-quick}
 mkdir -p $o
+root=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for tag in prev new prev2 new2; do
+  if [ "${tag:0:4}" = "prev" ]; then export COVA_HIP_LIB=$root/cova-web-object-detection_amd/lib/libcova_hip_prev.so; else unset COVA_HIP_LIB; fi
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -- python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --sustained-seconds 0 > $root/$o/${tag}_kt.log 2>&1
+  db=$(find /tmp/kt_$tag -name "*.db" | head -1)
+  [ -n "$db" ] && python $root/tools/rocpd_step.py $db 2 --order > $root/$o/${tag}_step_breakdown.txt
+  head -1 $root/$o/${tag}_step_breakdown.txt
+done
+unset COVA_HIP_LIB
+cd $root
 if [ "$2" != "notests" ]; then timeout 900 python -m pytest tests -m gpu -x -q > $o/gpu_tests.log 2>&1; grep -E "passed|failed" $o/gpu_tests.log | tail -2; fi
-timeout 300 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $o/gemm_bench.txt; cut -c1-50,140-260 $o/gemm_bench.txt
-timeout 300 python tools/ab_step.py 19 3 2>&1 | grep round > $o/ab_step_sgemm_pf2.txt; cut -c1-40,300-520 $o/ab_step_sgemm_pf2.txt
-timeout 300 python tools/ab_step.py 20 3 2 4 2>&1 | grep round > $o/ab_step_roipool_bwd.txt; cut -c1-40,300-520 $o/ab_step_roipool_bwd.txt

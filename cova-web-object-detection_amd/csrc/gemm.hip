@@ -85,7 +85,9 @@ __device__ __forceinline__ void stash_tile(float (*S)[LDT], int tid, const float
 // output tile halve the serial length and give every SIMD a second wave to switch to.
 // PF2: the operand tiles are fetched TWO k-tiles ahead (two register sets, the loop body twice per trip): a tile's loads
 // have two MFMA phases to land instead of one (cova_set_option(19, 1))
-template <bool TA, bool TB, int KS, bool PF2 = false>
+// MODE 2 (cova_set_option(19, 2)): TWO LDS buffers per k-group -- the next tile is stashed into the other buffer in the middle of
+// the current tile's MFMAs and ONE barrier per k-tile is left (the single-buffer loop: barrier, stash, barrier, MFMAs)
+template <bool TA, bool TB, int KS, int MODE = 0>
 __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Bm, int ldb,
                                                          float *__restrict__ C, int ldc,
@@ -93,11 +95,13 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
                                                          int K, int accumulate, int vecA, int vecB,
                                                          const uint8_t *__restrict__ emask, float einv)
 {
-    __shared__ __attribute__((aligned(16))) float As_[KS][BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs_[KS][BK][LDT];
+    constexpr bool PF2 = MODE == 1, DB = MODE == 2;
+    constexpr int NBUF = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float As_[KS * NBUF][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs_[KS * NBUF][BK][LDT];
     const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;       // k-group of this wave
-    float (*As)[LDT] = As_[grp];
-    float (*Bs)[LDT] = Bs_[grp];
+    float (*As)[LDT] = As_[grp * NBUF];
+    float (*Bs)[LDT] = Bs_[grp * NBUF];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -113,7 +117,35 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
     float va[EPT], vb[EPT];
     fetch_tile<!TA>(A, lda, m0, M, grp * BK, K, tid, vecA != 0, va);
     fetch_tile<TB>(Bm, ldb, n0, N, grp * BK, K, tid, vecB != 0, vb);
-    if (PF2) {
+    if (DB) {
+        // (every condition below is the same for both k-groups: k0 - grp * BK does not depend on the group)
+        stash_tile<!TA>(As_[grp * NBUF], tid, va);
+        stash_tile<TB>(Bs_[grp * NBUF], tid, vb);
+        __syncthreads();
+        if (KSTEP < K) {
+            fetch_tile<!TA>(A, lda, m0, M, grp * BK + KSTEP, K, tid, vecA != 0, va);
+            fetch_tile<TB>(Bm, ldb, n0, N, grp * BK + KSTEP, K, tid, vecB != 0, vb);
+        }
+        int cur = 0;
+        for (int k0 = grp * BK; k0 - grp * BK < K; k0 += KSTEP, cur ^= 1) {
+            float (*Ac)[LDT] = As_[grp * NBUF + cur];
+            float (*Bc)[LDT] = Bs_[grp * NBUF + cur];
+            const bool more = k0 + KSTEP - grp * BK < K;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) acc = mfma32(Ac[2 * kk + kh2][wm * 32 + li], Bc[2 * kk + kh2][wn * 32 + li], acc);
+            if (more) {                         // the other buffer was last read before the barrier that ended the previous tile
+                stash_tile<!TA>(As_[grp * NBUF + (cur ^ 1)], tid, va);
+                stash_tile<TB>(Bs_[grp * NBUF + (cur ^ 1)], tid, vb);
+                if (k0 + 2 * KSTEP - grp * BK < K) {
+                    fetch_tile<!TA>(A, lda, m0, M, k0 + 2 * KSTEP, K, tid, vecA != 0, va);
+                    fetch_tile<TB>(Bm, ldb, n0, N, k0 + 2 * KSTEP, K, tid, vecB != 0, vb);
+                }
+            }
+#pragma unroll
+            for (int kk = BK / 4; kk < BK / 2; ++kk) acc = mfma32(Ac[2 * kk + kh2][wm * 32 + li], Bc[2 * kk + kh2][wn * 32 + li], acc);
+            __syncthreads();                    // this tile fully consumed, the next one fully stashed
+        }
+    } else if (PF2) {
         float va1[EPT], vb1[EPT];
         fetch_tile<!TA>(A, lda, m0, M, grp * BK + KSTEP, K, tid, vecA != 0, va1);      // (past K: zeros, no loads)
         fetch_tile<TB>(Bm, ldb, n0, N, grp * BK + KSTEP, K, tid, vecB != 0, vb1);
@@ -502,7 +534,7 @@ inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && 
 
 int cova_internal_set_sgemm_f32(int v) { g_sgemm_f32 = v != 0; return COVA_OK; }
 int cova_internal_set_sgemm_direct(int v) { g_sgemm_direct = v; return COVA_OK; }
-int cova_internal_set_sgemm_pf2(int v) { g_sgemm_pf2 = v != 0; return COVA_OK; }
+int cova_internal_set_sgemm_pf2(int v) { g_sgemm_pf2 = v; return COVA_OK; }
 
 static int sgemm_launch(int transA, int transB, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias,
@@ -539,7 +571,8 @@ static int sgemm_launch(int transA, int transB, int M, int N, int K, const float
         if (!g_sgemm_f32 && emask == nullptr) {                                                                             \
             if (split) hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb); \
             else hipLaunchKernelGGL((sgemm_bf_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb);      \
-        } else if (split && g_sgemm_pf2) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2, true>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
+        } else if (split && g_sgemm_pf2 == 2) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
+        else if (split && g_sgemm_pf2 == 1) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2, 1>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
         else if (split) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 2>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
         else hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, va, vb, emask, einv); \
     } while (0)

@@ -71,7 +71,8 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
  * 16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0): A/B,
  * 17 = cova_bn_act_fwd_bits: elements of a thread in flight per trip (1, 2, 4): A/B,
  * 18 = cova_roipool_fwd(_bn): 0 = 4 loads per lane and map in flight, 1 = 8, 2 = 4 on XCD-contiguous work blocks, 3 = both (default): A/B,
- * 19 = cova_sgemm (LDS-tiled kernel, two k-groups): operand tiles fetched two k-tiles ahead (1) or one (0, default): A/B,
+ * 19 = cova_sgemm (LDS-tiled kernel, two k-groups): 0 = one LDS buffer, tiles one ahead; 1 = tiles two ahead; 2 = two LDS buffers per
+ *      k-group, one barrier per k-tile: A/B,
  * 20 = cova_roipool_bwd*: boxes of a row segment visited per round trip, 2 (default) or 4 (measured slower): A/B.
  * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);

@@ -75,12 +75,14 @@ def test_sgemm_two_tiles_ahead_is_bit_identical(ta, tb, M, N, K):
     bias = torch.randn(N, generator=g).to(DEV)
     C0, C1 = torch.full((M, N + 3), 7.0, device=DEV), torch.full((M, N + 3), 7.0, device=DEV)
     call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C0, N + 3, bias, 0)
-    query("cova_set_option", 19, 1)
-    try:
-        call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C1, N + 3, bias, 0)
-    finally:
-        query("cova_set_option", 19, 0)
-    assert torch.equal(C0, C1)
+    for mode in (1, 2):                # 2: two LDS buffers per k-group, one barrier per k-tile
+        query("cova_set_option", 19, mode)
+        try:
+            C1.fill_(7.0)
+            call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C1, N + 3, bias, 0)
+        finally:
+            query("cova_set_option", 19, 0)
+        assert torch.equal(C0, C1), mode
 
 
 @pytest.mark.parametrize("f32", [1, 0])

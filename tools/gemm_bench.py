@@ -47,6 +47,8 @@ for tA, tB, M, Nn, K, what in shapes:
     _lib.query("cova_set_option", 15, 0)
     _lib.query("cova_set_option", 19, 1)           # operand tiles two k-tiles ahead
     tp = timeit(lambda: call("cova_sgemm", tA, tB, M, Nn, K, A, lda, B, ldb, C, Nn, None, 0)) * 1e3
+    _lib.query("cova_set_option", 19, 2)           # two LDS buffers per k-group, one barrier per k-tile
+    tdb = timeit(lambda: call("cova_sgemm", tA, tB, M, Nn, K, A, lda, B, ldb, C, Nn, None, 0)) * 1e3
     _lib.query("cova_set_option", 19, 0)
-    print("%-32s M%5d N%5d K%5d  %6.1f us  %5.1f TF/s  (torch/hipBLASLt %6.1f us)  rel err %.1e | direct %5.1f / %5.1f / %5.1f us  rel err %.1e | two tiles ahead %5.1f us"
-          % (what, M, Nn, K, t * 1e3, 2 * M * Nn * K / t / 1e9, t2 * 1e3, err, td[0], td[1], td[2], errd, tp))
+    print("%-32s M%5d N%5d K%5d  %6.1f us  %5.1f TF/s  (torch/hipBLASLt %6.1f us)  rel err %.1e | direct %5.1f / %5.1f / %5.1f us  rel err %.1e | two tiles ahead %5.1f us | two LDS buffers %5.1f us"
+          % (what, M, Nn, K, t * 1e3, 2 * M * Nn * K / t / 1e9, t2 * 1e3, err, td[0], td[1], td[2], errd, tp, tdb))

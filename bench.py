@@ -416,18 +416,23 @@ def run(args, guard, rank, local_rank, world):
              "cova_bn_act2_fwd", "cova_roipool_fwd_bn", "cova_roipool_bwd_bn", "cova_roipool_bwd_bn_tail", "cova_bn1d_fwd",
              "cova_bn1d_bwd", "cova_sgemm", "cova_gat_fwd", "cova_gat_bwd"]
     timed = [n for n in timed if n in _lib.lib().protos]
-    # Inside the timed steps only the DOMINANT family's launches are bracketed by HIP events (8 per step: the roofline's
+    # Inside the timed steps only the DOMINANT family's launches are bracketed by HIP events (8 per such step: the roofline's
     # live measurement); the other kernels of `other_kernels` are timed in a separate short leg behind it -- bracketing all
     # ~45 launches of a step cost the headline 2 % (round 4's line against its own `sustained` leg)
     dominant = [n for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv3x3_wino", "cova_conv3x3_wino_pro")
                 if n in timed]
-    _lib.PROFILE = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else dominant)}
+    # ... and only in every EVENT_EVERY-th timed step (steps 0, 4, 8, ...): an event pair around a launch is two marker packets in
+    # the stream, ~20 us of lost back-to-back dispatch each pair -- with all 8 x 20 launches bracketed the headline of round 5's
+    # last pass read 9.25 ms beside 8.93 ms of the same kernels in the event-free `ab.default` leg
+    EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 4
+    prof = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else dominant)}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        _lib.PROFILE = prof if i % EVENT_EVERY == 0 else None
         loss, _ = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    prof, _lib.PROFILE = _lib.PROFILE, None
+    _lib.PROFILE = None
     if not os.environ.get("COVA_PROFILE_ALL"):
         _lib.PROFILE = {name: [] for name in timed if name not in dominant}
         for _ in range(min(args.steps, 5)):
@@ -611,9 +616,10 @@ def run(args, guard, rank, local_rank, world):
                         algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                         traffic=traffic, traffic_unit="B/launch", traffic_source=src, algorithmic_bytes=alg_bytes,
                         algorithmic_bytes_plain_launch=2 * map_bytes,
-                        profiling="HIP events on the launching stream around this family's launches INSIDE the timed steps (8 per step); "
-                                  "the kernels of `other_kernels` are timed in %d separate steps behind them; `sustained` and the `ab` "
-                                  "legs run without events" % min(args.steps, 5))
+                        profiling="HIP events on the launching stream around this family's launches INSIDE the timed steps, in every "
+                                  "4th of them (8 launches per such step: steps 0, 4, 8, ...; an event pair costs ~20 us of back-to-back "
+                                  "dispatch); the kernels of `other_kernels` are timed in %d separate steps behind them; `sustained` and "
+                                  "the `ab` legs run without events" % min(args.steps, 5))
         step_alg = fm["total"] * pages                                   # per rank
         # executed multiply-adds: every 3x3 convolution at the Winograd share of the kernel that ran
         _, wg4_n = mean_ms(["cova_conv3x3_wgrad4_partial"])

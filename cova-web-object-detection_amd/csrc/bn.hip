@@ -79,9 +79,20 @@ __device__ __forceinline__ void combine_partials(const float *__restrict__ parti
 {
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int p = slice; p < nparts; p += 16) {
-            a += (double)partial[((size_t)p * 2 + 0) * C + c];
-            b += (double)partial[((size_t)p * 2 + 1) * C + c];
+        for (int p0 = slice; p0 < nparts; p0 += 16 * 8) {        // eight rows in flight, added in the same order (see bn_tail.h)
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + 16 * u < nparts ? p0 + 16 * u : p0;
+                va[u] = partial[((size_t)p * 2 + 0) * C + c];
+                vb[u] = partial[((size_t)p * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + 16 * u < nparts) {
+                    a += (double)va[u];
+                    b += (double)vb[u];
+                }
         }
     s_a[slice * 64 + (threadIdx.x & 63)] = a;
     s_b[slice * 64 + (threadIdx.x & 63)] = b;

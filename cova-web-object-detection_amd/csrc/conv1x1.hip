@@ -731,7 +731,14 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_reduce_kernel(const float 
     const int i = blockIdx.x * 64 + tx;
     double s = 0.0;
     if (i < n)
-        for (int q = slice; q < nparts; q += 16) s += (double)ws[(size_t)q * n + i];
+        for (int q0 = slice; q0 < nparts; q0 += 16 * 8) {        // eight partial rows in flight, added in the same order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(q0 + 16 * u < nparts ? q0 + 16 * u : q0) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + 16 * u < nparts) s += (double)v[u];
+        }
     s_acc[slice][tx] = s;
     __syncthreads();
     if (slice == 0 && i < n) {

@@ -217,7 +217,14 @@ __global__ __launch_bounds__(1024) void vprod_reduce_kernel(const float *__restr
         else if (i < LIN_S) { base = ws + (size_t)nb * (CO * CI); n = CI * CI; nparts = 4 * nb; e = i - LIN_G; }
         else if (i < LIN_SU) { base = ws + (size_t)nb * (CO * CI) + (size_t)nb * 4 * (CI * CI); n = CI; nparts = 4 * nb; e = i - LIN_S; }
         else { base = ws + (size_t)nb * (CO * CI) + (size_t)nb * 4 * (CI * CI) + (size_t)nb * 4 * CI; n = CO; nparts = nb; e = i - LIN_SU; }
-        for (int q = slice; q < nparts; q += 16) s += (double)base[(size_t)q * n + e];
+        for (int q0 = slice; q0 < nparts; q0 += 16 * 8) {        // eight partial rows in flight, added in the same order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(q0 + 16 * u < nparts ? q0 + 16 * u : q0) * n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + 16 * u < nparts) s += (double)v[u];
+        }
     }
     s_acc[slice][tx] = s;
     __syncthreads();

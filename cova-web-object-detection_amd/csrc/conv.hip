@@ -376,11 +376,17 @@ __device__ __forceinline__ void c1b_static_for(F &&f)
     c1b_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// XCD-contiguous tile walk (cova_set_option(21, 1)): position w = blockIdx.x + k * gridDim.x of the persistent walk -> tile.
+// Workgroups go to the 8 XCDs round-robin, so (with gridDim.x and ntiles multiples of 8) block b belongs to XCD b & 7 and the
+// blocks of one XCD walk ONE contiguous eighth of the tile list: vertically adjacent tiles -- which share 5 of their 21 input
+// rows -- meet in that XCD's L2 a few iterations apart instead of being fetched from HBM by two XCDs.
+__device__ __forceinline__ int xcd_walk_tile(int w, int ntiles, int xw) { return xw ? (w & 7) * (ntiles >> 3) + (w >> 3) : w; }
+
 template <bool STATS>
 __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
     float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
-    int w_oihw, const BnTail tail)
+    int w_oihw, int xw, const BnTail tail)
 {
     using namespace c1b;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF + 4 * WB_VEC + 8 * 128];
@@ -453,7 +459,8 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         for (int it = 0; it < NPRE; ++it) refill_slot(it, dst);
     };
     if (tile < ntiles) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int pt = xcd_walk_tile(tile, ntiles, xw);
+        const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, b = pt / (tiles_x * tiles_y);
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) issue_slot(it, img + (size_t)b * 3 * H * W, ty, tx);
     }
@@ -523,12 +530,13 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
 #endif
     for (; tile < ntiles; tile += gridDim.x) {
         C1B_STAMP(0);
-        const int tx = tile % tiles_x;
-        const int ty = (tile / tiles_x) % tiles_y;
-        const int b = tile / (tiles_x * tiles_y);
+        const int pt = xcd_walk_tile(tile, ntiles, xw);
+        const int tx = pt % tiles_x;
+        const int ty = (pt / tiles_x) % tiles_y;
+        const int b = pt / (tiles_x * tiles_y);
         const int y0 = ty * TH, x0 = tx * TW;
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const int next = has_next ? tile + (int)gridDim.x : tile;       // (last tile: re-reads its own patch, unused)
+        const int next = xcd_walk_tile(has_next ? tile + (int)gridDim.x : tile, ntiles, xw);   // (last tile: re-reads its own patch, unused)
         const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
         const float *nimg = img + (size_t)(next / (tiles_x * tiles_y)) * 3 * H * W;
         const uint32_t *a_org = s_pp + cur * BUF + (4 * q) * SEGW + li;  // output row 2q (+ 2*SEGW: row 2q+1), dwords li..li+3
@@ -1414,7 +1422,7 @@ constexpr int NPRE_P = (PATCH_ITEMS + 255) / 256;                // 5 slots per 
 template <bool POOL>
 __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
     const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool, const int xw)
 {
     using namespace wg1r;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * D_DW + 2 * P_DW];
@@ -1425,7 +1433,7 @@ __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
     struct TileC { int b, y0, x0; };
     auto coords = [&](int t) {
         TileC c;
-        const int tt = t < ntiles ? t : ntiles - 1;                  // (past the end: the last tile again, unused)
+        const int tt = xcd_walk_tile(t < ntiles ? t : ntiles - 1, ntiles, xw);    // (past the end: the last tile again, unused)
         const int r_ = tt / tiles_x;
         c.x0 = (tt - r_ * tiles_x) * TW;
         c.b = r_ / tiles_y;
@@ -1779,6 +1787,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
+int g_conv1_xcd_walk = 0;    // 1: conv1 forward / weight gradient (bf16 split kernels) walk XCD-contiguous eighths of the tile list (xcd_walk_tile)
 int g_conv1_w4 = 0;          // 1: conv1 forward (bf16 split) with one wave per SIMD (conv1_fwd_w4.h: measured slower, A/B); 0: the 8-wave kernel
 int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) instead of the bf16-split one (A/B, tests)
 int g_conv1_wgrad_phases = 0; // 1: conv1 weight gradient on the phase-structured bf16 kernel instead of the role-split one (A/B)
@@ -1826,6 +1835,7 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 18) return cova_internal_set_roipool_variant(value);
     if (key == 19) return cova_internal_set_sgemm_pf2(value);
     if (key == 20) return cova_internal_set_roipool_bwd_nbx(value);
+    if (key == 21) { g_conv1_xcd_walk = value != 0; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1887,6 +1897,7 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
         const int tiles_x = cdiv(W1, c1b::TW), tiles_y = cdiv(H1, c1b::TH);
         const int ntiles = B * tiles_x * tiles_y;
         const dim3 pgrid(persistent_grid(ntiles, 1)), block(c1b::THREADS);
+        const int xw = g_conv1_xcd_walk && ntiles % 8 == 0 && pgrid.x % 8 == 0;
         if (g_conv1_w4) {
             if (stat_part)
                 hipLaunchKernelGGL(conv1_7x7_bf3w_kernel<true>, pgrid, dim3(c1w::THREADS), 0, (hipStream_t)stream, img, w_k, out,
@@ -1899,10 +1910,10 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
         }
         if (stat_part)
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out, stat_part,
-                               H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+                               H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, xw, t);
         else
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out,
-                               stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
+                               stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, xw, t);
         COVA_LAUNCH_CHECK();
         return COVA_OK;
     }
@@ -1963,7 +1974,8 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
         const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
         const int rgrid = persistent_grid(B * rtx * rty);
         hipLaunchKernelGGL(conv1_wgrad_rs_kernel<true>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, y1,
-                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{dp, idx, abc, H2, W2});
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{dp, idx, abc, H2, W2},
+                           (int)(g_conv1_xcd_walk && (B * rtx * rty) % 8 == 0 && rgrid % 8 == 0));
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
                            rgrid * 2, dw);
@@ -1998,7 +2010,8 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
         const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
         const int rgrid = persistent_grid(B * rtx * rty);
         hipLaunchKernelGGL(conv1_wgrad_rs_kernel<false>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, dy,
-                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{nullptr, nullptr, nullptr, 0, 0},
+                           (int)(g_conv1_xcd_walk && (B * rtx * rty) % 8 == 0 && rgrid % 8 == 0));
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
                            rgrid * 2, dw);

@@ -74,6 +74,8 @@ int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
  * 19 = cova_sgemm (LDS-tiled kernel, two k-groups): 0 = one LDS buffer, tiles one ahead; 1 = tiles two ahead; 2 = two LDS buffers per
  *      k-group, one barrier per k-tile: A/B,
  * 20 = cova_roipool_bwd*: boxes of a row segment visited per round trip, 2 (default) or 4 (measured slower): A/B.
+ * 21 = cova_conv1_fwd* / cova_conv1_wgrad* (bf16-split kernels): 1 = the persistent blocks walk XCD-contiguous eighths of the
+ *      tile list (same tiles, same arithmetic per tile; measured: no gain), 0 (default) = consecutive tiles to consecutive blocks.
  * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
 int cova_set_option(int key, int value);
 

@@ -525,6 +525,41 @@ def test_conv1_variants_multi_tile():
     query("cova_set_option", 2, 0)
 
 
+def test_conv1_xcd_contiguous_tile_walk():
+    """cova_set_option(21, 1): the persistent blocks of conv1 forward / weight gradient walk XCD-contiguous eighths of the tile
+    list.  A tile's arithmetic does not change: the forward map is bit-identical; statistics partials and the weight gradient
+    are the same sums in another association."""
+    B, H, W = 4, 256, 512                     # forward 4 x 16 x 8 = 512 tiles, weight gradient 4 x 32 x 16 = 2048: multiples of 8
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, H, W, generator=g)
+    wr = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x, wr, stride=2, padding=3)
+    H1, W1 = ref.shape[2], ref.shape[3]
+    dy = torch.randn(B, 64, H1, W1, generator=g)
+    (ref * dy).sum().backward()
+    wk = torch.empty(154, 64, device=DEV)
+    call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
+    nt = query("cova_conv1_num_partials", B, H, W)
+    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
+    outs, dws = [], []
+    try:
+        for walk in (0, 1):
+            query("cova_set_option", 21, walk)
+            out, part = torch.full((B, H1, W1, 64), float("nan"), device=DEV), torch.zeros(nt, 2, 64, device=DEV)
+            call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
+            close(nchw(out), ref, 1e-4, "conv1 fwd walk %d" % walk)
+            close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "conv1 stat sum walk %d" % walk)
+            close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv1 sumsq walk %d" % walk)
+            dw = torch.zeros(64, 3, 7, 7, device=DEV)
+            call("cova_conv1_wgrad", x.to(DEV), nhwc(dy), dw, ws, B, H, W)
+            close(dw, wr.grad, 2e-4, "conv1 wgrad walk %d" % walk)
+            outs.append(out.clone()); dws.append(dw.clone())
+    finally:
+        query("cova_set_option", 21, 0)
+    assert torch.equal(outs[0], outs[1])
+    close(dws[1], dws[0], 1e-5, "conv1 wgrad, the two walks")
+
+
 def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     """Fused data-gradient epilogue (ReLU mask + BatchNorm-backward sums) == plain data gradient followed by
     cova_bn_bwd_reduce, on a multi-tile problem, for both Winograd kernel families."""

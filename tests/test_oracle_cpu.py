@@ -354,3 +354,20 @@ def test_roialign_against_independent_dense_formulation(sr, aligned):
     for n in range(len(rois)):
         gref[page[n]] += contrib[n]
     assert np.abs(f.grad.numpy() - gref).max() <= 2e-5 * np.abs(gref).max()
+
+
+def test_maxpool_commutes_with_the_monotone_bn_relu_apply():
+    """DESIGN 12.7 (next lever): relu(fma(y, scale_c, shift_c)) is monotone in y with the direction of sign(scale_c), so the
+    stem's MaxPool2d(3, 2, 1) of it (models.py:49-51, torchvision's conv1 -> bn1 -> relu -> maxpool) equals the same apply on the
+    3x3 / stride-2 max (scale_c >= 0) or min (scale_c < 0) of y -- bit for bit, ties included."""
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(2, 64, 37, 50, generator=g) * 3
+    y[0, :, 4:9, 4:9] = 0.25                                   # a flat patch: ties inside the windows
+    gamma = torch.randn(64, generator=g)
+    gamma[3] = 0.0
+    invstd, mean, beta = torch.rand(64, generator=g) + 0.1, torch.randn(64, generator=g), torch.randn(64, generator=g)
+    scale = (gamma * invstd).view(1, -1, 1, 1)
+    shift = (beta - mean * gamma * invstd).view(1, -1, 1, 1)
+    ref = F.max_pool2d(torch.relu(torch.addcmul(shift, y, scale)), 3, 2, 1)
+    picked = torch.where(scale >= 0, F.max_pool2d(y, 3, 2, 1), -F.max_pool2d(-y, 3, 2, 1))
+    assert torch.equal(ref, torch.relu(torch.addcmul(shift, picked, scale)))

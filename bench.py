@@ -53,8 +53,8 @@ PEAK_HBM_TBS = 8.0
 SPLIT_PRODUCTS = 6                                 # bf16 MFMA products per f32 multiply-add of the split kernels
 WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3): the weight gradients
 WINO4_RATIO = 4.0                                  # ... / Winograd F(4x4,3x3): forward and data-gradient launches
-TRAFFIC_FILES = [os.path.join("profiles", "r05_hbm_traffic.json"), os.path.join("profiles", "r04_hbm_traffic.json"),
-                 os.path.join("profiles", "r03_hbm_traffic.json")]
+TRAFFIC_FILES = [os.path.join("profiles", "r06_hbm_traffic.json"), os.path.join("profiles", "r05_hbm_traffic.json"),
+                 os.path.join("profiles", "r04_hbm_traffic.json"), os.path.join("profiles", "r03_hbm_traffic.json")]
 
 WORKLOADS = {
     2: dict(name="configs[1]", H=1280, W=1280, pages=16, boxes=90, cs=12, backbone="resnet18", n_heads=1,
@@ -128,7 +128,8 @@ def read_traffic(kernel_key, pages):
     WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/hbm_traffic.py writes the file).  Since round 5
     the file holds the launches of ONE train step keyed by kernel variant (`step_kernels`) and their per-family means
     (`step_families`): the number is the mean over the variant mix the step launches, not over every launch of the
-    profiling run (which also carried the eval and drop-in legs' variants)."""
+    profiling run (which also carried the eval and drop-in legs' variants).
+    -> (family bytes per launch, source, step bytes, {kernel variant name: bytes per launch})"""
     for rel in TRAFFIC_FILES:          # the newest PMC pass that has the kernel (an older round's file is a stale number:
         path = os.path.join(ROOT, rel)  # the source is named in the line)
         if not os.path.exists(path):
@@ -137,11 +138,38 @@ def read_traffic(kernel_key, pages):
             d = json.load(open(path))
             e = d.get("step_families", {}).get(kernel_key) or d["kernels"][kernel_key]
             step = d.get("step_traffic_bytes")
-            return (e["traffic_bytes_per_launch"] * pages / d["pages"], rel + (":step_families" if "step_families" in d else ""),
-                    step * pages / d["pages"] if step else None)
+            scale = pages / d["pages"]
+            per_variant = {k: v["traffic_bytes_per_launch"] * scale for k, v in d.get("step_kernels", {}).items()}
+            return (e["traffic_bytes_per_launch"] * scale, rel + (":step_families" if "step_families" in d else ""),
+                    step * scale if step else None, per_variant)
         except Exception:
             continue
-    return None, None, None
+    return None, None, None, {}
+
+
+# Operands of the F(4x4,3x3) entry points by position (include/cova_hip.h); a profile record carries which were non-NULL
+W4_FULL_ARGS = ("in", "in2", "abc", "relu", "u", "addend", "act", "msc", "msh", "z", "mean", "invstd", "out", "part", "B", "H", "W")
+W4_TAIL_ARGS = W4_FULL_ARGS[:7] + ("act_bits",) + W4_FULL_ARGS[7:] + ("tail",)
+
+
+def w4_variant(name, present):
+    """The kernel variant a cova_conv3x3_wino4_full(_tail) call launches (the dispatch of csrc/conv_wino4.hip: launch_w4_pro) and
+    the 64-channel maps it must move: -> (template arguments "<STATS, PRO, ADD, BN>", PRO, maps read + written, role).
+    One map = B*H*W*64 floats.  Read: the input (two tensors under the two-tensor prologue), the residual-branch gradient
+    (ADD), z for the ReLU mask / xhat of the BatchNorm-backward sums (BN >= 1), the mask source (BN == 2: a full map, or 1/32
+    of one as bits); written: the output."""
+    d = dict(zip(W4_TAIL_ARGS if name.endswith("_tail") else W4_FULL_ARGS, present))
+    pro = 0 if not d["abc"] else (2 if d["in2"] else 1)
+    add = bool(d["addend"])
+    bn = 0 if not d["z"] else (1 if not (d["act"] or d.get("act_bits")) else 2)
+    stats = bool(d["part"]) or bn > 0
+    maps = 1 + (1 if pro == 2 else 0) + (1 if add else 0) + (1 if bn >= 1 else 0) + 1
+    if bn == 2:
+        maps += 1 if d["act"] else 1.0 / 32
+    role = ("data gradient + residual gradient" if add else "data gradient") if bn else \
+           ("forward, BatchNorm+ReLU on load" if pro else "forward")
+    targs = "<%s, %d, %s, %d>" % ("true" if stats else "false", pro, "true" if add else "false", bn)
+    return targs, pro, maps, role
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -421,11 +449,15 @@ def run(args, guard, rank, local_rank, world):
     # ~45 launches of a step cost the headline 2 % (round 4's line against its own `sustained` leg)
     dominant = [n for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv3x3_wino", "cova_conv3x3_wino_pro")
                 if n in timed]
-    # ... and only in every EVENT_EVERY-th timed step (steps 0, 4, 8, ...): an event pair around a launch is two marker packets in
+    # ... and only in every EVENT_EVERY-th timed step (steps 0, 5, 10, ...): an event pair around a launch is two marker packets in
     # the stream, ~20 us of lost back-to-back dispatch each pair -- with all 8 x 20 launches bracketed the headline of round 5's
-    # last pass read 9.25 ms beside 8.93 ms of the same kernels in the event-free `ab.default` leg
-    EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 4
-    prof = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else dominant)}
+    # last pass read 9.25 ms beside 8.93 ms of the same kernels in the event-free `ab.default` leg.  The same steps also bracket
+    # conv1 forward, conv1 weight gradient and the four 3x3 weight gradients (6 more pairs): the kernels whose time differs
+    # from box to box (round 5: conv1 forward 0.75 ms on the builder's boxes, 1.01 ms on the driver's), IN the step.
+    EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 5
+    in_step = dominant + [n for n in ("cova_conv1_fwd_tail", "cova_conv1_fwd", "cova_conv1_fwd_pool", "cova_conv1_wgrad_poolbwd",
+                                      "cova_conv3x3_wgrad4_partial") if n in timed]
+    prof = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else in_step)}
     t0 = time.perf_counter()
     for i in range(args.steps):
         _lib.PROFILE = prof if i % EVENT_EVERY == 0 else None
@@ -434,7 +466,7 @@ def run(args, guard, rank, local_rank, world):
     dt = time.perf_counter() - t0
     _lib.PROFILE = None
     if not os.environ.get("COVA_PROFILE_ALL"):
-        _lib.PROFILE = {name: [] for name in timed if name not in dominant}
+        _lib.PROFILE = {name: [] for name in timed if name not in in_step}
         for _ in range(min(args.steps, 5)):
             trainer.train_step(batch)
         barrier()
@@ -575,23 +607,53 @@ def run(args, guard, rank, local_rank, world):
         alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
         executed = alg / ratio                                            # f32 multiply-adds the Winograd form executes
         map_bytes = 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4)
-        # compulsory bytes of the launches as they run in the step: besides one input and one output map the fused
-        # variants read the residual-branch gradient and the mask / xhat operands of their epilogues --
-        # per train step 27 maps over 8 launches (ResNet-18) or 18 over 6 (ResNet-50 stem)
-        alg_bytes = int((27 / 8 if wl["backbone"] == "resnet18" else 18 / 6) * map_bytes)
+        # Compulsory bytes of the launches AS THEY RAN: every timed launch's variant and operand count follow from which
+        # arguments of its call were non-NULL (w4_variant: besides one input and one output map the fused variants read the
+        # residual-branch gradient and the mask / xhat operands of their epilogues).  ResNet-18 step: forward
+        # 4 x 2 maps, conv2 data gradient 2 x 3, conv1 data gradient 4 + 4 1/32 = 22 maps over 8 launches.
+        vrows, alg_bytes_total, conv_ms_total = {}, 0.0, 0.0
+        if use4:
+            for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail"):
+                for p in prof.get(n, []):
+                    targs, pro, maps, role = w4_variant(n, p[3])
+                    # (the two-tensor prologue runs the f32 main loop whatever the default is)
+                    kn = ("conv3x3_c64_wino4s_kernel" if split and pro != 2 else "conv3x3_c64_wino4_kernel") + targs
+                    e = vrows.setdefault(kn, {"variant": kn, "role": role, "launches": 0, "maps": round(maps, 4), "ms": 0.0})
+                    e["launches"] += 1
+                    e["ms"] += p[0].elapsed_time(p[1])
         roof = {"kernel": kname + " (forward + data-gradient launches of the step)", "launches_timed": conv_n}
         if conv_n:
-            traffic, src, step_traffic = read_traffic(kname, px_pages)
+            traffic, src, step_traffic, tv = read_traffic(kname, px_pages)
+            variants = []
+            for kn, e in sorted(vrows.items()):
+                vb = e["maps"] * map_bytes
+                ms = e["ms"] / e["launches"]
+                row = {"variant": kn, "role": e["role"], "launches": e["launches"], "maps": e["maps"],
+                       "algorithmic_bytes": int(vb), "avg_ms": round(ms, 4), "achieved_gb_per_s": round(vb / ms / 1e6, 1),
+                       "frac": round(vb / ms / 1e6 / (PEAK_HBM_TBS * 1e3), 4), "traffic": tv.get(kn)}
+                if tv.get(kn):
+                    row["traffic_over_algorithmic"] = round(tv[kn] / vb, 3)
+                variants.append(row)
+                alg_bytes_total += vb * e["launches"]
+                conv_ms_total += e["ms"]
+            if variants:
+                alg_bytes = int(alg_bytes_total / conv_n)                 # mean over the launches timed
+                if all(r["traffic"] for r in variants):                  # family traffic = the same launch mix as `achieved`
+                    traffic = sum(r["traffic"] * r["launches"] for r in variants) / conv_n
+                    src = src.replace(":step_families", ":step_kernels")
+            else:                                                          # F(2x2,3x3) launches (COVA_WINO4=0): input + output
+                alg_bytes = 2 * map_bytes
             f32_equiv = executed / conv_ms / 1e9                          # TFLOP/s of f32 multiply-adds executed
             if split:
                 # Six bf16-MFMA products per f32 multiply-add at 16x the f32-MFMA rate: the matrix floor of a launch is
-                # 6 * executed / 2.5 PFLOP/s = 0.07 ms against algorithmic_bytes / 8 TB/s = 0.18 ms -- in this
+                # 6 * executed / 2.5 PFLOP/s = 0.07 ms against algorithmic_bytes / 8 TB/s = 0.14 ms -- in this
                 # formulation the launch is bounded by HBM, and that is the roof it is priced against.
-                ach = alg_bytes / conv_ms / 1e6                           # GB/s
+                ach = alg_bytes / conv_ms / 1e6                           # GB/s  (= sum of bytes / sum of time over the launches)
                 roof.update(bound="hbm", algorithm="winograd F(4x4,3x3); transform-domain products on the bf16 matrix pipe, f32 "
                             "operands as three bf16 pieces, six products accumulated in f32 (v_mfma_f32_16x16x32_bf16)",
                             achieved=round(ach, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s", frac=round(ach / (PEAK_HBM_TBS * 1e3), 4),
-                            achieved_is="ALGORITHMIC bytes per launch (mean over the step's eight launches) / mean launch time",
+                            achieved_is="ALGORITHMIC bytes of the launches timed (per-variant operand table `variants`, derived from "
+                                        "each call's arguments) / their total time",
                             floors_ms={"hbm_algorithmic_bytes_at_8_TBps": round(alg_bytes / PEAK_HBM_TBS / 1e9, 4),
                                        "bf16_mfma_six_products_at_2.5_PFLOPs": round(SPLIT_PRODUCTS * executed / PEAK_BF16_MFMA_TFLOPS / 1e9, 4),
                                        "weight_stream_L2_to_registers_at_64_B_per_clk_CU": round(
@@ -608,18 +670,20 @@ def run(args, guard, rank, local_rank, world):
                             frac=round(f32_equiv / PEAK_F32_MFMA_TFLOPS, 4),
                             achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio)
             if traffic:
-                roof.update(hbm_achieved_tb_per_s=round(traffic / conv_ms / 1e9, 3), hbm_frac=round(traffic / conv_ms / 1e9 / PEAK_HBM_TBS, 4))
+                roof.update(hbm_achieved_tb_per_s=round(traffic / conv_ms / 1e9, 3), hbm_frac=round(traffic / conv_ms / 1e9 / PEAK_HBM_TBS, 4),
+                            traffic_over_algorithmic=round(traffic / alg_bytes, 3))
             if step_traffic:
                 roof.update(step_traffic_bytes=int(step_traffic))
             roof.update(avg_launch_ms=round(conv_ms, 4), executed_flop_per_launch=int(executed), algorithmic_flop_per_launch=int(alg),
                         algorithmic_achieved=round(alg / conv_ms / 1e9, 2),
                         algorithmic_frac_of_direct_conv_peak=round(alg / conv_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                         traffic=traffic, traffic_unit="B/launch", traffic_source=src, algorithmic_bytes=alg_bytes,
-                        algorithmic_bytes_plain_launch=2 * map_bytes,
-                        profiling="HIP events on the launching stream around this family's launches INSIDE the timed steps, in every "
-                                  "4th of them (8 launches per such step: steps 0, 4, 8, ...; an event pair costs ~20 us of back-to-back "
-                                  "dispatch); the kernels of `other_kernels` are timed in %d separate steps behind them; `sustained` and "
-                                  "the `ab` legs run without events" % min(args.steps, 5))
+                        algorithmic_bytes_plain_launch=2 * map_bytes, variants=variants,
+                        profiling="HIP events on the launching stream INSIDE the timed steps, in every %d-th of them (steps 0, %d, ...), "
+                                  "around this family's launches and around conv1 forward, conv1 weight gradient and the 3x3 weight "
+                                  "gradients (`other_kernels.*.in_step`): an event pair costs ~20 us of back-to-back dispatch; the "
+                                  "remaining kernels of `other_kernels` are timed in %d separate steps behind them; `sustained` and "
+                                  "the `ab` legs run without events" % (EVENT_EVERY, EVENT_EVERY, min(args.steps, 5)))
         step_alg = fm["total"] * pages                                   # per rank
         # executed multiply-adds: every 3x3 convolution at the Winograd share of the kernel that ran
         _, wg4_n = mean_ms(["cova_conv3x3_wgrad4_partial"])
@@ -663,7 +727,7 @@ def run(args, guard, rank, local_rank, world):
             on_bf16 = len(spec) > 5 and spec[5]
             ms, n = mean_ms(names, pred)
             if n:
-                o = {"avg_launch_ms": round(ms, 4), "launches_timed": n}
+                o = {"avg_launch_ms": round(ms, 4), "launches_timed": n, "in_step": any(x in in_step for x in names)}
                 if flop and on_bf16:       # six bf16 products per f32 multiply-add, against the pipe the kernel uses
                     o.update(f32_equivalent_tflops=round(flop / ms / 1e9, 1), executed_tflops_bf16_pipe=round(SPLIT_PRODUCTS * flop / ms / 1e9, 1),
                              frac_of_bf16_mfma_peak=round(SPLIT_PRODUCTS * flop / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 3))

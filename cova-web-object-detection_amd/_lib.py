@@ -99,7 +99,8 @@ def _arg(a):
 
 
 # Optional per-entry-point timing with HIP events on the launching stream (bench.py's roofline
-# leg): PROFILE = {entry point name: [(start_event, end_event, integer arguments of the call), ...]}
+# leg): PROFILE = {entry point name: [(start_event, end_event, integer arguments of the call, which arguments were
+# non-NULL -- one bool per positional argument: the kernel variant a launch took follows from it), ...]}
 PROFILE = None
 
 
@@ -142,7 +143,7 @@ def _launch(L, name, args, stream):
     rc = L.fn[name](*[_arg(a) for a in args], stream)
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, tuple(a for a in args if isinstance(a, int))))
+        prof.append((e0, e1, tuple(a for a in args if isinstance(a, int)), tuple(a is not None for a in args)))
     if rc != 0:
         raise CovaHipError("%s failed with status %d" % (name, rc))
 

@@ -66,8 +66,6 @@ class _Lib:
             self.cdll.cova_set_option(11, 0)
         if os.environ.get("COVA_WG4_PAIR_SYNC") in ("0", "1"):   # A/B: pacing of the weight gradient's block pairs
             self.cdll.cova_set_option(10, int(os.environ["COVA_WG4_PAIR_SYNC"]))
-        if os.environ.get("COVA_OPTION_21") in ("0", "1"):       # A/B: XCD-contiguous tile walk of the conv1 kernels
-            self.cdll.cova_set_option(21, int(os.environ["COVA_OPTION_21"]))
 
 
     def load_extra(self, header, lib_path):

@@ -376,17 +376,11 @@ __device__ __forceinline__ void c1b_static_for(F &&f)
     c1b_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// XCD-contiguous tile walk (cova_set_option(21, 1)): position w = blockIdx.x + k * gridDim.x of the persistent walk -> tile.
-// Workgroups go to the 8 XCDs round-robin, so (with gridDim.x and ntiles multiples of 8) block b belongs to XCD b & 7 and the
-// blocks of one XCD walk ONE contiguous eighth of the tile list: vertically adjacent tiles -- which share 5 of their 21 input
-// rows -- meet in that XCD's L2 a few iterations apart instead of being fetched from HBM by two XCDs.
-__device__ __forceinline__ int xcd_walk_tile(int w, int ntiles, int xw) { return xw ? (w & 7) * (ntiles >> 3) + (w >> 3) : w; }
-
 template <bool STATS>
 __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     const float *__restrict__ img, const float *__restrict__ wk, float *__restrict__ out,
     float *__restrict__ stat_part, int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles,
-    int w_oihw, int xw, const BnTail tail)
+    int w_oihw, const BnTail tail)
 {
     using namespace c1b;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF + 4 * WB_VEC + 8 * 128];
@@ -459,7 +453,7 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
         for (int it = 0; it < NPRE; ++it) refill_slot(it, dst);
     };
     if (tile < ntiles) {
-        const int pt = xcd_walk_tile(tile, ntiles, xw);
+        const int pt = tile;
         const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, b = pt / (tiles_x * tiles_y);
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) issue_slot(it, img + (size_t)b * 3 * H * W, ty, tx);
@@ -530,13 +524,13 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
 #endif
     for (; tile < ntiles; tile += gridDim.x) {
         C1B_STAMP(0);
-        const int pt = xcd_walk_tile(tile, ntiles, xw);
+        const int pt = tile;
         const int tx = pt % tiles_x;
         const int ty = (pt / tiles_x) % tiles_y;
         const int b = pt / (tiles_x * tiles_y);
         const int y0 = ty * TH, x0 = tx * TW;
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const int next = xcd_walk_tile(has_next ? tile + (int)gridDim.x : tile, ntiles, xw);   // (last tile: re-reads its own patch, unused)
+        const int next = has_next ? tile + (int)gridDim.x : tile;                               // (last tile: re-reads its own patch, unused)
         const int ntx = next % tiles_x, nty = (next / tiles_x) % tiles_y;
         const float *nimg = img + (size_t)(next / (tiles_x * tiles_y)) * 3 * H * W;
         const uint32_t *a_org = s_pp + cur * BUF + (4 * q) * SEGW + li;  // output row 2q (+ 2*SEGW: row 2q+1), dwords li..li+3
@@ -688,8 +682,6 @@ __global__ __launch_bounds__(c1b::THREADS) void conv1_7x7_bf3_kernel(
     }
     if (STATS) bn_tail_run(tail, stat_part, (int)gridDim.x, reinterpret_cast<double *>(lds));
 }
-
-#include "conv1_fwd_w4.h"
 
 // ------------------------------------------------------------------------------------
 // weight layout transforms (tiny; run once per step because the weights change every step)
@@ -1023,361 +1015,8 @@ __global__ __launch_bounds__(wg1::THREADS) void conv1_wgrad_v2_kernel(
 //   * LDS: 96 KB of packed dy1 + 48 KB shared in time by the pooled-gradient windows (while dy1 is finished) and the
 //     patch planes (during the MFMAs): four barriers per tile.
 // ------------------------------------------------------------------------------------
-#ifndef WG1B_ABL
-#define WG1B_ABL 0             // tools: 1 no prefetch slots in the MFMA loop, 2 no operand reads in it (stale registers)
-#endif
-#ifndef WG1B_PRIO
-#define WG1B_PRIO 0            // tools: 1 static priority for waves 4-7 in the MFMA loop, 2 alternating per pair of units
-#endif
-
-namespace wg1b {
-constexpr int TH = 8, TW = 32, THREADS = 512;
-constexpr int DYP_DW = 128 * 3 * 64;             // [pair 4 x 32][piece][channel]: 24,576 dwords
-constexpr int PROW = 3 * 72;                     // dwords per (c, r) row of the patch planes: [piece][parity][36]
-constexpr int PPV_DW = 3 * 19 * PROW;            // 12,312 dwords
-constexpr int WIN_W = TW / 2 + 1, NWIN = (TH / 2 + 1) * WIN_W, WIN_ITEMS = NWIN * 16;   // 17, 85, 1360
-constexpr int PATCH_ITEMS = 3 * 19 * 69;         // 3933 (c, r, column) pairs of rows (r, r+2)
-constexpr int NPRE_P = (PATCH_ITEMS + THREADS - 1) / THREADS;     // 8
-constexpr int NSLOT = NPRE_P + 8 + 3;            // prefetch slots per tile: patch | 8 rows of the y1 / dy column | pool windows
-}  // namespace wg1b
-
-// -DC1B_TRACE: stamps of the eight waves of block 0, tiles 8..27: 0 end of the MFMA loop, 1 after its barrier, 2 windows written,
-// 3 dy1 finished, 4 after its barrier, 5 patch written (+ barrier) = start of the next MFMA loop
-#ifdef C1B_TRACE
-__device__ unsigned long long g_wg1b_trace[8 * 20 * 8];
-#define WG1B_STAMP(slot)                                                                                      \
-    do {                                                                                                      \
-        if (blockIdx.x == 0 && tr_it >= 0 && tr_it < 20 && lane == 0)                                         \
-            g_wg1b_trace[(wave * 20 + tr_it) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                    \
-    } while (0)
-#else
-#define WG1B_STAMP(slot) do { } while (0)
-#endif
-
-template <bool POOL>
-__global__ __launch_bounds__(wg1b::THREADS) void conv1_wgrad_bf3_kernel(
-    const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
-{
-    using namespace wg1b;
-    constexpr int NPOOL = POOL ? 3 : 0;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[DYP_DW + PPV_DW];
-    uint32_t *s_dyp = lds;
-    uint32_t *s_x = lds + DYP_DW;                                    // patch planes | pooled-gradient windows
-    float *s_dpw = reinterpret_cast<float *>(s_x);                   // POOL: [window][64]
-    uint32_t *s_ixw = s_x + NWIN * 64;                               // POOL: [window][16] arg-max codes x4
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kh2 = lane >> 5;
-    const int cob = wave & 1, q = wave >> 1;
-
-    int toff[5];
-#pragma unroll
-    for (int tb = 0; tb < 5; ++tb) {
-        const int k = tb * 32 + li;
-        const int kk = k < 147 ? k : 0;                              // (columns 147..159 of the result are never read)
-        toff[tb] = ((kk / 49) * 19 + 4 * q + (kk % 49) / 7) * PROW + ((kk % 7) & 1) * 36 + ((kk % 7) >> 1) + 4 * kh2;
-    }
-    const int a_base = ((q * 32 + 4 * kh2) * 3) * 64 + cob * 32 + li;
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    // ---- prefetch registers of the NEXT tile (all loads unconditional at clamped addresses, validity as bits)
-    float pre[2 * NPRE_P];
-    unsigned premask = 0u;
-    f32x4 pd[8];
-    unsigned pd_in = 0u;
-    f32x4 pdp[POOL ? 3 : 1];
-    float pixf[POOL ? 3 : 1];
-    unsigned pool_in = 0u;
-    const int qx = tid >> 4, c4 = tid & 15;
-    // this thread's column of the tile: every wave gets four columns of one parity (wave-uniform candidate windows below),
-    // waves 0-3 odd and 4-7 even ones: the two waves of a SIMD (w, w + 4) are one of each (odd columns gather from twice
-    // as many windows: with the parity in bit 0 of the wave index two SIMDs carried both heavy waves), and the heavy one
-    // is the older wave, which the SIMD's arbitration favours (the other way round the phase was 1,000 cycles longer)
-    const int cc = (((qx & 3) << 1) | (((qx >> 4) & 1) ^ 1)) + 8 * ((qx >> 2) & 3);
-    // tile -> (image, first output row, first output column): computed ONCE per tile (three scalar divisions; recomputed in
-    // each of the 27 prefetch slots they were ~2,000 scalar instructions per tile and wave in the MFMA loop's stream)
-    struct TileC { int b, y0, x0; };
-    auto coords = [&](int t) {
-        TileC c;
-        const int r_ = t / tiles_x;
-        c.x0 = (t - r_ * tiles_x) * TW;
-        c.b = r_ / tiles_y;
-        c.y0 = (r_ - c.b * tiles_y) * TH;
-        return c;
-    };
-    auto issue_slot = [&](int n, const TileC &tc) {
-        const int b = tc.b, y0 = tc.y0, x0 = tc.x0;
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));          // the slot's index math stays here
-        if (n < NPRE_P) {                     // rows (r, r+2) of patch column j, channel c
-            const int item = n * THREADS + t_;
-            const int itc = item < PATCH_ITEMS ? item : PATCH_ITEMS - 1;
-            const int seg = itc / 69, j = itc - seg * 69;
-            const int c = seg / 19, r = seg - c * 19;
-            const int gy = 2 * y0 - 3 + r, gx = 2 * x0 - 3 + j;
-            const bool okx = item < PATCH_ITEMS && gx >= 0 && gx < W;
-            const bool ok0 = okx && gy >= 0 && gy < H, ok1 = okx && gy + 2 >= 0 && gy + 2 < H;
-            const int cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-            const int cy0 = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cy1 = gy + 2 < 0 ? 0 : (gy + 2 >= H ? H - 1 : gy + 2);
-            const float *img_b = img + (size_t)b * 3 * H * W;
-            pre[2 * n] = img_b[(unsigned)((c * H + cy0) * W + cx)];
-            pre[2 * n + 1] = img_b[(unsigned)((c * H + cy1) * W + cx)];
-            premask = (premask & ~(3u << (2 * n))) | ((ok0 ? 1u : 0u) << (2 * n)) | ((ok1 ? 2u : 0u) << (2 * n));
-        } else if (n < NPRE_P + 8) {          // row it of this thread's column: 4 channels of dy (POOL: y1)
-            const int it = n - NPRE_P;
-            const int gy = y0 + it, gx = x0 + cc;
-            const bool in = gy < H1 && gx < W1;
-            const int cy = gy < H1 ? gy : H1 - 1, cx = gx < W1 ? gx : W1 - 1;
-            pd[it] = *reinterpret_cast<const f32x4 *>(dy + (size_t)b * H1 * W1 * 64 + (unsigned)(((cy * W1 + cx) << 6) + c4 * 4));
-            pd_in = (pd_in & ~(1u << it)) | ((in ? 1u : 0u) << it);
-        } else if (POOL) {                    // (window, channel group) item of the pooled gradient
-            const int k = n - NPRE_P - 8;
-            const int item = t_ + k * THREADS;
-            const int itc = item < WIN_ITEMS ? item : WIN_ITEMS - 1;
-            const int wr = itc / (WIN_W * 16), wc = (itc >> 4) % WIN_W;
-            const int ph = (y0 >> 1) + wr, pw = (x0 >> 1) + wc;
-            const bool in = item < WIN_ITEMS && ph < pool.H2 && pw < pool.W2;
-            const int cph = ph < pool.H2 ? ph : pool.H2 - 1, cpw = pw < pool.W2 ? pw : pool.W2 - 1;
-            const unsigned o = (unsigned)((cph * pool.W2 + cpw) * 64 + (itc & 15) * 4);
-            pdp[POOL ? k : 0] = *reinterpret_cast<const f32x4 *>(pool.dp + (size_t)b * pool.H2 * pool.W2 * 64 + o);
-            pixf[POOL ? k : 0] = *reinterpret_cast<const float *>(pool.idx + (size_t)b * pool.H2 * pool.W2 * 64 + o);
-            pool_in = (pool_in & ~(1u << k)) | ((in ? 1u : 0u) << k);
-        }
-    };
-    // this thread's 4 channels of A | B | C; fetched where used (kept out of the MFMA loop's registers)
-    auto coef = [&](int which) {
-        int o = which * 64 + (tid & 15) * 4;
-        asm volatile("" : "+v"(o));
-        return *reinterpret_cast<const float4 *>(pool.abc + o);
-    };
-    auto write_windows = [&]() {
-#pragma unroll
-        for (int k = 0; k < NPOOL; ++k) {
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int item = t_ + k * THREADS;                             // = window * 16 + channel group
-            if (item < WIN_ITEMS) {
-                const bool in = (pool_in >> k) & 1u;
-                f32x4 v = pdp[POOL ? k : 0];
-                if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};                    // (no gradient from windows outside the map)
-                *reinterpret_cast<f32x4 *>(s_dpw + item * 4) = v;
-                s_ixw[item] = __builtin_bit_cast(uint32_t, pixf[POOL ? k : 0]);
-            }
-        }
-    };
-    // dy1 of this thread's column (POOL:  A * route(dp) + B * y1 + C, as conv1_wgrad_v2_kernel finishes it in LDS), split
-    // and packed by row pairs (2b, 2b+1) into s_dyp.  With four columns of one parity per wave the set of pooling windows
-    // that can route into a pixel (1, 2 or 4: 3x3 windows, stride 2) is wave-uniform.
-    auto finish_dy = [&]() {
-        float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA, cC = cA;
-        if (POOL) { cA = coef(0); cB = coef(1); cC = coef(2); }
-        const bool codd = (wave >> 2) == 0;                                 // == cc & 1
-        const int wc0 = codd ? (cc - 1) >> 1 : cc >> 1;                    // first candidate window column
-        const int kx0 = codd ? 2 : 1;                                      // its kx; the second (odd only): wc0+1, kx 0
-        auto batch = [&](const int bq, const int ne) {
-            float4 cur[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const bool in = (pd_in >> (2 * bq + rr)) & 1u;
-                const f32x4 pv = pd[2 * bq + rr];
-                float4 v = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                if (POOL) {
-                    v.x = fmaf(cB.x, v.x, cC.x); v.y = fmaf(cB.y, v.y, cC.y);
-                    v.z = fmaf(cB.z, v.z, cC.z); v.w = fmaf(cB.w, v.w, cC.w);
-                }
-                cur[rr] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (POOL) {
-                uint32_t word[3][2];
-                float4 dval[3][2];
-                // candidates of rows 2b, 2b+1: (row, window row - b, ky)
-                constexpr int crow[3] = {0, 1, 1}, cwr[3] = {0, 0, 1}, cky[3] = {1, 2, 0};
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (e >= ne) continue;
-                        const int win = (bq + cwr[k]) * WIN_W + wc0 + e;
-                        word[k][e] = s_ixw[win * 16 + c4];
-                        dval[k][e] = *reinterpret_cast<const float4 *>(s_dpw + win * 64 + c4 * 4);
-                    }
-                float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (e >= ne) continue;
-                        const uint32_t code = (uint32_t)(cky[k] * 3 + (e == 0 ? kx0 : 0));
-                        const float dv[4] = {dval[k][e].x, dval[k][e].y, dval[k][e].z, dval[k][e].w};
-#pragma unroll
-                        for (int jx = 0; jx < 4; ++jx)
-                            g[crow[k]][jx] += (((word[k][e] >> (8 * jx)) & 255u) == code) ? dv[jx] : 0.f;
-                    }
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    cur[rr].x = fmaf(cA.x, g[rr][0], cur[rr].x);
-                    cur[rr].y = fmaf(cA.y, g[rr][1], cur[rr].y);
-                    cur[rr].z = fmaf(cA.z, g[rr][2], cur[rr].z);
-                    cur[rr].w = fmaf(cA.w, g[rr][3], cur[rr].w);
-                }
-            }
-            u32x4 w0, w1, w2;
-            {
-                const float lo[4] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w}, hi[4] = {cur[1].x, cur[1].y, cur[1].z, cur[1].w};
-#pragma unroll
-                for (int jx = 0; jx < 4; ++jx) {
-                    uint32_t u0, u1, u2;
-                    bf3_split_pair(lo[jx], hi[jx], u0, u1, u2);
-                    w0[jx] = u0; w1[jx] = u1; w2[jx] = u2;
-                }
-            }
-            u32x4 *dst = reinterpret_cast<u32x4 *>(s_dyp + ((bq * 32 + cc) * 3) * 64 + c4 * 4);
-            dst[0] = w0;
-            dst[16] = w1;
-            dst[32] = w2;
-            __builtin_amdgcn_sched_barrier(0);       // one batch in flight at a time (registers)
-        };
-        if (codd) {
-#pragma unroll
-            for (int bq = 0; bq < 4; ++bq) batch(bq, 2);
-        } else {
-#pragma unroll
-            for (int bq = 0; bq < 4; ++bq) batch(bq, 1);
-        }
-    };
-    auto write_patch = [&]() {
-#pragma unroll
-        for (int n = 0; n < NPRE_P; ++n) {
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int item = n * THREADS + t_;
-            if (item < PATCH_ITEMS) {
-                const int seg = item / 69, j = item - seg * 69;          // seg = c * 19 + r
-                const float x0v = ((premask >> (2 * n)) & 1u) ? pre[2 * n] : 0.f;
-                const float x1v = ((premask >> (2 * n + 1)) & 1u) ? pre[2 * n + 1] : 0.f;
-                uint32_t q0, q1, q2;
-                bf3_split_pair(x0v, x1v, q0, q1, q2);
-                uint32_t *d = s_x + seg * PROW + (j & 1) * 36 + (j >> 1);
-                d[0] = q0;
-                d[72] = q1;
-                d[144] = q2;
-            }
-        }
-    };
-#ifdef C1B_TRACE
-    int tr_it = -8;
-#endif
-    // the prefetched tile -> LDS: windows | barrier | dy1 | barrier | patch | barrier
-    auto stage_tile = [&]() {
-        WG1B_STAMP(1);
-        if (POOL) {
-            write_windows();
-            __syncthreads();
-        }
-        WG1B_STAMP(2);
-        finish_dy();
-        WG1B_STAMP(3);
-        __syncthreads();
-        WG1B_STAMP(4);
-        write_patch();
-        __syncthreads();
-        WG1B_STAMP(5);
-    };
-
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
-        const TileC t0 = coords(tile);
-#pragma unroll
-        for (int n = 0; n < NSLOT; ++n)
-            if (n < NPRE_P + 8 + NPOOL) issue_slot(n, t0);
-        stage_tile();
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const bool has_next = tile + (int)gridDim.x < ntiles;
-        const TileC next = coords(has_next ? tile + (int)gridDim.x : tile);      // (last tile: re-reads itself, unused)
-        // Operands double-buffered in registers; every MFMA is followed by ONE of: a 4-dword operand read for the next
-        // group (A of the next K-step | B of the next group of tap blocks) or one prefetch slot of the next tile.
-        // The 20 (K-step, tap block) units of a tile are taken in PAIRS whose MFMAs alternate (two accumulators: a chain
-        // of MFMAs on ONE accumulator issues every ~64 cycles, and the partner wave does not get the gaps -- phase trace
-        // of that version: the older wave of a SIMD took 7,600 cycles for its 120 MFMAs, the younger finished 3,700
-        // later).  Product order  a0 b1, a1 b1, a0 b2, a0 b0, a1 b0, a2 b0:  a unit's B pieces 1 / 2 / 0 are dead after
-        // MFMAs 3 / 5 / 11 of its pair and the next pair's pieces are read into the same registers right there (24
-        // operand registers, no second set); the other slots carry the next K-step's A operand (double-buffered) and the
-        // next tile's prefetch.
-        u32x4 A[2][3], Bq[2][3];                                     // [K-step parity][piece] | [unit of the pair][piece]
-        auto load_a = [&](int ks, int pc) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) A[ks & 1][pc][i] = s_dyp[a_base + ((8 * ks + i) * 3 + pc) * 64];
-        };
-        auto load_bu = [&](int u, int unit, int pc) {                // unit = 5 ks + tb
-            const uint32_t *p_ = s_x + toff[unit % 5] + pc * 72 + 8 * (unit / 5);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Bq[u][pc][i] = p_[i];
-        };
-#if WG1B_PRIO == 1
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) { load_a(0, pc); load_bu(0, 0, pc); load_bu(1, 1, pc); }
-        c1b_static_for<10>([&](auto gc) {
-            constexpr int gp = decltype(gc)::value;                  // pair gp = units 2 gp, 2 gp + 1
-#if WG1B_PRIO == 2
-            if ((wave >> 2) == (gp & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-            constexpr bool more = gp + 1 < 10;
-            c1b_static_for<12>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, pr = m >> 1, u = m & 1, unit = 2 * gp + u;
-                constexpr int ks = unit / 5, tb = unit % 5;
-                constexpr int pa = (pr == 1 || pr == 4) ? 1 : (pr == 5 ? 2 : 0), pb = pr < 2 ? 1 : (pr == 2 ? 2 : 0);
-                acc[tb] = mfma32bf(A[ks & 1][pa], Bq[u][pb], acc[tb]);
-                // what follows this MFMA
-                constexpr int nunit = 2 * (gp + 1) + u;              // the unit that takes this one's operand registers
-                if constexpr (m == 2 || m == 3) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 1); }
-                else if constexpr (m == 4 || m == 5) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 2); }
-                else if constexpr (m == 10 || m == 11) { if (more && !(WG1B_ABL & 2)) load_bu(u, nunit, 0); }
-                else {
-                    // six free slots per pair (m = 0, 1, 6, 7, 8, 9): the next K-step's A operand in the pair that
-                    // starts K-step ks' = (2 gp) / 5 (its last unit is >= 3 units away), then prefetch slots
-                    constexpr int f = gp * 6 + (m < 2 ? m : m - 4);  // 0 .. 59
-                    constexpr int ks0 = (2 * gp) / 5;
-                    constexpr bool first_of_ks = (2 * gp) % 5 < 2;   // the pair holding unit 5 ks0 or 5 ks0 + 1
-                    if constexpr (first_of_ks && (m < 2 || m == 6)) {
-                        if (ks0 + 1 < 4 && !(WG1B_ABL & 2)) load_a(ks0 + 1, m < 2 ? m : 2);
-                    } else {
-                        // slots in order over the remaining free positions
-                        constexpr int used_a = 3 * ((2 * gp) / 5 + (first_of_ks ? 0 : 1));      // A positions before this pair
-                        constexpr int n = f - used_a - (first_of_ks ? 3 : 0);
-                        if constexpr (n >= 0) { if (n < NPRE_P + 8 + NPOOL && !(WG1B_ABL & 1)) issue_slot(n, next); }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-#if WG1B_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        WG1B_STAMP(0);
-        __syncthreads();                 // every wave is done with this tile's operands
-        if (has_next) stage_tile();
-#ifdef C1B_TRACE
-        ++tr_it;
-#endif
-    }
-    // partial layout: part[(block*4 + q)][co 64][k 160]
-    float *dst = part + ((size_t)(blockIdx.x * 4 + q)) * (64 * 160);
-#pragma unroll
-    for (int tb = 0; tb < 5; ++tb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cob * 32 + mfma32_row(r, lane);
-            dst[co * 160 + tb * 32 + li] = acc[tb][r];
-        }
-}
+// (The phase-structured kernel this comment was written for -- conv1_wgrad_bf3_kernel, 1.12 ms -- left the library in
+// round 6; the role-split kernel below keeps its arithmetic and operand layouts: DESIGN.md 11.8.)
 
 // ------------------------------------------------------------------------------------
 // conv1 weight gradient, ROLE-SPLIT form of conv1_wgrad_bf3_kernel (same arithmetic, same operand layouts, a quarter of
@@ -1408,6 +1047,7 @@ constexpr int NPRE_P = (PATCH_ITEMS + 255) / 256;                // 5 slots per 
 // -DC1B_TRACE: stamps of the eight waves of block 0, tiles 40..59: 0 tile start, 1 work done (before the barrier), 2 after the
 // barrier, 3 (staging waves) dy1 finished / loads not yet issued
 #ifdef C1B_TRACE
+__device__ unsigned long long g_wg1b_trace[8 * 20 * 8];
 #define WG1R_STAMP(slot)                                                                                      \
     do {                                                                                                      \
         if (blockIdx.x == 0 && tr_it >= 0 && tr_it < 20 && lane == 0)                                         \
@@ -1422,7 +1062,7 @@ constexpr int NPRE_P = (PATCH_ITEMS + 255) / 256;                // 5 slots per 
 template <bool POOL>
 __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
     const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ part,
-    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool, const int xw)
+    int H, int W, int H1, int W1, int tiles_x, int tiles_y, int ntiles, const PoolBwd pool)
 {
     using namespace wg1r;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * D_DW + 2 * P_DW];
@@ -1433,7 +1073,7 @@ __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
     struct TileC { int b, y0, x0; };
     auto coords = [&](int t) {
         TileC c;
-        const int tt = xcd_walk_tile(t < ntiles ? t : ntiles - 1, ntiles, xw);    // (past the end: the last tile again, unused)
+        const int tt = t < ntiles ? t : ntiles - 1;    // (past the end: the last tile again, unused)
         const int r_ = tt / tiles_x;
         c.x0 = (tt - r_ * tiles_x) * TW;
         c.b = r_ / tiles_y;
@@ -1787,10 +1427,7 @@ inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 
 int g_ablate = 0;            // conv3x3 v2 ablation mask (tools only)
 int g_grid_cap = 0;          // > 0: cap on persistent grids (tests force many tiles per block)
-int g_conv1_xcd_walk = 0;    // 1: conv1 forward / weight gradient (bf16 split kernels) walk XCD-contiguous eighths of the tile list (xcd_walk_tile)
-int g_conv1_w4 = 0;          // 1: conv1 forward (bf16 split) with one wave per SIMD (conv1_fwd_w4.h: measured slower, A/B); 0: the 8-wave kernel
 int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) instead of the bf16-split one (A/B, tests)
-int g_conv1_wgrad_phases = 0; // 1: conv1 weight gradient on the phase-structured bf16 kernel instead of the role-split one (A/B)
 
 }  // namespace
 
@@ -1822,11 +1459,9 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 5) { g_ablate = value; return COVA_OK; }
     if (key == 6) return cova_internal_set_wino_geometry(value);
     if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
-    if (key == 8) { g_conv1_wgrad_phases = value != 0; return COVA_OK; }
     if (key == 9) return cova_internal_set_wino4_f32(value);
     if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
     if (key == 11) return cova_internal_set_sgemm_f32(value);
-    if (key == 12) { g_conv1_w4 = value != 0; return COVA_OK; }
     if (key == 13) return cova_internal_set_pool_variant(value);
     if (key == 14) return cova_internal_set_bn1d_variant(value);
     if (key == 15) return cova_internal_set_sgemm_direct(value);
@@ -1835,7 +1470,6 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 18) return cova_internal_set_roipool_variant(value);
     if (key == 19) return cova_internal_set_sgemm_pf2(value);
     if (key == 20) return cova_internal_set_roipool_bwd_nbx(value);
-    if (key == 21) { g_conv1_xcd_walk = value != 0; return COVA_OK; }
     return COVA_ERR_BAD_ARG;
 }
 
@@ -1897,23 +1531,12 @@ static int conv1_fwd_launch(const float *img, const float *w_k, int w_oihw, floa
         const int tiles_x = cdiv(W1, c1b::TW), tiles_y = cdiv(H1, c1b::TH);
         const int ntiles = B * tiles_x * tiles_y;
         const dim3 pgrid(persistent_grid(ntiles, 1)), block(c1b::THREADS);
-        const int xw = g_conv1_xcd_walk && ntiles % 8 == 0 && pgrid.x % 8 == 0;
-        if (g_conv1_w4) {
-            if (stat_part)
-                hipLaunchKernelGGL(conv1_7x7_bf3w_kernel<true>, pgrid, dim3(c1w::THREADS), 0, (hipStream_t)stream, img, w_k, out,
-                                   stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
-            else
-                hipLaunchKernelGGL(conv1_7x7_bf3w_kernel<false>, pgrid, dim3(c1w::THREADS), 0, (hipStream_t)stream, img, w_k, out,
-                                   stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
-            COVA_LAUNCH_CHECK();
-            return COVA_OK;
-        }
         if (stat_part)
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<true>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out, stat_part,
-                               H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, xw, t);
+                               H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
         else
             hipLaunchKernelGGL(conv1_7x7_bf3_kernel<false>, pgrid, block, 0, (hipStream_t)stream, img, w_k, out,
-                               stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, xw, t);
+                               stat_part, H, W, H1, W1, tiles_x, tiles_y, ntiles, w_oihw, t);
         COVA_LAUNCH_CHECK();
         return COVA_OK;
     }
@@ -1970,26 +1593,20 @@ COVA_API int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const f
     const int H2 = cova_conv_out_size(H1, 3, 2, 1), W2 = cova_conv_out_size(W1, 3, 2, 1);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
-    if (!g_conv1_f32 && !g_conv1_wgrad_phases) {
+    if (!g_conv1_f32) {
         const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
         const int rgrid = persistent_grid(B * rtx * rty);
         hipLaunchKernelGGL(conv1_wgrad_rs_kernel<true>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, y1,
-                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{dp, idx, abc, H2, W2},
-                           (int)(g_conv1_xcd_walk && (B * rtx * rty) % 8 == 0 && rgrid % 8 == 0));
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{dp, idx, abc, H2, W2});
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
                            rgrid * 2, dw);
         COVA_LAUNCH_CHECK();
         return COVA_OK;
     }
-    if (g_conv1_f32)
-        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
-                           (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
-    else
-        hipLaunchKernelGGL(conv1_wgrad_bf3_kernel<true>, dim3(grid), dim3(wg1b::THREADS), 0,
-                           (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<true>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, y1, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{dp, idx, abc, H2, W2});
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 4, dw);
@@ -2006,26 +1623,20 @@ COVA_API int cova_conv1_wgrad(const float *img, const float *dy, float *dw, floa
     const int H1 = cova_conv_out_size(H, 7, 2, 3), W1 = cova_conv_out_size(W, 7, 2, 3);
     const int tiles_x = cdiv(W1, wg1::TW), tiles_y = cdiv(H1, wg1::TH);
     const int grid = persistent_grid(B * tiles_x * tiles_y);
-    if (!g_conv1_f32 && !g_conv1_wgrad_phases) {
+    if (!g_conv1_f32) {
         const int rtx = cdiv(W1, wg1r::TW), rty = cdiv(H1, wg1r::TH);
         const int rgrid = persistent_grid(B * rtx * rty);
         hipLaunchKernelGGL(conv1_wgrad_rs_kernel<false>, dim3(rgrid), dim3(wg1r::THREADS), 0, (hipStream_t)stream, img, dy,
-                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{nullptr, nullptr, nullptr, 0, 0},
-                           (int)(g_conv1_xcd_walk && (B * rtx * rty) % 8 == 0 && rgrid % 8 == 0));
+                           ws, H, W, H1, W1, rtx, rty, B * rtx * rty, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
         COVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0, (hipStream_t)stream, ws,
                            rgrid * 2, dw);
         COVA_LAUNCH_CHECK();
         return COVA_OK;
     }
-    if (g_conv1_f32)
-        hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
-                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
-    else
-        hipLaunchKernelGGL(conv1_wgrad_bf3_kernel<false>, dim3(grid), dim3(wg1b::THREADS), 0,
-                           (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
-                           B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
+    hipLaunchKernelGGL(conv1_wgrad_v2_kernel<false>, dim3(grid), dim3(wg1::THREADS), 0,
+                       (hipStream_t)stream, img, dy, ws, H, W, H1, W1, tiles_x, tiles_y,
+                       B * tiles_x * tiles_y, PoolBwd{nullptr, nullptr, nullptr, 0, 0});
     COVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64 * 160 / 64), dim3(1024), 0,
                        (hipStream_t)stream, ws, grid * 4, dw);

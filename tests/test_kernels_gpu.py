@@ -525,41 +525,6 @@ def test_conv1_variants_multi_tile():
     query("cova_set_option", 2, 0)
 
 
-def test_conv1_xcd_contiguous_tile_walk():
-    """cova_set_option(21, 1): the persistent blocks of conv1 forward / weight gradient walk XCD-contiguous eighths of the tile
-    list.  A tile's arithmetic does not change: the forward map is bit-identical; statistics partials and the weight gradient
-    are the same sums in another association."""
-    B, H, W = 4, 256, 512                     # forward 4 x 16 x 8 = 512 tiles, weight gradient 4 x 32 x 16 = 2048: multiples of 8
-    g = torch.Generator().manual_seed(21)
-    x = torch.rand(B, 3, H, W, generator=g)
-    wr = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_(True)
-    ref = F.conv2d(x, wr, stride=2, padding=3)
-    H1, W1 = ref.shape[2], ref.shape[3]
-    dy = torch.randn(B, 64, H1, W1, generator=g)
-    (ref * dy).sum().backward()
-    wk = torch.empty(154, 64, device=DEV)
-    call("cova_conv1_prep_weights", wr.detach().to(DEV), wk)
-    nt = query("cova_conv1_num_partials", B, H, W)
-    ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=DEV)
-    outs, dws = [], []
-    try:
-        for walk in (0, 1):
-            query("cova_set_option", 21, walk)
-            out, part = torch.full((B, H1, W1, 64), float("nan"), device=DEV), torch.zeros(nt, 2, 64, device=DEV)
-            call("cova_conv1_fwd", x.to(DEV), wk, out, part, B, H, W)
-            close(nchw(out), ref, 1e-4, "conv1 fwd walk %d" % walk)
-            close(part[:, 0].sum(0), ref.sum((0, 2, 3)), 1e-4, "conv1 stat sum walk %d" % walk)
-            close(part[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), 1e-4, "conv1 sumsq walk %d" % walk)
-            dw = torch.zeros(64, 3, 7, 7, device=DEV)
-            call("cova_conv1_wgrad", x.to(DEV), nhwc(dy), dw, ws, B, H, W)
-            close(dw, wr.grad, 2e-4, "conv1 wgrad walk %d" % walk)
-            outs.append(out.clone()); dws.append(dw.clone())
-    finally:
-        query("cova_set_option", 21, 0)
-    assert torch.equal(outs[0], outs[1])
-    close(dws[1], dws[0], 1e-5, "conv1 wgrad, the two walks")
-
-
 def test_conv3x3_dgrad_bnbwd_fusion_matches_unfused():
     """Fused data-gradient epilogue (ReLU mask + BatchNorm-backward sums) == plain data gradient followed by
     cova_bn_bwd_reduce, on a multi-tile problem, for both Winograd kernel families."""
@@ -1299,19 +1264,6 @@ def test_conv1_bf16_split_error_class(B, H, W, cap):
     finally:
         query("cova_set_option", 7, 0)
         query("cova_set_option", 2, 0)
-    # the one-wave-per-SIMD form of the forward (csrc/conv1_fwd_w4.h, cova_set_option(12, 1); measured slower, kept for A/B)
-    # accumulates every output in the same order: bit-identical output, statistics within their summation order
-    query("cova_set_option", 2, cap)
-    query("cova_set_option", 12, 1)
-    try:
-        nt = query("cova_conv1_num_partials", B, H, W)
-        out4, part4 = torch.zeros(B, H1, W1, 64, device=DEV), torch.zeros(nt, 2, 64, device=DEV)
-        call("cova_conv1_fwd_tail", xg, wg, out4, part4, B, H, W, None)
-        assert torch.equal(out4, outs[0][0])
-        close(part4.double().sum(0), outs[0][1].double().sum(0), 1e-5, "statistics of the 4-wave conv1 forward")
-    finally:
-        query("cova_set_option", 12, 0)
-        query("cova_set_option", 2, 0)
     print("conv1 error against fp64 (output, weight gradient, channel sums of squares): f32 MFMA %.2e %.2e %.2e | "
           "bf16 split %.2e %.2e %.2e" % (err[1] + err[0]))
     for a, b in zip(err[0], err[1]):
@@ -1426,10 +1378,10 @@ def test_conv1_kernels_do_not_depend_on_the_batch_partition():
 
 
 @pytest.mark.parametrize("B,H,W,cap", [(2, 150, 330, 0), (2, 150, 330, 7), (1, 70, 90, 0)])
-def test_conv1_wgrad_role_split_equals_phase_form(B, H, W, cap):
-    """The two bf16-split forms of the conv1 weight gradient (role-split waves, the default; phase-structured,
-    cova_set_option(8, 1)) and the f32-MFMA kernel on the same operands, pool backward folded in: equal to fp32
-    re-association, on maps with edge tiles, odd sizes and many tiles per block."""
+def test_conv1_wgrad_role_split_equals_f32_form(B, H, W, cap):
+    """The bf16-split conv1 weight gradient (role-split waves) and the f32-MFMA kernel (cova_set_option(7, 1)) on the same
+    operands, pool backward folded in: equal to fp32 re-association, on maps with edge tiles, odd sizes and many tiles per
+    block."""
     g = torch.Generator().manual_seed(H + W + cap)
     x = torch.rand(B, 3, H, W, generator=g).to(DEV)
     H1, W1 = query("cova_conv_out_size", H, 7, 2, 3), query("cova_conv_out_size", W, 7, 2, 3)
@@ -1445,19 +1397,16 @@ def test_conv1_wgrad_role_split_equals_phase_form(B, H, W, cap):
     out = {}
     query("cova_set_option", 2, cap)
     try:
-        for name, o7, o8 in (("f32", 1, 0), ("phases", 0, 1), ("roles", 0, 0)):
+        for name, o7 in (("f32", 1), ("roles", 0)):
             query("cova_set_option", 7, o7)
-            query("cova_set_option", 8, o8)
             dw = torch.zeros(64, 3, 7, 7, device=DEV)
             call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W)
             out[name] = dw
     finally:
         query("cova_set_option", 7, 0)
-        query("cova_set_option", 8, 0)
         query("cova_set_option", 2, 0)
     s = float(out["f32"].abs().max())
     assert float((out["roles"] - out["f32"]).abs().max()) <= 5e-7 * s
-    assert float((out["phases"] - out["f32"]).abs().max()) <= 5e-7 * s
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 14, 18), (2, 37, 52), (1, 64, 64)])

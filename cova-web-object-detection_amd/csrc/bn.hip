@@ -284,9 +284,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
 // decisions as one bit per element: bits[r][w] bit k = (out[r][32 w + k] > 0).  The data gradient that needs this map
 // only as its mask source (conv_wino4.hip, `act_bits`) then reads 1/32 of the bytes.  A thread owns 4 channels; the 8
 // lanes of a 32-channel word combine their nibbles with three lane exchanges.
-// U: elements a thread has in flight per trip (cova_set_option(17, u); the stride is a multiple of 8 lanes, so the 8 lanes of a
-// word stay together in every one of them)
-int g_bnact_unroll = 1;
+// U: elements a thread has in flight per trip (2 and 4 measured slower than 1 in round 5: the launch runs at the copy rate; the
+// stride is a multiple of 8 lanes, so the 8 lanes of a word stay together)
 template <int U>
 __global__ __launch_bounds__(256) void bn_act_fwd_bits_kernel(
     const float *__restrict__ z, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -414,7 +413,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // Neighbouring columns are neighbouring 16-lane groups of the same wave (L1 hits).
 // STRIP / PRE (cova_set_option(13, v), tools/ew_bench.py): rows per strip; PRE: the two new input rows of output row
 // oy + 1 are requested before output row oy is reduced and stored (12 instead of 6 loads of a thread in flight).
-int g_pool_variant = 12;     // one output row per thread, XCD-contiguous work blocks: measured fastest (tools/ew_bench.py)
 template <int POOL_STRIP, bool PRE, bool XCD = false, bool TILE2D = false>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -748,8 +746,6 @@ inline bool vec4_ok(const void *p, int ld)
 
 }  // namespace
 
-int cova_internal_set_pool_variant(int v) { g_pool_variant = v; return COVA_OK; }
-int cova_internal_set_bnact_unroll(int v) { g_bnact_unroll = v; return COVA_OK; }
 
 // ====================================================================================
 // C ABI
@@ -851,15 +847,8 @@ COVA_API int cova_bn_act_fwd_bits(const float *z, const float *scale, const floa
 {
     COVA_REQUIRE(z && scale && shift && out && bits && R > 0);
     COVA_REQUIRE(vec4_ok(z, 64) && vec4_ok(res, 64) && vec4_ok(out, 64) && vec4_ok(scale, 0) && vec4_ok(shift, 0));
-    if (g_bnact_unroll == 4)
-        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<4>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
-                           res, out, bits, R);
-    else if (g_bnact_unroll == 2)
-        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<2>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
-                           res, out, bits, R);
-    else
-        hipLaunchKernelGGL(bn_act_fwd_bits_kernel<1>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
-                           res, out, bits, R);
+    hipLaunchKernelGGL(bn_act_fwd_bits_kernel<1>, dim3(ew_grid(R * 16)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                       res, out, bits, R);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
@@ -963,32 +952,8 @@ COVA_API int cova_bn_relu_maxpool_fwd(const float *y, const float *scale, const 
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B,
                            H1, W1, H2, W2);
     };
-    auto launch2d = [&](auto kern) {
-        long long g = (long long)B * cdiv(H2, 4) * cdiv(W2, 4);
-        if (g > 0x7fffffffll) g = 0x7fffffffll;
-        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, idx, ymax, B,
-                           H1, W1, H2, W2);
-    };
-    switch (g_pool_variant) {
-    case 1: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, false); break;
-    case 2: launch(bn_relu_maxpool_fwd_kernel<8, false>, 8, false); break;
-    case 3: launch(bn_relu_maxpool_fwd_kernel<16, true>, 16, false); break;
-    case 4: launch(bn_relu_maxpool_fwd_kernel<8, true>, 8, false); break;
-    case 5: launch(bn_relu_maxpool_fwd_kernel<16, true>, 16, true); break;
-    case 6: launch(bn_relu_maxpool_fwd_kernel<4, true>, 4, false); break;
-    case 7: launch(bn_relu_maxpool_fwd_kernel<2, true>, 2, false); break;
-    case 8: launch(bn_relu_maxpool_fwd_kernel<4, false>, 4, false); break;
-    case 9: launch(bn_relu_maxpool_fwd_kernel<4, true, true>, 4, false); break;
-    case 10: launch(bn_relu_maxpool_fwd_kernel<2, true, true>, 2, false); break;
-    case 11: launch(bn_relu_maxpool_fwd_kernel<8, true, true>, 8, false); break;
-    case 13: launch(bn_relu_maxpool_fwd_kernel<2, false, true>, 2, false); break;
-    case 14: launch(bn_relu_maxpool_fwd_kernel<16, true, true>, 16, false); break;
-    case 15: launch(bn_relu_maxpool_fwd_kernel<1, false, false>, 1, false); break;
-    case 16: launch2d(bn_relu_maxpool_fwd_kernel<1, false, true, true>); break;
-    case 17: launch2d(bn_relu_maxpool_fwd_kernel<1, false, false, true>); break;
-    case 12: launch(bn_relu_maxpool_fwd_kernel<1, false, true>, 1, false); break;
-    default: launch(bn_relu_maxpool_fwd_kernel<16, false>, 16, true); break;     // (0: the round-2 shape)
-    }
+    // one output row per thread on XCD-contiguous work blocks: the fastest of 17 launch shapes measured in round 5
+    launch(bn_relu_maxpool_fwd_kernel<1, false, true>, 1, false);
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }

@@ -1443,16 +1443,8 @@ int cova_internal_ablate() { return g_ablate; }
 // test / tool hooks (not part of the path's contract): 2 = cap on persistent grids (tests force many tiles per
 // block), 5 = ablation mask of builds made with -DCOVA_ABLATE (tools/conv_bench.py), 6 = Winograd tile geometry
 int cova_internal_set_wino4_f32(int v);
-int cova_internal_set_wgrad4_pair_sync(int v);
-int cova_internal_set_sgemm_f32(int v);
-int cova_internal_set_pool_variant(int v);
 int cova_internal_set_bn1d_variant(int v);
-int cova_internal_set_sgemm_direct(int v);
 int cova_internal_set_gat_wide(int v);
-int cova_internal_set_bnact_unroll(int v);
-int cova_internal_set_roipool_variant(int v);
-int cova_internal_set_sgemm_pf2(int v);
-int cova_internal_set_roipool_bwd_nbx(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     if (key == 2) { g_grid_cap = value; return COVA_OK; }
@@ -1460,16 +1452,8 @@ COVA_API int cova_set_option(int key, int value)
     if (key == 6) return cova_internal_set_wino_geometry(value);
     if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
     if (key == 9) return cova_internal_set_wino4_f32(value);
-    if (key == 10) return cova_internal_set_wgrad4_pair_sync(value);
-    if (key == 11) return cova_internal_set_sgemm_f32(value);
-    if (key == 13) return cova_internal_set_pool_variant(value);
     if (key == 14) return cova_internal_set_bn1d_variant(value);
-    if (key == 15) return cova_internal_set_sgemm_direct(value);
     if (key == 16) return cova_internal_set_gat_wide(value);
-    if (key == 17) return cova_internal_set_bnact_unroll(value);
-    if (key == 18) return cova_internal_set_roipool_variant(value);
-    if (key == 19) return cova_internal_set_sgemm_pf2(value);
-    if (key == 20) return cova_internal_set_roipool_bwd_nbx(value);
     return COVA_ERR_BAD_ARG;
 }
 

@@ -82,8 +82,6 @@ struct Wg4Args {
     float *part;                     // [grid][9][64][64]
     const float *act_abc, *dz_abc;   // [3][64] = A | B | C, or nullptr (plain operand)
     float *dz_out;                   // nullable: the gradient operand as formed on load (A*dz + B*dz2 + C), NHWC [B,H,W,64]
-    unsigned *prog;                  // [grid] progress words of the blocks (launch tag << 16 | K-steps transformed), or nullptr
-    unsigned tag;                    // this launch's tag (the words of an earlier launch, or uninitialised memory, do not match it)
     int act_relu;
     int H, W, tiles_y, strips, nseg_y, seg_rows, nsegs;
 };
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
     using namespace wg4;
     __shared__ __attribute__((aligned(16))) float s_op[2 * BUF_FLOATS];
     __shared__ __attribute__((aligned(1024))) float s_raw[8 * RAW_FLOATS];      // wave-private pixel buffers
-    __shared__ __attribute__((aligned(256))) unsigned s_sync[64];               // the partner block's progress word (wave 0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W;
@@ -350,23 +347,8 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         int phi = 0;                                         // ring phase of the patch in the buffer
         int wg4_k = -1;                                      // (trace builds)
         (void)wg4_k;
-        // ---- the two position halves of a walk (blocks b, b ^ 8: same XCD, same pixels in the same order) are kept within two
-        // K-steps of each other, so that the second reader of a pixel finds it in the XCD's L2 (inside the
-        // train step the pair drifted apart behind the previous launches' cache contents and every pixel was fetched twice).
-        // Wave 0 publishes the block's progress after each transform and requests its partner's word as a global -> LDS
-        // copy behind the next patch's copies: no register, no wait of its own (the vmcnt(0) in front of the next
-        // transform covers it), L1 bypassed (sc0 sc1).  The leader sleeps while it is two K-steps ahead -- bounded: a
-        // partner that is not resident (a foreign kernel on its CU) costs time, never a hang.
-        const bool syncer = VROLE && wave == 0 && a.prog != nullptr && (G & 15) == 0;      // (wave-uniform)
-        int my_k = 0, nap_budget = 4096;
-        auto partner_k = [&](unsigned v) { return (v >> 16) == a.tag ? (int)(v & 0xFFFFu) : 0; };
-        const unsigned sync_lds = (unsigned)(size_t)(wg4_lds_void *)s_sync;
-        const unsigned *pword = a.prog + (blockIdx.x ^ 8u);
-        auto request_partner = [&]() __attribute__((always_inline)) {
-            unsigned zero = 0;
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2 sc0 sc1" ::"s"(sync_lds), "v"(zero), "s"(pword) : "memory", "m0");
-        };
-        if (syncer && lane == 0) s_sync[0] = 0;
+        // (The two position halves of a walk -- blocks b, b ^ 8: same XCD, same pixels in the same order -- run free.  A pacing
+        // through progress words was built and measured in round 5: same HBM traffic, 3 % slower)
         auto transform = [&](float *buf, const Wg4It &nxt, unsigned crm, unsigned ccm, unsigned nrm, unsigned ncm) __attribute__((always_inline)) {
             // this lane's channel of pair slot (p + phi) % 3, p = 0..2 (input role; gradient role: two fixed pairs)
             const float *pair_r[3];
@@ -377,16 +359,6 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                 pair_r[p] = raw_r + (VROLE ? 768 * ps : 512 * p);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's copies of the patch have landed
-            if (syncer) {
-                int pk = partner_k(*reinterpret_cast<volatile unsigned *>(s_sync));
-                while (my_k - pk >= 2 && nap_budget > 0) {
-                    __builtin_amdgcn_s_sleep(8);
-                    request_partner();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    pk = partner_k(*reinterpret_cast<volatile unsigned *>(s_sync));
-                    --nap_budget;
-                }
-            }
             const int nphi = (!VROLE || (WG4_ABL & 128)) ? 0 : (nxt.rr == 0 ? phi : (phi == 0 ? 2 : phi - 1));      // (phi + 2) % 3 down the strip
             const bool nedge = nrm != FULL || ncm != FULL;
             if (WG4_ABL & 8) { fetch(nxt, nedge, nphi); phi = nphi; return; }
@@ -429,11 +401,6 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
             WG4_STAMP(2);
             fetch(nxt, nedge, nphi);          // the buffer is free: the next patch is requested
             phi = nphi;
-            if (syncer) {
-                ++my_k;
-                __hip_atomic_store(a.prog + blockIdx.x, (a.tag << 16) | (unsigned)(my_k & 0xFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                request_partner();
-            }
             WG4_STAMP(3);
             // second stage row by row, stored as soon as a row is complete: position p = 6 al + b sits at float p of the
             // group-0 row (p < 9), at float p - 9 of the group-1 row otherwise
@@ -651,22 +618,11 @@ Wg4Geo wg4_geometry(int B, int H, int W)
     return g;
 }
 
-// 1: the two position halves of a walk pace each other through progress words.  Off by default: measured inside the train
-// step (profiles/r05_pmc_wgrad4_pair_pacing.txt) the launch fetches 2 x 634 MiB either way -- the compulsory 1.26 GB -- and
-// takes 3 % longer with the pacing (0.551-0.565 against 0.534-0.548 ms); kept for A/B (cova_set_option(10, 1))
-int g_wg4_pair_sync = 0;
-unsigned g_wg4_tag = 0;
-
 int launch_wgrad4(const float *act, const float *act_abc, int act_relu, const float *dz, const float *dz2,
                   const float *dz_abc, float *dz_out, float *ws, int B, int H, int W, hipStream_t st)
 {
     const Wg4Geo g = wg4_geometry(B, H, W);
-    // the progress words sit behind the partial sums in the workspace; K-steps per block < 65,536 or no pacing
-    const long long ksteps = (long long)g.nsegs * g.seg_rows / (g.grid / 2 > 0 ? g.grid / 2 : 1) + g.seg_rows;
-    unsigned *prog = (g_wg4_pair_sync && ksteps < 65000) ? reinterpret_cast<unsigned *>(ws + (size_t)g.grid * wg4::PART_FLOATS) : nullptr;
-    g_wg4_tag = (g_wg4_tag + 1) & 0xFFFFu;
-    if (g_wg4_tag == 0) g_wg4_tag = 1;
-    const Wg4Args a{act, dz, dz_abc ? dz2 : nullptr, ws, act_abc, dz_abc, dz_abc ? dz_out : nullptr, prog, g_wg4_tag, act_relu, H, W,
+    const Wg4Args a{act, dz, dz_abc ? dz2 : nullptr, ws, act_abc, dz_abc, dz_abc ? dz_out : nullptr, act_relu, H, W,
                     g.tiles_y, g.strips, g.nseg_y, g.seg_rows, g.nsegs};
     const dim3 grid(g.grid), blk(wg4::THREADS);
     const int prod = !dz_abc ? 0 : (dz2 ? 2 : 1);
@@ -680,8 +636,6 @@ int launch_wgrad4(const float *act, const float *act_abc, int act_relu, const fl
 
 }  // namespace
 
-int cova_internal_set_wgrad4_pair_sync(int v) { g_wg4_pair_sync = v != 0; return COVA_OK; }
-
 // ====================================================================================
 // C ABI
 // ====================================================================================
@@ -690,7 +644,7 @@ COVA_API int cova_conv3x3_wgrad4_num_partials(int B, int H, int W) { return wg4_
 COVA_API int cova_conv3x3_wgrad4_workspace_floats(int B, int H, int W)
 {
     const int grid = wg4_geometry(B, H, W).grid;
-    return grid * wg4::PART_FLOATS + ((grid + 63) & ~63);          // <= 256 blocks x 36,864 floats + one progress word per block
+    return grid * wg4::PART_FLOATS;          // <= 256 blocks x 36,864 floats
 }
 
 // Per-block partial sums of the weight gradient in the F(4x4,3x3) domain; operands transformed on load as

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4_kernel(const
     };
 
     constexpr bool W4_SIGNED_TILES = false;
+    constexpr bool w4_neg = false;
 #include "conv_wino4_epi.h"
 
 #pragma unroll 1
@@ -619,10 +620,22 @@ COVA_API int cova_conv3x3_wino4_num_tiles(int B, int H, int W)
     return B * cdiv(W, w4::TW) * cdiv(H, w4::TH);
 }
 
-COVA_API int cova_conv3x3_wino4_num_partials(int B, int H, int W)
+// Blocks of a launch: one per CU, or fewer on small maps -- even, and at most two per tile row of odd ty (the split main loop
+// walks the even and the odd tile rows with its even and odd blocks: conv_wino4_split.h) -- so that no block is idle
+static int w4_grid(int B, int H, int W)
 {
-    return cova_internal_persistent_grid2(cova_conv3x3_wino4_num_tiles(B, H, W), 1);
+    const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH);
+    int g = cova_internal_persistent_grid2(B * tiles_x * tiles_y, 1);
+    const int len_odd = B * tiles_x * (tiles_y / 2);
+    if (len_odd > 0) {
+        if (g > 2 * len_odd) g = 2 * len_odd;
+        g &= ~1;
+        if (g < 2) g = 2;
+    }
+    return g;
 }
+
+COVA_API int cova_conv3x3_wino4_num_partials(int B, int H, int W) { return w4_grid(B, H, W); }
 
 // 1: every launch on the f32 main loop (A/B, tests); 0 (default): the split main loop wherever it exists (one input tensor)
 int g_w4_f32 = 0;
@@ -700,7 +713,7 @@ int run_w4(const float *in, const float *in2, const float *pro_abc, int pro_relu
     COVA_REQUIRE(!(epi.act && epi.act_bits));
     const int tiles_x = cdiv(W, w4::TW), tiles_y = cdiv(H, w4::TH), ntiles = B * tiles_x * tiles_y;
     const W4Args a{in, pro_abc ? in2 : nullptr, u, out, stat_part, H, W, tiles_x, tiles_y, ntiles, pro_abc, pro_relu, epi, t};
-    const int grid = cova_internal_persistent_grid2(ntiles, 1);
+    const int grid = w4_grid(B, H, W);
     if (!pro_abc) launch_w4_pro<0>(a, grid, (hipStream_t)stream);
     else if (!in2) launch_w4_pro<1>(a, grid, (hipStream_t)stream);
     else launch_w4_pro<2>(a, grid, (hipStream_t)stream);

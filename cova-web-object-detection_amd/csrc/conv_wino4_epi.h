@@ -1,6 +1,6 @@
 // Textual include INSIDE the F(4x4,3x3) kernels of conv_wino4.hip (both main loops share it): the tile epilogue.
 // Needs in scope: a, late_args, KArgs, tile_of, acc[18], s_x, s_epi, s_red, cog, ph, lane, wave, H, W and the template
-// parameters STATS / ADD / BN, and a constexpr bool W4_SIGNED_TILES (the accumulators of tiles with odd tx + ty hold -M).
+// parameters STATS / ADD / BN, and a constexpr bool W4_SIGNED_TILES and a bool w4_neg (W4_SIGNED_TILES: this block's accumulators hold -M).
     // ---- tile epilogue: output transform Y = A^T M A.  This wave holds M[i = 3 ph + il][j] for (channels cog*16 + kq*4 .. +3,
     // tile l15); A^T over j in registers, then the partial sums over its three rows i for all four output rows; the
     // pair (ph 0, ph 1) of a channel group swaps the two output rows the other one owns (ph 0: rows 0-1, ph 1: rows 2-3).
@@ -19,7 +19,7 @@
         }
         const int tile_ = tile_of(k);
         const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y, b = tile_ / (a.tiles_x * a.tiles_y);
-        const float tsign = (W4_SIGNED_TILES && ((tx + ty) & 1)) ? -1.f : 1.f;
+        const float tsign = (W4_SIGNED_TILES && w4_neg) ? -1.f : 1.f;
         const KArgs la = late_args();
         const float *e_addend = la->epi.addend, *e_z = la->epi.z, *e_act = la->epi.act;
         float *e_out = la->out;
@@ -149,7 +149,7 @@
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = W4_SIGNED_TILES ? own[r] * tsign : own[r];      // (split loop: odd tiles were multiplied with -U)
+                    float v = W4_SIGNED_TILES ? own[r] * tsign : own[r];      // (split loop: odd tile rows were multiplied with -U)
                     if (BN == 3) {                  // inference: BatchNorm (running statistics) + residual + ReLU
                         v = fmaf(msc[r], v, msh[r]);
                         if (ADD) v += adv[r];

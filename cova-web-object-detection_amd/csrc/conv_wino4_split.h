@@ -84,12 +84,29 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
     }
     if (PRO || BN) __syncthreads();
 
-    // ---- the tiles of this block (same order as the f32 loop)
-    int first = blockIdx.x;
-    if ((gridDim.x & 7) == 0) first = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (first >= a.ntiles) return;
-    const int nk = (a.ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
-    auto tile_of = [&](int k) { return first + (k < nk ? k : nk - 1) * (int)gridDim.x; };
+    // ---- the tiles of this block.  The block tiles (8 x 32 pixels) are walked as TWO lists -- the tile rows of even ty and those
+    // of odd ty -- by the blocks of even and of odd blockIdx.x: a block multiplies with ONE weight image for its whole life (+U on
+    // even tile rows, -U on odd ones: see `ubase` below), the sign of a tile depends on its position in the map only (results do
+    // not depend on the batch a page sits in), and -- workgroups going to the eight XCDs in turn -- the blocks of an XCD all use
+    // the same image: each L2 holds one of the two.  XCD x walks one contiguous quarter of every slice of its list.
+    // (w4_grid() on the host keeps gridDim.x even and every block busy; a map of ONE tile row has no odd list.)
+    const int Gd = (int)gridDim.x;
+    const bool lists = a.tiles_y > 1;
+    const int w4_par = lists ? (int)(blockIdx.x & 1) : 0;
+    const int Gp = lists ? Gd >> 1 : Gd;
+    int bp = lists ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    if ((Gd & 7) == 0) bp = lists ? (int)((blockIdx.x & 7) >> 1) * (Gd >> 3) + (int)(blockIdx.x >> 3)
+                                  : (int)(blockIdx.x & 7) * (Gd >> 3) + (int)(blockIdx.x >> 3);
+    const int nrow = lists ? (w4_par ? a.tiles_y >> 1 : (a.tiles_y + 1) >> 1) : a.tiles_y;      // tile rows of a page in this list
+    const int per_page = nrow * a.tiles_x;
+    const int lenp = (a.ntiles / (a.tiles_x * a.tiles_y)) * per_page;
+    const int nk = bp < lenp ? (lenp - bp + Gp - 1) / Gp : 0;
+    auto tile_of = [&](int k) {
+        const int m = bp + (k < nk ? k : nk - 1) * Gp;
+        const int b_ = m / per_page, rem = m - b_ * per_page, j = rem / a.tiles_x, tx_ = rem - j * a.tiles_x;
+        return (b_ * a.tiles_y + (lists ? 2 * j + w4_par : j)) * a.tiles_x + tx_;
+    };
+    const bool w4_neg = w4_par != 0;
 
     // ---- plane copies (global -> LDS, 16 channels = 64 contiguous bytes per pixel and lane quad).  A slot = one 16-channel
     // group of the tile's 340 halo pixels = 22 wave instructions of 16 pixels; wave w issues j = w, w + 8, w + 16 (j < 22),
@@ -229,17 +246,14 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
 
     // ---- weights: position n = 18 ks + p of the 36-position stream is three 1 KB rows (pieces) of this wave's image;
     // wave-uniform base + this lane's fixed byte offset
-    // Tiles with odd tx + ty are multiplied with the image of -U and un-negated in the epilogue: the bf16 MFMA's accumulation is
-    // not sign-symmetric (its adder drops low product bits toward -inf: every output came out 7e-8 of the mean magnitude low,
+    // Odd tile rows are multiplied with the image of -U and un-negated in the epilogue: the bf16 MFMA's accumulation is not
+    // sign-symmetric (its adder drops low product bits toward -inf: every output came out 7e-8 of the mean magnitude low,
     // whatever its sign -- tools/w4s_bias.py, tools/probe/mfma_round_probe2.hip), a COHERENT offset that reductions over a map
-    // (BatchNorm sums, weight gradients) add up; alternating the sign by tile makes it cancel there.
-    const char *ubase0 = reinterpret_cast<const char *>(a.u) + (size_t)wave * (18 * 3 * 1024);
-    auto tile_ubase = [&](int k) {
-        const int tile_ = tile_of(k);
-        const int tx = tile_ % a.tiles_x, ty = (tile_ / a.tiles_x) % a.tiles_y;
-        return ubase0 + (((tx + ty) & 1) ? (size_t)w4::U_SPLIT_DWORDS * 4 : (size_t)0);
-    };
-    const char *ubase = tile_ubase(0), *ubase_next = tile_ubase(1);
+    // (BatchNorm sums, weight gradients) add up; alternating the sign by tile row makes it cancel there.  (Round 5 alternated in
+    // a checkerboard, (tx + ty) & 1, with every block taking tiles of both colours: both images streamed through every L2,
+    // FETCH_SIZE of the plain forward launch 1.96x its input against 1.27x for the f32 loop's single image.)
+    const char *const ubase = reinterpret_cast<const char *>(a.u) + (size_t)wave * (18 * 3 * 1024) +
+                              (w4_neg ? (size_t)w4::U_SPLIT_DWORDS * 4 : (size_t)0);
     const unsigned ulane = (unsigned)lane * 16u;
     constexpr int UR = W4S_LEAD + 1;
     static_assert(36 % UR == 0, "ring size must divide the 36-position stream");
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
     auto load_u = [&](const int n_, const int slot) {        // n_ >= 36: the position belongs to the NEXT tile of the stream
         if (W4S_ABL & 16) return;
         const int n = n_ % 36;
-        const char *ub_t = n_ >= 36 ? ubase_next : ubase;
+        const char *ub_t = ubase;
         const int ks = (W4S_ABL & 128) ? 0 : n / 18, p = (W4S_ABL & 128) ? 0 : n - 18 * ks;     // 128: always position 0 (L1 hits)
         if (W4S_ABL & 256) {                                         // 256: the operand from LDS (any 3 KB of the piece buffers)
 #pragma unroll
@@ -365,8 +379,6 @@ __global__ __launch_bounds__(w4::THREADS, 1) void conv3x3_c64_wino4s_kernel(cons
         step(k, I1{}, I0{});
         step(k, I1{}, I1{});
         step(k, I1{}, I2{});
-        ubase = ubase_next;
-        ubase_next = tile_ubase(k + 2);
         tile_epilogue(k);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the copies of the tile past the end have landed before the LDS is released)

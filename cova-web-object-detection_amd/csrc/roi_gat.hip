@@ -28,9 +28,8 @@ struct LazyFeat {
 // U: float4 loads per lane and map in flight per trip (4 U pixels of the bin; a bin of a large box is hundreds of pixels, and
 // a trip is a dependent memory round trip); XCD: consecutive blocks go to the eight XCDs in turn -- block b takes work block
 // (b % 8) * (grid / 8) + b / 8, so that the boxes of a page (adjacent in the box list) meet in ONE XCD's L2.
-// cova_set_option(18, v): 0 = <4, false> (rounds 1-4), 1 = <8, false>, 2 = <4, true>, 3 = <8, true> (default: 0.189 -> 0.174 ms
-// inside the step; 1: 0.178, 2: 0.186)
-int g_roipool_variant = 3;
+// 64-channel maps launch <8, true> (0.189 -> 0.174 ms inside the step against <4, false>; <8, false>: 0.178, <4, true>: 0.186),
+// wider maps <4, false> (bandwidth bound, eight loads per lane cost occupancy: configs[2] 1.51 against 1.59 ms).
 template <bool LAZY, int U = 4, bool XCD = false>
 __global__ __launch_bounds__(256) void roipool_fwd_kernel(
     const float *__restrict__ feat, const float *__restrict__ rois, int n_rois, int B, int C, int H,
@@ -227,8 +226,8 @@ __global__ __launch_bounds__(1024) void roipool_page_range_block_kernel(const fl
 // the arg-max, so this is the ReLU mask of the map's producer without reading the map.
 // gT / amT: the (masked) contributions and arg-max positions in [box][bin][channel] order (roipool_bwd_prep_kernel)
 // so that a wave's loads are 256 contiguous bytes.
-int g_roipool_bwd_nbx = 2;                        // cova_set_option(20, 2 | 4): boxes of a row segment visited per round trip (4 measured
-                                                  // slower: 0.146 against 0.123 ms for entry pass + rows -- 72 loads of which most bins miss the row)
+// NBX: boxes of a row segment visited per round trip (4 measured slower in round 5: 0.146 against 0.123 ms for entry pass + rows
+// -- 72 loads of which most bins miss the row)
 template <bool P33, int NBX = 2>                  // P33: the reference's 3x3 bins (models.py:58) as compile-time constants
 __global__ __launch_bounds__(256) void roipool_bwd_rows_kernel(
     const float *__restrict__ gT, const int32_t *__restrict__ amT, const float *__restrict__ rois,
@@ -1224,8 +1223,6 @@ inline int gat_wide_nd(int D)
 }  // namespace
 
 int cova_internal_set_gat_wide(int v) { g_gat_wide = v != 0; return COVA_OK; }
-int cova_internal_set_roipool_variant(int v) { g_roipool_variant = v; return COVA_OK; }
-int cova_internal_set_roipool_bwd_nbx(int v) { g_roipool_bwd_nbx = v == 4 ? 4 : 2; return COVA_OK; }
 
 // ====================================================================================
 // C ABI
@@ -1245,12 +1242,8 @@ COVA_API int cova_roipool_fwd(const float *feat, const float *rois, int n_rois, 
         const LazyFeat none{nullptr, nullptr, nullptr};
         // (wider maps: the channel-block loop multiplies the trips, the launch is bandwidth bound and loses occupancy with eight
         // loads per lane -- configs[2]: 1.51 ms with variant 0, 1.59 with 3; the default applies to 64-channel maps only)
-        switch (g_roipool_variant == 3 && C > 64 ? 0 : g_roipool_variant) {
-        case 1: COVA_ROIPOOL_FWD(false, 8, false, feat, nullptr, none); break;
-        case 2: COVA_ROIPOOL_FWD(false, 4, true, feat, nullptr, none); break;
-        case 3: COVA_ROIPOOL_FWD(false, 8, true, feat, nullptr, none); break;
-        default: COVA_ROIPOOL_FWD(false, 4, false, feat, nullptr, none); break;
-        }
+        if (C > 64) COVA_ROIPOOL_FWD(false, 4, false, feat, nullptr, none);
+        else COVA_ROIPOOL_FWD(false, 8, true, feat, nullptr, none);
     }
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -1269,12 +1262,8 @@ COVA_API int cova_roipool_fwd_bn(const float *z, const float *x, const float *sc
         const LazyFeat lzf{x, scale, shift};
         // (wider maps: the channel-block loop multiplies the trips, the launch is bandwidth bound and loses occupancy with eight
         // loads per lane -- configs[2]: 1.51 ms with variant 0, 1.59 with 3; the default applies to 64-channel maps only)
-        switch (g_roipool_variant == 3 && C > 64 ? 0 : g_roipool_variant) {
-        case 1: COVA_ROIPOOL_FWD(true, 8, false, z, zmax, lzf); break;
-        case 2: COVA_ROIPOOL_FWD(true, 4, true, z, zmax, lzf); break;
-        case 3: COVA_ROIPOOL_FWD(true, 8, true, z, zmax, lzf); break;
-        default: COVA_ROIPOOL_FWD(true, 4, false, z, zmax, lzf); break;
-        }
+        if (C > 64) COVA_ROIPOOL_FWD(true, 4, false, z, zmax, lzf);
+        else COVA_ROIPOOL_FWD(true, 8, true, z, zmax, lzf);
     }
     COVA_LAUNCH_CHECK();
     return COVA_OK;
@@ -1348,7 +1337,7 @@ static int launch_roipool_bwd(const float *gout, int ld_g, const float *pooled, 
         hipLaunchKernelGGL((roipool_bwd_prep_kernel<false, false>), pgrid, dim3(256), 0, st, gout, ld_g, pooled, ld_p, zmax,
                            argmax, n_rois, C, PH * PW, mean, invstd, gT, amT, partial, rois, B, page_range, t);
     COVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((PH == 3 && PW == 3 ? (g_roipool_bwd_nbx == 4 ? roipool_bwd_rows_kernel<true, 4> : roipool_bwd_rows_kernel<true, 2>)
+    hipLaunchKernelGGL((PH == 3 && PW == 3 ? roipool_bwd_rows_kernel<true, 2>
                                            : roipool_bwd_rows_kernel<false>),
                        dim3(roipool_bwd_grid(B, H, W), C / 64), dim3(256), 0, st, gT, amT, rois, page_range, n_rois,
                        B, C, H, W, PH, PW, spatial_scale, gfeat);

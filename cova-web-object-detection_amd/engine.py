@@ -397,10 +397,10 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
     # the Winograd images of the 3x3 weights: one small launch, on the side stream under conv1 + pool
     if bottleneck:
-        w4 = OPTIONS.wino4 and training
+        w4 = OPTIONS.wino4
         sv["_w3"] = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], images, w4, side=True)
     else:
-        w4 = OPTIONS.wino4 and (training or (not training and not save))
+        w4 = OPTIONS.wino4
         sv["_w3"] = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4, side=True)
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
@@ -494,7 +494,7 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     images = p1
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     infer = not training and not save
-    w4 = OPTIONS.wino4 and (training or infer)        # (an eval-mode forward that keeps its graph runs F(2x2,3x3))
+    w4 = OPTIONS.wino4
     wf, wd, w3_done = sv.pop("_w3")                   # (requested in front of the stem, convstack_fwd)
     side_wait(images, w3_done)
     sv["wd"], sv["w4"] = wd, w4
@@ -572,7 +572,7 @@ def conv1x1(inp, in2, abc, relu, w, w_trans, out, part, R, cin, cout, addend=Non
 def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    w4 = OPTIONS.wino4 and training
+    w4 = OPTIONS.wino4
     sv["w4"] = w4
     nt = conv3_num_partials(B, H2, W2, w4)
 

@@ -36,76 +36,24 @@ def nchw(x):   # NHWC gpu -> NCHW cpu
     return x.cpu().permute(0, 3, 1, 2).contiguous()
 
 
-@pytest.mark.parametrize("direct", [1, 2, 3])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(130, 992, 608), (1440, 976, 976), (976, 976, 1440), (45, 72, 64), (33, 100, 196), (64, 64, 1028)])
-def test_sgemm_register_direct_form(ta, tb, M, N, K, direct):
-    """cova_set_option(15, .): the GEMM whose waves stream their operands straight into registers (no LDS tiles, no barriers
-    in the k loop; 1 = k-groups chosen as usual, 2 / 3 = two / one forced) against fp64 and against the LDS-tiled kernel."""
-    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
-    A = torch.randn((K, M) if ta else (M, K), generator=g)
-    B = torch.randn((N, K) if tb else (K, N), generator=g)
-    bias = torch.randn(N, generator=g)
-    ref = ((A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()).float()
-    Ag, Bg = A.to(DEV), B.to(DEV)
-    C0, C = torch.full((M, N + 4), 7.0, device=DEV), torch.full((M, N + 4), 7.0, device=DEV)
-    call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C0, N + 4, bias.to(DEV), 0)
-    query("cova_set_option", 15, direct)
-    try:
-        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C, N + 4, bias.to(DEV), 0)
-        close(C[:, :N], ref, 2e-5, "sgemm direct")
-        close(C[:, :N], C0[:, :N], 1e-5, "sgemm direct against the tiled kernel")
-        assert (C[:, N:] == 7.0).all()
-        C2 = C.clone()
-        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C2, N + 4, bias.to(DEV), 0)
-        assert torch.equal(C2, C)                                  # deterministic
-        call("cova_sgemm", ta, tb, M, N, K, Ag, A.shape[1], Bg, B.shape[1], C, N + 4, None, 1)
-        close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm direct accumulate")
-    finally:
-        query("cova_set_option", 15, 0)
-
-
-@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(130, 992, 608), (1440, 992, 992), (992, 992, 1440), (45, 70, 257), (64, 64, 1028), (70, 33, 640)])
-def test_sgemm_two_tiles_ahead_is_bit_identical(ta, tb, M, N, K):
-    """cova_set_option(19, 1): operand tiles fetched two k-tiles ahead (two register sets): the same products in the same order."""
-    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
-    A = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
-    B = torch.randn((N, K) if tb else (K, N), generator=g).to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    C0, C1 = torch.full((M, N + 3), 7.0, device=DEV), torch.full((M, N + 3), 7.0, device=DEV)
-    call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C0, N + 3, bias, 0)
-    for mode in (1, 2):                # 2: two LDS buffers per k-group, one barrier per k-tile
-        query("cova_set_option", 19, mode)
-        try:
-            C1.fill_(7.0)
-            call("cova_sgemm", ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C1, N + 3, bias, 0)
-        finally:
-            query("cova_set_option", 19, 0)
-        assert torch.equal(C0, C1), mode
-
-
-@pytest.mark.parametrize("f32", [1, 0])
-@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3)])
-def test_sgemm(ta, tb, M, N, K, f32):
-    """f32 = 1: the f32-MFMA kernel (the path's default); 0: the bf16-split kernel kept for A/B (cova_set_option(11, 0))."""
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3), (1440, 976, 976), (976, 976, 1440),
+                                   (64, 64, 1028), (70, 33, 640)])
+def test_sgemm(ta, tb, M, N, K):
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
     B = torch.randn((N, K) if tb else (K, N), generator=g)
     bias = torch.randn(N, generator=g)
     ref = ((A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()).float()
     C = torch.full((M, N + 3), 7.0, device=DEV)
-    query("cova_set_option", 11, f32)
-    try:
-        call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3,
-             bias.to(DEV), 0)
-        close(C[:, :N], ref, 2e-5, "sgemm")
-        assert (C[:, N:] == 7.0).all()
-        call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, None, 1)
-        close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
-    finally:
-        query("cova_set_option", 11, 1)
+    call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, bias.to(DEV), 0)
+    close(C[:, :N], ref, 2e-5, "sgemm")
+    assert (C[:, N:] == 7.0).all()
+    C2 = torch.full((M, N + 3), 7.0, device=DEV)
+    call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C2, N + 3, bias.to(DEV), 0)
+    assert torch.equal(C2, C)                                  # deterministic
+    call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, None, 1)
+    close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 16, 64), (2, 37, 50), (1, 64, 64)])
@@ -286,14 +234,6 @@ def test_bn_relu_maxpool(B, H1, W1):
     call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, out, idx, ymax, B, H1, W1)
     close(nchw(out), ref, 1e-5, "maxpool fwd")
     close(torch.relu(ymax * st.scale + st.shift), out, 1e-6, "arg-max pre-activation")
-    for variant in range(0, 18):       # launch shapes of the same arithmetic (cova_set_option(13, .)): identical bits
-        query("cova_set_option", 13, variant)
-        try:
-            o2, i2, y2 = torch.empty_like(out), torch.empty_like(idx), torch.empty_like(ymax)
-            call("cova_bn_relu_maxpool_fwd", yg, st.scale, st.shift, o2, i2, y2, B, H1, W1)
-        finally:
-            query("cova_set_option", 13, 12)
-        assert torch.equal(o2, out) and torch.equal(i2, idx) and torch.equal(y2, ymax), variant
     npart = query("cova_bn_relu_maxpool_bwd_num_partials", B, H1, W1)
     bpart = torch.empty(npart, 2, 64, device=DEV)
     dpg = nhwc(dp)
@@ -348,17 +288,6 @@ def test_roipool_matches_oracle_bit_exact():
     call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_m, 576, arg_m)
     call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, out_l, 576, arg_l, zmax)
     assert torch.equal(out_l, out_m) and torch.equal(arg_l, arg_m)
-    for variant in (0, 1, 2):          # cova_set_option(18, .): 4 / 8 loads in flight, XCD-contiguous work blocks or not: same bits
-        query("cova_set_option", 18, variant)
-        try:
-            o2, a2 = torch.empty_like(out_m), torch.empty_like(arg_m)
-            o3, a3, z3 = torch.empty_like(out_l), torch.empty_like(arg_l), torch.empty_like(zmax)
-            call("cova_roipool_fwd", fmat, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, o2, 576, a2)
-            call("cova_roipool_fwd_bn", z, xres, scale, shift, rois.to(DEV), n, B, C, H, W, 3, 3, 0.25, o3, 576, a3, z3)
-        finally:
-            query("cova_set_option", 18, 3)
-        assert torch.equal(o2, out_m) and torch.equal(a2, arg_m), variant
-        assert torch.equal(o3, out_l) and torch.equal(a3, arg_l) and torch.equal(z3[arg_l >= 0], zmax[arg_l >= 0]), variant
     valid = arg_l >= 0
     pos = arg_l.clamp_min(0).long()
     page = rois[:, 0].long().to(DEV).view(n, 1)
@@ -367,13 +296,6 @@ def test_roipool_matches_oracle_bit_exact():
     scratch = torch.empty(query("cova_roipool_bwd_workspace_words", n, B, C, 3, 3), dtype=torch.int32, device=DEV)
     g_plain = torch.empty(B, H, W, C, device=DEV)
     call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_plain, scratch)
-    query("cova_set_option", 20, 4)        # four boxes per round trip instead of two: the same adds in the same order
-    try:
-        g_two = torch.empty(B, H, W, C, device=DEV)
-        call("cova_roipool_bwd", gout.to(DEV), 576, rois.to(DEV), arg_l, n, B, C, H, W, 3, 3, 0.25, g_two, scratch)
-    finally:
-        query("cova_set_option", 20, 2)
-    assert torch.equal(g_two, g_plain)
     npart = query("cova_roipool_bwd_bn_num_partials", n)
     part = torch.empty(npart, 2, C, device=DEV)
     gmask = torch.empty(B, H, W, C, device=DEV)
@@ -790,14 +712,6 @@ def test_batchnorm_finalize_as_launch_tail(B, H, W, cap):
             call("cova_bn_act_fwd", z, 64, msc, msh, x2, 64, act, 64, B * H * W, 64, 1)
             call("cova_bn_act_fwd_bits", z, msc, msh, x2, act2, bits, B * H * W)
             assert torch.equal(act, act2)
-            for un in (2, 4):                  # cova_set_option(17, .): two / four elements of a thread in flight
-                query("cova_set_option", 17, un)
-                try:
-                    act3, bits3 = torch.empty_like(x), torch.empty_like(bits)
-                    call("cova_bn_act_fwd_bits", z, msc, msh, x2, act3, bits3, B * H * W)
-                finally:
-                    query("cova_set_option", 17, 1)
-                assert torch.equal(act3, act2) and torch.equal(bits3, bits)
             sh = torch.arange(32, device=DEV, dtype=torch.int32).view(1, 1, 32)
             assert torch.equal(((bits.view(-1, 2, 1) >> sh) & 1).view(B, H, W, 64).bool(), act > 0)
             add = x2 * 0.5
@@ -923,7 +837,7 @@ def test_conv3x3_winograd_f4x4_wgrad(B, H, W, cap):
     try:
         ws = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", B, H, W), device=DEV)
         nblk = query("cova_conv3x3_wgrad4_num_partials", B, H, W)
-        assert ws.numel() == nblk * 9 * 4096 + ((nblk + 63) // 64) * 64        # transformed partial sums + one progress word per block
+        assert ws.numel() == nblk * 9 * 4096                                   # transformed partial sums
         dw = torch.zeros(64, 64, 3, 3, device=DEV)
         call("cova_conv3x3_wgrad4", x, dy, dw, ws, B, H, W)
         close(dw, wr.grad, 5e-5, "F(4x4) wgrad vs fp64")      # (random data: no coherent signal; the F(2x2) test allows 2e-4)

@@ -43,6 +43,7 @@ import time
 import traceback
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL: before the HIP runtime starts
+os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")     # the `ab` legs switch kernel forms inside this process (include/cova_hip.h)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -51,7 +52,6 @@ PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, f32-in
 PEAK_BF16_MFMA_TFLOPS = 2500.0                     # ... dense bf16 MFMA (the three-piece split kernels run six products per f32 product)
 PEAK_HBM_TBS = 8.0
 SPLIT_PRODUCTS = 6                                 # bf16 MFMA products per f32 multiply-add of the split kernels
-WINO_RATIO = 2.25                                  # multiplies of direct 3x3 / Winograd F(2x2,3x3): the weight gradients
 WINO4_RATIO = 4.0                                  # ... / Winograd F(4x4,3x3): forward and data-gradient launches
 TRAFFIC_FILES = [os.path.join("profiles", "r06_hbm_traffic.json"), os.path.join("profiles", "r05_hbm_traffic.json"),
                  os.path.join("profiles", "r04_hbm_traffic.json"), os.path.join("profiles", "r03_hbm_traffic.json")]
@@ -436,9 +436,7 @@ def run(args, guard, rank, local_rank, world):
         trainer.train_step(batch)
     barrier()
     guard.enter("timed steps")
-    timed = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv1_fwd_tail", "cova_conv3x3_wino",
-             "cova_conv3x3_wino_pro", "cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
-             "cova_conv3x3_wgrad_wino_partial", "cova_conv3x3_wgrad_wino_finish", "cova_conv3x3_wgrad4_partial",
+    timed = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv1_fwd_tail", "cova_conv3x3_wgrad4_partial",
              "cova_conv3x3_wgrad4_finish", "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad",
              "cova_bn_relu_maxpool_fwd", "cova_conv1x1", "cova_conv1x1_wgrad", "cova_bn_act_fwd", "cova_bn_act_fwd_bits",
              "cova_bn_act2_fwd", "cova_roipool_fwd_bn", "cova_roipool_bwd_bn", "cova_roipool_bwd_bn_tail", "cova_bn1d_fwd",
@@ -447,8 +445,7 @@ def run(args, guard, rank, local_rank, world):
     # Inside the timed steps only the DOMINANT family's launches are bracketed by HIP events (8 per such step: the roofline's
     # live measurement); the other kernels of `other_kernels` are timed in a separate short leg behind it -- bracketing all
     # ~45 launches of a step cost the headline 2 % (round 4's line against its own `sustained` leg)
-    dominant = [n for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv3x3_wino", "cova_conv3x3_wino_pro")
-                if n in timed]
+    dominant = [n for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail") if n in timed]
     # ... and only in every EVENT_EVERY-th timed step (steps 0, 5, 10, ...): an event pair around a launch is two marker packets in
     # the stream, ~20 us of lost back-to-back dispatch each pair -- with all 8 x 20 launches bracketed the headline of round 5's
     # last pass read 9.25 ms beside 8.93 ms of the same kernels in the event-free `ab.default` leg.  The same steps also bracket
@@ -599,11 +596,10 @@ def run(args, guard, rank, local_rank, world):
         fm = flop_model(wl)
         px_pages = pages
         w4_ms, w4_n = mean_ms(["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail"])
-        w2_ms, w2_n = mean_ms(["cova_conv3x3_wino", "cova_conv3x3_wino_pro"])
-        use4 = w4_n > 0
-        split = use4 and os.environ.get("COVA_W4_F32") != "1"        # the bf16 three-piece main loop (default since round 5)
-        conv_ms, conv_n, ratio = (w4_ms, w4_n, WINO4_RATIO) if use4 else (w2_ms, w2_n, WINO_RATIO)
-        kname = ("conv3x3_c64_wino4s_kernel" if split else "conv3x3_c64_wino4_kernel") if use4 else "conv3x3_c64_wino_kernel"
+        use4 = True                                                   # (F(4x4,3x3) is the only 3x3 family of the product since round 6)
+        split = os.environ.get("COVA_W4_F32") != "1"                 # the bf16 three-piece main loop (default since round 5)
+        conv_ms, conv_n, ratio = w4_ms, w4_n, WINO4_RATIO
+        kname = "conv3x3_c64_wino4s_kernel" if split else "conv3x3_c64_wino4_kernel"
         alg = fm["conv3_launch_per_page"] * px_pages                     # algorithmic FLOPs per launch
         executed = alg / ratio                                            # f32 multiply-adds the Winograd form executes
         map_bytes = 4 * 64 * px_pages * (wl["H"] // 4) * (wl["W"] // 4)
@@ -641,7 +637,7 @@ def run(args, guard, rank, local_rank, world):
                 if all(r["traffic"] for r in variants):                  # family traffic = the same launch mix as `achieved`
                     traffic = sum(r["traffic"] * r["launches"] for r in variants) / conv_n
                     src = src.replace(":step_families", ":step_kernels")
-            else:                                                          # F(2x2,3x3) launches (COVA_WINO4=0): input + output
+            else:
                 alg_bytes = 2 * map_bytes
             f32_equiv = executed / conv_ms / 1e9                          # TFLOP/s of f32 multiply-adds executed
             if split:
@@ -665,7 +661,7 @@ def run(args, guard, rank, local_rank, world):
                                             "note": "the round-4 line's `frac` (f32 multiply-adds executed over the 157.3 TFLOP/s the f32-MFMA "
                                                     "main loop is bounded by); the wino4_f32 A/B leg runs that loop"})
             else:
-                roof.update(bound="mfma", algorithm="winograd %s, exact f32 MFMA (v_mfma_f32_16x16x4_f32)" % ("F(4x4,3x3)" if use4 else "F(2x2,3x3)"),
+                roof.update(bound="mfma", algorithm="winograd F(4x4,3x3), exact f32 MFMA (v_mfma_f32_16x16x4_f32)",
                             achieved=round(f32_equiv, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(f32_equiv / PEAK_F32_MFMA_TFLOPS, 4),
                             achieved_is="EXECUTED MFMA FLOP/s (algorithmic / %g)" % ratio)
@@ -686,8 +682,7 @@ def run(args, guard, rank, local_rank, world):
                                   "the `ab` legs run without events" % (EVENT_EVERY, EVENT_EVERY, min(args.steps, 5)))
         step_alg = fm["total"] * pages                                   # per rank
         # executed multiply-adds: every 3x3 convolution at the Winograd share of the kernel that ran
-        _, wg4_n = mean_ms(["cova_conv3x3_wgrad4_partial"])
-        wg_ratio = WINO4_RATIO if wg4_n else WINO_RATIO
+        wg_ratio = WINO4_RATIO
         step_exec = (fm["total"] - fm["wino"] + fm["wino"] / 3 / wg_ratio + 2 * fm["wino"] / 3 / ratio) * pages
         step = {"algorithmic_gflop_per_page": round(fm["total"] / 1e9, 2),
                 "algorithmic_tflops": round(step_alg / (ms_per_step * 1e-3) / 1e12, 2),
@@ -704,12 +699,9 @@ def run(args, guard, rank, local_rank, world):
         c1_split = os.environ.get("COVA_CONV1_F32") != "1"
         specs = [("conv1_7x7_fwd", ["cova_conv1_fwd", "cova_conv1_fwd_tail"], None, f_conv1, 0, c1_split),
                  ("conv1_7x7_wgrad_with_pool_backward", ["cova_conv1_wgrad_poolbwd", "cova_conv1_wgrad"], None, f_conv1, 0, c1_split),
-                 ("conv3x3_wgrad_winograd_f2x2", ["cova_conv3x3_wgrad_wino_pro", "cova_conv3x3_wgrad_wino",
-                                                  "cova_conv3x3_wgrad_wino_partial"], None,
-                  fm["conv3_launch_per_page"] * pages / WINO_RATIO, 0),
                  ("conv3x3_wgrad_winograd_f4x4", ["cova_conv3x3_wgrad4_partial"], None,
                   fm["conv3_launch_per_page"] * pages / WINO4_RATIO, 0),
-                 ("conv3x3_wgrad_finish_all_convs", ["cova_conv3x3_wgrad_wino_finish", "cova_conv3x3_wgrad4_finish"], None, 0, 0),
+                 ("conv3x3_wgrad_finish_all_convs", ["cova_conv3x3_wgrad4_finish"], None, 0, 0),
                  ("bn_act_fwd_bits", ["cova_bn_act_fwd_bits"], None, 0, pages * 64 * 4 * 3 * hw),
                  ("roipool_fwd_lazy_feature", ["cova_roipool_fwd_bn"], None, 0, 0),
                  ("roipool_bwd_with_bn_tail", ["cova_roipool_bwd_bn", "cova_roipool_bwd_bn_tail"], None, 0, 0),

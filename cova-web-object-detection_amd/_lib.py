@@ -62,11 +62,6 @@ class _Lib:
             self.cdll.cova_set_option(7, 1)
         if os.environ.get("COVA_W4_F32") == "1":         # A/B: F(4x4,3x3) forward / data gradient on the f32-MFMA main loop
             self.cdll.cova_set_option(9, 1)
-        if os.environ.get("COVA_SGEMM_F32") == "0":      # A/B: the dense GEMMs of the head on the bf16-split kernel (slower)
-            self.cdll.cova_set_option(11, 0)
-        if os.environ.get("COVA_WG4_PAIR_SYNC") in ("0", "1"):   # A/B: pacing of the weight gradient's block pairs
-            self.cdll.cova_set_option(10, int(os.environ["COVA_WG4_PAIR_SYNC"]))
-
 
     def load_extra(self, header, lib_path):
         """Register the entry points of another C-ABI library (tools-only probes) under the same call()."""

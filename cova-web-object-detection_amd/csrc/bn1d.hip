@@ -353,6 +353,7 @@ inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 int cova_internal_set_bn1d_variant(int v) { g_bn1d_variant = v; return COVA_OK; }
+int cova_internal_get_bn1d_variant() { return (int)g_bn1d_variant; }
 
 COVA_API int cova_bn1d_fwd(const float *x, int ldx, int R, int C, const float *gamma, const float *beta,
                            float *running_mean, float *running_var, long long *num_batches_tracked, float momentum,

@@ -12,6 +12,7 @@
 // Roofline bookkeeping: 2*64*64*9 = 73,728 FLOP per output pixel
 // for conv3x3 (fwd, dgrad and wgrad each), 2*64*147 = 18,816 FLOP per output pixel for conv1.
 #include "common.h"
+#include <stdlib.h>
 #include "bf3.h"
 #include "bn_tail.h"
 #include <utility>
@@ -1406,8 +1407,10 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *_
 }
 
 extern int g_grid_cap;
+bool g_options_frozen = false;       // cova_set_option: the option state is fixed from the library's first query or launch on
 inline int persistent_grid(int ntiles, int blocks_per_cu = 1)
 {
+    g_options_frozen = true;             // every size query and every launch of the big kernels comes through here
     // compute units of the CURRENT device (the caller launches under the device guard of its tensors; the host
     // queries run under the same guard): cached per device id, not once per process
     static int cus_of[64] = {0};
@@ -1434,8 +1437,6 @@ int g_conv1_f32 = 0;         // 1: conv1 forward on the f32 MFMA kernel (v2) ins
 // shared with conv_wino.hip (same shared object; hidden visibility)
 int cova_internal_persistent_grid(int ntiles) { return persistent_grid(ntiles); }
 int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu) { return persistent_grid(ntiles, blocks_per_cu); }
-extern "C" int cova_internal_set_wino_geometry(int v);
-int cova_internal_ablate() { return g_ablate; }
 
 // ====================================================================================
 // C ABI
@@ -1445,16 +1446,32 @@ int cova_internal_ablate() { return g_ablate; }
 int cova_internal_set_wino4_f32(int v);
 int cova_internal_set_bn1d_variant(int v);
 int cova_internal_set_gat_wide(int v);
+// The option state is a per-process constant: mutable until the first query or launch, fixed afterwards (include/cova_hip.h) --
+// unless the process opted in with COVA_ALLOW_OPTION_CHANGES=1 (tests, bench.py's A/B legs).
+int cova_internal_get_bn1d_variant();
+int cova_internal_get_gat_wide();
+int cova_internal_get_wino4_f32();
 COVA_API int cova_set_option(int key, int value)
 {
-    if (key == 2) { g_grid_cap = value; return COVA_OK; }
-    if (key == 5) { g_ablate = value; return COVA_OK; }
-    if (key == 6) return cova_internal_set_wino_geometry(value);
-    if (key == 7) { g_conv1_f32 = value != 0; return COVA_OK; }
-    if (key == 9) return cova_internal_set_wino4_f32(value);
-    if (key == 14) return cova_internal_set_bn1d_variant(value);
-    if (key == 16) return cova_internal_set_gat_wide(value);
-    return COVA_ERR_BAD_ARG;
+    static const bool allow = [] { const char *e = getenv("COVA_ALLOW_OPTION_CHANGES"); return e != nullptr && e[0] == '1'; }();
+    int cur;
+    switch (key) {
+    case 2: cur = g_grid_cap; break;
+    case 7: cur = g_conv1_f32; value = value != 0; break;
+    case 9: cur = cova_internal_get_wino4_f32(); value = value != 0; break;
+    case 14: cur = cova_internal_get_bn1d_variant(); break;
+    case 16: cur = cova_internal_get_gat_wide(); value = value != 0; break;
+    default: return COVA_ERR_BAD_ARG;
+    }
+    if (cur == value) return COVA_OK;
+    if (g_options_frozen && !allow) return COVA_ERR_BAD_ARG;
+    switch (key) {
+    case 2: g_grid_cap = value; return COVA_OK;
+    case 7: g_conv1_f32 = value; return COVA_OK;
+    case 9: return cova_internal_set_wino4_f32(value);
+    case 14: return cova_internal_set_bn1d_variant(value);
+    default: return cova_internal_set_gat_wide(value);
+    }
 }
 
 #ifdef C1B_TRACE
@@ -1550,12 +1567,6 @@ COVA_API int cova_conv1_fwd_tail(const float *img, const float *w_oihw, float *o
                                  int W, const cova_bn_tail *tail, void *stream)
 {
     return conv1_fwd_launch(img, w_oihw, 1, out, stat_part, B, H, W, tail, stream);
-}
-
-COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
-{
-    const int ntiles = B * cdiv(W, 32) * cdiv(H, 4);              // upper bound for both weight-gradient forms
-    return persistent_grid(ntiles) * 2 * 9 * 4096 + 16 * 4096;   // + Q buffer of the Winograd form
 }
 
 COVA_API int cova_conv1_wgrad_workspace_floats(int B, int H, int W)

@@ -491,15 +491,15 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
     // f32 once.  The two position groups of a (co, ci) block are the waves w and w ^ 1: group 1 hands its nine values per
     // entry over through the operand buffers (idle now), group 0 adds and stores -- 9 x 4096 floats per block instead of
     // 18 x 4096: half the partial traffic of the launch and a quarter for the fold kernel, which no longer transforms.
-    auto fold = [&](auto hsel, auto psel) __attribute__((always_inline)) {
-        constexpr int HALF = decltype(hsel)::value, PG = decltype(psel)::value;
+    // (the transform of a wave's entries is specialised by its position half and group; the exchange around the block barrier is
+    // ONE piece of code every wave runs -- a barrier reached from four different instantiations works on gfx950, where s_barrier
+    // counts arrivals whatever their program counter, but is not something to rely on)
+    auto fold_values = [&](auto hsel, auto psel, auto esel, float (&tv)[4][9]) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(hsel)::value, PG = decltype(psel)::value, e = decltype(esel)::value;
         constexpr double G[6][3] = {{0.25, 0.0, 0.0},         {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-        float *dst = a.part + (size_t)blockIdx.x * PART_FLOATS;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float *xch = s_op + (e & 1) * (4 * 36 * 64) + (wave >> 1) * (36 * 64) + lane;       // [entry r][k 9][lane 64]
-            float tv[4][9];
+        {
+            {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double T[9];
@@ -529,31 +529,40 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
 #pragma unroll
                 for (int k = 0; k < 9; ++k) tv[r][k] = (float)T[k];
             }
-            if (PG == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) xch[(r * 9 + k) * 64] = tv[r][k];
-            }
-            __syncthreads();              // (area e & 1 is written again in round e + 2: the barrier of round e + 1 lies between)
-            if (PG == 0) {
-                const int i = e >> 1, j = e & 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int k = 0; k < 9; ++k)
-                        dst[k * 4096 + (16 * (2 * cp + i) + 4 * kq + r) * 64 + 16 * (2 * np + j) + l15] =
-                            tv[r][k] + xch[(r * 9 + k) * 64];
             }
         }
     };
-    __syncthreads();                      // every wave is out of its last operand reads (blocks without K-steps included)
-    {
+    float *dst = a.part + (size_t)blockIdx.x * PART_FLOATS;
+    auto fold_round = [&](auto esel) __attribute__((always_inline)) {
+        constexpr int e = decltype(esel)::value;
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
-        if (half == 0) { if (pg == 0) fold(H0{}, H0{}); else fold(H0{}, H1{}); }
-        else           { if (pg == 0) fold(H1{}, H0{}); else fold(H1{}, H1{}); }
-    }
+        float *xch = s_op + (e & 1) * (4 * 36 * 64) + (wave >> 1) * (36 * 64) + lane;       // [entry r][k 9][lane 64]
+        float tv[4][9];
+        if (half == 0) { if (pg == 0) fold_values(H0{}, H0{}, esel, tv); else fold_values(H0{}, H1{}, esel, tv); }
+        else           { if (pg == 0) fold_values(H1{}, H0{}, esel, tv); else fold_values(H1{}, H1{}, esel, tv); }
+        if (pg == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) xch[(r * 9 + k) * 64] = tv[r][k];
+        }
+        __syncthreads();              // (area e & 1 is written again in round e + 2: the barrier of round e + 1 lies between)
+        if (pg == 0) {
+            const int i = e >> 1, j = e & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    dst[k * 4096 + (16 * (2 * cp + i) + 4 * kq + r) * 64 + 16 * (2 * np + j) + l15] =
+                        tv[r][k] + xch[(r * 9 + k) * 64];
+        }
+    };
+    __syncthreads();                      // every wave is out of its last operand reads (blocks without K-steps included)
+    fold_round(std::integral_constant<int, 0>{});
+    fold_round(std::integral_constant<int, 1>{});
+    fold_round(std::integral_constant<int, 2>{});
+    fold_round(std::integral_constant<int, 3>{});
 }
 
 // Fold of the per-block partials (already transformed: part[block][r * 3 + t][co][ci]), up to four convolutions in one launch:

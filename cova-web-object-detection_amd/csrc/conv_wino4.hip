@@ -640,6 +640,7 @@ COVA_API int cova_conv3x3_wino4_num_partials(int B, int H, int W) { return w4_gr
 // 1: every launch on the f32 main loop (A/B, tests); 0 (default): the split main loop wherever it exists (one input tensor)
 int g_w4_f32 = 0;
 int cova_internal_set_wino4_f32(int v) { g_w4_f32 = v != 0; return COVA_OK; }
+int cova_internal_get_wino4_f32() { return (int)g_w4_f32; }
 
 // floats per convolution and direction of the transformed-weight buffers: [f32 register image | bf16-piece register image]
 COVA_API int cova_conv3x3_wino4_u_floats(void) { return w4::U_TOTAL; }

@@ -146,9 +146,11 @@ __global__ __launch_bounds__(1024) void linear_small_bwd_w_kernel(const float *_
                 }
 #pragma unroll
                 for (int k = 0; k < KN; ++k) dv[u][k] = (k < NC) ? dy[(size_t)nn * NC + k] : 0.f;
-                if (!ok) {
+                if (!ok) {              // padding slot: both factors zero (0 * x of a clamped row would be NaN where that x is inf)
 #pragma unroll
                     for (int k = 0; k < KN; ++k) dv[u][k] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[u][j] = 0.f;
                 }
             }
 #pragma unroll

@@ -1223,6 +1223,7 @@ inline int gat_wide_nd(int D)
 }  // namespace
 
 int cova_internal_set_gat_wide(int v) { g_gat_wide = v != 0; return COVA_OK; }
+int cova_internal_get_gat_wide() { return (int)g_gat_wide; }
 
 // ====================================================================================
 // C ABI

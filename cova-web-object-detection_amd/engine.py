@@ -271,8 +271,8 @@ def bn_backward(dout, ldd, act, lda, z, ldz, st, R, dz, lddz, dres=None, lddres=
 
 
 # ------------------------------------------------------------------------------- conv stack
-# 3x3 convolutions: Winograd kernels only.  The weight gradient is F(2x2,3x3) (csrc/conv_wino.hip); forward and data
-# gradient run as F(4x4,3x3) (csrc/conv_wino4.hip: 1.78x fewer MFMAs again) or F(2x2,3x3).  BatchNorm+ReLU between
+# 3x3 convolutions: Winograd F(4x4,3x3) kernels only (csrc/conv_wino4.hip forward / data gradient, csrc/conv_wgrad4.hip weight
+# gradient; the F(2x2,3x3) kernels of rounds 1-3 are a test-support library now, tools/csrc).  BatchNorm+ReLU between
 # the two convs of a block and the BatchNorm-backward "apply" passes are evaluated on load inside the consuming
 # convolutions: a1 and dz are never written to HBM.
 class _BnTailStruct(ctypes.Structure):
@@ -309,56 +309,14 @@ class BnTail:
 
 
 class Options:
-    """The one set of run-time switches of the path (process-wide; read at call time)."""
-    wino4 = os.environ.get("COVA_WINO4", "1") != "0"     # F(4x4,3x3) forward / data-gradient launches in training steps
+    """The run-time switches of the path (process-wide; read at call time)."""
     # data-parallel steps: the head's gradient all-reduce is issued under the conv-stack backward (trainer.py)
     overlap_allreduce = os.environ.get("COVA_OVERLAP_ALLREDUCE", "1") != "0"
     # BatchNorm finalize as the tail of the producing convolution launch (no separate finalize launches)
     bn_tail = os.environ.get("COVA_BN_TAIL", "1") != "0"
-    # weight gradients of the 3x3 convolutions as F(4x4,3x3) (csrc/conv_wgrad4.hip) instead of F(2x2,3x3)
-    wgrad4 = os.environ.get("COVA_WGRAD4", "1") != "0"
-    # small launches that nothing on the critical path waits for on a side stream under the big kernels: the Winograd
-    # weight images (under conv1 + pool), the transposed neighbour index of the GAT backward (under the conv stack), the fold of
-    # the 3x3 weight-gradient partials (under conv1's weight gradient).  OFF by default: measured 0.1-0.2 ms SLOWER per step
-    # (tools/ab_step.py 0 4: 9.40-9.57 against 9.27-9.41 ms) -- the big kernels are persistent grids of one block per CU with
-    # most of its LDS, a co-running block of another kernel delays one of their blocks and with it the launch's tail
-    side_stream = os.environ.get("COVA_SIDE_STREAM", "0") != "0"
 
 
 OPTIONS = Options()
-
-_SIDE_STREAMS = {}
-
-
-def side_stream_of(device):
-    st = _SIDE_STREAMS.get(device)
-    if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
-
-
-def side_run(like, fn, after=None):
-    """Enqueue fn()'s launches on `like`'s device's side stream -- behind `after` (an event of the main stream) or, when None,
-    behind everything enqueued on the main stream so far -- and return (fn's result, the event the consumer waits for with
-    side_wait).  Outputs must be allocated by the caller BEFORE `after` is recorded (the allocator knows only the main
-    stream); inputs that the main stream frees while the side work may still read them need record_stream()."""
-    dev = like.device
-    main, side = torch.cuda.current_stream(dev), side_stream_of(dev)
-    if after is None:
-        side.wait_stream(main)
-    else:
-        side.wait_event(after)
-    with torch.cuda.stream(side):
-        out = fn()
-        done = torch.cuda.Event()
-        done.record(side)
-    return out, done
-
-
-def side_wait(like, done):
-    if done is not None:
-        torch.cuda.current_stream(like.device).wait_event(done)
-
 
 CONV3_KEYS = ["convnet.4.0.conv1", "convnet.4.0.conv2", "convnet.4.1.conv1", "convnet.4.1.conv2"]
 BN3_KEYS = ["convnet.4.0.bn1.", "convnet.4.0.bn2.", "convnet.4.1.bn1.", "convnet.4.1.bn2."]
@@ -378,13 +336,6 @@ def is_bottleneck(params):
     return "convnet.4.0.conv3.weight" in params
 
 
-def prep_wino(w, like):
-    """conv3x3 OIHW weight -> Winograd-domain forward / data-gradient operands"""
-    a, b = _empty((16, 16, 4, 64), like), _empty((16, 16, 4, 64), like)
-    call("cova_conv3x3_prep_weights_wino", w, a, b)
-    return a, b
-
-
 @on_device_of(0)
 def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     """images NCHW [B,3,H,W] -> feature map NHWC [B,Hf,Wf,C]  (models.py:49-51,125);
@@ -395,13 +346,11 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     H2, W2 = query("cova_conv_out_size", H1, 3, 2, 1), query("cova_conv_out_size", W1, 3, 2, 1)
     bottleneck = is_bottleneck(params)
     sv = {"images": images, "dims": (B, H, W, H1, W1, H2, W2), "kind": "bottleneck" if bottleneck else "basic"}
-    # the Winograd images of the 3x3 weights: one small launch, on the side stream under conv1 + pool
+    # the Winograd images of the 3x3 weights: one small launch
     if bottleneck:
-        w4 = OPTIONS.wino4
-        sv["_w3"] = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], images, w4, side=True)
+        sv["_w3"] = conv3_weights([params["convnet.4.%d.conv2.weight" % b] for b in (0, 1, 2)], images)
     else:
-        w4 = OPTIONS.wino4
-        sv["_w3"] = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images, w4, side=True)
+        sv["_w3"] = conv3_weights([params[k + ".weight"] for k in CONV3_KEYS], images)
     # conv1 + bn1 + relu + maxpool
     y1 = _empty((B, H1, W1, C64), images)
     nt1 = query("cova_conv1_num_partials", B, H, W)
@@ -427,54 +376,37 @@ def convstack_fwd(images, params, buffers, training, save=True, lazy_out=False):
     return feat, (sv if save else None)
 
 
-def conv3_num_partials(B, H, W, wino4):
-    return query("cova_conv3x3_wino4_num_partials" if wino4 else "cova_conv3x3_wino_num_partials", B, H, W)
+def conv3_num_partials(B, H, W):
+    return query("cova_conv3x3_wino4_num_partials", B, H, W)
 
 
 def conv3x3_pro(u, inp, in2, abc, relu, addend, act, msc, msh, z, mean, invstd, out, part, B, H, W, tail=None,
                 act_bits=None):
-    """conv3x3 of f(A*inp + B*in2 + C) (abc / in2 nullable) with the fused epilogue of cova_conv3x3_wino_pro.
-    u = ("w4", operand) for the F(4x4,3x3) kernel or ("w2", operand) for F(2x2,3x3); tail (F(4x4) only): BnTail;
-    act_bits (with a tail only): the mask source `act` as one bit per element (cova_bn_act_fwd_bits)."""
-    kind, uw = u
+    """conv3x3 of f(A*inp + B*in2 + C) (abc / in2 nullable) with the fused epilogue of cova_conv3x3_wino4_full.
+    u = the F(4x4,3x3) weight operand (conv3_weights); tail: BnTail; act_bits (with a tail only): the mask source `act`
+    as one bit per element (cova_bn_act_fwd_bits)."""
     if tail is not None:
-        assert kind == "w4"
         if act_bits is not None:
             act = None
-        call("cova_conv3x3_wino4_full_tail", inp, in2, abc, relu, uw, addend, act, act_bits, msc, msh, z, mean, invstd,
+        call("cova_conv3x3_wino4_full_tail", inp, in2, abc, relu, u, addend, act, act_bits, msc, msh, z, mean, invstd,
              out, part, B, H, W, tail.ptr)
-    elif kind == "w4":
-        call("cova_conv3x3_wino4_full", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
-             B, H, W)
     else:
-        call("cova_conv3x3_wino_pro", inp, in2, abc, relu, uw, addend, act, msc, msh, z, mean, invstd, out, part,
+        call("cova_conv3x3_wino4_full", inp, in2, abc, relu, u, addend, act, msc, msh, z, mean, invstd, out, part,
              B, H, W)
 
 
-def conv3_weights(ws, like, wino4, side=False):
-    """3x3 weights (a list of up to four OIHW tensors) -> ([forward operands], [data-gradient operands]), each tagged
-    with its kernel family; the F(4x4) operands of all of them come from ONE launch.  side=True: that launch goes to the side
-    stream behind everything enqueued so far (call it BEFORE the stem is enqueued) and the result carries a third element,
-    the event to side_wait for in front of the first 3x3 launch."""
-    if wino4:
-        n = len(ws)
-        uf, ud = _empty((n, query("cova_conv3x3_wino4_u_floats")), like), _empty((n, query("cova_conv3x3_wino4_u_floats")), like)
-        prep = lambda: call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
-        done = None
-        if side and OPTIONS.side_stream:
-            _, done = side_run(like, prep)
-        else:
-            prep()
-        res = [("w4", uf[i]) for i in range(n)], [("w4", ud[i]) for i in range(n)]
-        return res + (done,) if side else res
-    pairs = [prep_wino(w, like) for w in ws]
-    res = [("w2", a) for a, _ in pairs], [("w2", b) for _, b in pairs]
-    return res + (None,) if side else res
+def conv3_weights(ws, like):
+    """3x3 weights (a list of up to four OIHW tensors) -> ([forward operands], [data-gradient operands]) of the F(4x4,3x3)
+    kernels, all from ONE launch."""
+    n = len(ws)
+    uf, ud = _empty((n, query("cova_conv3x3_wino4_u_floats")), like), _empty((n, query("cova_conv3x3_wino4_u_floats")), like)
+    call("cova_conv3x3_wino4_prep_multi", *(list(ws) + [None] * (4 - n)), uf, ud)
+    return [uf[i] for i in range(n)], [ud[i] for i in range(n)]
 
 
 def conv_bn_fwd(u, inp, abc, relu, out, prefix, params, buffers, training, part, nt, R, B, H, W):
     """3x3 conv (input relu?(abc . inp) on load) followed by a BatchNorm whose statistics it produces -> BNState"""
-    if training and u[0] == "w4" and tails_on():
+    if training and tails_on():
         st, tail = bn_tail_fwd(prefix, params, buffers, C64, inp, R)
         conv3x3_pro(u, inp, None, abc, relu, None, None, None, None, None, None, None, out, part, B, H, W, tail)
         return st
@@ -494,12 +426,10 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
     images = p1
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     infer = not training and not save
-    w4 = OPTIONS.wino4
-    wf, wd, w3_done = sv.pop("_w3")                   # (requested in front of the stem, convstack_fwd)
-    side_wait(images, w3_done)
-    sv["wd"], sv["w4"] = wd, w4
+    wf, wd = sv.pop("_w3")                            # (requested in front of the stem, convstack_fwd)
+    sv["wd"] = wd
     R = B * H2 * W2
-    nt = conv3_num_partials(B, H2, W2, w4)
+    nt = conv3_num_partials(B, H2, W2)
     x = p1
     blocks = []
     for blk in (0, 1):
@@ -508,26 +438,20 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             # prologues / epilogues -- two launches per BasicBlock, nothing else touches the maps
             bna = bn_params(BN3_KEYS[2 * blk], params, buffers, C64, images, False)
             bnb = bn_params(BN3_KEYS[2 * blk + 1], params, buffers, C64, images, False)
-            ua, ub = wf[2 * blk][1], wf[2 * blk + 1][1]
-            if w4:
-                # F(4x4,3x3): conv1 plain; conv2 reads relu(bn1(z1)) formed on load and either carries bn2 + identity +
-                # ReLU in its epilogue, or (last block, lazy feature map) leaves them to RoIPool
-                z1 = _empty((B, H2, W2, C64), images)
-                call("cova_conv3x3_wino4", x, ua, z1, None, B, H2, W2)
-                if blk == 1 and lazy_out:
-                    z2 = _empty((B, H2, W2, C64), images)
-                    call("cova_conv3x3_wino4_pro", z1, bna.abc, 1, ub, z2, None, B, H2, W2)
-                    feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
-                    blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=None, bna=bna, bnb=bnb))
-                    continue
-                out = _empty((B, H2, W2, C64), images)
-                call("cova_conv3x3_wino4_bnact", z1, bna.abc, 1, ub, x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
-                blocks.append(dict(x=x, z1=z1, a1=None, z2=None, out=out, bna=bna, bnb=bnb))
-            else:
-                a1, out = _empty((B, H2, W2, C64), images), _empty((B, H2, W2, C64), images)
-                call("cova_conv3x3_wino_bnact", x, ua, None, bna.scale, bna.shift, 1, a1, B, H2, W2)
-                call("cova_conv3x3_wino_bnact", a1, ub, x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
-                blocks.append(dict(x=x, z1=None, a1=a1, z2=None, out=out, bna=bna, bnb=bnb))
+            ua, ub = wf[2 * blk], wf[2 * blk + 1]
+            # conv1 plain; conv2 reads relu(bn1(z1)) formed on load and either carries bn2 + identity + ReLU in its epilogue,
+            # or (last block, lazy feature map) leaves them to RoIPool
+            z1 = _empty((B, H2, W2, C64), images)
+            call("cova_conv3x3_wino4", x, ua, z1, None, B, H2, W2)
+            if blk == 1 and lazy_out:
+                z2 = _empty((B, H2, W2, C64), images)
+                call("cova_conv3x3_wino4_pro", z1, bna.abc, 1, ub, z2, None, B, H2, W2)
+                feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
+                blocks.append(dict(x=x, z1=z1, a1=None, z2=z2, out=None, bna=bna, bnb=bnb))
+                continue
+            out = _empty((B, H2, W2, C64), images)
+            call("cova_conv3x3_wino4_bnact", z1, bna.abc, 1, ub, x, bnb.scale, bnb.shift, 1, out, B, H2, W2)
+            blocks.append(dict(x=x, z1=z1, a1=None, z2=None, out=out, bna=bna, bnb=bnb))
             x = feat = out
             continue
         part = _empty((nt, 2, C64), images) if training else None
@@ -540,7 +464,7 @@ def _layer1_basic_fwd(p1, params, buffers, training, save, lazy_out, sv):
             feat = LazyFeature(z2, x, bnb.scale, bnb.shift)
         else:
             out = _empty((B, H2, W2, C64), images)
-            if blk == 0 and training and sv["w4"] and tails_on():
+            if blk == 0 and training and tails_on():
                 # ... with its ReLU decisions as bits: the mask source of the next block's conv1 data gradient
                 out_bits = _empty((R, 2), images, torch.int32)
                 call("cova_bn_act_fwd_bits", z2, bnb.scale, bnb.shift, x, out, out_bits, R)
@@ -572,9 +496,7 @@ def conv1x1(inp, in2, abc, relu, w, w_trans, out, part, R, cin, cout, addend=Non
 def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    w4 = OPTIONS.wino4
-    sv["w4"] = w4
-    nt = conv3_num_partials(B, H2, W2, w4)
+    nt = conv3_num_partials(B, H2, W2)
 
     def stats(cin, cout):
         n = query("cova_conv1x1_num_partials", R, cin, cout)
@@ -583,8 +505,7 @@ def _layer1_bottleneck_fwd(p1, params, buffers, training, lazy_out, sv):
     def bn(prefix, C, part, n):
         return bn_params(prefix, params, buffers, C, p1, training, part, n, R, unit="pages")
 
-    ufs, uds, w3_done = sv.pop("_w3")
-    side_wait(p1, w3_done)
+    ufs, uds = sv.pop("_w3")
     x, cin, blocks, feat = p1, C64, [], None
     pending = None      # (z3, other, abc): the previous block's output relu(abc . (z3, other)), not yet written
     for blk in (0, 1, 2):
@@ -690,9 +611,8 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
     Returns the ReLU-masked gradient w.r.t. the max-pool output (sv['pool_part'] holds the stem's sums)."""
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
-    nt = conv3_num_partials(B, H2, W2, sv["w4"])
-    ws3 = _empty((query("cova_conv3x3_wgrad4_workspace_floats" if OPTIONS.wgrad4 else
-                        "cova_conv3x3_wgrad_workspace_floats", B, H2, W2),), g)
+    nt = conv3_num_partials(B, H2, W2)
+    ws3 = _empty((query("cova_conv3x3_wgrad4_workspace_floats", B, H2, W2),), g)
     ws1 = _empty((max(query("cova_conv1x1_wgrad_workspace_floats", R, C256, C64),
                       query("cova_conv1x1_vprod_workspace_floats", R)),), g)
     nd = query("cova_conv1x1_lin_dgrad_num_partials", R)
@@ -712,16 +632,11 @@ def _layer1_bottleneck_bwd(sv, g, params, gout, grads, head_part):
         grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
         # conv2 (3x3): Winograd weight / data gradient, bn1's ReLU mask + sums in the epilogue
         dw = _gbuf(gout, pre + "conv2.weight", (C64, C64, 3, 3), g)
-        d_in, d_in2, d_abc = dy2, s["z2"], abc2
-        if OPTIONS.wgrad4:
-            # ... with dz2 = abc2 . (dy2, z2) as its side output: the data gradient below reads one tensor, no prologue
-            dzm = _empty((B, H2, W2, C64), g) if sv["w4"] else None
-            call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dzm, ws3, B, H2, W2)
-            call("cova_conv3x3_wgrad4_finish", ws3, dw, None, None, None, None, None, None, B, H2, W2)
-            if dzm is not None:
-                d_in, d_in2, d_abc = dzm, None, None
-        else:
-            call("cova_conv3x3_wgrad_wino_pro", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dw, ws3, B, H2, W2)
+        # ... with dz2 = abc2 . (dy2, z2) as its side output: the data gradient below reads one tensor, no prologue
+        dzm = _empty((B, H2, W2, C64), g)
+        call("cova_conv3x3_wgrad4_partial", s["z1"], bn1.abc, 1, dy2, s["z2"], abc2, dzm, ws3, B, H2, W2)
+        call("cova_conv3x3_wgrad4_finish", ws3, dw, None, None, None, None, None, None, B, H2, W2)
+        d_in, d_in2, d_abc = dzm, None, None
         grads[pre + "conv2.weight"] = dw
         dy1 = _empty((B, H2, W2, C64), g)
         part = _empty((nt, 2, C64), g)
@@ -796,7 +711,7 @@ def dgrad_bn_bwd(u, g_in, g_in2, g_abc, addend, act, msc, msh, z, st, out, part,
     """Data-gradient conv3x3 (input g_abc . (g_in, g_in2) on load, + addend) whose epilogue masks with the ReLU of
     BatchNorm `st` and takes its backward sums; -> (dgamma, dbeta, abc) of that BatchNorm (finalized by the launch's tail
     or by a separate cova_bn_finalize_bwd_abc).  ``count`` = elements per channel of that BatchNorm."""
-    if u[0] == "w4" and tails_on() and not st.frozen:
+    if tails_on() and not st.frozen:
         dg, db, abc, tail = bn_tail_bwd(st, count, gout, prefix, out)
         conv3x3_pro(u, g_in, g_in2, g_abc, 0, addend, act, msc, msh, z, st.mean, st.invstd, out, part, B, H, W, tail,
                     act_bits=act_bits)
@@ -826,25 +741,19 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     R = B * H2 * W2
     # weight gradients: the four launches leave their per-block partial sums in four workspaces, ONE launch at the end
     # folds and transforms them (4 x 67 MB at configs[1]; a shared workspace would need a finish launch per convolution)
-    wg = "cova_conv3x3_wgrad4" if OPTIONS.wgrad4 else "cova_conv3x3_wgrad_wino"
-    nws = query("cova_conv3x3_wgrad4_workspace_floats" if OPTIONS.wgrad4 else "cova_conv3x3_wgrad_workspace_floats",
-                B, H2, W2)
+    wg = "cova_conv3x3_wgrad4"
+    nws = query("cova_conv3x3_wgrad4_workspace_floats", B, H2, W2)
     ws_all = _empty((4, nws), dfeat)
     jobs = []
 
     def wgrad(act, act_abc, act_relu, dz, dz2, dz_abc, dw):
         """-> the gradient operand dz_abc . (dz, dz2) as a materialised map (F(4x4) kernel's side output) or None"""
-        out = None
-        if OPTIONS.wgrad4:
-            if dz_abc is not None and sv["w4"]:
-                out = torch.empty_like(dz)
-            call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, out, ws_all[len(jobs)], B, H2, W2)
-        else:
-            call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, ws_all[len(jobs)], B, H2, W2)
+        out = torch.empty_like(dz) if dz_abc is not None else None
+        call(wg + "_partial", act, act_abc, act_relu, dz, dz2, dz_abc, out, ws_all[len(jobs)], B, H2, W2)
         jobs.append(dw)
         return out
 
-    nt = conv3_num_partials(B, H2, W2, sv["w4"])
+    nt = conv3_num_partials(B, H2, W2)
     # head_part = (partials, count): dfeat is already ReLU-masked and the BatchNorm-backward sums of
     # the last bn2 were taken by cova_roipool_bwd_bn
     dA, pend = dfeat, None                  # pend = (dgamma, dbeta, abc) of the bn2 in front of dA, when already known
@@ -904,12 +813,7 @@ def _layer1_bwd_fused(sv, dfeat, gout, grads, head_part=None):
     fin = []
     for i in range(4):
         fin += [ws_all[i], jobs[i]]
-    if OPTIONS.side_stream:
-        # the fold of the partials (0.1 ms, 0.3 GB) under conv1's weight gradient: convstack_bwd waits for it at its end
-        _, sv["_wg_done"] = side_run(dfeat, lambda: call(wg + "_finish", *fin, B, H2, W2))
-        ws_all.record_stream(side_stream_of(dfeat.device))       # (freed on return: not to be reused before the fold has read it)
-    else:
-        call(wg + "_finish", *fin, B, H2, W2)
+    call(wg + "_finish", *fin, B, H2, W2)
     return dA
 
 
@@ -938,7 +842,12 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None, want_dimg=F
     The data-gradient convs carry the ReLU mask and the BatchNorm-backward reduction of the layer
     in front of them in their epilogue (and its finalize in their tail), so only the last block's bn2
     (whose incoming gradient is RoIPool's scatter) needs a stand-alone reduction / finalize.
-    ``params`` is needed by the resnet50 extension only (its 1x1 convs read the weights directly)."""
+    ``params`` is needed by the resnet50 extension (its 1x1 convs read the weights directly) and by ``want_dimg``
+    (conv1's weight)."""
+    if want_dimg and (params is None or "convnet.0.weight" not in params):
+        raise ValueError("convstack_bwd(want_dimg=True) needs params with 'convnet.0.weight' (the transposed conv1)")
+    if sv["kind"] == "bottleneck" and params is None:
+        raise ValueError("convstack_bwd of the resnet50 stack needs params (its 1x1 convolutions read the weights)")
     B, H, W, H1, W1, H2, W2 = sv["dims"]
     R = B * H2 * W2
     grads = {}
@@ -984,7 +893,6 @@ def convstack_bwd(sv, dfeat, gout=None, head_part=None, params=None, want_dimg=F
         dimg = torch.empty_like(sv["images"])
         call("cova_conv1_dgrad", dy1, params["convnet.0.weight"], dimg, B, H, W)
         grads["__images__"] = dimg
-    side_wait(dfeat, sv.pop("_wg_done", None))          # the 3x3 weight gradients' fold (side stream) is part of this call's result
     return grads
 
 
@@ -1228,16 +1136,11 @@ def gat_stack_fwd(comb, T, N, F, D, ctx, params, n_heads=1, n_gat_layers=1):
     return layers
 
 
-def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None, csr_side=None):
-    """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F].  csr_side: (index, event) of a
-    transposed neighbour index already built on the side stream (model_fwd)."""
+def gat_stack_bwd(layers, dcomb, T, N, F, D, params, gout=None):
+    """dcomb[:, F:] = dL/d(context); accumulates dL/d(own features) into dcomb[:, :F]."""
     grads = {}
     g, ldg = dcomb[:, F:], T
-    if csr_side is not None:
-        csr, done = csr_side
-        side_wait(dcomb, done)
-    else:
-        csr = gat_transpose(layers[0]["heads"][0]["ctx"])
+    csr = gat_transpose(layers[0]["heads"][0]["ctx"])
     for l in reversed(range(len(layers))):
         heads = layers[l]["heads"]
         dh = D // len(heads)
@@ -1324,19 +1227,6 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     D = cfg["hidden_dim"] if cfg["use_context"] else 0
     T = F + D
     align = cfg.get("roi_op", "pool") == "align"
-    csr_side = None
-    if (save and training and D > 0 and N > 0 and OPTIONS.side_stream and context_indices.dtype == torch.int64
-            and context_indices.is_contiguous() and context_indices.device == images.device):
-        # the transposed neighbour index of the GAT backward depends on context_indices only: three small launches, on the
-        # side stream under the conv stack.  A COPY of the cached workspace (the side stream's own) goes into the saved
-        # state: another forward before this one's backward would overwrite the workspace.
-        main_stream = torch.cuda.current_stream(images.device)
-
-        def build_csr():
-            c = gat_transpose(context_indices).clone()
-            c.record_stream(main_stream)        # allocated under the side stream, read (and freed) under the main one
-            return c
-        csr_side = side_run(images, build_csr)
     feat, sv_conv = convstack_fwd(images, params, buffers, training, save, lazy_out=not align)
     comb = _empty((N, T), images)
     scale = cfg.get("spatial_scale") or feat.shape[1] / images.shape[2]   # models.py:56
@@ -1356,7 +1246,6 @@ def model_fwd(cfg, params, buffers, images, bboxes, additional_feats, context_in
     if D > 0:
         sv["gat"] = gat_stack_fwd(comb, T, N, F, D, context_indices, params, cfg.get("n_heads", 1),
                                   cfg.get("n_gat_layers", 1))
-        sv["gat_csr"] = csr_side
     logits, sv["dec"] = decoder_fwd(comb, N, T, params, buffers, training, cfg["drop_prob"], seeds,
                                     masks)
     return logits, (sv if save else None)
@@ -1371,7 +1260,7 @@ def model_bwd(sv, dlogits, params, gout=None, after_head=None, want_dimg=False):
     N, F, D, T, n_vis, Hd, A = (sv[k] for k in ("N", "F", "D", "T", "n_vis", "Hd", "A"))
     dcomb, grads = decoder_bwd(sv["dec"], dlogits, params, gout)
     if D > 0:
-        grads.update(gat_stack_bwd(sv["gat"], dcomb, T, N, F, D, params, gout, sv.get("gat_csr")))
+        grads.update(gat_stack_bwd(sv["gat"], dcomb, T, N, F, D, params, gout))
     if A > 0:
         st = sv["addl"]
         dz = _empty((N, A), dcomb)

@@ -158,14 +158,21 @@ class HotPathTrainer:
         (one all-reduce of an ok flag, so a KeyError on one rank raises on all of them), then rank 0's parameters and
         buffers -- what was loaded, not the Adam moments or the step count -- replace every rank's."""
         missing = [k for k in list(self.params) + list(self.buffers) if k not in state_dict]
+        # sizes are part of the validation every rank agrees on BEFORE any copy / broadcast: a tensor of the wrong size on
+        # one rank raising inside copy_ would leave the other ranks blocked in dist.broadcast
+        bad = [k for k in list(self.params) + list(self.buffers)
+               if k in state_dict and (not torch.is_tensor(state_dict[k]) or
+                                       state_dict[k].numel() != (self.params[k] if k in self.params else self.buffers[k]).numel())]
         if broadcast and self.world_size > 1:
-            self._all_ranks_ok(not missing, "load_state_dict")
+            self._all_ranks_ok(not missing and not bad, "load_state_dict")
         if missing:
             raise KeyError("state_dict lacks %s" % missing[:4])
+        if bad:
+            raise ValueError("state_dict entries of the wrong size: %s" % bad[:4])
         for k, p in self.params.items():
             p.copy_(state_dict[k].to(p.device).view_as(p))
         for k in self.buffers:
-            self.buffers[k].copy_(state_dict[k].to(self.device))
+            self.buffers[k].copy_(state_dict[k].to(self.device).view_as(self.buffers[k]))
         if broadcast and self.world_size > 1:
             import torch.distributed as dist
             for t in [self.pbucket.flat] + [self.buffers[k] for k in sorted(self.buffers)]:
@@ -182,13 +189,16 @@ class HotPathTrainer:
         rank must call (validated on all ranks first) after which every rank holds rank 0's moments, step count and
         hyper-parameters."""
         ok = all(k in state for k in ("step", "exp_avg", "exp_avg_sq"))
+        sized = ok and all(torch.is_tensor(state[k]) and state[k].numel() == self.exp_avg.numel() for k in ("exp_avg", "exp_avg_sq"))
         if broadcast and self.world_size > 1:
-            self._all_ranks_ok(ok, "load_optimizer_state_dict")
+            self._all_ranks_ok(ok and sized, "load_optimizer_state_dict")       # (sizes too: see load_state_dict)
         if not ok:
             raise KeyError("optimizer state lacks one of step / exp_avg / exp_avg_sq")
+        if not sized:
+            raise ValueError("optimizer state moments of the wrong size (expected %d elements)" % self.exp_avg.numel())
         self.step_count = int(state["step"])
-        self.exp_avg.copy_(state["exp_avg"].to(self.device))
-        self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device))
+        self.exp_avg.copy_(state["exp_avg"].to(self.device).view_as(self.exp_avg))
+        self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device).view_as(self.exp_avg_sq))
         self.hp.update(state.get("hp", {}))
         if broadcast and self.world_size > 1:
             import torch.distributed as dist

@@ -55,28 +55,18 @@ typedef struct cova_bn_tail {
  * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
-/* test / tool hook, not part of the path's contract: 2 = cap on the persistent grids (tests force many
- * tiles per block), 5 = ablation mask (builds with -DCOVA_ABLATE only), 6 = F(2x2) Winograd tile geometry (1 | 2),
- * 7 = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): A/B,
- * 8 = conv1 weight gradient (bf16-split) in its phase-structured form (1) instead of the role-split one (0, default): A/B,
- * 9 = F(4x4,3x3) forward / data-gradient launches on the f32-MFMA main loop (1) instead of the bf16-split one (0, default): A/B,
- * 10 = F(4x4,3x3) weight gradient: the two position halves of a walk pace each other through progress words (1) or run free
- *      (0, default: the pacing measured 3 % slower at the same HBM traffic, profiles/r05_pmc_wgrad4_pair_pacing.txt): A/B,
- * 11 = cova_sgemm on the f32-MFMA kernel (1, default) or the bf16-split one (0: measured slower, csrc/gemm.hip): A/B,
- * 12 = conv1 forward (bf16 split) with one wave per SIMD (1: measured slower, csrc/conv1_fwd_w4.h) or the 8-wave kernel (0, default): A/B,
- * 13 = cova_bn_relu_maxpool_fwd launch shape (0..17: strip height / grid cap / row prefetch / XCD-contiguous blocks / 4 x 4 tiles,
- *      csrc/bn.hip; default 12 = one output row per thread on XCD-contiguous blocks): A/B,
- * 14 = cova_bn1d_fwd / _bwd in the float4 form with every row of a thread in registers (1, default) or the 128-slice form (0): A/B,
- * 15 = cova_sgemm in the register-direct form (1; 2 / 3: two / one k-group forced) or on the LDS-tiled kernel (0): A/B (csrc/gemm.hip),
- * 16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0): A/B,
- * 17 = cova_bn_act_fwd_bits: elements of a thread in flight per trip (1, 2, 4): A/B,
- * 18 = cova_roipool_fwd(_bn): 0 = 4 loads per lane and map in flight, 1 = 8, 2 = 4 on XCD-contiguous work blocks, 3 = both (default): A/B,
- * 19 = cova_sgemm (LDS-tiled kernel, two k-groups): 0 = one LDS buffer, tiles one ahead; 1 = tiles two ahead; 2 = two LDS buffers per
- *      k-group, one barrier per k-tile: A/B,
- * 20 = cova_roipool_bwd*: boxes of a row segment visited per round trip, 2 (default) or 4 (measured slower): A/B.
- * 21 = cova_conv1_fwd* / cova_conv1_wgrad* (bf16-split kernels): 1 = the persistent blocks walk XCD-contiguous eighths of the
- *      tile list (same tiles, same arithmetic per tile; measured: no gain), 0 (default) = consecutive tiles to consecutive blocks.
- * Options 7-9 change the result of the matching *_num_partials queries: set them before any query. */
+/* Test / A-B hooks, not part of the path's contract (five keys; everything else is refused):
+ *   2  = cap on the persistent grids (tests force many tiles per block); 0 = none,
+ *   7  = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): bench.py's `ab` leg,
+ *   9  = F(4x4,3x3) forward / data-gradient launches on the f32-MFMA main loop (1) instead of the bf16-split one (0, default): `ab` leg,
+ *   14 = cova_bn1d_fwd / _bwd in the float4 form (1, default: taken when the operands are 16-byte aligned) or the 128-slice form (0),
+ *   16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0).
+ * 14 and 16 select between two kernels that both run by default (by alignment / by shape): the tests use them to compare the forms.
+ * The option state is a PER-PROCESS CONSTANT: it may be set until the library's first query or launch and is fixed from then on
+ * (launches captured into a hipGraph, workspace sizes already queried and a trainer's buffers all depend on it) -- a later
+ * cova_set_option that would CHANGE a value returns COVA_ERR_BAD_ARG (10001).  A process that sets COVA_ALLOW_OPTION_CHANGES=1
+ * in its environment before the library is loaded keeps them mutable (the test suite and bench.py's `ab` legs, which re-query
+ * every workspace size per step, do); options 7 and 9 change the result of the matching *_num_partials queries. */
 int cova_set_option(int key, int value);
 
 /* weight layout transforms (OIHW -> kernel layouts); run once per optimizer step */
@@ -115,54 +105,12 @@ int cova_conv1_wgrad_poolbwd(const float *img, const float *y1, const float *dp,
                              const float *abc, float *dw, float *ws, int B, int H, int W,
                              void *stream);
 
-/* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC [B,H,W,64] (torchvision BasicBlock / Bottleneck conv2; models.py:49-51), as
- * Winograd convolutions in exact f32 arithmetic (the direct implicit-GEMM kernels of round 1 live in tools/csrc).
- * F(2x2,3x3) form (2.25x fewer MFMAs than direct, same fp32 error): weights are transformed once per step into
- * u_fwd / u_dgrad [16,16,4,64]; with u_dgrad it is the data gradient; addend (nullable, NHWC) is added to the result
- * (residual-branch gradient).  With act / z / mean / invstd the data gradient is fused with the ReLU mask and the
- * BatchNorm-backward reduction of the layer in front of the conv: out = dy = (conv + addend) * (act > 0), stat_part =
- * (sum dy, sum dy*xhat); otherwise stat_part (nullable) = (sum y, sum y^2).  stat_part has one row per persistent
- * block: [cova_conv3x3_wino_num_partials][2][64]. */
-/* rows of the statistics partials of cova_conv3x3_wino(_pro): one per persistent block (depends on the
- * device's CU count and on cova_set_option 2 / 6: query it right before allocating) */
-int cova_conv3x3_wino_num_partials(int B, int H, int W);
-int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_dgrad, void *stream);
-int cova_conv3x3_wino(const float *in, const float *u, const float *addend, const float *act,
-                      const float *z, const float *mean, const float *invstd, float *out,
-                      float *stat_part, int B, int H, int W, void *stream);
-/* Inference form of cova_conv3x3_wino: out = f(scale[c]*conv(in) + shift[c] + addend), f = ReLU if relu --
- * the BatchNorm (running statistics, cova_bn_eval_params), residual add (addend, nullable) and ReLU that
- * follow each conv of a BasicBlock (models.py:49-51 -> torchvision BasicBlock.forward), evaluated in the
- * epilogue in cova_bn_act_fwd's operation order (bit-identical to conv + cova_bn_act_fwd). */
-int cova_conv3x3_wino_bnact(const float *in, const float *u, const float *addend, const float *scale,
-                            const float *shift, int relu, float *out, int B, int H, int W, void *stream);
-/* input transformed on load: f(A[c]*in + B[c]*in2 + C[c]), f = ReLU if pro_relu; pro_abc [3,64]
- * (nullable = plain input); in2 nullable (B ignored).  Folds BatchNorm+ReLU (models.py:49-51 via
- * torchvision BasicBlock bn1/relu), or the BatchNorm-backward apply, into the consuming conv.
- * Epilogue mask: act > 0, or fma(mask_scale, z, mask_shift) > 0 when act == NULL. */
-int cova_conv3x3_wino_pro(const float *in, const float *in2 /*nullable*/,
-                          const float *pro_abc /*nullable*/, int pro_relu, const float *u,
-                          const float *addend /*nullable*/, const float *act /*nullable*/,
-                          const float *mask_scale /*nullable*/, const float *mask_shift /*nullable*/,
-                          const float *z /*nullable*/, const float *mean /*nullable*/,
-                          const float *invstd /*nullable*/, float *out, float *stat_part /*nullable*/,
-                          int B, int H, int W, void *stream);
-int cova_conv3x3_wgrad_wino(const float *act, const float *dz, float *dw /*OIHW*/, float *ws, int B,
-                            int H, int W, void *stream);   /* weight gradient, Winograd F(2x2,3x3) form */
-int cova_conv3x3_wgrad_wino_pro(const float *act, const float *act_abc /*nullable*/, int act_relu,
-                                const float *dz, const float *dz2 /*nullable*/,
-                                const float *dz_abc /*nullable*/, float *dw, float *ws, int B, int H,
-                                int W, void *stream);
-/* the same in two steps, so that one launch finishes the weight gradients of several convolutions: the per-block
- * partial sums only (own workspace per convolution) ... */
-int cova_conv3x3_wgrad_wino_partial(const float *act, const float *act_abc, int act_relu, const float *dz,
-                                    const float *dz2, const float *dz_abc, float *ws, int B, int H, int W,
-                                    void *stream);
-/* ... and the fp64 fold + final transform of up to four of them (pairs 1..3 nullable) into OIHW [64,64,3,3] */
-int cova_conv3x3_wgrad_wino_finish(const float *ws0, float *dw0, const float *ws1, float *dw1, const float *ws2,
-                                   float *dw2, const float *ws3, float *dw3, int B, int H, int W, void *stream);
-int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W);
-/* Weight gradient in Winograd F(4x4,3x3) form (csrc/conv_wgrad4.hip; 1.78x fewer MFMAs than the F(2x2,3x3) form above,
+/* nn.Conv2d(64,64,3,1,1,bias=False) on NHWC [B,H,W,64] (torchvision BasicBlock / Bottleneck conv2; models.py:49-51) runs as
+ * Winograd F(4x4,3x3) convolutions in f32-class arithmetic (below).  The F(2x2,3x3) kernels of rounds 1-3 (forward, data
+ * gradient, weight gradient) left the product library in round 6: tools/csrc/conv_wino_f2x2.hip + tools/include/cova_wino_f2x2.h,
+ * built as a test-support library (the F(4x4) kernel tests cross-check against them); the direct implicit-GEMM kernels of
+ * round 1 live in tools/csrc as well. */
+/* Weight gradient in Winograd F(4x4,3x3) form (csrc/conv_wgrad4.hip; 1.78x fewer MFMAs than the F(2x2,3x3) form,
  * fp32 error 3.7e-6 of the gradient's scale): replaces autograd's conv2d weight gradient of the four layer1 3x3
  * convolutions (torchvision BasicBlock conv1 / conv2, models.py:49-51; loss.backward() at train.py:59).  Same two-step
  * contract as cova_conv3x3_wgrad_wino_partial / _finish: activation = relu?(A*act + C) on load (act_abc nullable),

@@ -1359,3 +1359,20 @@ def test_conv1_data_gradient_and_pool_backward_operand(B, H, W):
     want = abc[0].cpu().double() * route + abc[1].cpu().double() * y1.cpu().double() + abc[2].cpu().double()
     assert torch.isfinite(got).all()
     close(got, want, 1e-6, "pool-backward operand")
+
+
+def test_option_state_is_fixed_after_the_first_query():
+    """cova_set_option: mutable until the library's first query or launch, refused afterwards (10001) unless the process opted in
+    with COVA_ALLOW_OPTION_CHANGES=1 (this suite and bench.py do); setting a key to the value it has always succeeds."""
+    import os
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('COVA_ALLOW_OPTION_CHANGES', None)\n"
+            "import cova_amd; from cova_web_object_detection_amd import _lib; q = _lib.query\n"
+            "r = [q('cova_set_option', 9, 1), q('cova_set_option', 9, 0), q('cova_set_option', 3, 1)]\n"
+            "n = q('cova_conv3x3_wino4_num_partials', 2, 64, 64)\n"
+            "r += [q('cova_set_option', 9, 0), q('cova_set_option', 9, 1), q('cova_set_option', 2, 5), q('cova_set_option', 2, 0)]\n"
+            "print(r)" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "[0, 0, 10001, 0, 10001, 10001, 0]", out.stdout

@@ -724,33 +724,6 @@ def test_input_layout_and_index_dtype_do_not_change_the_result():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cova_h64_n90", "cova_h128_ragged"])
-def test_f2x2_conv_path_keeps_reference_parity(name, monkeypatch):
-    """The F(2x2,3x3) forward / data-gradient launches (engine.OPTIONS.wino4 = False; the default is F(4x4,3x3),
-    csrc/conv_wino4.hip, which every other model test runs) against the same reference fixtures and the
-    forced-routing oracle, at the same bounds."""
-    monkeypatch.setattr(engine.OPTIONS, "wino4", False)
-    fx, cfg, sd, batch = load_case(name)
-    img_h = int(fx["meta/img_h"])
-    args = dev_batch(batch)
-    m = build(cfg, img_h, sd)
-    m.train()
-    logits = m(*args)
-    routing = routing_from_saved(logits.grad_fn.sv)
-    loss = torch.nn.CrossEntropyLoss(reduction="sum")(logits, batch["labels"].to(DEV))
-    loss.backward()
-    assert relerr(logits.detach().cpu(), fx["train/logits"]) < LOGIT_TOL
-    assert abs(loss.item() - float(fx["train/loss"])) <= LOSS_TOL * abs(float(fx["train/loss"]))
-    grads = {k: p.grad for k, p in m.named_parameters()}
-    _, _, grads_ref, _, _ = O.loss_and_grads(sd, batch["images"], batch["bboxes"], batch["additional_feats"],
-                                             batch["context_indices"], batch["labels"], cfg, None, routing)
-    compare_grads(grads, grads_ref, rtol=GRAD_TOL, outlier_frac=0.0)
-    for k, buf in m.named_buffers():
-        if "buf/" + k in fx:
-            assert relerr(buf.cpu(), fx["buf/" + k]) < 1e-4, k
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("training", [True, False])
 def test_gradient_with_respect_to_the_images(training):
     """`images.requires_grad` (the reference gets d loss / d images from autograd through nn.Conv2d, models.py:94-122): the

@@ -20,7 +20,7 @@
 //     a double-buffered 2 x 20 KB LDS ring, one 4-channel chunk per barrier; a lane's 16 positions
 //     are contiguous (4 ds_read_b128 per channel block), rows padded to 20 floats (conflict free).
 // Per tile: 16 chunks x (16 A reads + 32 adds + 32 B reads + 32 MFMAs) per wave.
-#include "common.h"
+#include "../../cova-web-object-detection_amd/csrc/common.h"
 
 namespace {
 
@@ -584,9 +584,27 @@ __global__ void prep_wino_kernel(const float *__restrict__ w, float *__restrict_
 
 }  // namespace
 
-extern int cova_internal_persistent_grid(int ntiles);
-extern int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu);
-extern int cova_internal_ablate();
+// (this library's own copies of the product library's launch helpers: persistent grid = one block per CU and blocks_per_cu,
+// capped for the tests; ablation mask of -DCOVA_ABLATE builds)
+static int g_f2_grid_cap = 0, g_f2_ablate = 0;
+static int cova_internal_persistent_grid2(int ntiles, int blocks_per_cu)
+{
+    static int cus_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cus_of[dev];
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        cus_of[dev] = cus;
+    }
+    int g = ntiles < cus * blocks_per_cu ? ntiles : cus * blocks_per_cu;
+    if (g_f2_grid_cap > 0 && g > g_f2_grid_cap) g = g_f2_grid_cap;
+    return g;
+}
+static int cova_internal_persistent_grid(int ntiles) { return cova_internal_persistent_grid2(ntiles, 1); }
+static int cova_internal_ablate() { return g_f2_ablate; }
 
 // u_fwd / u_dgrad: [16 chunks][4 ci][64 co][16 positions] floats each (65,536)
 COVA_API int cova_conv3x3_prep_weights_wino(const float *w_oihw, float *u_fwd, float *u_dgrad,
@@ -636,11 +654,19 @@ static void launch_wino_epi(const WinoArgs &a)
 // by instruction issue (MFMA + VALU + LDS share the SIMD's issue slots), not by latencies a second
 // block could hide -- and 0.5-1 % slower over the whole step (twice the statistics partials, more halo).
 static int g_wino_geometry = 1;
-extern "C" int cova_internal_set_wino_geometry(int v)
+COVA_API int cova_wino_f2x2_set_option(int key, int v)
 {
-    if (v != 1 && v != 2) return COVA_ERR_BAD_ARG;
+    if (key == 2) { g_f2_grid_cap = v; return COVA_OK; }
+    if (key == 5) { g_f2_ablate = v; return COVA_OK; }
+    if (key != 6 || (v != 1 && v != 2)) return COVA_ERR_BAD_ARG;
     g_wino_geometry = v;
     return COVA_OK;
+}
+
+COVA_API int cova_conv3x3_wgrad_workspace_floats(int B, int H, int W)
+{
+    const int ntiles = B * cdiv(W, 32) * cdiv(H, 4);
+    return cova_internal_persistent_grid(ntiles) * 2 * 9 * 4096 + 16 * 4096;   // + Q buffer of the Winograd form
 }
 
 template <class G>

@@ -253,6 +253,44 @@ def cpu_baseline(wl, full=False):
     return out
 
 
+# ------------------------------------------------------------------------------------ per-kernel clock
+def clock_leg(args):
+    """Effective shader clock of the step's big kernels on THIS box: a short run of this script (3 timed steps) under
+    `rocprofv3 --pmc GRBM_GUI_ACTIVE` (counters only: no tracing domain beside them), clock = counter / 8 XCDs / launch
+    duration -- the recipe of MI355X_MICROARCH.md.  The MFMA-dense kernels run power-limited (conv1 forward 1.96 GHz on the
+    round-5 boxes against 2.35 GHz for the memory-bound passes): a box on which conv1 forward takes 1.0 instead of 0.77 ms
+    shows here whether it is the clock.  Failures are reported, never raised."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="cova_clk_", dir="/tmp")
+    cmd = [exe, "--pmc", "GRBM_GUI_ACTIVE", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--sustained-seconds", "0", "--no-ab", "--no-clock-leg", "--config", str(args.config)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        dbs = [os.path.join(d, f) for d, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+        if not dbs:
+            return {"error": "no rocprofv3 database (rc %d): %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+        db = sqlite3.connect(dbs[0])
+        rows = db.execute("select kernel_name, count(*), avg(value), avg(duration), sum(duration) from counters_collection "
+                          "where counter_name = 'GRBM_GUI_ACTIVE' group by kernel_name order by sum(duration) desc").fetchall()
+        out = {"how": "GRBM_GUI_ACTIVE / 8 XCDs / launch duration over every launch of a 2 + 3 step run under rocprofv3 --pmc "
+                      "(launch times under the counter pass run ~1 % long)", "kernels": []}
+        for name, n, val, dur, _ in rows[:14]:
+            name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            out["kernels"].append({"kernel": name[:72], "launches": n, "mean_us": round(dur / 1e3, 1),
+                                   "effective_ghz": round(val / 8.0 / dur, 3)})
+        return out
+    except Exception as e:          # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------ launch
 def free_port():
     s = socket.socket()
@@ -332,6 +370,9 @@ def main():
     ap.add_argument("--roi-op", choices=("pool", "align"), default="pool",
                     help="pool = the reference's RoIPool (the metric's configuration); align = the RoIAlign variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ab", action="store_true", help="skip the A/B legs (f32-MFMA forms of conv1 / the 3x3 main loop)")
+    ap.add_argument("--no-clock-leg", action="store_true",
+                    help="skip the per-kernel effective-clock leg (a 5-step child run under rocprofv3 --pmc GRBM_GUI_ACTIVE)")
     ap.add_argument("--cpu-baseline-quick", action="store_true",
                     help="16-page CPU leg with 1 warm-up + 3 timed steps (default: 3 + 5 as SURVEY.md 8d asks)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
@@ -520,7 +561,7 @@ def run(args, guard, rank, local_rank, world):
     # kernels that run on the bf16 matrix pipe by default -- conv1 forward + weight gradient (cova_set_option 7) and the
     # F(4x4,3x3) forward / data-gradient main loop (option 9) -- each 3 warm-up + 10 timed steps
     ab = {}
-    if world == 1:
+    if world == 1 and not args.no_ab:
         guard.enter("A/B legs")
         pre7, pre9 = os.environ.get("COVA_CONV1_F32") == "1", os.environ.get("COVA_W4_F32") == "1"
         for key, opt, pre, what in (("default", 0, False, "the headline's kernels, timed like the other two legs (no events)"),
@@ -764,6 +805,9 @@ def run(args, guard, rank, local_rank, world):
                                    "(0 on one rank)"}
         if dropin:
             out["dropin_module_loop"] = dropin
+        if world == 1 and not args.no_clock_leg and args.roi_op == "pool":
+            torch.cuda.synchronize()
+            out["clock_leg"] = clock_leg(args)
         if world == 1 and not args.no_cpu_baseline and args.roi_op == "pool":
             out["cpu_baseline"] = cpu_baseline(wl, not args.cpu_baseline_quick)
         print(json.dumps(out), flush=True)

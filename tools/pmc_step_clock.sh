@@ -6,7 +6,7 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/r5b; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for f32 in 0 1; do
-  COVA_W4_F32=$f32 rocprofv3 --pmc GRBM_GUI_ACTIVE -d /tmp/pmcclk_$f32 -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --sustained-seconds 0 > /tmp/pmcclk_$f32.log 2>&1
+  COVA_W4_F32=$f32 rocprofv3 --pmc GRBM_GUI_ACTIVE -d /tmp/pmcclk_$f32 -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-clock-leg --no-ab --sustained-seconds 0 > /tmp/pmcclk_$f32.log 2>&1
   db=$(find /tmp/pmcclk_$f32 -name "*.db" | head -1)
   echo "== COVA_W4_F32=$f32: kernel, launches, mean us, effective GHz (GRBM_GUI_ACTIVE / 8 / duration)"
   [ -n "$db" ] && python - "$db" <<'PY'

@@ -9,7 +9,7 @@ if [ "$2" != "notests" ]; then timeout 900 python -m pytest tests -m gpu -x -q >
 cd /tmp && export TMPDIR=/tmp
 for tag in prev new prev2 new2; do
   if [ "${tag:0:4}" = "prev" ]; then [ -z "$COVA_AB_LIB" ] && continue; export COVA_HIP_LIB=$COVA_AB_LIB; else unset COVA_HIP_LIB; fi
-  rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -- python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --sustained-seconds 0 > $root/$o/${tag}_kt.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -- python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-clock-leg --no-ab --sustained-seconds 0 > $root/$o/${tag}_kt.log 2>&1
   db=$(find /tmp/kt_$tag -name "*.db" | head -1)
   [ -n "$db" ] && python $root/tools/rocpd_step.py $db 2 --order > $root/$o/${tag}_step_breakdown.txt
   head -1 $root/$o/${tag}_step_breakdown.txt

@@ -1,14 +1,15 @@
 """Interleaved A/B of the train step at configs[1] in ONE process: alternates cova_set_option(<key>, 0 / 1) every 10 steps,
 <rounds> times, and prints the step time of every leg plus the mean launch times of the big kernels in each mode.
-  python tools/ab_step.py [key=9] [rounds=4]        key 9: F(4x4) split / f32 main loop, 7: conv1 split / f32, 10: wgrad4 pacing on / off"""
+  python tools/ab_step.py [key=9] [rounds=4]        key 9: F(4x4) split / f32 main loop, 7: conv1 split / f32"""
 import os, sys, time
+os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cova_amd  # noqa: F401
 import bench
 from cova_web_object_detection_amd import _lib, weights
 from cova_web_object_detection_amd.trainer import HotPathTrainer
-key = int(sys.argv[1]) if len(sys.argv) > 1 else 9          # key 0: engine.OPTIONS.side_stream on (value 0) / off (value 1)
+key = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 vals = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 1)      # the two option values that alternate
 dev = torch.device("cuda", 0)
@@ -23,14 +24,10 @@ names = ["cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail", "cova_conv3x
 for _ in range(5):
     tr.train_step(batch)
 torch.cuda.synchronize()
-# option value 1 = the A/B alternative (f32 kernels for keys 7 and 9, pair pacing for key 10)
+# option value 1 = the A/B alternative (f32 kernels for keys 7 and 9)
 for r in range(rounds):
     for val in vals:
-        if key == 0:
-            from cova_web_object_detection_amd import engine
-            engine.OPTIONS.side_stream = val == 0
-        else:
-            _lib.query("cova_set_option", key, val)
+        _lib.query("cova_set_option", key, val)
         for _ in range(3):
             tr.train_step(batch)
         torch.cuda.synchronize()

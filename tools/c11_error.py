@@ -4,6 +4,7 @@ csrc/conv1x1_lin.hip) against fp64, beside a plain f32 GEMM of the same operands
   max   = max |got - ref| / max |ref|        rms = rms(got - ref) / rms(ref)        bias = mean(got - ref) / mean |ref|
 (the bias column is what a coherent rounding direction of the bf16 MFMA would show; odd row tiles / blocks are multiplied with
 negated activations and negated back).  python tools/c11_error.py [R]"""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os
 import sys
 

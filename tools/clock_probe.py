@@ -1,6 +1,7 @@
 """Does a launch on the bf16 matrix pipe slow the matrix-bound launch behind it?  Times the plain F(4x4) forward launch
 (HIP events around it) alone, behind the f32-MFMA conv1 forward and behind the bf16-split conv1 forward, back to back
 on one stream, at the bench shapes."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

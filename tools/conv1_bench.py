@@ -1,6 +1,7 @@
 """conv1 (7x7 stride 2, 3 -> 64) forward on the benchmark page batch (16 x 3 x 1280 x 1280): the bf16-split kernel
 (csrc/conv.hip, conv1_7x7_bf3_kernel) against the f32-MFMA kernel (cova_set_option(7, 1)), time per launch and error of
 both against a float64 convolution on a smaller batch."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -99,14 +100,12 @@ case = wgrad_case(B, H, W, 7)
 x, y, dp, idx, abc = case
 ws = torch.empty(query("cova_conv1_wgrad_workspace_floats", B, H, W), device=dev)
 dw = torch.zeros(64, 3, 7, 7, device=dev)
-for f32, phases in ((1, 0), (0, 1), (0, 0), (1, 0), (0, 1), (0, 0)):
+for f32 in (1, 0, 1, 0):
     call("cova_set_option", 7, f32)
-    call("cova_set_option", 8, phases)
     ms = t(lambda: call("cova_conv1_wgrad_poolbwd", x, y, dp, idx, abc, dw, ws, B, H, W))
     print("wgrad 16 x 1280 x 1280: %s %.3f ms per call (partials + reduce)"
-          % ("f32 mfma              " if f32 else ("bf16 split, phases    " if phases else "bf16 split, role split"), ms), flush=True)
+          % ("f32 mfma              " if f32 else "bf16 split, role split", ms), flush=True)
 call("cova_set_option", 7, 0)
-call("cova_set_option", 8, 0)
 # the same without the folded pool backward (dy given): isolates the pooled-gradient window loads
 dyt = torch.randn(B, 640, 640, 64, device=dev)
 for f32 in (1, 0):

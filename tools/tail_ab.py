@@ -1,4 +1,5 @@
 """Gradient difference of one train step between the in-launch finalize paths (OPTIONS.bn_tail) on and off, per key."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests")))

@@ -1,5 +1,6 @@
 """Signed (systematic) error of the F(4x4,3x3) launches against a float64 convolution: per-channel SUMS of the output -- what
 BatchNorm-backward style reductions over millions of positions see -- on the f32 and on the split main loop."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

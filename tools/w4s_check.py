@@ -1,5 +1,6 @@
 """Split (bf16-piece) main loop of the F(4x4,3x3) kernels against the f32 main loop: values, statistics, error against
 fp64, and time per variant on the benchmark map (16 x 320 x 320 x 64).  cova_set_option(9, 1) selects the f32 loop."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
 """Time of the F(4x4,3x3) variants the train step launches, split main loop (16 x 320 x 320 x 64); --f32 adds the f32 loop."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

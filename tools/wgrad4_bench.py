@@ -1,6 +1,7 @@
 """Weight gradient of the 3x3 convolution on the benchmark map (16 x 320 x 320 x 64): F(4x4,3x3) (csrc/conv_wgrad4.hip)
 against F(2x2,3x3) (csrc/conv_wino.hip), per operand-prologue variant, partial-sum launches only + the finish launches.
 COVA_HIP_LIB selects an ablation build (tools/wg4_abl_build.sh)."""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

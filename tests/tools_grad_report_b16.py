@@ -4,6 +4,7 @@ the bf16-split conv1 kernels on and off and the split / f32 F(4x4) main loops: l
 against the oracle forced to the HIP forward's discrete decisions, and the decisions that differ from the UNFORCED oracle's
 (count, place, distance of the pre-activation from zero).  Reference: train.py:47-60.
   python tests/tools_grad_report_b16.py [pages=16] > profiles/r05_grad_parity_1280_b16.txt      (about 4 minutes of host time)"""
+import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

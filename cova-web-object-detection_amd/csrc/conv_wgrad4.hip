@@ -302,20 +302,23 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
             Wg4It it = it_;
             if (WG4_ABL & 32) { it.seg = walker; seg_setup(it); }
             const int gy0 = 4 * it.ty - (VROLE ? 1 : 0), gx0 = 16 * it.strip + 4 * tcol - (VROLE ? 1 : 0);
-            const float *src = VROLE ? a.act : a.dz;
+            // (64-bit base of the walk's page, wave-uniform; 32-bit byte offsets inside the page: any batch size)
+            const size_t pgb = (size_t)it.b * (size_t)H * (size_t)W * 256u;
+            const char *src = reinterpret_cast<const char *>(VROLE ? a.act : a.dz) + pgb;
+            const char *src2 = TWO ? reinterpret_cast<const char *>(a.dz2) + pgb : nullptr;
             int ps = br + phi;                                   // pair slot (the gradient role has no ring: phi = 0)
             if (VROLE && ps >= 3) ps -= 3;
             const unsigned dst = raw_lds + (VROLE ? 3072u * (unsigned)ps : 2048u * (unsigned)br) + 1024u * (unsigned)bc;
             if (!edge) {                                         // scalar base of the row pair + the block column
-                const unsigned off = (unsigned)(((it.b * H + gy0 + 2 * br) * W + gx0) * 256 + 512 * bc);     // (< 4 GB: host check)
-                wg4_copy16(reinterpret_cast<const char *>(src) + off, laneoff, dst);
-                if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2) + off, laneoff, dst + 4096);
+                const unsigned off = (unsigned)(((gy0 + 2 * br) * W + gx0) * 256 + 512 * bc);     // (a page < 4 GB: host check)
+                wg4_copy16(src + off, laneoff, dst);
+                if (TWO) wg4_copy16(src2 + off, laneoff, dst + 4096);
             } else {
                 const int r = 2 * br + (sub >> 1), c = 2 * bc + (sub & 1);
                 const int gy = min(max(gy0 + r, 0), H - 1), gx = min(max(gx0 + c, 0), W - 1);
-                const unsigned eo = (unsigned)(((it.b * H + gy) * W + gx) * 256 + c4 * 16);
-                wg4_copy16(reinterpret_cast<const char *>(src), eo, dst);
-                if (TWO) wg4_copy16(reinterpret_cast<const char *>(a.dz2), eo, dst + 4096);
+                const unsigned eo = (unsigned)((gy * W + gx) * 256 + c4 * 16);
+                wg4_copy16(src, eo, dst);
+                if (TWO) wg4_copy16(src2, eo, dst + 4096);
             }
         };
         // a continued walk of the input role keeps row pair 0 (wave-uniform)
@@ -340,9 +343,11 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
         int emit_k = 0;                                      // tiles transformed so far by this wave
         unsigned emit_lane = (unsigned)lane * 4u;
         asm volatile("" : "+v"(emit_lane));
-        unsigned cur_org = 0;                                // element offset of the current tile's pixel (0, 0)
+        unsigned cur_org = 0;                                // element offset of the current tile's pixel (0, 0) inside its page
+        char *cur_out = reinterpret_cast<char *>(a.dz_out);  // ... and that page of the side output
         auto origin = [&](const Wg4It &it) __attribute__((always_inline)) {
-            return (unsigned)(((it.b * H + 4 * it.ty) * W + 16 * it.strip + 4 * tcol) * 64);
+            cur_out = reinterpret_cast<char *>(a.dz_out) + (size_t)it.b * (size_t)H * (size_t)W * 256u;
+            return (unsigned)(((4 * it.ty) * W + 16 * it.strip + 4 * tcol) * 64);
         };
         int phi = 0;                                         // ring phase of the patch in the buffer
         int wg4_k = -1;                                      // (trace builds)
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(wg4::THREADS, 1) void conv3x3_wgrad4_kernel(const W
                         if (emit_now && (!cedge || (((crm >> r) & (ccm >> c) & 1u) != 0u))) {
                             unsigned ob = (cur_org + (unsigned)((r * W + c) * 64)) * 4u;
                             asm volatile("" : "+s"(ob));
-                            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dz_out) + ob + emit_lane) = v;
+                            *reinterpret_cast<float *>(cur_out + ob + emit_lane) = v;
                         }
                     }
                 }
@@ -665,7 +670,7 @@ COVA_API int cova_conv3x3_wgrad4_partial(const float *act, const float *act_abc,
                                          int W, void *stream)
 {
     COVA_REQUIRE(act && dz && ws && B > 0 && H > 0 && W > 0);
-    COVA_REQUIRE((long long)B * H * W * 256 < (1ll << 32));          // 32-bit byte offsets of the pixel rows
+    COVA_REQUIRE((long long)H * W * 256 < (1ll << 32));              // 32-bit byte offsets of the pixel rows inside a page
     COVA_REQUIRE(dz_out == nullptr || dz_abc != nullptr);
     return launch_wgrad4(act, act_abc, act_relu, dz, dz2, dz_abc, dz_out, ws, B, H, W, (hipStream_t)stream);
 }

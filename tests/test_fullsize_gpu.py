@@ -252,3 +252,35 @@ def test_activations_beyond_2_31_elements_index_correctly():
     m = re.search(r"pages\s+96 .*logits err ([0-9.e+-]+)\s+loss ratio ([0-9.]+)\s+grad err ([0-9.e+-]+)", out.stdout)
     assert m, out.stdout[-2000:]
     assert float(m.group(1)) < 1e-4 and abs(float(m.group(2)) - 1.0) < 1e-5 and float(m.group(3)) < 1e-3
+
+
+def test_weight_gradient_of_a_batch_beyond_4_gb_per_tensor():
+    """cova_conv3x3_wgrad4_partial on 165 maps of 320 x 320 x 64 -- 4.3 GB per operand: byte offsets from the tensor base no
+    longer fit 32 bits (rounds 4-5 refused such batches; the kernel now addresses a page through its own 64-bit base).
+    The weight gradient is a sum over pages: the 165-page launch equals the launches over pages [0, 100) and [100, 165) added
+    (fp32 re-association of the fixed-order fold), and the side output of the LAST pages -- the ones beyond 4 GB -- is the operand
+    A*dz + B*dz2 + C there."""
+    B, H, W = 165, 320, 320
+    assert B * H * W * 256 >= 1 << 32
+    g = torch.Generator(device=DEV).manual_seed(7)
+    mk = lambda: torch.randn((B, H, W, 64), device=DEV, generator=g)
+    act, dz, dz2 = mk(), mk(), mk()
+    abc_a = torch.randn((3, 64), device=DEV, generator=g)
+    abc_d = torch.randn((3, 64), device=DEV, generator=g)
+
+    def wgrad(lo, hi, want_out):
+        n = hi - lo
+        ws = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", n, H, W), device=DEV)
+        out = torch.full((n, H, W, 64), float("nan"), device=DEV) if want_out else None
+        dw = torch.empty(64, 64, 3, 3, device=DEV)
+        call("cova_conv3x3_wgrad4_partial", act[lo:hi], abc_a, 1, dz[lo:hi], dz2[lo:hi], abc_d, out, ws, n, H, W)
+        call("cova_conv3x3_wgrad4_finish", ws, dw, None, None, None, None, None, None, n, H, W)
+        return dw, out
+
+    dw_all, out_all = wgrad(0, B, True)
+    dw_a, _ = wgrad(0, 100, False)
+    dw_b, out_b = wgrad(100, B, True)
+    assert rel(dw_all, dw_a + dw_b) < 2e-5
+    assert torch.equal(out_all[100:], out_b)
+    ref = torch.addcmul(torch.addcmul(abc_d[2].expand_as(dz[160:]), dz2[160:], abc_d[1]), dz[160:], abc_d[0])
+    assert rel(out_all[160:], ref) < 1e-6

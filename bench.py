@@ -15,13 +15,21 @@ bench.py --gpus N` launches itself through torch.distributed.run when it is not 
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- the dominant kernel family (Winograd F(4x4,3x3) conv3x3 64->64, forward + data gradient), timed live with
-                  HIP events on the launching stream inside the timed steps.  Since round 5 its transform-domain products run
-                  on the bf16 matrix pipe (f32 operands as three bf16 pieces, six products): the launch's matrix floor drops
-                  below its HBM floor, so `bound` = "hbm", `achieved` = ALGORITHMIC bytes per launch / mean launch time,
-                  `traffic` = the PMC bytes; the bf16-pipe rate, the f32-equivalent rate (the round-4 `frac`) and the
-                  per-floor times are reported beside it.  COVA_W4_F32=1 selects the f32-MFMA main loop (`bound` = "mfma").
+                  HIP events on the launching stream inside the timed steps (every 5th).  Its transform-domain products run on
+                  the bf16 matrix pipe (f32 operands as three bf16 pieces, six products): the launch's matrix floor is below its
+                  HBM floor, so `bound` = "hbm" and `achieved` = ALGORITHMIC bytes / time.  Since round 6 the bytes follow from
+                  the launches the step really issues: every timed call's variant and operand count are derived from which of its
+                  arguments were non-NULL (`variants`: per variant launches, maps moved, bytes, mean time, frac, PMC traffic);
+                  the family `frac` = sum of bytes / sum of time (`hbm_algorithmic_frac` is the same number under a name that
+                  says what it is; `f32_equivalent` keeps the round-1..4 definition, executed f32 multiply-adds over the f32-MFMA
+                  peak, for comparison across rounds; `hbm_frac` prices the PMC traffic instead).  COVA_W4_F32=1 selects the
+                  f32-MFMA main loop (`bound` = "mfma").
+  other_kernels-- conv1 forward / weight gradient and the 3x3 weight gradients timed INSIDE the timed steps (`in_step`: the
+                  kernels whose time differs between boxes), the rest in five separate steps behind them.
   ab           -- same process, same trainer, no events: 10 steps each on the default kernels and with conv1 / the 3x3 main
-                  loop on their f32-MFMA forms.
+                  loop on their f32-MFMA forms (the process keeps the library's options mutable: COVA_ALLOW_OPTION_CHANGES).
+  clock_leg    -- effective shader clock per kernel on this box (a 5-step child run under rocprofv3 --pmc GRBM_GUI_ACTIVE):
+                  the MFMA-dense kernels run power-limited, and by how much differs from box to box.
   sustained    -- >= 5 s of back-to-back train steps after the headline measurement (same batch), reported
                   separately: long enough for an external utilisation sampler to see the GPU work.
   step         -- whole-step FLOP accounting: algorithmic TFLOP/s, fraction of the direct-convolution MFMA
@@ -689,6 +697,7 @@ def run(args, guard, rank, local_rank, world):
                 roof.update(bound="hbm", algorithm="winograd F(4x4,3x3); transform-domain products on the bf16 matrix pipe, f32 "
                             "operands as three bf16 pieces, six products accumulated in f32 (v_mfma_f32_16x16x32_bf16)",
                             achieved=round(ach, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s", frac=round(ach / (PEAK_HBM_TBS * 1e3), 4),
+                            hbm_algorithmic_frac=round(ach / (PEAK_HBM_TBS * 1e3), 4),
                             achieved_is="ALGORITHMIC bytes of the launches timed (per-variant operand table `variants`, derived from "
                                         "each call's arguments) / their total time",
                             floors_ms={"hbm_algorithmic_bytes_at_8_TBps": round(alg_bytes / PEAK_HBM_TBS / 1e9, 4),

@@ -15,7 +15,7 @@ bench.py --gpus N` launches itself through torch.distributed.run when it is not 
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- the dominant kernel family (Winograd F(4x4,3x3) conv3x3 64->64, forward + data gradient), timed live with
-                  HIP events on the launching stream inside the timed steps (every 5th).  Its transform-domain products run on
+                  HIP events on the launching stream inside the timed steps (every 10th).  Its transform-domain products run on
                   the bf16 matrix pipe (f32 operands as three bf16 pieces, six products): the launch's matrix floor is below its
                   HBM floor, so `bound` = "hbm" and `achieved` = ALGORITHMIC bytes / time.  Since round 6 the bytes follow from
                   the launches the step really issues: every timed call's variant and operand count are derived from which of its
@@ -495,12 +495,12 @@ def run(args, guard, rank, local_rank, world):
     # live measurement); the other kernels of `other_kernels` are timed in a separate short leg behind it -- bracketing all
     # ~45 launches of a step cost the headline 2 % (round 4's line against its own `sustained` leg)
     dominant = [n for n in ("cova_conv3x3_wino4_full", "cova_conv3x3_wino4_full_tail") if n in timed]
-    # ... and only in every EVENT_EVERY-th timed step (steps 0, 5, 10, ...): an event pair around a launch is two marker packets in
+    # ... and only in every EVENT_EVERY-th timed step (steps 0, 10, ...: 14 pairs per such step, ~0.3 % of the 20 steps' time): an event pair around a launch is two marker packets in
     # the stream, ~20 us of lost back-to-back dispatch each pair -- with all 8 x 20 launches bracketed the headline of round 5's
     # last pass read 9.25 ms beside 8.93 ms of the same kernels in the event-free `ab.default` leg.  The same steps also bracket
     # conv1 forward, conv1 weight gradient and the four 3x3 weight gradients (6 more pairs): the kernels whose time differs
     # from box to box (round 5: conv1 forward 0.75 ms on the builder's boxes, 1.01 ms on the driver's), IN the step.
-    EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 5
+    EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 10
     in_step = dominant + [n for n in ("cova_conv1_fwd_tail", "cova_conv1_fwd", "cova_conv1_fwd_pool", "cova_conv1_wgrad_poolbwd",
                                       "cova_conv3x3_wgrad4_partial") if n in timed]
     prof = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else in_step)}

@@ -1451,6 +1451,8 @@ int cova_internal_set_gat_wide(int v);
 int cova_internal_get_bn1d_variant();
 int cova_internal_get_gat_wide();
 int cova_internal_get_wino4_f32();
+int cova_internal_get_sgemm_dma();
+int cova_internal_set_sgemm_dma(int v);
 COVA_API int cova_set_option(int key, int value)
 {
     static const bool allow = [] { const char *e = getenv("COVA_ALLOW_OPTION_CHANGES"); return e != nullptr && e[0] == '1'; }();
@@ -1461,6 +1463,7 @@ COVA_API int cova_set_option(int key, int value)
     case 9: cur = cova_internal_get_wino4_f32(); value = value != 0; break;
     case 14: cur = cova_internal_get_bn1d_variant(); break;
     case 16: cur = cova_internal_get_gat_wide(); value = value != 0; break;
+    case 22: cur = cova_internal_get_sgemm_dma(); value = value != 0; break;
     default: return COVA_ERR_BAD_ARG;
     }
     if (cur == value) return COVA_OK;
@@ -1470,6 +1473,7 @@ COVA_API int cova_set_option(int key, int value)
     case 7: g_conv1_f32 = value; return COVA_OK;
     case 9: return cova_internal_set_wino4_f32(value);
     case 14: return cova_internal_set_bn1d_variant(value);
+    case 22: return cova_internal_set_sgemm_dma(value);
     default: return cova_internal_set_gat_wide(value);
     }
 }

@@ -17,6 +17,7 @@
 // barrier, stash, barrier -- and splitting a tile on its way into LDS lengthens exactly that), a register-direct form without LDS
 // tiles, operand tiles two k-tiles ahead, two LDS buffers per k-group.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -163,6 +164,197 @@ __global__ __launch_bounds__(256 * KS) void sgemm_kernel(const float *__restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same product with the operand tiles brought in by global -> LDS copies (global_load_lds_dwordx4: no staging registers,
+// no stash instructions, one LDS-only block barrier per k-tile) -- the form cova_sgemm takes whenever the operands allow 16-byte
+// pieces (round 6; the six products of the head: 260 -> 197 us with 64 x 64 tiles, profiles/r06_gemm_bench.txt).
+//   * block tile (32 WM) x 64, waves of 32 x 32 (v_mfma_f32_32x32x2_f32), k-tiles of 32 in a ring of DS stages per k-group; the
+//     copies of the k-tile DS - 1 ahead are issued right behind the barrier that releases the slot they land in;
+//   * KS = 2: two k-groups of waves per block take alternate k-tiles (each with its own ring) and add their accumulators at the
+//     end through LDS, group 0 + group 1: for grids that leave CUs without a block of their own otherwise;
+//   * a k-contiguous operand (X[row][k]) lands as 16-byte pieces in the order the MFMA's lanes read them with ds_read_b128:
+//     copy piece c = (row block rb = c >> 1, k half kb = c & 1), lane = s * 16 + r -> row 16 rb + r, k = 16 kb + 4 s: a copy
+//     instruction covers 16 rows x 64 bytes (16 cache lines), a read group of 16 lanes covers the 16 different 16-byte columns of
+//     the LDS (conflict-free); the lane with k-half kh uses k = 16 kh + kk for MFMA kk -- the order of k inside a tile is free as
+//     long as both operands agree;
+//   * a row-contiguous operand (X[k][row]) lands as [k][rows of the tile] and is read with ds_read_b32 (lanes = consecutive rows);
+//   * two accumulators per wave (even / odd kk, added at the end in a fixed order): a dependent chain of 32x32x2 MFMAs on one
+//     accumulator issues every ~128 cycles, two chains keep the pipe busy from one wave;
+//   * rows past M / N are clamped (their outputs are never stored); a k past K is clamped and both of its operands are zeroed
+//     in registers (last k-tile only).
+typedef __attribute__((address_space(3))) void gd_lds_void;
+
+__device__ __forceinline__ void gd_copy16(const char *base, unsigned off_bytes, unsigned lds_base_bytes)
+{
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base_bytes), "v"(off_bytes), "s"(base) : "memory", "m0");
+}
+
+template <int N_>
+__device__ __forceinline__ void gd_wait_vm()
+{
+    static_assert(N_ >= 0 && N_ < 64, "vmcnt");
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N_ == 0, "add the count");
+}
+
+template <bool TA, bool TB, int WM, int KS, int DS>
+__global__ __launch_bounds__(128 * WM * KS) void sgemm_dma_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Bm,
+                                                                  int ldb, float *__restrict__ C, int ldc,
+                                                                  const float *__restrict__ bias, int M, int N, int K, int accumulate,
+                                                                  const uint8_t *__restrict__ emask, float einv)
+{
+    constexpr int KT = 32;                               // k-tile
+    constexpr int RA = 32 * WM, RB = 64;                 // rows of the A / B tile of a stage
+    constexpr int NW = 2 * WM;                           // waves of a k-group
+    constexpr int NA = (RA / 8) / NW, NB = (RB / 8) / NW;       // this wave's 1 KB copies per stage (a tile of R rows = R / 8 pieces)
+    constexpr int A_FLOATS = RA * KT, STAGE_FLOATS = (RA + RB) * KT;
+    constexpr bool AK = !TA, BKC = TB;                   // operand stored k-contiguous?
+    __shared__ __attribute__((aligned(1024))) float s_t[KS][DS][STAGE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KS == 2 ? wave_all / NW : 0, wave = wave_all % NW;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * RA, n0 = blockIdx.x * RB;
+    const int li = lane & 31, kh = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(gd_lds_void *)&s_t[grp][0][0];
+
+    // ---- copy pieces.  k-contiguous tile: piece c = (rb = c >> 1, kb = c & 1), lane = s * 16 + r -> row 16 rb + r, k = 16 kb + 4 s.
+    // Row-contiguous tile of R rows: R / 4 lanes per k-row, 256 / R k-rows per piece: k = c * (256 / R) + lane / (R / 4), rows 4 (lane % (R / 4)) ...
+    int a_row[NA], b_row[NB];                            // (clamped to the operand; fixed over the k-tiles)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+        a_row[i] = AK ? min(m0 + 16 * ((wave + i * NW) >> 1) + (lane & 15), M - 1) : min(m0 + 4 * (lane % (RA / 4)), M - 4);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        b_row[i] = BKC ? min(n0 + 16 * ((wave + i * NW) >> 1) + (lane & 15), N - 1) : min(n0 + 4 * (lane % (RB / 4)), N - 4);
+    auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+        const int k0 = t * KT;
+        const unsigned dst = lds0 + (unsigned)slot * (unsigned)(STAGE_FLOATS * 4);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = wave + i * NW;
+            unsigned o;
+            if (AK) o = (unsigned)(a_row[i] * lda + min(k0 + 16 * (c & 1) + 4 * (lane >> 4), K - 4)) * 4u;
+            else o = (unsigned)(min(k0 + c * (256 / RA) + lane / (RA / 4), K - 1) * lda + a_row[i]) * 4u;
+            gd_copy16(reinterpret_cast<const char *>(A), o, dst + (unsigned)c * 1024u);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = wave + i * NW;
+            unsigned o;
+            if (BKC) o = (unsigned)(b_row[i] * ldb + min(k0 + 16 * (c & 1) + 4 * (lane >> 4), K - 4)) * 4u;
+            else o = (unsigned)(min(k0 + c * (256 / RB) + lane / (RB / 4), K - 1) * ldb + b_row[i]) * 4u;
+            gd_copy16(reinterpret_cast<const char *>(Bm), o, dst + (unsigned)(A_FLOATS * 4) + (unsigned)c * 1024u);
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    // operand addresses of this lane inside a stage (floats)
+    const int a_rd = AK ? ((wm * 2 + (li >> 4)) * 2 + kh) * 256 + (li & 15) * 4 : (kh * 16) * RA + wm * 32 + li;
+    const int b_rd = A_FLOATS + (BKC ? ((wn * 2 + (li >> 4)) * 2 + kh) * 256 + (li & 15) * 4 : (kh * 16) * RB + wn * 32 + li);
+
+    const int ntiles = (K + KT - 1) / KT;
+    const int nit = (ntiles + KS - 1) / KS;              // k-tiles grp, grp + KS, ... : the same count for every group (the barriers match)
+#pragma unroll
+    for (int it = 0; it < DS - 1; ++it) issue(grp + KS * it, it);
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+        const int t = grp + KS * it;
+        gd_wait_vm<(NA + NB) * (DS - 2)>();             // this wave's copies of k-tile t have landed (the DS - 2 younger groups may be in flight) ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... and everybody's; the slot of the k-tile before has been read by all
+                                                       // (LDS-only barrier: __syncthreads() would wait for the copies in flight)
+        issue(grp + KS * (it + DS - 1), (it + DS - 1) % DS);                 // (past the end: clamped addresses, never read)
+        const float *st = &s_t[grp][it % DS][0];
+        const float *ta = st + a_rd, *tb = st + b_rd;
+        float av[16], bv[16];
+        if (AK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(ta + 64 * q);
+                av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) av[kk] = ta[RA * kk];
+        }
+        if (BKC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(tb + 64 * q);
+                bv[4 * q] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) bv[kk] = tb[RB * kk];
+        }
+        const int kv = K - t * KT - 16 * kh;            // this lane's k = 16 kh + kk is inside K for kk < kv
+        if (kv < 16) {                                 // (last k-tile of a K that is not a multiple of 32; a k-tile past the end)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk >= kv) { av[kk] = 0.f; bv[kk] = 0.f; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            acc0 = mfma32(av[kk], bv[kk], acc0);
+            acc1 = mfma32(av[kk + 1], bv[kk + 1], acc1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the copies past the end have landed before the LDS is reused / released)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+    if (KS == 2) {                                     // group 1 hands its sum over through its (idle) ring: [wave][r][lane]
+        __syncthreads();
+        float *red = &s_t[KS - 1][0][0] + wave * (16 * 64);
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc0[r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] += red[r * 64 + lane];
+    }
+    const int gn = n0 + wn * 32 + li;
+    if (gn >= N) return;
+    const float bv = bias ? bias[gn] : 0.f;
+    // three epilogues, chosen block-uniformly: plain, += C, Dropout backward -- each with its 16 operands requested by unconditional
+    // loads in front of the first use (a load behind a branch costs a vmcnt(0) at the join: sixteen round trips instead of one)
+    auto epilogue = [&](auto mode_t) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_t)::value;
+        float old[16];
+        uint8_t keep[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = min(m0 + wm * 32 + mfma32_row(r, lane), M - 1);       // (clamped: a valid address; not stored)
+            if (MODE == 1) old[r] = C[(size_t)gm * ldc + gn];
+            if (MODE == 2) keep[r] = emask[(size_t)gm * N + gn];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 32 + mfma32_row(r, lane);
+            if (gm < M) {
+                float v = acc0[r] + bv;
+                if (MODE == 1) v += old[r];
+                if (MODE == 2) v = keep[r] ? v * einv : 0.f;                      // cova_dropout_bwd on the result
+                C[(size_t)gm * ldc + gn] = v;
+            }
+        }
+    };
+    if (emask != nullptr) epilogue(std::integral_constant<int, 2>{});
+    else if (accumulate) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+int g_sgemm_dma = 1;         // cova_set_option(22, .): 1 = the LDS-DMA kernel wherever the operands allow it (default), 0 = never
+
 inline int vec_ok(const float *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 }  // namespace
@@ -176,6 +368,33 @@ static int sgemm_launch(int transA, int transB, int M, int N, int K, const float
     const dim3 grid(cdiv(N, BN), cdiv(M, BM));
     hipStream_t st = (hipStream_t)stream;
     const int va = vec_ok(A, lda), vb = vec_ok(B, ldb);
+    // 16-byte pieces of both operands: aligned bases and leading dimensions, K a multiple of 4, a row-contiguous operand's row
+    // count a multiple of 4 (a piece never straddles the edge); 32-bit byte offsets inside an operand
+    const long long a_bytes = 4ll * (transA ? (long long)K * lda : (long long)M * lda), b_bytes = 4ll * (transB ? (long long)N * ldb : (long long)K * ldb);
+    const bool dma = g_sgemm_dma && va && vb && (K & 3) == 0 && K >= 4 && (!transA || ((M & 3) == 0 && M >= 4)) &&
+                     (transB || ((N & 3) == 0 && N >= 4)) && a_bytes < (1ll << 31) && b_bytes < (1ll << 31);
+    if (dma) {
+        // tile shape by the grid it makes (measured on the six products of the head, profiles/r06_gemm_bench.txt): 32 x 64 tiles with two
+        // k-groups per block when even those leave at most one block per CU (the GAT weight gradient, 768 x 608 x 1440: 33 -> 22 us);
+        // 64 x 64 tiles otherwise, with two k-groups when they leave at most one block per CU and K is long (eight waves on the CU
+        // instead of four); 32 x 64 tiles without the k-groups lost wherever they were tried (two waves per block: 20 -> 30, 33 -> 50 us)
+        const long long blocks64 = (long long)cdiv(M, 64) * cdiv(N, 64), blocks32 = (long long)cdiv(M, 32) * cdiv(N, 64);
+        const int shape = blocks32 <= 256 && K >= 8 * 32 ? 2 : (blocks64 <= 256 && K >= 16 * 32 ? 1 : 0);
+        const dim3 g32(cdiv(N, 64), cdiv(M, 32));
+#define SGEMM_DMA(TA_, TB_)                                                                                                      \
+    do {                                                                                                                        \
+        if (shape == 0) hipLaunchKernelGGL((sgemm_dma_kernel<TA_, TB_, 2, 1, 4>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, emask, einv); \
+        else if (shape == 1) hipLaunchKernelGGL((sgemm_dma_kernel<TA_, TB_, 2, 2, 3>), grid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, emask, einv); \
+        else hipLaunchKernelGGL((sgemm_dma_kernel<TA_, TB_, 1, 2, 4>), g32, dim3(256), 0, st, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, emask, einv); \
+    } while (0)
+        if (!transA && !transB) SGEMM_DMA(false, false);
+        else if (!transA && transB) SGEMM_DMA(false, true);
+        else if (transA && !transB) SGEMM_DMA(true, false);
+        else SGEMM_DMA(true, true);
+#undef SGEMM_DMA
+        COVA_LAUNCH_CHECK();
+        return COVA_OK;
+    }
     // two k-groups per block when there are at least four k-tiles and the grid alone does not fill the chip twice over
     const bool split = K >= 4 * BK && (long long)grid.x * grid.y < 2 * 4 * 256;
 #define SGEMM_LAUNCH(TA_, TB_)                                                                                              \
@@ -191,6 +410,9 @@ static int sgemm_launch(int transA, int transB, int M, int N, int K, const float
     COVA_LAUNCH_CHECK();
     return COVA_OK;
 }
+
+int cova_internal_get_sgemm_dma() { return g_sgemm_dma; }
+int cova_internal_set_sgemm_dma(int v) { g_sgemm_dma = v != 0; return COVA_OK; }
 
 COVA_API int cova_sgemm(int transA, int transB, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias,

@@ -55,13 +55,15 @@ typedef struct cova_bn_tail {
  * nn.ReLU, nn.MaxPool2d(3,2,1), 2 x BasicBlock(64) as called at models.py:125 `self.convnet(images)`
  */
 int cova_conv_out_size(int in_size, int kernel, int stride, int pad);
-/* Test / A-B hooks, not part of the path's contract (five keys; everything else is refused):
+/* Test / A-B hooks, not part of the path's contract (six keys; everything else is refused):
  *   2  = cap on the persistent grids (tests force many tiles per block); 0 = none,
  *   7  = conv1 forward and weight gradient on the f32-MFMA kernels (1) instead of the bf16-split ones (0, default): bench.py's `ab` leg,
  *   9  = F(4x4,3x3) forward / data-gradient launches on the f32-MFMA main loop (1) instead of the bf16-split one (0, default): `ab` leg,
  *   14 = cova_bn1d_fwd / _bwd in the float4 form (1, default: taken when the operands are 16-byte aligned) or the 128-slice form (0),
  *   16 = cova_gat_fwd / _bwd with every 64-channel chunk of a neighbour row in flight (1, default; K <= 64, D <= 512) or chunk by chunk (0).
- * 14 and 16 select between two kernels that both run by default (by alignment / by shape): the tests use them to compare the forms.
+ *   22 = cova_sgemm with the operand tiles brought in by global -> LDS copies (1, default: taken when both operands allow 16-byte
+ *        pieces) or staged through registers (0: the kernel every other shape takes).
+ * 14, 16 and 22 select between two kernels that both run by default (by alignment / by shape): the tests use them to compare the forms.
  * The option state is a PER-PROCESS CONSTANT: it may be set until the library's first query or launch and is fixed from then on
  * (launches captured into a hipGraph, workspace sizes already queried and a trainer's buffers all depend on it) -- a later
  * cova_set_option that would CHANGE a value returns COVA_ERR_BAD_ARG (10001).  A process that sets COVA_ALLOW_OPTION_CHANGES=1

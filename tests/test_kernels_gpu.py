@@ -38,7 +38,7 @@ def nchw(x):   # NHWC gpu -> NCHW cpu
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (45, 70, 33), (130, 992, 608), (1, 5, 3), (1440, 976, 976), (976, 976, 1440),
-                                   (64, 64, 1028), (70, 33, 640)])
+                                   (64, 64, 1028), (70, 33, 640), (132, 100, 612), (4, 4, 4), (68, 36, 36), (256, 192, 96), (2100, 2048, 72)])
 def test_sgemm(ta, tb, M, N, K):
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
@@ -54,6 +54,33 @@ def test_sgemm(ta, tb, M, N, K):
     assert torch.equal(C2, C)                                  # deterministic
     call("cova_sgemm", ta, tb, M, N, K, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], C, N + 3, None, 1)
     close(C[:, :N], 2 * ref - bias, 2e-5, "sgemm accumulate")
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1440, 992, 992), (1440, 768, 608), (768, 608, 1440), (132, 100, 612), (64, 64, 16), (2100, 2048, 72)])
+def test_sgemm_lds_dma_kernel_against_the_register_staged_one(ta, tb, M, N, K):
+    """cova_sgemm's two kernels (operand tiles by global -> LDS copies, taken whenever 16-byte pieces are possible; operand tiles
+    staged through registers, any shape) sum a dot product in different orders: same result to f32 round-off, each of them
+    bit-reproducible, sub-matrix views (leading dimensions, offset bases) included.  The shapes take all three tile forms of the
+    first kernel (64 x 64 tiles with one or two k-groups per block, 32 x 64 tiles with two)."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    lda, ldb = (M if ta else K) + 8, (K if tb else N) + 4
+    A = torch.randn((K if ta else M), lda, generator=g).to(DEV)
+    B = torch.randn((N if tb else K), ldb, generator=g).to(DEV)
+    Av, Bv = A[:, 4:], B[:, 4:]                        # 16-byte aligned views inside wider rows
+    ref = ((Av[:, :M].t() if ta else Av[:, :K]).double() @ (Bv[:, :K].t() if tb else Bv[:, :N]).double()).float()
+    out = []
+    try:
+        for v in (1, 0, 1):
+            assert query("cova_set_option", 22, v) == 0
+            C = torch.full((M, N + 4), 7.0, device=DEV)
+            call("cova_sgemm", ta, tb, M, N, K, Av, lda, Bv, ldb, C, N + 4, None, 0)
+            assert (C[:, N:] == 7.0).all()
+            close(C[:, :N], ref, 2e-5, "sgemm option 22 = %d" % v)
+            out.append(C)
+    finally:
+        query("cova_set_option", 22, 1)
+    assert torch.equal(out[0], out[2])
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 16, 64), (2, 37, 50), (1, 64, 64)])

@@ -1247,90 +1247,92 @@ __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
     {
         const int st = tid - 256;                                    // 0 .. 255
         const int pw = wave - 4, c4 = st & 15;
-        const bool codd = (pw & 1) != 0;                             // this wave's four columns are odd | even
-        const int cc = 2 * ((pw >> 1) * 4 + ((st >> 4) & 3)) + (pw & 1);
+        // wave = (column group cg: columns 8 cg .. 8 cg + 7, row pair hp: rows 2 hp, 2 hp + 1 of the tile); lanes = (4 columns, 16
+        // channel quads).  It finishes its row pair for the group's four EVEN columns, then for the four ODD ones: an odd column
+        // gathers from twice as many pool windows, and with whole waves of one column parity (rounds 4-5: wave = 4 columns x 4 rows)
+        // the two odd-column waves were the launch's critical path (4 100 against 3 000 cycles per tile) -- now the four staging
+        // waves do the same work.  Same arithmetic per element, same LDS layout: bit-identical results.
+        const int hp = pw & 1;
+        const int cbase = 2 * ((pw >> 1) * 4 + ((st >> 4) & 3));     // this lane's even column; its odd one: + 1
         f32x4 cA = {0.f, 0.f, 0.f, 0.f}, cB = cA, cC = cA;
         if (POOL) {
             cA = *reinterpret_cast<const f32x4 *>(pool.abc + c4 * 4);
             cB = *reinterpret_cast<const f32x4 *>(pool.abc + 64 + c4 * 4);
             cC = *reinterpret_cast<const f32x4 *>(pool.abc + 128 + c4 * 4);
         }
-        struct Ops {                             // what a thread loads for its column of a tile
-            f32x4 yv[4];                         // dy (POOL: y1) of rows 0..3, 4 channels
-            f32x4 dpv[3][2];                     // POOL: pooled gradient of windows (P0, P0+1, P0+2) x (W0 [, W0+1])
-            uint32_t cdv[3][2];                  //       their four arg-max codes
-            unsigned ok;                         // bits 0-3 rows inside the map (with the column), bits 4-9 windows inside
+        struct Ops {                             // what a thread loads for its two columns of a tile ([0] even, [1] odd)
+            f32x4 yv[2][2];                      // dy (POOL: y1) of rows 2 hp, 2 hp + 1, 4 channels
+            f32x4 dpv[2][2][2];                  // POOL: pooled gradient of windows (P0 + hp, P0 + hp + 1) x (W0 [, W0 + 1: odd column])
+            uint32_t cdv[2][2][2];               //       their four arg-max codes
+            unsigned ok;                         // bits 2 par + rr: row inside the map (with the column); bits 4 + 4 par + 2 k + e: window inside
         };
         Ops opa, opb, opc;                       // three sets: a tile's operands are requested two tiles before they are used
         // (a clamp-free form of these loads for interior tiles -- wave-uniform row bases + one constant lane offset, 22 loads
         // back to back -- measured SLOWER on the same box: 1.14 against 1.06 ms per launch)
         auto load_tile = [&](Ops &o_, const TileC &tc) {
             if (WG1R_ABL & 1) return;
-            auto &yv = o_.yv; auto &dpv = o_.dpv; auto &cdv = o_.cdv;
             unsigned ok = 0u;
             const float *yb = dy + (size_t)tc.b * H1 * W1 * 64;
-            const int gx = tc.x0 + cc, cx = gx < W1 ? gx : W1 - 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gy = tc.y0 + r, cy = gy < H1 ? gy : H1 - 1;
-                yv[r] = *reinterpret_cast<const f32x4 *>(yb + (unsigned)(((cy * W1 + cx) << 6) + c4 * 4));
-                ok |= (gy < H1 && gx < W1) ? (1u << r) : 0u;
-            }
-            if (POOL) {
-                const float *db = pool.dp + (size_t)tc.b * pool.H2 * pool.W2 * 64;
-                const uint8_t *ib = pool.idx + (size_t)tc.b * pool.H2 * pool.W2 * 64;
-                const int P0 = tc.y0 >> 1, W0 = codd ? (gx - 1) >> 1 : gx >> 1;
+            for (int par = 0; par < 2; ++par) {
+                const int gx = tc.x0 + cbase + par, cx = gx < W1 ? gx : W1 - 1;
 #pragma unroll
-                for (int p_ = 0; p_ < 3; ++p_) {
-                    const int ph = P0 + p_, cph = ph < pool.H2 ? ph : pool.H2 - 1;
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int gy = tc.y0 + 2 * hp + rr, cy = gy < H1 ? gy : H1 - 1;
+                    o_.yv[par][rr] = *reinterpret_cast<const f32x4 *>(yb + (unsigned)(((cy * W1 + cx) << 6) + c4 * 4));
+                    ok |= (gy < H1 && gx < W1) ? (1u << (2 * par + rr)) : 0u;
+                }
+                if (POOL) {
+                    const float *db = pool.dp + (size_t)tc.b * pool.H2 * pool.W2 * 64;
+                    const uint8_t *ib = pool.idx + (size_t)tc.b * pool.H2 * pool.W2 * 64;
+                    const int P0 = (tc.y0 >> 1) + hp, W0 = par ? (gx - 1) >> 1 : gx >> 1;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (e == 1 && !codd) continue;
-                        const int pwc = W0 + e, cpw = pwc < pool.W2 ? pwc : pool.W2 - 1;
-                        const unsigned o = (unsigned)((cph * pool.W2 + cpw) * 64 + c4 * 4);
-                        dpv[p_][e] = *reinterpret_cast<const f32x4 *>(db + o);
-                        cdv[p_][e] = *reinterpret_cast<const uint32_t *>(ib + o);
-                        ok |= (ph < pool.H2 && pwc < pool.W2) ? (1u << (4 + p_ * 2 + e)) : 0u;
+                    for (int k = 0; k < 2; ++k) {
+                        const int ph = P0 + k, cph = ph < pool.H2 ? ph : pool.H2 - 1;
+#pragma unroll
+                        for (int e = 0; e <= par; ++e) {
+                            const int pwc = W0 + e, cpw = pwc < pool.W2 ? pwc : pool.W2 - 1;
+                            const unsigned o = (unsigned)((cph * pool.W2 + cpw) * 64 + c4 * 4);
+                            o_.dpv[par][k][e] = *reinterpret_cast<const f32x4 *>(db + o);
+                            o_.cdv[par][k][e] = *reinterpret_cast<const uint32_t *>(ib + o);
+                            ok |= (ph < pool.H2 && pwc < pool.W2) ? (1u << (4 + 4 * par + 2 * k + e)) : 0u;
+                        }
                     }
                 }
             }
             o_.ok = ok;
         };
-        // rows 0, 1 | 2, 3 of the column -> dy1, split by row pairs -> dst
+        // rows 2 hp, 2 hp + 1 of the even, then of the odd column -> dy1, split by the row pair -> dst
         auto finish = [&](const Ops &o_, uint32_t *dst) {
             if (WG1R_ABL & 4) return;
-            const auto &yv = o_.yv; const auto &dpv = o_.dpv; const auto &cdv = o_.cdv;
             const unsigned ok = o_.ok;
-            const int kx0 = codd ? 2 : 1;                            // kx of window column W0; W0 + 1 (odd columns): kx 0
 #pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {                         // row pair hp: rows 2 hp (even), 2 hp + 1 (odd)
+            for (int par = 0; par < 2; ++par) {
+                const int kx0 = par ? 2 : 1;                         // kx of window column W0; W0 + 1 (odd columns): kx 0
                 float d[2][4];
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const int r = 2 * hp + rr;
                     float g[4] = {0.f, 0.f, 0.f, 0.f};
                     if (POOL) {
                         // even row: window row hp with ky 1; odd row: window row hp with ky 2, hp + 1 with ky 0
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             if (rr == 0 && k == 1) continue;
-                            const int p_ = hp + k;
                             const uint32_t ky = rr == 0 ? 1u : (k == 0 ? 2u : 0u);
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                if (e == 1 && !codd) continue;
+                            for (int e = 0; e <= par; ++e) {
                                 const uint32_t code = ky * 3u + (e == 0 ? (uint32_t)kx0 : 0u);
-                                const bool win = (ok >> (4 + p_ * 2 + e)) & 1u;
+                                const bool win = (ok >> (4 + 4 * par + 2 * k + e)) & 1u;
 #pragma unroll
                                 for (int jx = 0; jx < 4; ++jx)
-                                    g[jx] += (win && ((cdv[p_][e] >> (8 * jx)) & 255u) == code) ? dpv[p_][e][jx] : 0.f;
+                                    g[jx] += (win && ((o_.cdv[par][k][e] >> (8 * jx)) & 255u) == code) ? o_.dpv[par][k][e][jx] : 0.f;
                             }
                         }
                     }
-                    const bool in = (ok >> r) & 1u;
+                    const bool in = (ok >> (2 * par + rr)) & 1u;
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
-                        float v = yv[r][jx];
+                        float v = o_.yv[par][rr][jx];
                         if (POOL) v = fmaf(cA[jx], g[jx], fmaf(cB[jx], v, cC[jx]));
                         d[rr][jx] = in ? v : 0.f;
                     }
@@ -1342,10 +1344,10 @@ __global__ __launch_bounds__(wg1r::THREADS) void conv1_wgrad_rs_kernel(
                     bf3_split_pair(d[0][jx], d[1][jx], u0, u1, u2);
                     w0[jx] = u0; w1[jx] = u1; w2[jx] = u2;
                 }
-                u32x4 *o_ = reinterpret_cast<u32x4 *>(dst + ((hp * 16 + cc) * 3) * 64 + c4 * 4);
-                o_[0] = w0;
-                o_[16] = w1;
-                o_[32] = w2;
+                u32x4 *o4 = reinterpret_cast<u32x4 *>(dst + ((hp * 16 + cbase + par) * 3) * 64 + c4 * 4);
+                o4[0] = w0;
+                o4[16] = w1;
+                o4[32] = w2;
             }
         };
         if (t0 < ntiles) {                       // prologue: the first tile's dy1 -> buffer 0; the next two tiles' operands in registers

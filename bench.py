@@ -501,7 +501,7 @@ def run(args, guard, rank, local_rank, world):
     # conv1 forward, conv1 weight gradient and the four 3x3 weight gradients (6 more pairs): the kernels whose time differs
     # from box to box (round 5: conv1 forward 0.75 ms on the builder's boxes, 1.01 ms on the driver's), IN the step.
     EVENT_EVERY = 1 if os.environ.get("COVA_PROFILE_ALL") else 10
-    in_step = dominant + [n for n in ("cova_conv1_fwd_tail", "cova_conv1_fwd", "cova_conv1_fwd_pool", "cova_conv1_wgrad_poolbwd",
+    in_step = dominant + [n for n in ("cova_conv1_fwd_tail", "cova_conv1_fwd", "cova_conv1_wgrad_poolbwd",
                                       "cova_conv3x3_wgrad4_partial") if n in timed]
     prof = {name: [] for name in (_lib.lib().protos if os.environ.get("COVA_PROFILE_ALL") else in_step)}
     t0 = time.perf_counter()

@@ -30,7 +30,7 @@ buf = (ctypes.c_ulonglong * n)()
 assert _lib.lib().cdll.cova_wg1b_trace_read(buf) == 0
 t0 = buf[(0 * 20 + 3) * 8 + 0]
 for wave in range(8):
-    print("wave %d (%s)" % (wave, "multiplies" if wave < 4 else "stages, %s columns" % ("odd" if wave & 1 else "even")))
+    print("wave %d (%s)" % (wave, "multiplies" if wave < 4 else "stages: column group %d, row pair %d" % ((wave - 4) >> 1, (wave - 4) & 1)))
     for it in (3, 4, 5, 6):
         st = [buf[(wave * 20 + it) * 8 + k] for k in range(4)]
         if wave < 4:

@@ -1,5 +1,5 @@
-"""Weight gradient of the 3x3 convolution on the benchmark map (16 x 320 x 320 x 64): F(4x4,3x3) (csrc/conv_wgrad4.hip)
-against F(2x2,3x3) (csrc/conv_wino.hip), per operand-prologue variant, partial-sum launches only + the finish launches.
+"""Weight gradient of the 3x3 convolution on the benchmark map (16 x 320 x 320 x 64): F(4x4,3x3) (csrc/conv_wgrad4.hip),
+per operand-prologue variant, partial-sum launches only + the finish launch (40 warm-up launches: the first case a process times runs slow).
 COVA_HIP_LIB selects an ablation build (tools/wg4_abl_build.sh)."""
 import os as _os; _os.environ.setdefault("COVA_ALLOW_OPTION_CHANGES", "1")
 import os, sys, time
@@ -15,11 +15,10 @@ dy = torch.randn(B, H, W, 64, device=dev, generator=g) * (torch.rand(B, H, W, 64
 z = torch.randn(B, H, W, 64, device=dev, generator=g)
 abc_a, abc_d = torch.randn(3, 64, device=dev, generator=g), torch.randn(3, 64, device=dev, generator=g)
 ws4 = torch.empty(query("cova_conv3x3_wgrad4_workspace_floats", B, H, W), device=dev)
-ws2 = torch.empty(query("cova_conv3x3_wgrad_workspace_floats", B, H, W), device=dev)
 dw = torch.empty(64, 64, 3, 3, device=dev)
 
 def t(fn, n=20):
-    for _ in range(3): fn()
+    for _ in range(40): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
@@ -31,8 +30,6 @@ for name, pa, pd in (("00", False, 0), ("10", True, 0), ("02", False, 2), ("12",
     args = (x, abc_a if pa else None, 1, dy, z if pd == 2 else None, abc_d if pd else None)
     dzo = torch.empty_like(dy) if (pd and "--emit" in sys.argv) else None
     t4 = t(lambda: call("cova_conv3x3_wgrad4_partial", *args, dzo, ws4, B, H, W))
-    t2 = t(lambda: call("cova_conv3x3_wgrad_wino_partial", *args, ws2, B, H, W))
-    print("prologue act=%d grad=%d   F(4x4) %.3f ms   F(2x2) %.3f ms" % (pa, pd, t4, t2), flush=True)
+    print("prologue act=%d grad=%d   F(4x4) %.3f ms" % (pa, pd, t4), flush=True)
 f4 = t(lambda: call("cova_conv3x3_wgrad4_finish", ws4, dw, ws4, dw, ws4, dw, ws4, dw, B, H, W))
-f2 = t(lambda: call("cova_conv3x3_wgrad_wino_finish", ws2, dw, ws2, dw, ws2, dw, ws2, dw, B, H, W))
-print("finish (4 convolutions)   F(4x4) %.3f ms   F(2x2) %.3f ms" % (f4, f2))
+print("finish (4 convolutions)   F(4x4) %.3f ms" % f4)

@@ -112,28 +112,48 @@ def _device_of(name, args):
     return dev
 
 
+_Tensor = torch.Tensor
+
+
 def call(name, *args, stream=None):
     """Call a stream-taking entry point with tensors/None/scalars; raises on a non-zero status.
 
     The launch goes to the device the tensors live on, on THAT device's current stream: the
     reference picks ``cuda:<-d>`` (main.py:17, evaluate.py:92) and never calls set_device, so the
-    process' current device may well be another GPU."""
-    L = lib()
-    dev = _device_of(name, args)
-    if dev is not None and dev.index != torch.cuda.current_device():
+    process' current device may well be another GPU.
+
+    One pass over the arguments (tensor -> pointer, device agreement): this function sits in front of every launch, and behind
+    a host read (the reference's loop has two per step, train.py:54,57) the head's 5-20 us kernels wait for it."""
+    L = _LIB if _LIB is not None else lib()
+    dev = -1
+    cargs = []
+    for a in args:
+        if isinstance(a, _Tensor):
+            if not a.is_cuda:
+                raise CovaHipError("%s: got a %s tensor; the hot path runs on the ROCm device only "
+                                   "(no CPU fallback)" % (name, a.device))
+            d = a.get_device()
+            if dev < 0:
+                dev = d
+            elif d != dev:
+                raise CovaHipError("%s: tensor arguments on different devices (cuda:%d, cuda:%d)" % (name, dev, d))
+            cargs.append(a.data_ptr())
+        else:
+            cargs.append(a)
+    if dev >= 0 and dev != torch.cuda.current_device():
         with torch.cuda.device(dev):
-            return _launch(L, name, args, stream)
-    return _launch(L, name, args, stream)
+            return _launch(L, name, args, cargs, stream)
+    return _launch(L, name, args, cargs, stream)
 
 
-def _launch(L, name, args, stream):
+def _launch(L, name, args, cargs, stream):
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
     prof = PROFILE.get(name) if PROFILE is not None else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = L.fn[name](*[_arg(a) for a in args], stream)
+    rc = L.fn[name](*cargs, stream)
     if prof is not None:
         e1.record()
         prof.append((e0, e1, tuple(a for a in args if isinstance(a, int)), tuple(a is not None for a in args)))

@@ -81,10 +81,10 @@ if os.environ.get("POISON_LDS") == "1":
     _real_launch = _lib._launch
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
 
-    def _launch_poisoned(L, name, a, stream):
+    def _launch_poisoned(L, name, a, cargs, stream):
         if not name.startswith("cova_probe"):
-            _real_launch(L, "cova_probe_lds_fill", (0x7FC00000, 2 * n_cu), stream)
-        return _real_launch(L, name, a, stream)
+            _real_launch(L, "cova_probe_lds_fill", (0x7FC00000, 2 * n_cu), [0x7FC00000, 2 * n_cu], stream)
+        return _real_launch(L, name, a, cargs, stream)
     _lib._launch = _launch_poisoned
     print("(LDS of every CU NaN-filled in front of every launch)")
 ref_loss, ref = step()

@@ -8,3 +8,4 @@ mkdir -p $root/build
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/probe/mfma_round_probe.hip -o $root/build/mfma_round_probe 2>/dev/null && echo built mfma_round_probe
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/probe/mfma_round_probe2.hip -o $root/build/mfma_round_probe2 2>/dev/null && echo built mfma_round_probe2
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/probe/gap_probe.hip -o $root/build/gap_probe 2>/dev/null && echo built gap_probe
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/probe/dma_probe.hip -o $root/build/dma_probe 2>/dev/null && echo built dma_probe
